@@ -1,0 +1,157 @@
+/* pips_hip.h — C ABI of the MI355X-native KKT linear-system backend for PIPS-IPM++ (libpipship.so).
+ *
+ * Every entry point returns 0 on success and a non-zero PIPS_ERR_* code on failure; pips_hip_last_error() gives the
+ * message.  The C++ adapter maps non-zero onto the reference's convention of printing and calling
+ * MPI_Abort (PardisoSolver.C:201-204,222-225).  No call throws, none takes or returns a C++/torch type.
+ *
+ * "host" pointers are ordinary memory, "dev" pointers are HIP device memory of the device the handle was created on.
+ * All matrices are CSR, row-major, 0-based, int32 indices, fp64 values (SparseStorage.h:45-50).
+ */
+#ifndef PIPS_HIP_H
+#define PIPS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pips_hip_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int pips_hip_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 1. Leaf solver handle: drop-in for DoubleLinearSolver behind DistributedFactory::make_leaf_solver
+ *    (DoubleLinearSolver.h:24-72, DistributedFactory.cpp:66-112).  Replaces PardisoSolver / Ma27Solver / Ma57Solver.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* pattern of the lower-triangular CSR matrix the solver will factorise (SparseSymmetricMatrix, isLower;
+ * PardisoSolver.C:51-135 reads the same krowM/jcolM).  The arrays are copied.  device < 0: current device. */
+int pips_hip_ldl_create(void** handle, int n, const int* krow, const int* jcol, int device, int flags);
+/* optional: the leading n_primal rows are expected to yield positive pivots, the rest negative
+ * (= the inertia the regularisation loop asks for: DistributedLeafLinearSystem.C:22, LinearSystem.C:296-325) */
+int pips_hip_ldl_set_inertia_hint(void* handle, int n_primal);
+/* relative pivot threshold / replacement (times max|K|); PARDISO's counterpart is the 1e-8 pivot perturbation */
+int pips_hip_ldl_set_pivot_rule(void* handle, double thr_rel, double repl_rel);
+/* iterative-refinement steps applied by every solve (PardisoProjectSolver.C:72 uses iparm[7]=2) */
+int pips_hip_ldl_set_refinement(void* handle, int steps);
+/* symbolic phase (ordering, supernodes, device allocation); pattern-only, done once */
+int pips_hip_ldl_analyze(void* handle);
+/* = DoubleLinearSolver::matrixChanged(): numeric LDL^T of the current values (host array of length nnz, CSR order) */
+int pips_hip_ldl_factor(void* handle, const double* vals_host);
+/* = DoubleLinearSolver::solve(int nrhss, double* rhss, int* colSparsity) (PardisoSolver.C:276-352): nrhs contiguous
+ * right-hand sides of length ld >= n, overwritten by the solutions.  nrhs = 1 is DoubleLinearSolver::solve(Vector&). */
+int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs_inout_host, int ld);
+/* = DoubleLinearSolver::get_inertia(): (positive, negative, zero/perturbed) pivots of the last factorisation */
+int pips_hip_ldl_inertia(void* handle, int* pos, int* neg, int* zero);
+/* diagnostics of the symbolic phase: what[0]=nnz(L) what[1]=n_head what[2]=tail m what[3]=#head supernodes
+ * what[4]=#levels what[5]=factor flops (rounded) */
+int pips_hip_ldl_info(void* handle, int64_t* what, int n_what);
+/* copies the fill-reducing permutation (perm[k] = original index eliminated k-th) */
+int pips_hip_ldl_get_perm(void* handle, int* perm);
+void pips_hip_ldl_destroy(void* handle);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 2. Dense root solver: drop-in for DeSymIndefSolver (DeSymIndefSolver.C:56-168; dsytrf_/dsytrs_).
+ * ------------------------------------------------------------------------------------------------------------- */
+int pips_hip_dense_ldl_create(void** handle, int n, int n_primal, int device);
+/* = DeSymIndefSolver::matrixChanged(): A is the n x n row-major DenseSymmetricMatrix storage (DenseStorage.C:64-83,
+ * lower triangle authoritative, lda = n); it is copied to the device and factorised */
+int pips_hip_dense_ldl_factor(void* handle, const double* A_host, int lda);
+/* factorise a matrix that already lives on the device in column-major-lower form (fused path, see section 3) */
+int pips_hip_dense_ldl_factor_dev(void* handle, const double* A_dev, int lda);
+int pips_hip_dense_ldl_solve(void* handle, int nrhs, double* rhs_inout_host, int ld);
+int pips_hip_dense_ldl_solve_dev(void* handle, double* rhs_inout_dev);
+int pips_hip_dense_ldl_inertia(void* handle, int* pos, int* neg, int* zero);
+void pips_hip_dense_ldl_destroy(void* handle);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 3. Batched, device-resident fast path for all leaves owned by one GPU.  Replaces the host loops of
+ *    DistributedRootLinearSystem::factor2 (:206-243), sLinsysRootAug::assembleLocalKKT (:210-227),
+ *    DistributedLeafLinearSystem::addTermToSchurComplBlocked (:214-252) with
+ *    addBiTLeftKiBiRightToResBlockedParallelSolvers / addLeftBorderTimesDenseColsToResTranspDense
+ *    (DistributedLinearSystem.C:766-1047,1115-1175), and the leaf parts of Lsolve/Ltsolve
+ *    (addLniziLinkCons DistributedLeafLinearSystem.C:171-212, LniTransMult DistributedLinearSystem.C:430-483).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* S = dimension of the root Schur complement (n0 + my0 + myl + mzl); stream: hipStream_t or NULL (default stream) */
+int pips_hip_batch_create(void** handle, int n_blocks, int S, int device, void* stream);
+/* block b: lower CSR pattern of K_b (n x n), leading primal rows, and Br_b^T as CSR with S rows over n columns
+ * (build it with pips_border_assemble); Bt_* may be NULL for a block without border.  Arrays are copied. */
+int pips_hip_batch_set_block(void* handle, int b, int n, int n_primal, const int* K_rowptr, const int* K_colidx,
+                             const int* Bt_rowptr, const int* Bt_colidx, const double* Bt_val);
+int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps, double thr_rel, double repl_rel);
+/* symbolic phase for all blocks (n_threads host threads) + device setup */
+int pips_hip_batch_analyze(void* handle, int n_threads);
+/* upload all values of K_b (CSR order, host) — needed once; afterwards only diagonals change (a2) */
+int pips_hip_batch_set_values(void* handle, int b, const double* K_val_host);
+/* K diagonals of all blocks from one flat device vector (block after block, rows in [x|y|z] order):
+ * put_primal_diagonal / clear_dual_equality_diagonal / put_dual_inequalites_diagonal / add_regularization_local_kkt
+ * (DistributedLeafLinearSystem.C:88-143) collapsed into one scatter */
+int pips_hip_batch_set_diagonals_dev(void* handle, const double* diag_dev);
+int pips_hip_batch_set_diagonals(void* handle, const double* diag_host);
+/* factor every K_b and accumulate  SC -= sum_b Br_b^T K_b^-1 Br_b  into SC_dev: S x S, column-major with leading
+ * dimension ldSC, lower triangle written (== the upper triangle of the reference's row-major layout's transpose; the
+ * matrix is symmetric).  SC_dev may be NULL to factor only.  Asynchronous on the handle's stream. */
+int pips_hip_batch_factor(void* handle, double* SC_dev, int ldSC);
+/* x_b := K_b^-1 x_b for every block; x_dev is the flat vector of all blocks (sum of n).  Asynchronous. */
+int pips_hip_batch_solve_dev(void* handle, double* x_dev);
+int pips_hip_batch_solve(void* handle, double* x_host);
+/* b0 += alpha * sum_b Br_b^T z_b   (addLniziLinkCons uses alpha = -1) */
+int pips_hip_batch_border_tmult_dev(void* handle, const double* z_dev, double* b0_dev, double alpha);
+/* t_b += alpha * Br_b x0 for every block   (LniTransMult) */
+int pips_hip_batch_border_mult_dev(void* handle, const double* x0_dev, double* t_dev, double alpha);
+int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero);
+/* what[0]=sum nnz(L) what[1]=sum n what[2]=sum n_head what[3]=sum tail m what[4]=#head supernodes what[5]=max levels
+ * what[6]=factor flops what[7]=border (TRSM+SYRK) flops what[8]=arena bytes what[9]=max tail tile columns */
+int pips_hip_batch_info(void* handle, int64_t* what, int n_what);
+int pips_hip_batch_sync(void* handle);
+/* per-phase device time of the last pips_hip_batch_factor in ms (HIP events on the handle's stream):
+ * ms[0]=scatter ms[1]=head ms[2]=tail update GEMM ms[3]=tail diag ms[4]=tail trsm ms[5]=Schur SYRK ms[6]=total
+ * cnt[i] = number of kernel launches of phase i.  Enable with pips_hip_batch_set_timing(handle, 1). */
+int pips_hip_batch_set_timing(void* handle, int on);
+int pips_hip_batch_get_timing(void* handle, double* ms, int64_t* cnt, int n);
+void pips_hip_batch_destroy(void* handle);
+
+/* plain device buffers for hosts that do not bring their own allocator */
+int pips_hip_malloc(void** dev_ptr, size_t bytes);
+int pips_hip_free(void* dev_ptr);
+int pips_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int pips_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int pips_hip_memset(void* dst_dev, int value, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 4. Reduction of the Schur complement and of b0 across the GPUs of a node (replaces MPI_Allreduce in
+ *    DistributedRootLinearSystem::reduceKKTdense :860-881 / submatrixAllReduce* :1614-1707 and
+ *    PIPS_MPIsumArrayInPlace in sLinsysRootAug::Lsolve :340-341).  RCCL over xGMI.
+ * ------------------------------------------------------------------------------------------------------------- */
+int pips_hip_comm_unique_id(void* id128);                 /* 128-byte ncclUniqueId, produced on rank 0 */
+int pips_hip_comm_create(void** comm, const void* id128, int n_ranks, int rank, int device);
+int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
+void pips_hip_comm_destroy(void* comm);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 5. Host harness helpers (no GPU needed): synthetic arrowhead LP of SURVEY.md §8d, leaf KKT / border assembly.
+ * ------------------------------------------------------------------------------------------------------------- */
+int pips_gen_row_nnz(int n_i, double rho);
+int pips_gen_block(uint64_t seed, int block, int n_i, int my_i, int n0, int myl, double rho, int* W_rowptr,
+                   int* W_colidx, double* W_val, int* T_rowptr, int* T_colidx, double* T_val, int* F_rowptr,
+                   int* F_colidx, double* F_val, double* c, double* xstar);
+int pips_gen_root(uint64_t seed, int n0, int myl, int* F0_rowptr, int* F0_colidx, double* F0_val, double* c0,
+                  double* xstar0);
+int pips_gen_diagonal(uint64_t seed, int block, int n, double lo, double hi, double* d);
+int pips_kkt_leaf_assemble(int nx, int my, int mz, const int* Q_rowptr, const int* Q_colidx, const double* Q_val,
+                           const int* B_rowptr, const int* B_colidx, const double* B_val, const int* D_rowptr,
+                           const int* D_colidx, const double* D_val, int* K_rowptr, int* K_colidx, double* K_val,
+                           int* diag_pos);
+int pips_border_assemble(int nx, int my, int mz, int n0, int n_empty, int myl, int mzl, const int* R_rowptr,
+                         const int* R_colidx, const double* R_val, const int* A_rowptr, const int* A_colidx,
+                         const double* A_val, const int* C_rowptr, const int* C_colidx, const double* C_val,
+                         const int* F_rowptr, const int* F_colidx, const double* F_val, const int* G_rowptr,
+                         const int* G_colidx, const double* G_val, int* Bt_rowptr, int* Bt_colidx, double* Bt_val);
+/* symbolic analysis only (CPU): fills what[] like pips_hip_ldl_info and optionally perm/colcount (may be NULL) */
+int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, int S, const int* Bt_rowptr,
+                        const int* Bt_colidx, int force_n_head, int64_t* what, int n_what, int* perm, int* colcount);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIPS_HIP_H */

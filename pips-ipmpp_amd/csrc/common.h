@@ -1,0 +1,105 @@
+// Shared host-side declarations for the MI355X KKT backend (libpipship.so).
+// Everything here is internal; the public surface is include/pips_hip.h.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace pips {
+
+// ---- error handling --------------------------------------------------------------------------
+// C-ABI entry points return 0 on success; the adapter maps non-zero onto the reference's abort
+// convention (PardisoSolver.C:201-204).  The message of the last failure is kept per thread.
+void set_last_error(const std::string& msg);
+const char* last_error();
+
+enum : int {
+   PIPS_OK = 0,
+   PIPS_ERR_ARG = 1,
+   PIPS_ERR_STATE = 2,
+   PIPS_ERR_HIP = 3,
+   PIPS_ERR_NUMERIC = 4,
+   PIPS_ERR_NO_DEVICE = 5,
+   PIPS_ERR_RCCL = 6,
+};
+
+#define PIPS_FAIL(code, ...)                                   \
+   do {                                                        \
+      char _buf[512];                                          \
+      snprintf(_buf, sizeof(_buf), __VA_ARGS__);               \
+      ::pips::set_last_error(_buf);                            \
+      return (code);                                           \
+   } while (0)
+
+// ---- ordering (order.cpp) --------------------------------------------------------------------
+// Constrained approximate-minimum-degree ordering of a symmetric pattern.
+//  n            dimension
+//  ap/ai        full symmetric adjacency (both triangles, no diagonal), CSR
+//  n_primal     rows [0,n_primal) are primal (expected positive pivots); rows >= n_primal are dual rows
+//               (expected negative pivots, possibly structurally zero diagonal).  A dual row becomes
+//               eligible only after all its primal neighbours are eliminated, which keeps every leading
+//               principal block of [D W^T; W 0] nonsingular (see DESIGN.md "static pivoting").
+//               n_primal < 0: unconstrained.
+//  perm[k]      = original index eliminated k-th ; colcount[k] = #off-diagonal entries in column k of L
+void constrained_amd(int n, const std::vector<int>& ap, const std::vector<int>& ai, int n_primal,
+                     std::vector<int>& perm, std::vector<int>& colcount);
+
+// ---- symbolic analysis of one leaf block (symbolic.cpp) --------------------------------------
+struct HeadSupernode {
+   int c0;          // first column (permuted index)
+   int w;           // width
+   int r;           // number of rows below the diagonal block
+   int level;       // elimination-tree level among head supernodes (0 = leaves)
+   int64_t panel;   // offset (doubles) of the (w+r) x w column-major panel inside the block arena
+   int64_t rows;    // offset (ints) of the r row indices inside BlockSym::rowidx
+};
+
+struct BlockSym {
+   int n = 0;          // dimension of K_i
+   int n_primal = -1;  // leading primal rows (inertia hint)
+   int nb = 0;         // number of border columns of this block that are non-empty (compressed)
+   int n_head = 0;     // columns [0,n_head) (permuted) are factorised by the sparse head kernels
+   int m = 0;          // dense tail dimension = n - n_head
+   int m_pad = 0;      // m rounded up to the tile size (identity padding)
+   int nb_pad = 0;     // nb rounded up to the tile size (zero padding)
+   int ldT = 0;        // leading dimension of the tail panel = m_pad + nb_pad
+   int64_t T_off = 0;  // offset of the tail panel in the block arena
+   int64_t arena = 0;  // arena size in doubles
+   int n_levels = 0;
+   std::vector<int> perm, iperm;        // perm[new] = old ; iperm[old] = new
+   std::vector<int> bmap;               // compressed border index -> Schur column id
+   std::vector<HeadSupernode> sn;       // head supernodes, ascending c0
+   std::vector<int> sn_of_col;          // [n_head]
+   std::vector<int> rowidx;             // concatenated below-rows of head supernodes
+                                        //   value < n : permuted row of K ; value >= n : n + compressed border index
+   std::vector<int64_t> a_dst;          // [nnz(K lower)] arena offset of every CSR entry
+   std::vector<int64_t> b_dst;          // [nnz(border)]  arena offset of every border entry, -1 if it lands in SC (never)
+   std::vector<signed char> psign;      // [n] expected pivot sign in permuted order (+1/-1/0)
+   int64_t nnzL = 0;                    // stored entries of L (head panels + dense tail lower triangle)
+   double flops_factor = 0;             // head + tail factor flops
+   double flops_border = 0;             // border TRSM + Schur SYRK flops
+   std::vector<int> colcount;           // AMD column counts (diagnostics)
+};
+
+struct CsrPattern {
+   int nrows = 0, ncols = 0;
+   const int* rowptr = nullptr;
+   const int* colidx = nullptr;
+};
+
+struct AnalyzeOptions {
+   int tile = 128;            // dense tile size
+   int max_sn_width = 32;     // head supernode width cap
+   int min_tail = 256;        // do not open a dense tail smaller than this
+   int force_n_head = -1;     // >=0: override the cost model (tests)
+   double head_cost = 1.0e-11;  // seconds per scattered update entry (cost model)
+   double mfma_rate = 4.0e13;   // sustained dense FP64 flop/s (cost model)
+};
+
+// K: lower-triangular CSR pattern of K_i (n x n).  border: CSR with S rows (Schur column ids) over the n rows of K_i,
+// i.e. the pattern of Br_i^T (border_left_transp in DistributedLeafLinearSystem.C:214-252).  May be empty (nrows = 0).
+int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, const AnalyzeOptions& opt,
+                  BlockSym& out);
+
+}  // namespace pips

@@ -1,0 +1,717 @@
+// HIP kernels (gfx950 / CDNA4) of the KKT backend.  Included once by engine.hip.
+//
+//  head  : supernodal sparse LDL^T for the low-fill leading part of every leaf block.  One workgroup per supernode and
+//          elimination-tree level; the w x w pivot block is factorised in LDS, the sub-diagonal panel is solved with
+//          coalesced column reads, and the Schur update is scattered into ancestors / the dense tail / the root Schur
+//          complement with hardware FP64 atomics.
+//  tail  : left-looking tiled dense LDL^T (128 x 128 tiles) on the FP64 matrix cores (v_mfma_f64_16x16x4_f64),
+//          operands staged through LDS with register prefetch.  The border rows of the augmented system ride along as
+//          extra tile rows, so the same GEMM kernel produces  L21 = Br^T K^-T  and finally  SC -= L21 D L21^T.
+//  solve : level-scheduled head substitution + tiled dense TRSV using the pre-inverted diagonal tiles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pips {
+
+constexpr int TILE = 128;
+constexpr int KB = 16;          // k-depth of one LDS stage of the tile GEMM
+constexpr int LDS_PAD = 16;     // LDS row padding (doubles): 144*8 B = 1152 B -> half-wave k-groups hit disjoint banks
+constexpr int LDSW = TILE + LDS_PAD;
+
+struct SnDesc {
+   long long panel;  // global arena offset of the (w+r) x w panel
+   long long rows;   // global offset into rowidx
+   int w, r, c0, blk;
+};
+
+struct BlkDesc {
+   long long arena_off;  // block arena base (doubles)
+   long long T;          // global arena offset of the tail panel
+   long long sncol_off;  // offset into sn_of_col (values are global supernode ids)
+   long long xw_off;     // offset of the permuted work vector (length n_head + m_pad)
+   long long x_off;      // offset into flat original-order vectors (sum of n over preceding blocks)
+   long long bmap_off;   // offset into bmap
+   long long winv_off;   // offset into winv (ntc tiles of TILE*TILE)
+   long long dt_off;     // offset into dtail (m_pad)
+   int n, n_head, m, m_pad, nb, nb_pad, ldT, ntc, ntr;
+   int pad0;
+   double thr, repl;     // pivot threshold / replacement magnitude (absolute)
+};
+
+struct TileTask { int blk, ti, tj, pad; };
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double fix_pivot(double d, int sign, double thr, double repl, bool& perturbed) {
+   perturbed = false;
+   if (sign > 0) {
+      if (!(d > thr)) { d = repl; perturbed = true; }
+   } else if (sign < 0) {
+      if (!(d < -thr)) { d = -repl; perturbed = true; }
+   } else {
+      if (!(fabs(d) > thr)) { d = (d < 0.0) ? -repl : repl; perturbed = true; }
+   }
+   return d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// value scatter: arena[dst[p]] = val[p]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_scatter(const long long* __restrict__ dst, const double* __restrict__ val, double* __restrict__ arena,
+                          long long n) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      arena[dst[i]] = val[i];
+}
+
+// K values <- diagonal vector (a2: put_primal_diagonal / put_dual_inequalites_diagonal / regularisation)
+__global__ void k_put_diag(const long long* __restrict__ kdiag, const double* __restrict__ diag, double* __restrict__ kval,
+                           long long n) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      kval[kdiag[i]] = diag[i];
+}
+
+__global__ void k_tail_pad_diag(const BlkDesc* __restrict__ blks, double* __restrict__ arena, int nblk) {
+   const int b = blockIdx.x;
+   if (b >= nblk) return;
+   const BlkDesc bd = blks[b];
+   for (int t = bd.m + threadIdx.x; t < bd.m_pad; t += blockDim.x) arena[bd.T + t + (long long)t * bd.ldT] = 1.0;
+}
+
+// max |K| per block -> pivot thresholds
+__global__ void k_block_absmax(const double* __restrict__ kval, const long long* __restrict__ kptr, BlkDesc* blks,
+                               double thr_rel, double repl_rel) {
+   const int b = blockIdx.x;
+   double mx = 0.0;
+   for (long long i = kptr[b] + threadIdx.x; i < kptr[b + 1]; i += blockDim.x) mx = fmax(mx, fabs(kval[i]));
+   __shared__ double red[256];
+   red[threadIdx.x] = mx;
+   __syncthreads();
+   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) {
+      const double a = red[0] > 0.0 ? red[0] : 1.0;
+      blks[b].thr = thr_rel * a;
+      blks[b].repl = repl_rel * a;
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head supernode factorisation (one workgroup per supernode)
+// ------------------------------------------------------------------------------------------------
+constexpr int HEAD_WMAX = 32;   // widest head supernode (solve kernels)
+
+// BLOCK threads; WMAX widest supernode handled; LCAP doubles of L21 cached in LDS; PCAP ints of the position table
+template <int BLOCK, int WMAX, int LCAP, int PCAP>
+__global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict__ sns, int sn_begin,
+                                                      const BlkDesc* __restrict__ blks,
+                                                      const int* __restrict__ rowidx, const int* __restrict__ sncol,
+                                                      const signed char* __restrict__ psign,
+                                                      const long long* __restrict__ psign_off,
+                                                      const int* __restrict__ bmap, double* __restrict__ arena,
+                                                      double* __restrict__ SC, int ldSC, int* __restrict__ inertia) {
+   __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w
+   __shared__ double dk[WMAX];
+   __shared__ double Ls[LCAP];
+   __shared__ int pos[PCAP];
+   __shared__ int cnt[3];
+
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   double* P = arena + sn.panel;
+   const int* rows = rowidx + sn.rows;
+   const signed char* ps = psign + psign_off[sn.blk] + sn.c0;
+
+   if (tid < 3) cnt[tid] = 0;
+   for (int i = tid; i < w * w; i += BLOCK) Ld[i] = P[(i % w) + (long long)(i / w) * ld];
+   __syncthreads();
+
+   // ---- LDL^T of the w x w pivot block (right-looking, column by column)
+   for (int k = 0; k < w; ++k) {
+      if (tid == 0) {
+         bool pert;
+         const double d = fix_pivot(Ld[k + k * w], ps[k], bd.thr, bd.repl, pert);
+         dk[k] = d;
+         if (pert) ++cnt[2]; else if (d > 0) ++cnt[0]; else ++cnt[1];
+      }
+      __syncthreads();
+      const double d = dk[k];
+      // trailing update with the unscaled column k
+      for (int idx = tid; idx < (w - k - 1) * (w - k - 1); idx += BLOCK) {
+         const int i = k + 1 + idx % (w - k - 1), j = k + 1 + idx / (w - k - 1);
+         if (i >= j) Ld[i + j * w] -= Ld[i + k * w] * Ld[j + k * w] / d;
+      }
+      __syncthreads();
+      for (int i = k + 1 + tid; i < w; i += BLOCK) Ld[i + k * w] /= d;
+      __syncthreads();
+   }
+   // write back L11 (unit lower, D on the diagonal)
+   for (int i = tid; i < w * w; i += BLOCK) {
+      const int rr = i % w, cc = i / w;
+      if (rr > cc) P[rr + (long long)cc * ld] = Ld[i];
+      else if (rr == cc) P[rr + (long long)cc * ld] = dk[cc];
+   }
+   if (tid == 0) {
+      if (cnt[0]) atomicAdd(&inertia[3 * sn.blk + 0], cnt[0]);
+      if (cnt[1]) atomicAdd(&inertia[3 * sn.blk + 1], cnt[1]);
+      if (cnt[2]) atomicAdd(&inertia[3 * sn.blk + 2], cnt[2]);
+   }
+   if (r == 0) return;
+
+   // ---- L21 := A21 L11^-T D^-1, one row per thread (coalesced along the rows of each column)
+   const bool cacheL = (long long)r * w <= LCAP;
+   for (int a = tid; a < r; a += BLOCK) {
+      double y[WMAX];
+      double* row = P + w + a;
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) {
+         if (k < w) {
+            double v = row[(long long)k * ld];
+#pragma unroll
+            for (int l = 0; l < k; ++l) v -= y[l] * Ld[k + l * w];
+            y[k] = v;
+         }
+      }
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) {
+         if (k < w) {
+            const double l = y[k] / dk[k];
+            row[(long long)k * ld] = l;
+            if (cacheL) Ls[a * w + k] = l;
+         }
+      }
+   }
+   __syncthreads();
+
+   // ---- Schur update, scattered with FP64 atomics.  Rows below are sorted: head columns < tail columns < border.
+   const int n = bd.n, n_head = bd.n_head;
+   double* T = arena + bd.T;
+   const int* bm = bmap + bd.bmap_off;
+   int b0 = 0;
+   while (b0 < r) {
+      const int cb0 = rows[b0];
+      int b1;          // end of the segment of columns sharing one target
+      int kind;        // 0 head supernode, 1 tail, 2 border
+      SnDesc tg;
+      if (cb0 < n_head) {
+         kind = 0;
+         const int tsn = sncol[bd.sncol_off + cb0];
+         tg = sns[tsn];
+         b1 = b0 + 1;
+         while (b1 < r && rows[b1] < tg.c0 + tg.w) ++b1;
+         // position table of rows[a], a in [b0,r), inside the target panel
+         const int* trows = rowidx + tg.rows;
+         const bool tbl = (r - b0) <= PCAP;
+         if (tbl) {
+            for (int a = b0 + tid; a < r; a += BLOCK) {
+               const int ra = rows[a];
+               int p;
+               if (ra < tg.c0 + tg.w) p = ra - tg.c0;
+               else {
+                  int lo = 0, hi = tg.r;
+                  while (lo < hi) { const int mid = (lo + hi) >> 1; if (trows[mid] < ra) lo = mid + 1; else hi = mid; }
+                  p = tg.w + lo;
+               }
+               pos[a - b0] = p;
+            }
+            __syncthreads();
+         }
+         const int tld = tg.w + tg.r;
+         double* TP = arena + tg.panel;
+         for (int b = b0; b < b1; ++b) {
+            const int lc = rows[b] - tg.c0;
+            for (int a = b + tid; a < r; a += BLOCK) {
+               double u = 0.0;
+               for (int k = 0; k < w; ++k) {
+                  const double la = cacheL ? Ls[a * w + k] : P[w + a + (long long)k * ld];
+                  const double lb = cacheL ? Ls[b * w + k] : P[w + b + (long long)k * ld];
+                  u += la * lb * dk[k];
+               }
+               int p;
+               if (tbl) p = pos[a - b0];
+               else {
+                  const int ra = rows[a];
+                  if (ra < tg.c0 + tg.w) p = ra - tg.c0;
+                  else {
+                     int lo = 0, hi = tg.r;
+                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (trows[mid] < ra) lo = mid + 1; else hi = mid; }
+                     p = tg.w + lo;
+                  }
+               }
+               atomic_add_f64(TP + p + (long long)lc * tld, -u);
+            }
+         }
+         __syncthreads();
+      } else {
+         kind = cb0 < n ? 1 : 2;
+         b1 = b0 + 1;
+         if (kind == 1) { while (b1 < r && rows[b1] < n) ++b1; } else b1 = r;
+         for (int b = b0; b < b1; ++b) {
+            const int cb = rows[b];
+            for (int a = b + tid; a < r; a += BLOCK) {
+               double u = 0.0;
+               for (int k = 0; k < w; ++k) {
+                  const double la = cacheL ? Ls[a * w + k] : P[w + a + (long long)k * ld];
+                  const double lb = cacheL ? Ls[b * w + k] : P[w + b + (long long)k * ld];
+                  u += la * lb * dk[k];
+               }
+               const int ra = rows[a];
+               if (kind == 1) {
+                  const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
+                  atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -u);
+               } else {
+                  atomic_add_f64(SC + bm[ra - n] + (long long)bm[cb - n] * ldSC, -u);
+               }
+            }
+         }
+      }
+      b0 = b1;
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile GEMM on the FP64 matrix cores.
+//   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
+//   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
+//   MODE 2 (schur) : SC[bmap(ti), bmap(tj)] -= A(ti,0:K) diag(d) B(tj,0:K)^T   ti,tj border tile rows, K = m_pad
+// 256 threads = 4 waves in a 2 x 2 grid, each wave owns a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x4 accumulators.
+// The A-panel fragment is fed as the MFMA "B" operand so that the lane index runs along C's rows (memory-contiguous).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tile_gemm(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                  double* __restrict__ arena, const double* __restrict__ dtail,
+                                                  const double* __restrict__ winv, const int* __restrict__ bmap,
+                                                  double* __restrict__ SC, int ldSC) {
+   __shared__ double As[KB * LDSW];
+   __shared__ double Bs[KB * LDSW];
+
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int wr = wave & 1, wc = wave >> 1;
+   const int ld = bd.ldT;
+   double* T = arena + bd.T;
+
+   int K;
+   const double* Ap;  // A panel: rows of C
+   const double* Bp;  // B panel: columns of C
+   long long ldb;
+   const double* dv = nullptr;
+   if (MODE == 0) {
+      K = task.tj * TILE;
+      Ap = T + (long long)task.ti * TILE;
+      Bp = T + (long long)task.tj * TILE;
+      ldb = ld;
+      dv = dtail + bd.dt_off;
+   } else if (MODE == 1) {
+      K = TILE;
+      Ap = T + (long long)task.ti * TILE + (long long)task.tj * TILE * ld;
+      Bp = winv + bd.winv_off + (long long)task.tj * TILE * TILE;
+      ldb = TILE;
+   } else {
+      K = bd.m_pad;
+      Ap = T + bd.m_pad + (long long)task.ti * TILE;
+      Bp = T + bd.m_pad + (long long)task.tj * TILE;
+      ldb = ld;
+      dv = dtail + bd.dt_off;
+   }
+
+   double4_t acc[4][4];
+#pragma unroll
+   for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+   // staging: thread -> row (tid & 127), k-group (tid >> 7) of 8 consecutive k
+   const int srow = tid & 127, sk = (tid >> 7) * 8;
+   double ra[8], rb[8];
+   auto prefetch = [&](int k0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+         const int k = k0 + sk + e;
+         ra[e] = Ap[srow + (long long)k * ld];
+         double v = Bp[srow + (long long)k * ldb];
+         if (MODE != 1) v *= dv[k];
+         rb[e] = v;
+      }
+   };
+   if (K > 0) prefetch(0);
+   for (int k0 = 0; k0 < K; k0 += KB) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+         As[(sk + e) * LDSW + srow] = ra[e];
+         Bs[(sk + e) * LDSW + srow] = rb[e];
+      }
+      __syncthreads();
+      if (k0 + KB < K) prefetch(k0 + KB);
+#pragma unroll
+      for (int kk = 0; kk < KB; kk += 4) {
+         const int kl = kk + (lane >> 4);
+         double fa[4], fb[4];
+#pragma unroll
+         for (int i = 0; i < 4; ++i) fa[i] = As[kl * LDSW + wr * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+         for (int j = 0; j < 4; ++j) fb[j] = Bs[kl * LDSW + wc * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+               // M index <- B panel (C column), N index <- A panel (C row)
+               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+   }
+
+   // epilogue: lane holds C(row = rbase + (lane&15), col = cbase + (lane>>4) + 4*reg)
+#pragma unroll
+   for (int i = 0; i < 4; ++i) {
+      const int row = wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+         for (int q = 0; q < 4; ++q) {
+            const int col = wc * 64 + j * 16 + (lane >> 4) + 4 * q;
+            const double v = acc[i][j][q];
+            if (MODE == 0) {
+               double* c = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
+               *c -= v;
+            } else if (MODE == 1) {
+               double* c = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
+               *c = v;
+            } else {
+               const int gi = task.ti * TILE + row, gj = task.tj * TILE + col;
+               if (gi < bd.nb && gj < bd.nb && gi >= gj) {
+                  const int* bm = bmap + bd.bmap_off;
+                  atomic_add_f64(SC + bm[gi] + (long long)bm[gj] * ldSC, -v);
+               }
+            }
+         }
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// diagonal tile: LDL^T of the 128 x 128 tile in LDS, then Winv = D^-1 L^-1 (built in the free upper triangle)
+// ------------------------------------------------------------------------------------------------
+constexpr int DLD = TILE + 1;
+
+__global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                  double* __restrict__ arena, double* __restrict__ dtail,
+                                                  double* __restrict__ winv, const signed char* __restrict__ psign,
+                                                  const long long* __restrict__ psign_off, int* __restrict__ inertia) {
+   extern __shared__ double As[];  // TILE * DLD doubles, As[col * DLD + row]
+   __shared__ double dcur;
+   __shared__ int cnt[3];
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, tj = task.tj, ld = bd.ldT;
+   double* C = arena + bd.T + (long long)tj * TILE + (long long)tj * TILE * ld;
+   const signed char* ps = psign + psign_off[task.blk] + bd.n_head + tj * TILE;
+   if (tid < 3) cnt[tid] = 0;
+   for (int idx = tid; idx < TILE * TILE; idx += 256) {
+      const int rr = idx & (TILE - 1), cc = idx >> 7;
+      As[cc * DLD + rr] = C[rr + (long long)cc * ld];
+   }
+   __syncthreads();
+   const int tx = tid & 15, ty = tid >> 4;
+   for (int k = 0; k < TILE; ++k) {
+      if (tid == 0) {
+         const int gk = tj * TILE + k;
+         const int sgn = gk < bd.m ? ps[k] : 1;
+         bool pert;
+         const double d = fix_pivot(As[k * DLD + k], sgn, bd.thr, bd.repl, pert);
+         dcur = d;
+         As[k * DLD + k] = d;
+         if (gk < bd.m) { if (pert) ++cnt[2]; else if (d > 0) ++cnt[0]; else ++cnt[1]; }
+      }
+      __syncthreads();
+      const double dinv = 1.0 / dcur;
+      for (int j = k + 1 + ty; j < TILE; j += 16) {
+         const double ajk = As[k * DLD + j] * dinv;
+         for (int i = j + tx; i < TILE; i += 16) As[j * DLD + i] -= As[k * DLD + i] * ajk;
+      }
+      __syncthreads();
+      for (int i = k + 1 + tid; i < TILE; i += 256) As[k * DLD + i] *= dinv;
+      __syncthreads();
+   }
+   // store L (unit lower) and D
+   for (int idx = tid; idx < TILE * TILE; idx += 256) {
+      const int rr = idx & (TILE - 1), cc = idx >> 7;
+      if (rr >= cc) C[rr + (long long)cc * ld] = As[cc * DLD + rr];
+   }
+   if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = As[tid * DLD + tid];
+   if (tid == 0) {
+      if (cnt[0]) atomicAdd(&inertia[3 * task.blk + 0], cnt[0]);
+      if (cnt[1]) atomicAdd(&inertia[3 * task.blk + 1], cnt[1]);
+      if (cnt[2]) atomicAdd(&inertia[3 * task.blk + 2], cnt[2]);
+   }
+   __syncthreads();
+   // X = L^-1, column c by thread c:  X[i][c] (i > c) kept at As[i * DLD + c] (upper triangle of the LDS image)
+   if (tid < TILE) {
+      const int c = tid;
+      for (int i = c + 1; i < TILE; ++i) {
+         double s = As[c * DLD + i];  // L[i][c] * x_c, x_c = 1
+         for (int l = c + 1; l < i; ++l) s += As[l * DLD + i] * As[l * DLD + c];
+         As[i * DLD + c] = -s;
+      }
+   }
+   __syncthreads();
+   // Winv[n][k] = X[n][k] / d_n  (row-major in n: Winv stored column-major with row index n -> same layout as a panel)
+   double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
+   for (int idx = tid; idx < TILE * TILE; idx += 256) {
+      const int nn = idx & (TILE - 1), kk = idx >> 7;
+      double x;
+      if (nn == kk) x = 1.0;
+      else if (nn > kk) x = As[nn * DLD + kk];
+      else x = 0.0;
+      W[nn + (long long)kk * TILE] = x / As[nn * DLD + nn];
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// solves
+// ------------------------------------------------------------------------------------------------
+// gather/scatter between original-order flat vectors and the permuted work vectors
+__global__ void k_permute_in(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
+                             const long long* __restrict__ perm_off, const double* __restrict__ x, long long x_stride_off,
+                             double* __restrict__ xw, int nblk) {
+   const int b = blockIdx.y;
+   const BlkDesc bd = blks[b];
+   const int* p = perm + perm_off[b];
+   const int len = bd.n_head + bd.m_pad;
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x)
+      xw[bd.xw_off + k] = k < bd.n ? x[x_stride_off + bd.x_off + p[k]] : 0.0;
+}
+
+__global__ void k_permute_out(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
+                              const long long* __restrict__ perm_off, double* __restrict__ x, long long x_stride_off,
+                              const double* __restrict__ xw, int nblk) {
+   const int b = blockIdx.y;
+   const BlkDesc bd = blks[b];
+   const int* p = perm + perm_off[b];
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < bd.n; k += gridDim.x * blockDim.x)
+      x[x_stride_off + bd.x_off + p[k]] = xw[bd.xw_off + k];
+}
+
+// head forward: y_J = L11^-1 b_J ; b[rows] -= L21 y_J (atomics) ; one wave per supernode
+__global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns, int sn_begin,
+                                                const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                const double* __restrict__ arena, double* __restrict__ xw) {
+   __shared__ double y[HEAD_WMAX];
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const double* P = arena + sn.panel;
+   double* xb = xw + bd.xw_off;
+   if (tid < w) y[tid] = xb[sn.c0 + tid];
+   __syncthreads();
+   for (int k = 0; k < w; ++k) {
+      const double yk = y[k];
+      if (tid > k && tid < w) y[tid] -= P[tid + (long long)k * ld] * yk;
+      __syncthreads();
+   }
+   if (tid < w) xb[sn.c0 + tid] = y[tid];
+   const int* rows = rowidx + sn.rows;
+   for (int a = tid; a < r; a += 64) {
+      const int ra = rows[a];
+      if (ra >= bd.n) break;  // border rows do not take part in solves with K_i
+      double s = 0.0;
+      for (int k = 0; k < w; ++k) s += P[w + a + (long long)k * ld] * y[k];
+      atomic_add_f64(xb + ra, -s);
+   }
+}
+
+// head diagonal scaling: z = D^-1 y for the head columns
+__global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
+                              const double* __restrict__ arena, double* __restrict__ xw) {
+   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsn; s += gridDim.x * blockDim.x) {
+      const SnDesc sn = sns[s];
+      const BlkDesc bd = blks[sn.blk];
+      const int ld = sn.w + sn.r;
+      for (int k = 0; k < sn.w; ++k) xw[bd.xw_off + sn.c0 + k] /= arena[sn.panel + k + (long long)k * ld];
+   }
+}
+
+// head backward: x_J = L11^-T (z_J - L21^T x_below)
+__global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns, int sn_begin,
+                                                const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                const double* __restrict__ arena, double* __restrict__ xw) {
+   __shared__ double y[HEAD_WMAX];
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const double* P = arena + sn.panel;
+   double* xb = xw + bd.xw_off;
+   const int* rows = rowidx + sn.rows;
+   for (int k = 0; k < w; ++k) {
+      double s = 0.0;
+      for (int a = tid; a < r; a += 64) {
+         const int ra = rows[a];
+         if (ra < bd.n) s += P[w + a + (long long)k * ld] * xb[ra];
+      }
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+      if (tid == 0) y[k] = xb[sn.c0 + k] - s;
+   }
+   __syncthreads();
+   for (int k = w - 1; k >= 0; --k) {
+      const double yk = y[k];
+      if (tid < k) y[tid] -= P[k + (long long)tid * ld] * yk;
+      __syncthreads();
+   }
+   if (tid < w) xb[sn.c0 + tid] = y[tid];
+}
+
+// tail forward step j: tiles i >= j of block b:  b_i -= L(i,j-1) (d z)_{j-1}  (j >= 1) ; tile i == j: z_j = Winv_j b_j
+__global__ __launch_bounds__(128) void k_tail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                 const double* __restrict__ arena, const double* __restrict__ dtail,
+                                                 const double* __restrict__ winv, double* __restrict__ xw, int j) {
+   __shared__ double v[TILE];
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, ti = task.ti, ld = bd.ldT;
+   double* xt = xw + bd.xw_off + bd.n_head;
+   double acc = xt[ti * TILE + tid];
+   if (j >= 1) {
+      v[tid] = xt[(j - 1) * TILE + tid] * dtail[bd.dt_off + (j - 1) * TILE + tid];
+      __syncthreads();
+      const double* L = arena + bd.T + (long long)ti * TILE + tid + (long long)(j - 1) * TILE * ld;
+#pragma unroll 8
+      for (int c = 0; c < TILE; ++c) acc -= L[(long long)c * ld] * v[c];
+      __syncthreads();
+   }
+   if (ti == j) {
+      v[tid] = acc;
+      __syncthreads();
+      const double* W = winv + bd.winv_off + (long long)j * TILE * TILE + tid;
+      double z = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < TILE; ++c) z += W[(long long)c * TILE] * v[c];
+      acc = z;
+   }
+   xt[ti * TILE + tid] = acc;
+}
+
+// tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} (if i+1 < ntc) ; tile j == i: x_i = Winv_i^T (d_i z_i)
+__global__ __launch_bounds__(128) void k_tail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                 const double* __restrict__ arena, const double* __restrict__ dtail,
+                                                 const double* __restrict__ winv, double* __restrict__ xw, int i) {
+   __shared__ double v[TILE];
+   __shared__ double part[2][TILE];
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, tj = task.ti, ld = bd.ldT, lane = tid & 63, wave = tid >> 6;
+   double* xt = xw + bd.xw_off + bd.n_head;
+   double acc = xt[tj * TILE + tid];
+   if (i + 1 < bd.ntc) {
+      v[tid] = xt[(i + 1) * TILE + tid];
+      __syncthreads();
+      // out[c] = sum_r L[r][c] v[r]; each wave reduces 64 rows for every column, lanes along rows (coalesced)
+      const double* L = arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld;
+      for (int c = 0; c < TILE; ++c) {
+         double s = L[wave * 64 + lane + (long long)c * ld] * v[wave * 64 + lane];
+         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+         if (lane == 0) part[wave][c] = s;
+      }
+      __syncthreads();
+      acc -= part[0][tid] + part[1][tid];
+   }
+   if (tj == i) {
+      __syncthreads();
+      v[tid] = acc * dtail[bd.dt_off + i * TILE + tid];
+      __syncthreads();
+      // x[c] = sum_n Winv[n][c] v[n] : column c of Winv is contiguous in n
+      const double* W = winv + bd.winv_off + (long long)i * TILE * TILE + (long long)tid * TILE;
+      double x = 0.0;
+#pragma unroll 8
+      for (int nn = 0; nn < TILE; ++nn) x += W[nn] * v[nn];
+      acc = x;
+   }
+   xt[tj * TILE + tid] = acc;
+}
+
+// y = alpha * K x + beta-free accumulate (y must be initialised): symmetric lower CSR, one thread per row, atomics for
+// the transposed part.  Used by iterative refinement:  r = b - K x.
+__global__ void k_sym_spmv_sub(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+                               long long nrows_total, const long long* __restrict__ row_blk_base) {
+   // rowptr is global over all blocks (entries index kval), colidx is block-local; row_blk_base[row] = x_off of its block
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows_total; i += (long long)gridDim.x * blockDim.x) {
+      const long long base = row_blk_base[i];
+      const double xi = x[i];
+      double s = 0.0;
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+         const long long j = base + colidx[p];
+         const double a = val[p];
+         s += a * x[j];
+         if (j != i) atomic_add_f64(y + j, -a * xi);
+      }
+      atomic_add_f64(y + i, -s);
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// border products (K12 / K15):  b0 -= sum_i Br_i^T z_i   and   t_i = Br_i x0
+// Bt is the CSR of Br_i^T (rows = Schur column ids), concatenated over blocks.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_border_tmult(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                               const double* __restrict__ val, const int* __restrict__ row_sc,
+                               const long long* __restrict__ row_xoff, const double* __restrict__ z,
+                               double* __restrict__ b0, long long nrows, double alpha) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      double s = 0.0;
+      const long long xo = row_xoff[i];
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * z[xo + colidx[p]];
+      if (s != 0.0) atomic_add_f64(b0 + row_sc[i], alpha * s);
+   }
+}
+
+__global__ void k_border_mult(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                              const double* __restrict__ val, const int* __restrict__ row_sc,
+                              const long long* __restrict__ row_xoff, const double* __restrict__ x0,
+                              double* __restrict__ t, long long nrows, double alpha) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      const double xs = alpha * x0[row_sc[i]];
+      if (xs == 0.0) continue;
+      const long long xo = row_xoff[i];
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) atomic_add_f64(t + xo + colidx[p], val[p] * xs);
+   }
+}
+
+// dense helpers for the root system
+__global__ void k_copy_lower_to_padded(const double* __restrict__ src, int lds, int n, double* __restrict__ dst, int ldd,
+                                       int npad, int rowmajor) {
+   // dst (col-major, npad x npad) lower := src lower (col-major, symmetric storage with the lower triangle authoritative);
+   // identity on the padding
+   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (long long)npad * npad;
+        idx += (long long)gridDim.x * blockDim.x) {
+      const int r = (int)(idx % npad), c = (int)(idx / npad);
+      double v = 0.0;
+      if (r < n && c < n) { if (r >= c) v = rowmajor ? src[(long long)r * lds + c] : src[r + (long long)c * lds]; }
+      else if (r == c) v = 1.0;
+      dst[r + (long long)c * ldd] = v;
+   }
+}
+
+__global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, double a, long long n) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      y[i] += a * x[i];
+}
+
+__global__ void k_add_entries(double* __restrict__ M, const long long* __restrict__ idx, const double* __restrict__ v,
+                              long long n) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      atomic_add_f64(M + idx[i], v[i]);
+}
+
+}  // namespace pips

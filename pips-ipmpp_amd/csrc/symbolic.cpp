@@ -1,0 +1,233 @@
+// Symbolic analysis of one leaf KKT block K_i together with its border Br_i.
+//
+// Runs once per block on the host (the sparsity pattern is invariant across IPM iterations: the leaf solver is
+// constructed once around a non-owning pointer to K_i, DistributedLeafLinearSystem.C:10-42, PardisoSolver.h:49-50).
+// It produces everything the device kernels need so that a numeric factorisation only moves values:
+//   * a constrained AMD ordering (order.cpp),
+//   * the split of the permuted matrix into a sparse "head" (supernodal, LDS-staged panels, scattered updates) and a
+//     dense "tail" (tiled MFMA LDL^T) chosen by a cost model,
+//   * the border columns of Br_i appended as extra rows of every panel (the augmented partial factorisation that
+//     PardisoSchurSolver.C:83-389 obtains from PARDISO's iparm[37]; here it yields  -Br_i^T K_i^-1 Br_i  directly
+//     in the trailing S x S block),
+//   * scatter maps from CSR entries of K_i / Br_i^T into the factor arena.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+
+namespace pips {
+
+static inline int round_up(int x, int t) { return (x + t - 1) / t * t; }
+
+int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, const AnalyzeOptions& opt,
+                  BlockSym& out) {
+   const int n = K.nrows;
+   if (n <= 0 || K.ncols != n) PIPS_FAIL(PIPS_ERR_ARG, "analyze_block: K must be square, got %d x %d", K.nrows, K.ncols);
+   if (border.nrows > 0 && border.ncols != n)
+      PIPS_FAIL(PIPS_ERR_ARG, "analyze_block: border has %d columns, K has %d rows", border.ncols, n);
+   out = BlockSym();
+   out.n = n;
+   out.n_primal = n_primal;
+
+   // ---- full symmetric adjacency without the diagonal
+   std::vector<int> ap(n + 1, 0), ai;
+   for (int i = 0; i < n; ++i)
+      for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+         const int j = K.colidx[p];
+         if (j < 0 || j > i) PIPS_FAIL(PIPS_ERR_ARG, "analyze_block: K must be lower-triangular CSR (row %d col %d)", i, j);
+         if (j != i) { ++ap[i + 1]; ++ap[j + 1]; }
+      }
+   for (int i = 0; i < n; ++i) ap[i + 1] += ap[i];
+   ai.resize(ap[n]);
+   {
+      std::vector<int> fill(ap.begin(), ap.end() - 1);
+      for (int i = 0; i < n; ++i)
+         for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+            const int j = K.colidx[p];
+            if (j != i) { ai[fill[i]++] = j; ai[fill[j]++] = i; }
+         }
+   }
+   constrained_amd(n, ap, ai, n_primal, out.perm, out.colcount);
+   out.iperm.assign(n, 0);
+   for (int k = 0; k < n; ++k) out.iperm[out.perm[k]] = k;
+   out.psign.assign(n, 0);
+   if (n_primal >= 0)
+      for (int k = 0; k < n; ++k) out.psign[k] = out.perm[k] < n_primal ? 1 : -1;
+
+   // ---- compressed border columns (the reference skips empty border columns too: DistributedLinearSystem.C:870-874)
+   std::vector<int> bidx(border.nrows, -1);
+   for (int s = 0; s < border.nrows; ++s)
+      if (border.rowptr[s + 1] > border.rowptr[s]) { bidx[s] = (int)out.bmap.size(); out.bmap.push_back(s); }
+   const int nb = out.nb = (int)out.bmap.size();
+
+   // ---- head / tail cut from the cost model
+   int n_head = n;
+   if (opt.force_n_head >= 0) {
+      n_head = std::min(opt.force_n_head, n);
+   } else {
+      std::vector<double> head(n + 1, 0.0);
+      for (int k = 0; k < n; ++k) {
+         const double c = out.colcount[k] + 1.0;
+         head[k + 1] = head[k] + opt.head_cost * 0.5 * c * c;
+      }
+      double best = head[n];
+      for (int k = 0; k <= n; ++k) {
+         const double m = n - k;
+         if (m < opt.min_tail) break;
+         const double tail = (m * m * m / 3.0 + (double)nb * m * m + (double)nb * nb * m) / opt.mfma_rate;
+         if (head[k] + tail < best) { best = head[k] + tail; n_head = k; }
+      }
+   }
+   const int m = n - n_head;
+   out.n_head = n_head;
+   out.m = m;
+   out.m_pad = m > 0 ? round_up(m, opt.tile) : 0;
+   out.nb_pad = round_up(nb, opt.tile);
+   out.ldT = out.m_pad + out.nb_pad;
+
+   // ---- permuted strict-lower pattern by column (only columns < n_head are needed) + border rows per column
+   std::vector<int> cp(n_head + 1, 0);
+   auto for_each_head_entry = [&](auto&& f) {
+      for (int i = 0; i < n; ++i)
+         for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+            const int j = K.colidx[p];
+            if (j == i) continue;
+            const int a = out.iperm[i], b = out.iperm[j];
+            const int c = std::min(a, b), r = std::max(a, b);
+            if (c < n_head) f(c, r);
+         }
+      for (int s = 0; s < border.nrows; ++s)
+         for (int p = border.rowptr[s]; p < border.rowptr[s + 1]; ++p) {
+            const int c = out.iperm[border.colidx[p]];
+            if (c < n_head) f(c, n + bidx[s]);
+         }
+   };
+   for_each_head_entry([&](int c, int) { ++cp[c + 1]; });
+   for (int j = 0; j < n_head; ++j) cp[j + 1] += cp[j];
+   std::vector<int> ci(cp[n_head]);
+   {
+      std::vector<int> fill(cp.begin(), cp.end() - 1);
+      for_each_head_entry([&](int c, int r) { ci[fill[c]++] = r; });
+   }
+
+   // ---- column structures of the head (merge children), elimination-tree parents
+   std::vector<std::vector<int>> S(n_head);
+   std::vector<int> parent(n_head, -1), first_child(n_head, -1), next_sib(n_head, -1), mark(n + nb, -1);
+   for (int j = 0; j < n_head; ++j) {
+      auto& Sj = S[j];
+      for (int p = cp[j]; p < cp[j + 1]; ++p) {
+         const int r = ci[p];
+         if (mark[r] != j) { mark[r] = j; Sj.push_back(r); }
+      }
+      for (int c = first_child[j]; c >= 0; c = next_sib[c])
+         for (int r : S[c])
+            if (r != j && mark[r] != j) { mark[r] = j; Sj.push_back(r); }
+      std::sort(Sj.begin(), Sj.end());
+      if (!Sj.empty() && Sj[0] < n_head) {
+         parent[j] = Sj[0];
+         next_sib[j] = first_child[Sj[0]];
+         first_child[Sj[0]] = j;
+      }
+   }
+
+   // ---- fundamental supernodes (width-capped)
+   out.sn_of_col.assign(n_head, -1);
+   for (int j = 0; j < n_head;) {
+      int e = j;
+      while (e + 1 < n_head && e + 1 - j < opt.max_sn_width && parent[e] == e + 1 && S[e].size() == S[e + 1].size() + 1) ++e;
+      HeadSupernode sn;
+      sn.c0 = j;
+      sn.w = e - j + 1;
+      sn.r = (int)S[e].size();
+      sn.level = 0;
+      sn.panel = 0;
+      sn.rows = (int64_t)out.rowidx.size();
+      out.rowidx.insert(out.rowidx.end(), S[e].begin(), S[e].end());
+      for (int c = j; c <= e; ++c) out.sn_of_col[c] = (int)out.sn.size();
+      out.sn.push_back(sn);
+      j = e + 1;
+   }
+   // levels (children precede parents in column order)
+   int n_levels = 0;
+   for (auto& sn : out.sn) {
+      n_levels = std::max(n_levels, sn.level + 1);
+      const int p = parent[sn.c0 + sn.w - 1];
+      if (p >= 0) {
+         auto& ps = out.sn[out.sn_of_col[p]];
+         ps.level = std::max(ps.level, sn.level + 1);
+      }
+   }
+   out.n_levels = n_levels;
+   { std::vector<std::vector<int>>().swap(S); }
+
+   // ---- arena layout
+   int64_t off = 0;
+   double fl = 0;
+   int64_t nnzL = 0;
+   for (auto& sn : out.sn) {
+      sn.panel = off;
+      off += (int64_t)(sn.w + sn.r) * sn.w;
+      const double w = sn.w, r = sn.r;
+      fl += w * w * w / 3.0 + w * w * r + w * r * r;
+      nnzL += (int64_t)sn.w * (sn.w + 1) / 2 + (int64_t)sn.r * sn.w;
+   }
+   off = (off + 15) / 16 * 16;
+   out.T_off = off;
+   off += (int64_t)out.ldT * out.m_pad;
+   out.arena = (off + 15) / 16 * 16;
+   {
+      const double dm = m, dn = nb;
+      fl += dm * dm * dm / 3.0;
+      nnzL += (int64_t)m * (m + 1) / 2;
+      out.flops_border = dn * dm * dm + dn * dn * dm;
+   }
+   out.flops_factor = fl;
+   out.nnzL = nnzL;
+
+   // ---- scatter maps
+   auto head_dst = [&](int c, int r) -> int64_t {
+      const HeadSupernode& sn = out.sn[out.sn_of_col[c]];
+      const int ld = sn.w + sn.r;
+      int pos;
+      if (r < sn.c0 + sn.w) {
+         pos = r - sn.c0;
+      } else {
+         const int* b = out.rowidx.data() + sn.rows;
+         const int* it = std::lower_bound(b, b + sn.r, r);
+         if (it == b + sn.r || *it != r) return -1;
+         pos = sn.w + (int)(it - b);
+      }
+      return sn.panel + pos + (int64_t)(c - sn.c0) * ld;
+   };
+   out.a_dst.resize(K.rowptr[n]);
+   for (int i = 0; i < n; ++i)
+      for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+         const int a = out.iperm[i], b = out.iperm[K.colidx[p]];
+         const int c = std::min(a, b), r = std::max(a, b);
+         int64_t d;
+         if (c < n_head)
+            d = head_dst(c, r);
+         else
+            d = out.T_off + (r - n_head) + (int64_t)(c - n_head) * out.ldT;
+         if (d < 0) PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, entry (%d,%d) not in the symbolic structure", i, K.colidx[p]);
+         out.a_dst[p] = d;
+      }
+   if (border.nrows > 0) {
+      out.b_dst.resize(border.rowptr[border.nrows]);
+      for (int s = 0; s < border.nrows; ++s)
+         for (int p = border.rowptr[s]; p < border.rowptr[s + 1]; ++p) {
+            const int c = out.iperm[border.colidx[p]];
+            int64_t d;
+            if (c < n_head)
+               d = head_dst(c, n + bidx[s]);
+            else
+               d = out.T_off + (out.m_pad + bidx[s]) + (int64_t)(c - n_head) * out.ldT;
+            if (d < 0) PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, border entry (%d,%d) not in the structure", s, border.colidx[p]);
+            out.b_dst[p] = d;
+         }
+   }
+   return PIPS_OK;
+}
+
+}  // namespace pips

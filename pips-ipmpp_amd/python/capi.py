@@ -1,0 +1,401 @@
+"""ctypes binding of libpipship.so (the C ABI in include/pips_hip.h).
+
+This module is plumbing for the tests and bench.py: it mirrors the reference's plug-in surface
+(`DoubleLinearSolver`: matrixChanged / solve / get_inertia, PIPS-IPM/Core/LinearSolvers/DoubleLinearSolver.h:24-72)
+on top of the C entry points.  There is NO CPU fallback: if the shared library is missing, or no GPU is visible when a
+compute call is made, the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # torch (if present) must load its HIP runtime first so that libpipship binds to the same libamdhip64.so.7
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpipship.so")
+
+
+class PipsHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise PipsHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The MI355X backend has no CPU fallback.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+lib.pips_hip_last_error.restype = C.c_char_p
+lib.pips_hip_device_count.restype = C.c_int
+
+# every symbol include/pips_hip.h declares (tests/test_capi_symbols.py checks the header against this list)
+SYMBOLS = [
+    "pips_hip_last_error", "pips_hip_device_count",
+    "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement",
+    "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
+    "pips_hip_ldl_get_perm", "pips_hip_ldl_destroy",
+    "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
+    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_destroy",
+    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_analyze",
+    "pips_hip_batch_set_values", "pips_hip_batch_set_diagonals_dev", "pips_hip_batch_set_diagonals", "pips_hip_batch_factor",
+    "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
+    "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
+    "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
+    "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
+    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
+    "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
+    "pips_border_assemble", "pips_symbolic_probe",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib.pips_hip_last_error()
+        raise PipsHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def device_count():
+    return int(lib.pips_hip_device_count())
+
+
+def _ptr(a):
+    """numpy array / torch tensor / int / None -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    if torch is not None and isinstance(a, torch.Tensor):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# host harness helpers: synthetic arrowhead LP, leaf KKT and border assembly
+# ----------------------------------------------------------------------------------------------------------------------
+class Csr:
+    """Plain CSR triple, row-major, 0-based, int32/fp64 (SparseStorage.h:45-50)."""
+
+    def __init__(self, nrows, ncols, rowptr, colidx, val):
+        self.nrows, self.ncols = int(nrows), int(ncols)
+        self.rowptr, self.colidx, self.val = _i32(rowptr), _i32(colidx), _f64(val)
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val, self.colidx, self.rowptr), shape=(self.nrows, self.ncols))
+
+
+def gen_block(seed, block, n_i, my_i, n0, myl, rho=1e-3):
+    """W_i (my_i x n_i), T_i (my_i x n0), F_i (myl x n_i), c_i, x*_i of block `block` >= 1."""
+    kw = int(lib.pips_gen_row_nnz(C.c_int(n_i), C.c_double(rho)))
+    kw = min(kw, n_i)
+    W = Csr(my_i, n_i, np.zeros(my_i + 1, np.int32), np.zeros(my_i * kw, np.int32), np.zeros(my_i * kw))
+    kt = min(2, n0)
+    T = Csr(my_i, n0, np.zeros(my_i + 1, np.int32), np.zeros(my_i * kt, np.int32), np.zeros(my_i * kt))
+    kf = min(4, n_i)
+    F = Csr(myl, n_i, np.zeros(myl + 1, np.int32), np.zeros(myl * kf, np.int32), np.zeros(myl * kf))
+    c = np.zeros(n_i)
+    xs = np.zeros(n_i)
+    rc = lib.pips_gen_block(C.c_uint64(seed), C.c_int(block), C.c_int(n_i), C.c_int(my_i), C.c_int(n0), C.c_int(myl),
+                            C.c_double(rho), _ptr(W.rowptr), _ptr(W.colidx), _ptr(W.val), _ptr(T.rowptr), _ptr(T.colidx),
+                            _ptr(T.val), _ptr(F.rowptr), _ptr(F.colidx), _ptr(F.val), _ptr(c), _ptr(xs))
+    _check(rc, "pips_gen_block")
+    return W, T, F, c, xs
+
+
+def gen_root(seed, n0, myl):
+    kf = min(2, n0)
+    F0 = Csr(myl, n0, np.zeros(myl + 1, np.int32), np.zeros(myl * kf, np.int32), np.zeros(myl * kf))
+    c0 = np.zeros(n0)
+    x0 = np.zeros(n0)
+    _check(lib.pips_gen_root(C.c_uint64(seed), C.c_int(n0), C.c_int(myl), _ptr(F0.rowptr), _ptr(F0.colidx), _ptr(F0.val),
+                             _ptr(c0), _ptr(x0)), "pips_gen_root")
+    return F0, c0, x0
+
+
+def gen_diagonal(seed, block, n, lo=-4.0, hi=4.0):
+    d = np.zeros(n)
+    _check(lib.pips_gen_diagonal(C.c_uint64(seed), C.c_int(block), C.c_int(n), C.c_double(lo), C.c_double(hi), _ptr(d)),
+           "pips_gen_diagonal")
+    return d
+
+
+def kkt_leaf_assemble(nx, B, D=None, Q=None):
+    """Lower CSR of K_i = [Q+Dx B^T D^T; B 0 0; D 0 0] with explicit diagonal (create_kkt,
+    DistributedLeafLinearSystem.C:44-72).  Returns (Csr, diag_pos)."""
+    my = B.nrows if B is not None else 0
+    mz = D.nrows if D is not None else 0
+    n = nx + my + mz
+    rowptr = np.zeros(n + 1, np.int32)
+
+    def trip(M):
+        return (None, None, None) if M is None else (_ptr(M.rowptr), _ptr(M.colidx), _ptr(M.val))
+
+    args = [C.c_int(nx), C.c_int(my), C.c_int(mz), *trip(Q), *trip(B), *trip(D)]
+    _check(lib.pips_kkt_leaf_assemble(*args, _ptr(rowptr), None, None, None), "pips_kkt_leaf_assemble")
+    nnz = int(rowptr[n])
+    colidx = np.zeros(nnz, np.int32)
+    val = np.zeros(nnz)
+    diag_pos = np.zeros(n, np.int32)
+    _check(lib.pips_kkt_leaf_assemble(*args, _ptr(rowptr), _ptr(colidx), _ptr(val), _ptr(diag_pos)),
+           "pips_kkt_leaf_assemble")
+    return Csr(n, n, rowptr, colidx, val), diag_pos
+
+
+def border_assemble(nx, my, mz, n0, n_empty, R=None, A=None, Cm=None, F=None, G=None):
+    """Br_i^T as CSR with S = n0 + n_empty + myl + mzl rows over N_i = nx+my+mz columns (BorderBiBlock, RACFG_BLOCK.h)."""
+    myl = F.nrows if F is not None else 0
+    mzl = G.nrows if G is not None else 0
+    S = n0 + n_empty + myl + mzl
+
+    def trip(M):
+        return (None, None, None) if M is None else (_ptr(M.rowptr), _ptr(M.colidx), _ptr(M.val))
+
+    rowptr = np.zeros(S + 1, np.int32)
+    args = [C.c_int(nx), C.c_int(my), C.c_int(mz), C.c_int(n0), C.c_int(n_empty), C.c_int(myl), C.c_int(mzl), *trip(R),
+            *trip(A), *trip(Cm), *trip(F), *trip(G)]
+    _check(lib.pips_border_assemble(*args, _ptr(rowptr), None, None), "pips_border_assemble")
+    nnz = int(rowptr[S])
+    colidx = np.zeros(nnz, np.int32)
+    val = np.zeros(nnz)
+    _check(lib.pips_border_assemble(*args, _ptr(rowptr), _ptr(colidx), _ptr(val)), "pips_border_assemble")
+    return Csr(S, nx + my + mz, rowptr, colidx, val)
+
+
+def symbolic_probe(K, n_primal=-1, Bt=None, force_n_head=-1, want_perm=False):
+    what = np.zeros(10, np.int64)
+    perm = np.zeros(K.nrows, np.int32) if want_perm else None
+    cc = np.zeros(K.nrows, np.int32) if want_perm else None
+    S = Bt.nrows if Bt is not None else 0
+    _check(lib.pips_symbolic_probe(C.c_int(K.nrows), C.c_int(n_primal), _ptr(K.rowptr), _ptr(K.colidx), C.c_int(S),
+                                   _ptr(Bt.rowptr) if Bt is not None else None,
+                                   _ptr(Bt.colidx) if Bt is not None else None, C.c_int(force_n_head), _ptr(what),
+                                   C.c_int(10), _ptr(perm), _ptr(cc)), "pips_symbolic_probe")
+    info = dict(nnzL=int(what[0]), n=int(what[1]), n_head=int(what[2]), m=int(what[3]), n_sn=int(what[4]),
+                n_levels=int(what[5]), flops_factor=int(what[6]), flops_border=int(what[7]), arena_bytes=int(what[8]),
+                ntc=int(what[9]))
+    if want_perm:
+        info["perm"] = perm
+        info["colcount"] = cc
+    return info
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# DoubleLinearSolver mirror: sparse leaf solver
+# ----------------------------------------------------------------------------------------------------------------------
+class HipLdlSolver:
+    """Mirror of `DoubleLinearSolver` for a leaf KKT block (replaces PardisoProjectSolver / Ma27Solver / Ma57Solver).
+
+    The solver keeps a reference to the caller's CSR value array like the reference keeps a pointer to the
+    SparseSymmetricMatrix (PardisoSolver.h:49-50): mutate `K.val` in place, then call matrixChanged().
+    """
+
+    def __init__(self, K, n_primal=-1, device=-1, refine_steps=1):
+        self.K = K
+        self.n = K.nrows
+        self._h = C.c_void_p()
+        _check(lib.pips_hip_ldl_create(C.byref(self._h), C.c_int(K.nrows), _ptr(K.rowptr), _ptr(K.colidx), C.c_int(device),
+                                       C.c_int(0)), "pips_hip_ldl_create")
+        if n_primal >= 0:
+            _check(lib.pips_hip_ldl_set_inertia_hint(self._h, C.c_int(n_primal)), "pips_hip_ldl_set_inertia_hint")
+        _check(lib.pips_hip_ldl_set_refinement(self._h, C.c_int(refine_steps)), "pips_hip_ldl_set_refinement")
+
+    def set_pivot_rule(self, thr_rel, repl_rel):
+        _check(lib.pips_hip_ldl_set_pivot_rule(self._h, C.c_double(thr_rel), C.c_double(repl_rel)), "set_pivot_rule")
+
+    def analyze(self):
+        _check(lib.pips_hip_ldl_analyze(self._h), "pips_hip_ldl_analyze")
+
+    def matrixChanged(self):
+        _check(lib.pips_hip_ldl_factor(self._h, _ptr(self.K.val)), "pips_hip_ldl_factor")
+
+    def diagonalChanged(self, idiag=0, extent=0):
+        self.matrixChanged()
+
+    def solve(self, x):
+        """x: (n,) or (nrhs, n) float64 C-contiguous; overwritten by the solution (one RHS per row, PardisoSolver.C:276)."""
+        assert x.dtype == np.float64 and x.flags.c_contiguous
+        nrhs = 1 if x.ndim == 1 else x.shape[0]
+        ld = x.shape[-1]
+        _check(lib.pips_hip_ldl_solve(self._h, C.c_int(nrhs), _ptr(x), C.c_int(ld)), "pips_hip_ldl_solve")
+        return x
+
+    def reports_inertia(self):
+        return True
+
+    def get_inertia(self):
+        p, n, z = C.c_int(), C.c_int(), C.c_int()
+        _check(lib.pips_hip_ldl_inertia(self._h, C.byref(p), C.byref(n), C.byref(z)), "pips_hip_ldl_inertia")
+        return p.value, n.value, z.value
+
+    def info(self):
+        what = np.zeros(6, np.int64)
+        _check(lib.pips_hip_ldl_info(self._h, _ptr(what), C.c_int(6)), "pips_hip_ldl_info")
+        return dict(nnzL=int(what[0]), n_head=int(what[1]), m=int(what[2]), n_sn=int(what[3]), n_levels=int(what[4]),
+                    flops=int(what[5]))
+
+    def close(self):
+        if self._h:
+            lib.pips_hip_ldl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipDenseLdlSolver:
+    """Mirror of DeSymIndefSolver (DeSymIndefSolver.C:56-168): dense symmetric indefinite root solver."""
+
+    def __init__(self, n, n_primal=-1, device=-1):
+        self.n = n
+        self._h = C.c_void_p()
+        _check(lib.pips_hip_dense_ldl_create(C.byref(self._h), C.c_int(n), C.c_int(n_primal), C.c_int(device)),
+               "pips_hip_dense_ldl_create")
+
+    def matrixChanged(self, A_rowmajor_lower):
+        A = _f64(A_rowmajor_lower)
+        _check(lib.pips_hip_dense_ldl_factor(self._h, _ptr(A), C.c_int(A.shape[1])), "pips_hip_dense_ldl_factor")
+
+    def matrixChanged_dev(self, A_dev, lda):
+        _check(lib.pips_hip_dense_ldl_factor_dev(self._h, _ptr(A_dev), C.c_int(lda)), "pips_hip_dense_ldl_factor_dev")
+
+    def solve(self, x):
+        assert x.dtype == np.float64 and x.flags.c_contiguous
+        nrhs = 1 if x.ndim == 1 else x.shape[0]
+        _check(lib.pips_hip_dense_ldl_solve(self._h, C.c_int(nrhs), _ptr(x), C.c_int(x.shape[-1])), "dense solve")
+        return x
+
+    def solve_dev(self, x_dev):
+        _check(lib.pips_hip_dense_ldl_solve_dev(self._h, _ptr(x_dev)), "pips_hip_dense_ldl_solve_dev")
+
+    def get_inertia(self):
+        p, n, z = C.c_int(), C.c_int(), C.c_int()
+        _check(lib.pips_hip_dense_ldl_inertia(self._h, C.byref(p), C.byref(n), C.byref(z)), "dense inertia")
+        return p.value, n.value, z.value
+
+    def close(self):
+        if self._h:
+            lib.pips_hip_dense_ldl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# batched device-resident path
+# ----------------------------------------------------------------------------------------------------------------------
+class LeafBatch:
+    """All leaf blocks owned by one GPU (the children of sLinsysRootAug that are not dummies on this rank)."""
+
+    def __init__(self, n_blocks, S, device=-1, stream=None):
+        self.n_blocks, self.S = n_blocks, S
+        self._h = C.c_void_p()
+        _check(lib.pips_hip_batch_create(C.byref(self._h), C.c_int(n_blocks), C.c_int(S), C.c_int(device), _ptr(stream)),
+               "pips_hip_batch_create")
+        self.n = [0] * n_blocks
+
+    def set_block(self, b, K, n_primal, Bt=None):
+        self.n[b] = K.nrows
+        _check(lib.pips_hip_batch_set_block(self._h, C.c_int(b), C.c_int(K.nrows), C.c_int(n_primal), _ptr(K.rowptr),
+                                            _ptr(K.colidx), _ptr(Bt.rowptr) if Bt is not None else None,
+                                            _ptr(Bt.colidx) if Bt is not None else None,
+                                            _ptr(Bt.val) if Bt is not None else None), "pips_hip_batch_set_block")
+
+    def set_options(self, force_n_head=-1, refine_steps=-1, thr_rel=-1.0, repl_rel=-1.0):
+        _check(lib.pips_hip_batch_set_options(self._h, C.c_int(force_n_head), C.c_int(refine_steps), C.c_double(thr_rel),
+                                              C.c_double(repl_rel)), "pips_hip_batch_set_options")
+
+    def analyze(self, n_threads=8):
+        _check(lib.pips_hip_batch_analyze(self._h, C.c_int(n_threads)), "pips_hip_batch_analyze")
+
+    def set_values(self, b, vals):
+        _check(lib.pips_hip_batch_set_values(self._h, C.c_int(b), _ptr(_f64(vals))), "pips_hip_batch_set_values")
+
+    def set_diagonals(self, diag):
+        if torch is not None and isinstance(diag, torch.Tensor):
+            _check(lib.pips_hip_batch_set_diagonals_dev(self._h, _ptr(diag)), "pips_hip_batch_set_diagonals_dev")
+        else:
+            _check(lib.pips_hip_batch_set_diagonals(self._h, _ptr(_f64(diag))), "pips_hip_batch_set_diagonals")
+
+    def factor(self, SC_dev=None, ldSC=0):
+        _check(lib.pips_hip_batch_factor(self._h, _ptr(SC_dev), C.c_int(ldSC)), "pips_hip_batch_factor")
+
+    def solve(self, x):
+        if torch is not None and isinstance(x, torch.Tensor):
+            _check(lib.pips_hip_batch_solve_dev(self._h, _ptr(x)), "pips_hip_batch_solve_dev")
+        else:
+            assert x.dtype == np.float64 and x.flags.c_contiguous
+            _check(lib.pips_hip_batch_solve(self._h, _ptr(x)), "pips_hip_batch_solve")
+        return x
+
+    def border_tmult(self, z_dev, b0_dev, alpha):
+        _check(lib.pips_hip_batch_border_tmult_dev(self._h, _ptr(z_dev), _ptr(b0_dev), C.c_double(alpha)), "border_tmult")
+
+    def border_mult(self, x0_dev, t_dev, alpha):
+        _check(lib.pips_hip_batch_border_mult_dev(self._h, _ptr(x0_dev), _ptr(t_dev), C.c_double(alpha)), "border_mult")
+
+    def inertia(self, b):
+        p, n, z = C.c_int(), C.c_int(), C.c_int()
+        _check(lib.pips_hip_batch_inertia(self._h, C.c_int(b), C.byref(p), C.byref(n), C.byref(z)), "batch inertia")
+        return p.value, n.value, z.value
+
+    def info(self):
+        what = np.zeros(10, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(10)), "pips_hip_batch_info")
+        keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc"]
+        return {k: int(v) for k, v in zip(keys, what)}
+
+    def sync(self):
+        _check(lib.pips_hip_batch_sync(self._h), "pips_hip_batch_sync")
+
+    def set_timing(self, on=True):
+        _check(lib.pips_hip_batch_set_timing(self._h, C.c_int(1 if on else 0)), "set_timing")
+
+    def get_timing(self):
+        ms = np.zeros(8)
+        cnt = np.zeros(8, np.int64)
+        _check(lib.pips_hip_batch_get_timing(self._h, _ptr(ms), _ptr(cnt), C.c_int(8)), "get_timing")
+        names = ["scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur", "total"]
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(names)}
+
+    def close(self):
+        if self._h:
+            lib.pips_hip_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
