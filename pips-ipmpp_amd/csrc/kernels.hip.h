@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
                if (kind == 1) {
                   const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
                   atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -u);
-               } else {
+               } else if (SC) {  // SC == nullptr: factor-only call, the Schur contribution is not wanted
                   atomic_add_f64(SC + bm[ra - n] + (long long)bm[cb - n] * ldSC, -u);
                }
             }
