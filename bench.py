@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — KKT factor+solve work units per second on N MI355X (BASELINE.json metric).
+
+One step = one work unit of SURVEY.md §8d: 1 factorize (leaf diagonal update, all leaf LDL^T factors, Schur contributions
+sum_i Br_i^T K_i^-1 Br_i, SC all-reduce, root finalize, dense root LDL^T) + 4 solveCompressed (Lsolve, root solve, Ltsolve).
+N = 1 runs BASELINE.json configs[1]: 64 scenario blocks x 10k vars (my_i = 5k), ~0.1 % fill, Schur dim 2000, all leaves
+batched on one device.  N > 1 shards 64 blocks per GPU (weak scaling), one process per GPU, RCCL all-reduce of SC and b0.
+All inputs are resident in HBM before the timed region.  `value` counts 64-block scenario groups processed per second
+(= N x IPM-iteration linear-algebra units per second), so it is the whole-job aggregate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+TILE = 128
+R_SOLVES = 4
+
+
+def update_kernel_algorithmic_flops(m, nb):
+    """Algorithmic flops of the tail update GEMM for one block with dense tail m and nb border rows: for tile column j
+    (K = j*TILE already factored columns) every lower-triangle entry of the tile column, plus its nb border entries,
+    receives one length-K dot product (2K flops).  Summed: ~ m^3/3 + nb*m^2."""
+    fl = 0.0
+    j = 0
+    while j * TILE < m:
+        K = j * TILE
+        tc = min(TILE, m - K)
+        below = m - K - tc
+        entries = tc * below + tc * (tc + 1) / 2.0 + nb * tc
+        fl += 2.0 * K * entries
+        j += 1
+    return fl
+
+
+def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
+    S = n0 + myl
+    bt = pa.LeafBatch(len(blocks), S, device=device)
+    vals, diags = [], []
+    for i, b in enumerate(blocks):
+        W, T, F, c, xs = pa.gen_block(seed, b + 1, n_i, my_i, n0, myl, rho)
+        K, dpos = pa.kkt_leaf_assemble(n_i, W)
+        Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F)
+        diag = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
+        K.val[dpos] = diag
+        bt.set_block(i, K, n_i, Bt)
+        vals.append(K.val)
+        diags.append(diag)
+    bt.analyze(min(16, os.cpu_count() or 8))
+    for i in range(len(blocks)):
+        bt.set_values(i, vals[i])
+    return bt, np.concatenate(diags)
+
+
+def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
+    """Reference-style CPU path timed on a bounded sample and extrapolated linearly (all blocks are statistically
+    identical and independent): per block PARDISO phase 12 (or the oracle LDL^T) + multi-RHS solves for the border
+    columns (K5) + the sparse accumulation (K6) + 2*R single solves; plus the dense root dsytrf."""
+    from oracle import oracle as orc
+    from oracle import pardiso_mkl as pm
+    import scipy.sparse as sp
+    import psutil
+    cores = min(8, os.cpu_count() or 1)          # bounded: the sample must not exhaust the host
+    mem_ok = psutil.virtual_memory().available > 48 * 2**30
+    W, T, F, c, xs = pa.gen_block(seed, 1, n_i, my_i, n0, myl, rho)
+    K, dpos = pa.kkt_leaf_assemble(n_i, W)
+    K.val[dpos] = np.concatenate([pa.gen_diagonal(seed, 1, n_i), -1e-8 * np.ones(my_i)])
+    Ks = sp.csr_matrix((K.val, K.colidx, K.rowptr), shape=(K.nrows, K.ncols))
+    Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F).to_scipy()
+    S = n0 + myl
+    n_rhs_sample = min(32, S)
+    if pm.available() and mem_ok:
+        kind_detail = f"MKL PARDISO mtype -2 with the reference's iparm (PardisoProjectSolver.C:68-77), {cores} threads"
+        solver = pm.MklPardisoSolver(Ks, num_threads=cores)
+        used = cores
+    else:
+        kind_detail = "oracle_ldl.c up-looking LDL^T, 1 thread"
+        info = pa.symbolic_probe(K, n_i, want_perm=True)
+        solver = orc.OracleLdl(Ks, perm=info["perm"], n_primal=n_i)
+        used = 1
+    t0 = time.perf_counter()
+    solver.matrixChanged()
+    t_factor = time.perf_counter() - t0
+    cols = np.nonzero(np.diff(Bt.indptr) > 0)[0][:n_rhs_sample]
+    dense = np.ascontiguousarray(Bt[cols].toarray())
+    t0 = time.perf_counter()
+    solver.solve(dense)
+    SCrows = (Bt @ dense.T).T  # noqa: F841  (K6)
+    t_schur = (time.perf_counter() - t0) * (S / max(1, len(cols)))
+    x = np.random.default_rng(0).standard_normal(K.nrows)
+    t0 = time.perf_counter()
+    solver.solve(x)
+    t_solve = time.perf_counter() - t0
+    M = np.random.default_rng(1).standard_normal((S, S))
+    M = np.tril(M @ M.T + S * np.eye(S))
+    root = orc.DenseRootSolver(S)
+    t0 = time.perf_counter()
+    root.matrixChanged(M)
+    t_root = time.perf_counter() - t0
+    per_group = 64 * (t_factor + t_schur + 2 * R_SOLVES * t_solve) + t_root
+    return {
+        "value": 1.0 / per_group, "unit": "64-block work units/s", "cores": used, "kind": "port",
+        "sample": (f"1 of {n_blocks_total} blocks: factor {t_factor:.1f}s, {len(cols)} of {S} border columns solved "
+                   f"(extrapolated {t_schur:.1f}s), 1 single solve {t_solve*1e3:.0f}ms, root dsytrf {t_root:.2f}s; "
+                   f"x64 blocks per unit, {2*R_SOLVES} leaf solves per block; {kind_detail}"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks-per-gpu", type=int, default=64)
+    ap.add_argument("--n", type=int, default=10000, help="variables per block")
+    ap.add_argument("--schur-dim", type=int, default=2000)
+    ap.add_argument("--rho", type=float, default=1e-3)
+    ap.add_argument("--seed", type=int, default=20261002)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import pips_ipmpp_amd as pa
+
+    n_i, my_i = a.n, a.n // 2
+    n0 = myl = a.schur_dim // 2
+    S = n0 + myl
+    bpg = a.blocks_per_gpu
+    blocks = list(range(rank * bpg, (rank + 1) * bpg))
+    n_blocks_total = bpg * world
+
+    comm = None
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(pa.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm = pa.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+
+    bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank)
+    F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
+    kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, comm=comm, rank=rank, n_ranks=world)
+    dev = torch.device("cuda", local_rank)
+    diag = torch.tensor(diag_h, device=dev)
+    xd0 = torch.tensor(pa.gen_diagonal(a.seed, 0, n0), device=dev)
+    g = torch.Generator(device="cpu").manual_seed(a.seed + rank)
+    rhs_leaf = torch.randn(diag.numel(), dtype=torch.float64, generator=g).to(dev)
+    g0 = torch.Generator(device="cpu").manual_seed(a.seed)
+    rhs0 = torch.randn(S, dtype=torch.float64, generator=g0).to(dev)
+    b_leaf = torch.empty_like(rhs_leaf)
+    b0 = torch.empty_like(rhs0)
+
+    def step():
+        kkt.factorize(diag, xd0)
+        for _ in range(R_SOLVES):
+            b_leaf.copy_(rhs_leaf)
+            b0.copy_(rhs0)
+            kkt.solve_compressed(b0, b_leaf)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (tile update GEMM), timed live with HIP events on the library's stream
+    bt.set_timing(True)
+    kkt.factorize(diag, xd0)
+    tm = bt.get_timing()
+    bt.set_timing(False)
+    info = bt.info()
+    upd_ms, upd_launches = tm["tail_update"]
+    # per-block tail sizes are statistically equal; use the exact aggregate from the symbolic phase
+    m_avg = info["m"] / len(blocks)
+    alg_flops = len(blocks) * update_kernel_algorithmic_flops(int(round(m_avg)), S)
+    achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    roofline = {
+        "kernel": "k_tile_gemm<0> (tail update, FP64 MFMA 16x16x4)", "bound": "mfma", "achieved": round(achieved, 2),
+        "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
+        "traffic": None, "launches_per_factorize": upd_launches, "ms_per_factorize": round(upd_ms, 3),
+        "algorithmic_flops_per_factorize": alg_flops,
+        "phase_ms": {k: round(v[0], 3) for k, v in tm.items()},
+    }
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        out = {
+            "metric": "KKT factor+solve per IPM iter/sec, N-block arrowhead LP",
+            "value": round(world * a.steps / dt, 4), "unit": "64-block work units/s (1 factorize + 4 solveCompressed)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
+                                   f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""),
+                       "solves_per_unit": R_SOLVES, "iter_per_s": round(a.steps / dt, 4),
+                       "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1),
+                       "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},
+            "roofline": roofline,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pa, a.seed, n_i, my_i, n0, myl, a.rho, n_blocks_total)
+            except Exception as e:  # the baseline must never break the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "64-block work units/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,28 @@ int pips_hip_batch_set_timing(void* handle, int on);
 int pips_hip_batch_get_timing(void* handle, double* ms, int64_t* cnt, int n);
 void pips_hip_batch_destroy(void* handle);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * 3b. Fused two-level system of one rank: leaves + replicated dense root + Schur reduction.
+ *     factorize      = DistributedRootLinearSystem::factor2 (:206-243): initializeKKT, children factor2, assembleLocalKKT,
+ *                      reduceKKT, finalizeKKT (sLinsysRootAug::finalizeKKTdense :1769-1796), factorizeKKT
+ *     solve_compressed = DistributedLinearSystem::solveCompressed (:409-420): Lsolve / Dsolve / Ltsolve
+ *                      (sLinsysRootAug.C:323-365); root vector layout [x0 | y0 | ylink | zlink] (mz0 = 0)
+ * ------------------------------------------------------------------------------------------------------------- */
+/* batch: analyzed leaf batch (created with the same S).  A0 (my0 x n0), F0 (myl x n0), G0 (mzl x n0) are the root's own
+ * constraint blocks (CSR, may be NULL).  comm: handle from pips_hip_comm_create or NULL when n_ranks == 1. */
+int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, int mzl, const int* A0_rowptr,
+                        const int* A0_colidx, const double* A0_val, const int* F0_rowptr, const int* F0_colidx,
+                        const double* F0_val, const int* G0_rowptr, const int* G0_colidx, const double* G0_val, void* comm,
+                        int rank, int n_ranks);
+/* leaf_diag_dev: flat K diagonals of this rank's blocks (NULL: keep); xdiag0_dev: n0 primal diagonal of the root
+ * (xDiag); zdiag_link_dev: mzl entries or NULL.  Asynchronous on the batch's stream. */
+int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev);
+/* in place: b0 (S doubles, replicated on every rank) and the flat leaf vector of this rank's blocks */
+int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev);
+int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld);
+int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero);
+void pips_hip_kkt_destroy(void* handle);
+
 /* plain device buffers for hosts that do not bring their own allocator */
 int pips_hip_malloc(void** dev_ptr, size_t bytes);
 int pips_hip_free(void* dev_ptr);

@@ -645,6 +645,34 @@ struct DenseLdl {
    }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// fused two-level KKT system of one rank: leaves (Engine) + replicated dense root (DenseLdl) + Schur reduction.
+// Mirrors DistributedRootLinearSystem::factor2 (:206-243) and DistributedLinearSystem::solveCompressed (:409-420)
+// with sLinsysRootAug::{finalizeKKTdense, Lsolve, Dsolve, Ltsolve} (sLinsysRootAug.C:1769-1796, 323-365).
+// ---------------------------------------------------------------------------------------------------------------
+typedef int (*allreduce_fn)(void* comm, double* buf, size_t n, void* stream);
+
+struct KktSystem {
+   Engine* leaves = nullptr;
+   std::unique_ptr<DenseLdl> root;
+   int n0 = 0, my0 = 0, myl = 0, mzl = 0, S = 0;
+   int rank = 0, n_ranks = 1;
+   void* comm = nullptr;
+   double *d_SC = nullptr, *d_t = nullptr, *d_fin_val = nullptr;
+   long long* d_fin_idx = nullptr;
+   long long n_fin = 0;
+   ~KktSystem() {
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx};
+      for (void* p : ptrs)
+         if (p) (void)hipFree(p);
+   }
+};
+
+__global__ void k_add_diag(double* __restrict__ M, int ld, int off, const double* __restrict__ d, int n) {
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+      M[(long long)(off + i) * ld + off + i] += d[i];
+}
+
 }  // namespace pips
 
 // =================================================================================================================
@@ -1063,6 +1091,117 @@ int pips_hip_memset(void* dst, int value, size_t bytes) {
    HIP_TRY(hipMemset(dst, value, bytes));
    return PIPS_OK;
 }
+
+// ---- fused KKT system ---------------------------------------------------------------------------------------------
+int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
+
+int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, int mzl, const int* A0_rowptr,
+                        const int* A0_colidx, const double* A0_val, const int* F0_rowptr, const int* F0_colidx,
+                        const double* F0_val, const int* G0_rowptr, const int* G0_colidx, const double* G0_val, void* comm,
+                        int rank, int n_ranks) {
+   Engine* e = (Engine*)batch;
+   if (!handle || !e || !e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_create: the leaf batch must be analyzed first");
+   const int S = n0 + my0 + myl + mzl;
+   if (S != e->S) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_create: n0+my0+myl+mzl = %d but the batch was created with S = %d", S, e->S);
+   auto k = std::make_unique<KktSystem>();
+   k->leaves = e;
+   k->n0 = n0; k->my0 = my0; k->myl = myl; k->mzl = mzl; k->S = S;
+   k->comm = comm; k->rank = rank; k->n_ranks = n_ranks;
+   HIP_TRY(hipSetDevice(e->device));
+   k->root = std::make_unique<DenseLdl>();
+   k->root->n = S;
+   k->root->n_primal = n0;
+   k->root->device = e->device;
+   k->root->stream = e->stream;
+   k->root->thr_rel = e->thr_rel;
+   k->root->repl_rel = e->repl_rel;
+   int rc = k->root->init();
+   if (rc) return rc;
+   HIP_TRY(hipMalloc((void**)&k->d_SC, (size_t)S * S * sizeof(double)));
+   HIP_TRY(hipMalloc((void**)&k->d_t, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
+   // constant root blocks added by finalizeKKTdense: A0 at row n0, F0 at row n0+my0, G0 at row n0+my0+myl
+   // (sLinsysRootAug.C:270-320, 1782-1796).  SC is column-major with the lower triangle valid: (r,c) -> r + c*S.
+   std::vector<long long> idx;
+   std::vector<double> val;
+   auto add = [&](const int* rp, const int* ci, const double* v, int rows, int r0) {
+      if (!rp) return;
+      for (int r = 0; r < rows; ++r)
+         for (int p = rp[r]; p < rp[r + 1]; ++p) { idx.push_back((long long)(r0 + r) + (long long)ci[p] * S); val.push_back(v[p]); }
+   };
+   add(A0_rowptr, A0_colidx, A0_val, my0, n0);
+   add(F0_rowptr, F0_colidx, F0_val, myl, n0 + my0);
+   add(G0_rowptr, G0_colidx, G0_val, mzl, n0 + my0 + myl);
+   k->n_fin = (long long)idx.size();
+   if ((rc = dev_upload(&k->d_fin_idx, idx, nullptr))) return rc;
+   if ((rc = dev_upload(&k->d_fin_val, val, nullptr))) return rc;
+   *handle = k.release();
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   Engine* e = k->leaves;
+   HIP_TRY(hipSetDevice(e->device));
+   int rc;
+   if (leaf_diag_dev && (rc = pips_hip_batch_set_diagonals_dev(e, leaf_diag_dev))) return rc;
+   const size_t n = (size_t)k->S * k->S;
+   HIP_TRY(hipMemsetAsync(k->d_SC, 0, n * sizeof(double), e->stream));            // initializeKKT (:840-847)
+   if ((rc = e->factor(k->d_SC, k->S))) return rc;                               // children factor2 + assembleLocalKKT
+   if (k->n_ranks > 1) {                                                          // reduceKKT (:860-881)
+      if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
+      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_SC, n, e->stream))) return rc;
+   }
+   // finalizeKKTdense
+   if (xdiag0_dev && k->n0 > 0)
+      hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->n0, 256)), dim3(256), 0, e->stream, k->d_SC, k->S, 0, xdiag0_dev, k->n0);
+   if (k->n_fin > 0)
+      hipLaunchKernelGGL(k_add_entries, dim3(grid_for(k->n_fin, 256)), dim3(256), 0, e->stream, k->d_SC, k->d_fin_idx,
+                         k->d_fin_val, k->n_fin);
+   if (zdiag_link_dev && k->mzl > 0)
+      hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, k->d_SC, k->S,
+                         k->n0 + k->my0 + k->myl, zdiag_link_dev, k->mzl);
+   HIP_TRY(hipGetLastError());
+   return k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)
+}
+
+int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || !b0_dev || !b_leaf_dev) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_solve_compressed: bad arguments");
+   Engine* e = k->leaves;
+   HIP_TRY(hipSetDevice(e->device));
+   int rc;
+   // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
+   if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(b0_dev, 0, (size_t)k->S * sizeof(double), e->stream));
+   if ((rc = e->solve(b_leaf_dev))) return rc;
+   if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, b0_dev, -1.0))) return rc;
+   if (k->n_ranks > 1 && (rc = pips_hip_allreduce_sum(k->comm, b0_dev, (size_t)k->S, e->stream))) return rc;
+   // Dsolve (mz0 = 0: no z0 elimination; solveReducedLinkCons :384-466 reduces to the plain SC solve)
+   if ((rc = k->root->solve_dev(b0_dev))) return rc;
+   // Ltsolve: b_i -= K_i^-1 Br_i x0 (LniTransMult, DistributedLinearSystem.C:430-483)
+   HIP_TRY(hipMemsetAsync(k->d_t, 0, (size_t)e->n_total * sizeof(double), e->stream));
+   if ((rc = pips_hip_batch_border_mult_dev(e, b0_dev, k->d_t, 1.0))) return rc;
+   if ((rc = e->solve(k->d_t))) return rc;
+   hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
+   HIP_TRY(hipGetLastError());
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (SC_dev) *SC_dev = k->d_SC;
+   if (ld) *ld = k->S;
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   return pips_hip_dense_ldl_inertia(k->root.get(), pos, neg, zero);
+}
+
+void pips_hip_kkt_destroy(void* handle) { delete (KktSystem*)handle; }
 
 // ---- symbolic probe (CPU only) -------------------------------------------------------------------------------------
 int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, int S, const int* Bt_rowptr,

@@ -54,6 +54,8 @@ SYMBOLS = [
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
+    "pips_hip_kkt_create", "pips_hip_kkt_factorize", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
+    "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
@@ -392,6 +394,83 @@ class LeafBatch:
     def close(self):
         if self._h:
             lib.pips_hip_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator over the GPUs of one node (replaces the MPI communicator of the reference's collectives)."""
+
+    def __init__(self, id_bytes, n_ranks, rank, device):
+        self._h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(id_bytes)
+        _check(lib.pips_hip_comm_create(C.byref(self._h), buf, C.c_int(n_ranks), C.c_int(rank), C.c_int(device)),
+               "pips_hip_comm_create")
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _check(lib.pips_hip_comm_unique_id(buf), "pips_hip_comm_unique_id")
+        return bytes(buf)
+
+    def allreduce_sum(self, t, n=None, stream=None):
+        n = t.numel() if n is None else n
+        _check(lib.pips_hip_allreduce_sum(self._h, _ptr(t), C.c_size_t(n), _ptr(stream)), "pips_hip_allreduce_sum")
+
+    def close(self):
+        if self._h:
+            lib.pips_hip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class KktSystem:
+    """Mirror of the root linear system's factor2()/solveCompressed() for the blocks one rank owns."""
+
+    def __init__(self, batch, n0, my0, myl, mzl, A0=None, F0=None, G0=None, comm=None, rank=0, n_ranks=1):
+        self.batch = batch
+        self.S = n0 + my0 + myl + mzl
+        self._h = C.c_void_p()
+
+        def trip(M):
+            return (None, None, None) if M is None else (_ptr(M.rowptr), _ptr(M.colidx), _ptr(M.val))
+
+        _check(lib.pips_hip_kkt_create(C.byref(self._h), batch._h, C.c_int(n0), C.c_int(my0), C.c_int(myl), C.c_int(mzl),
+                                       *trip(A0), *trip(F0), *trip(G0), comm._h if comm is not None else None,
+                                       C.c_int(rank), C.c_int(n_ranks)), "pips_hip_kkt_create")
+
+    def factorize(self, leaf_diag_dev, xdiag0_dev, zdiag_link_dev=None):
+        _check(lib.pips_hip_kkt_factorize(self._h, _ptr(leaf_diag_dev), _ptr(xdiag0_dev), _ptr(zdiag_link_dev)),
+               "pips_hip_kkt_factorize")
+
+    def solve_compressed(self, b0_dev, b_leaf_dev):
+        _check(lib.pips_hip_kkt_solve_compressed(self._h, _ptr(b0_dev), _ptr(b_leaf_dev)), "pips_hip_kkt_solve_compressed")
+
+    def schur_ptr(self):
+        p = C.c_void_p()
+        ld = C.c_int()
+        _check(lib.pips_hip_kkt_get_schur(self._h, C.byref(p), C.byref(ld)), "pips_hip_kkt_get_schur")
+        return p.value, ld.value
+
+    def schur_to_host(self):
+        p, ld = self.schur_ptr()
+        out = np.zeros(self.S * self.S)
+        self.batch.sync()
+        _check(lib.pips_hip_memcpy_d2h(_ptr(out), C.c_void_p(p), C.c_size_t(out.nbytes)), "memcpy_d2h")
+        return out
+
+    def root_inertia(self):
+        p, n, z = C.c_int(), C.c_int(), C.c_int()
+        _check(lib.pips_hip_kkt_root_inertia(self._h, C.byref(p), C.byref(n), C.byref(z)), "root inertia")
+        return p.value, n.value, z.value
+
+    def close(self):
+        if self._h:
+            lib.pips_hip_kkt_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

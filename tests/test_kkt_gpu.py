@@ -1,0 +1,71 @@
+"""GPU parity of the fused two-level system (factor2 + solveCompressed) against the oracle restatement."""
+import numpy as np
+import pytest
+
+import pips_ipmpp_amd as pa
+from oracle import oracle as orc
+from tests.util import Problem, hip_lower_as_rowmajor
+
+pytestmark = pytest.mark.gpu
+
+
+def build_system(prob, blocks=None, comm=None, rank=0, n_ranks=1):
+    blocks = list(range(prob.N)) if blocks is None else blocks
+    bt = pa.LeafBatch(len(blocks), prob.S)
+    for i, b in enumerate(blocks):
+        bt.set_block(i, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    bt.analyze(4)
+    for i, b in enumerate(blocks):
+        bt.set_values(i, prob.blocks[b]["K"].val)
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=n_ranks)
+    return bt, kkt
+
+
+@pytest.mark.parametrize("shape", [(3, 200, 24, 16, 0.04), (4, 1000, 100, 100, 0.01)])
+def test_factorize_and_solve_compressed(shape):
+    import torch
+    N, n_i, n0, myl, rho = shape
+    prob = Problem(77, N, n_i, n_i // 2, n0, myl, rho)
+    S = prob.S
+    bt, kkt = build_system(prob)
+    diag = torch.tensor(np.concatenate([b["diag"] for b in prob.blocks]), device="cuda")
+    xd0 = torch.tensor(prob.x_diag0, device="cuda")
+    kkt.factorize(diag, xd0)
+    got = hip_lower_as_rowmajor(kkt.schur_to_host(), S)
+    # oracle: assembleLocalKKT + finalizeKKTdense + dsytrf
+    SCo = prob.oracle_finalize(prob.oracle_schur())
+    want = np.tril(SCo)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9
+    root = orc.DenseRootSolver(S)
+    root.matrixChanged(want)
+    assert kkt.root_inertia() == (prob.n0, prob.myl, 0)
+    assert root.get_inertia()[:2] == (prob.n0, prob.myl)
+    # solveCompressed
+    rng = np.random.default_rng(5)
+    b0 = rng.standard_normal(S)
+    bl = rng.standard_normal(N * prob.n_leaf)
+    b0_d = torch.tensor(b0, device="cuda")
+    bl_d = torch.tensor(bl, device="cuda")
+    kkt.solve_compressed(b0_d, bl_d)
+    bt.sync()
+    leaf = [prob.oracle_leaf(b) for b in range(N)]
+    b0_o = b0.copy()
+    bs_o = [bl.reshape(N, -1)[b].copy() for b in range(N)]
+    orc.solve_compressed(b0_o, bs_o, leaf, [prob.Bt_scipy(b) for b in range(N)], root, prob.n0, 0, 0, prob.myl, 0)
+    x0 = b0_d.cpu().numpy()
+    xl = bl_d.cpu().numpy().reshape(N, -1)
+    assert np.linalg.norm(x0 - b0_o) / np.linalg.norm(b0_o) < 1e-8
+    for b in range(N):
+        assert np.linalg.norm(xl[b] - bs_o[b]) / np.linalg.norm(bs_o[b]) < 1e-8
+    # the result solves the full arrowhead system  [K_i Br_i; Br_i^T K_0] x = b
+    r0 = (prob.oracle_finalize(np.zeros((S, S))))
+    K0 = np.tril(r0) + np.tril(r0, -1).T
+    res0 = K0 @ x0 - b0
+    num = 0.0
+    for b in range(N):
+        Bt = prob.Bt_scipy(b)
+        ri = prob.K_full(b) @ xl[b] + Bt.T @ x0 - bl.reshape(N, -1)[b]
+        res0 += Bt @ xl[b]
+        num += ri @ ri
+    num += res0 @ res0
+    assert np.sqrt(num) / np.sqrt(b0 @ b0 + bl @ bl) < 1e-9
