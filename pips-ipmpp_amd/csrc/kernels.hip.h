@@ -281,18 +281,30 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
 //   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
 //   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
 //   MODE 2 (schur) : SC[bmap(ti), bmap(tj)] -= A(ti,0:K) diag(d) B(tj,0:K)^T   ti,tj border tile rows, K = m_pad
-// 256 threads = 4 waves in a 2 x 2 grid, each wave owns a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x4 accumulators.
-// The A-panel fragment is fed as the MFMA "B" operand so that the lane index runs along C's rows (memory-contiguous).
+// 256 threads = 4 waves in a 2 x 2 grid, each wave owns a 64 x 64 sub-tile.
+//
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction).  Measured on MI355X
+// (tools/mb2.hip, profiles/r1_fp64_issue_rates.txt) it sustains 72.6 TFLOP/s (17 cycles/instruction/SIMD) whereas
+// v_mfma_f64_16x16x4_f64 tops out at 47 TFLOP/s (106-138 cycles), so the 4x4x4 form is the FP64 roofline path.
+// Lane maps (probed with tools/probe44.hip):  A lane = 16k + 4b + i,  B lane = 16k + 4b + j,  D lane = 16i + 4b + j.
+// We put C rows on (b,j) — 16 consecutive rows, a different row per block — and 4 C columns on i, so one instruction
+// produces a 16 x 4 sub-tile: the row-panel fragment is the plain [k][row] LDS image (one ds_read_b64, 16 rows x 4 k),
+// the column-panel fragment is 4 columns x 4 k broadcast to the four blocks (LDS broadcast read, no conflict).
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tile_gemm(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
-                                                  double* __restrict__ arena, const double* __restrict__ dtail,
-                                                  const double* __restrict__ winv, const int* __restrict__ bmap,
-                                                  double* __restrict__ SC, int ldSC) {
+__global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
+                                                     const BlkDesc* __restrict__ blks, double* __restrict__ arena,
+                                                     const double* __restrict__ dtail, const double* __restrict__ winv,
+                                                     const int* __restrict__ bmap, double* __restrict__ SC, int ldSC) {
    __shared__ double As[KB * LDSW];
    __shared__ double Bs[KB * LDSW];
 
-   const TileTask task = tasks[blockIdx.x];
+   // XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
+   // slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
+   const int per = (n_tasks + 7) >> 3;
+   const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+   if (tix >= n_tasks) return;
+   const TileTask task = tasks[tix];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -324,11 +336,11 @@ __global__ __launch_bounds__(256) void k_tile_gemm(const TileTask* __restrict__ 
       dv = dtail + bd.dt_off;
    }
 
-   double4_t acc[4][4];
+   double acc[4][16];
 #pragma unroll
    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int c = 0; c < 16; ++c) acc[i][c] = 0.0;
 
    // staging: thread -> row (tid & 127), k-group (tid >> 7) of 8 consecutive k
    const int srow = tid & 127, sk = (tid >> 7) * 8;
@@ -344,6 +356,8 @@ __global__ __launch_bounds__(256) void k_tile_gemm(const TileTask* __restrict__ 
       }
    };
    if (K > 0) prefetch(0);
+   const int rlane = wr * 64 + (lane & 15);   // row-panel fragment offset
+   const int clane = wc * 64 + (lane & 3);    // column-panel fragment offset (broadcast over the 4 blocks)
    for (int k0 = 0; k0 < K; k0 += KB) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -354,44 +368,44 @@ __global__ __launch_bounds__(256) void k_tile_gemm(const TileTask* __restrict__ 
       if (k0 + KB < K) prefetch(k0 + KB);
 #pragma unroll
       for (int kk = 0; kk < KB; kk += 4) {
-         const int kl = kk + (lane >> 4);
-         double fa[4], fb[4];
+         const int kl = (kk + (lane >> 4)) * LDSW;
+         double fr[4];
 #pragma unroll
-         for (int i = 0; i < 4; ++i) fa[i] = As[kl * LDSW + wr * 64 + i * 16 + (lane & 15)];
+         for (int i = 0; i < 4; ++i) fr[i] = As[kl + rlane + i * 16];
 #pragma unroll
-         for (int j = 0; j < 4; ++j) fb[j] = Bs[kl * LDSW + wc * 64 + j * 16 + (lane & 15)];
+         for (int h = 0; h < 2; ++h) {   // two halves of the column fragments keep the live registers under the 256 cap
+            double fc[8];
 #pragma unroll
-         for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 8; ++c) fc[c] = Bs[kl + clane + (h * 8 + c) * 4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-               // M index <- B panel (C column), N index <- A panel (C row)
-               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+               for (int i = 0; i < 4; ++i)
+                  acc[i][h * 8 + c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], fr[i], acc[i][h * 8 + c], 0, 0, 0);
+         }
       }
       __syncthreads();
    }
 
-   // epilogue: lane holds C(row = rbase + (lane&15), col = cbase + (lane>>4) + 4*reg)
+   // epilogue: lane holds C(row = wr*64 + 16 i + (lane&15), col = wc*64 + 4 c + (lane>>4))
 #pragma unroll
    for (int i = 0; i < 4; ++i) {
       const int row = wr * 64 + i * 16 + (lane & 15);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-         for (int q = 0; q < 4; ++q) {
-            const int col = wc * 64 + j * 16 + (lane >> 4) + 4 * q;
-            const double v = acc[i][j][q];
-            if (MODE == 0) {
-               double* c = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
-               *c -= v;
-            } else if (MODE == 1) {
-               double* c = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
-               *c = v;
-            } else {
-               const int gi = task.ti * TILE + row, gj = task.tj * TILE + col;
-               if (gi < bd.nb && gj < bd.nb && gi >= gj) {
-                  const int* bm = bmap + bd.bmap_off;
-                  atomic_add_f64(SC + bm[gi] + (long long)bm[gj] * ldSC, -v);
-               }
+      for (int c = 0; c < 16; ++c) {
+         const int col = wc * 64 + c * 4 + (lane >> 4);
+         const double v = acc[i][c];
+         if (MODE == 0) {
+            double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
+            *cp -= v;
+         } else if (MODE == 1) {
+            double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
+            *cp = v;
+         } else {
+            const int gi = task.ti * TILE + row, gj = task.tj * TILE + col;
+            if (gi < bd.nb && gj < bd.nb && gi >= gj) {
+               const int* bm = bmap + bd.bmap_off;
+               atomic_add_f64(SC + bm[gi] + (long long)bm[gj] * ldSC, -v);
             }
          }
       }
