@@ -128,7 +128,7 @@ class OracleLdl:
         self.vals = np.ascontiguousarray(self.K.data, dtype=np.float64).copy()
         amax = float(np.abs(self.vals).max()) if self.vals.size else 1.0
         amax = amax if amax > 0 else 1.0
-        lib().oracle_ldl_factor(self._f, _p(self.vals), _p(self.psign), C.c_double(self.thr_rel * amax),
+        lib().oracle_ldl_factor(self._f, _p(self.vals), _p(self.psign), C.c_double(self.thr_rel), C.c_double(self.repl_rel),
                                 C.c_double(self.repl_rel * amax))
 
     def _solve_raw(self, x):

@@ -160,6 +160,7 @@ struct TailCtx {
    int* d_inertia;
    hipStream_t stream;
    PhaseTimer* timer;
+   const double* d_pref;
 };
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
@@ -174,7 +175,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       }
       if (c.timer) c.timer->begin(c.stream, 3);
       hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds, c.stream, p.d_tasks + p.diag[j].off,
-                         c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia);
+                         c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
       if (c.timer) c.timer->end(c.stream);
       if (p.trsm[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 4);
@@ -207,7 +208,7 @@ static int tail_bwd(const TailCtx& c, double* xw) {
    const TailPlan& p = *c.plan;
    for (int i = p.ntc_max - 1; i >= 0; --i)
       if (p.bwd[i].cnt > 0)
-         hipLaunchKernelGGL(k_tail_bwd, dim3(p.bwd[i].cnt), dim3(128), 0, c.stream, p.d_tasks + p.bwd[i].off, c.d_blks,
+         hipLaunchKernelGGL(k_tail_bwd, dim3(p.bwd[i].cnt), dim3(256), 0, c.stream, p.d_tasks + p.bwd[i].off, c.d_blks,
                             c.d_arena, c.d_dtail, c.d_winv, xw, i);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;
@@ -254,7 +255,7 @@ struct Engine {
    PhaseTimer timer;
 
    double *d_arena = nullptr, *d_kval = nullptr, *d_bval = nullptr, *d_winv = nullptr, *d_dtail = nullptr, *d_xw = nullptr;
-   double *d_rhs = nullptr, *d_res = nullptr, *d_stage = nullptr;
+   double *d_rhs = nullptr, *d_res = nullptr, *d_stage = nullptr, *d_pref = nullptr;
    long long *d_kdst = nullptr, *d_bdst = nullptr, *d_kdiag = nullptr, *d_kptr = nullptr, *d_psign_off = nullptr,
              *d_perm_off = nullptr, *d_rowbase = nullptr, *d_bt_xoff = nullptr;
    SnDesc* d_sns = nullptr;
@@ -266,12 +267,12 @@ struct Engine {
 
    ~Engine() { release(); }
    void release() {
-      void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_kdst, d_bdst, d_kdiag, d_kptr,
+      void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_sncol, d_bmap, d_perm,
                       d_inertia, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
-      d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = nullptr;
+      d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = d_pref = nullptr;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_rowidx = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
@@ -281,7 +282,7 @@ struct Engine {
 
    TailCtx ctx() {
       return TailCtx{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
-                     timer.on ? &timer : nullptr};
+                     timer.on ? &timer : nullptr, d_pref};
    }
 
    int analyze_host(int n_threads) {
@@ -340,7 +341,7 @@ struct Engine {
          d.ntc = s.m_pad / TILE;
          d.ntr = s.m > 0 ? s.ldT / TILE : 0;
          d.pad0 = 0;
-         d.thr = 0; d.repl = 1;
+         d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
          arena += s.arena;
          xw += s.n_head + s.m_pad;
          winv += (long long)d.ntc * TILE * TILE;
@@ -439,6 +440,7 @@ struct Engine {
       HIP_TRY(hipMalloc((void**)&d_winv, std::max<long long>(winv, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_dtail, std::max<long long>(dt, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_xw, std::max<long long>(xw_total, 1) * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_pref, std::max<long long>(xw_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_rhs, std::max<long long>(n_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_res, std::max<long long>(n_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_stage, std::max<long long>(n_total, 1) * sizeof(double)));
@@ -486,6 +488,7 @@ struct Engine {
       if (nnzB_total > 0)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzB_total, 256)), dim3(256), 0, stream, d_bdst, d_bval, d_arena, nnzB_total);
       hipLaunchKernelGGL(k_tail_pad_diag, dim3(nblk), dim3(128), 0, stream, d_blks, d_arena, nblk);
+      hipLaunchKernelGGL(k_pref_init, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, d_kval, d_kdiag, d_pref);
       if (timer.on) timer.end(stream);
       // the whole-factor record (phase 6) was pushed first; close it at the end
       const size_t total_rec = 0;
@@ -493,13 +496,14 @@ struct Engine {
          if (timer.on) timer.begin(stream, 1);
          if (L.small_cnt > 0)
             hipLaunchKernelGGL((k_head_factor<64, 8, 512, 64>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
-                               d_blks, d_rowidx, d_sncol, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia);
+                               d_blks, d_rowidx, d_sncol, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
          if (L.large_cnt > 0)
             hipLaunchKernelGGL((k_head_factor<256, 32, 4096, 4096>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
                                L.large_begin, d_blks, d_rowidx, d_sncol, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
-                               d_inertia);
+                               d_inertia, d_pref);
          if (timer.on) timer.end(stream);
       }
+      hipLaunchKernelGGL(k_pref_tail, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_arena, d_pref, 0);
       HIP_TRY(hipGetLastError());
       TailCtx c = ctx();
       int rc = tail_factor(c, SC, ldSC);
@@ -578,14 +582,14 @@ struct DenseLdl {
    std::vector<BlkDesc> h_blks;
    TailPlan plan;
    BlkDesc* d_blks = nullptr;
-   double *d_R = nullptr, *d_winv = nullptr, *d_dtail = nullptr, *d_xw = nullptr, *d_in = nullptr;
+   double *d_R = nullptr, *d_winv = nullptr, *d_dtail = nullptr, *d_xw = nullptr, *d_in = nullptr, *d_pref = nullptr;
    signed char* d_psign = nullptr;
    long long *d_psign_off = nullptr, *d_kptr = nullptr;
    int* d_inertia = nullptr;
    int h_inertia[3] = {0, 0, 0};
 
    ~DenseLdl() {
-      void* ptrs[] = {d_blks, d_R, d_winv, d_dtail, d_xw, d_in, d_psign, d_psign_off, d_kptr, d_inertia};
+      void* ptrs[] = {d_blks, d_R, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -598,14 +602,14 @@ struct DenseLdl {
       BlkDesc d{};
       d.n = n; d.n_head = 0; d.m = n; d.m_pad = npad; d.nb = 0; d.nb_pad = 0; d.ldT = npad;
       d.ntc = d.ntr = npad / TILE;
-      d.thr = 0; d.repl = 1;
+      d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
       h_blks.assign(1, d);
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
       if ((rc = plan.build(h_blks))) return rc;
       std::vector<signed char> ps(npad, 1);
       for (int i = 0; i < n; ++i) ps[i] = n_primal < 0 ? 0 : (i < n_primal ? 1 : -1);
       if ((rc = dev_upload(&d_psign, ps, stream))) return rc;
-      std::vector<long long> zero(1, 0), kp = {0, (long long)npad * npad};
+      std::vector<long long> zero(1, 0), kp = {0, (long long)npad};   // fallback magnitude from the diagonal only
       if ((rc = dev_upload(&d_psign_off, zero, stream))) return rc;
       if ((rc = dev_upload(&d_kptr, kp, stream))) return rc;
       HIP_TRY(hipMalloc((void**)&d_R, (size_t)npad * npad * sizeof(double)));
@@ -613,10 +617,11 @@ struct DenseLdl {
       HIP_TRY(hipMalloc((void**)&d_winv, (size_t)npad * TILE * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_dtail, (size_t)npad * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_xw, (size_t)npad * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_pref, (size_t)npad * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_inertia, 3 * sizeof(int)));
       return PIPS_OK;
    }
-   TailCtx ctx() { return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr}; }
+   TailCtx ctx() { return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref}; }
 
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)
    // rowmajor = 1: A_dev is row-major (the reference's DenseStorage), 0: column-major; lower triangle authoritative
@@ -624,7 +629,8 @@ struct DenseLdl {
       HIP_TRY(hipSetDevice(device));
       hipLaunchKernelGGL(k_copy_lower_to_padded, dim3(grid_for((long long)npad * npad, 256)), dim3(256), 0, stream, A_dev,
                          lda, n, d_R, npad, npad, rowmajor);
-      hipLaunchKernelGGL(k_block_absmax, dim3(1), dim3(256), 0, stream, d_R, d_kptr, d_blks, thr_rel, repl_rel);
+      hipLaunchKernelGGL(k_pref_tail, dim3(8, 1), dim3(256), 0, stream, d_blks, d_R, d_pref, 1);
+      hipLaunchKernelGGL(k_block_absmax, dim3(1), dim3(256), 0, stream, d_pref, d_kptr, d_blks, thr_rel, repl_rel);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, 3 * sizeof(int), stream));
       int rc = tail_factor(ctx(), nullptr, 0);
       if (rc) return rc;

@@ -36,7 +36,8 @@ struct BlkDesc {
    long long dt_off;     // offset into dtail (m_pad)
    int n, n_head, m, m_pad, nb, nb_pad, ldT, ntc, ntr;
    int pad0;
-   double thr, repl;     // pivot threshold / replacement magnitude (absolute)
+   double thr_rel, repl_rel;  // pivot threshold / replacement relative to the pivot's reference magnitude pref[k]
+   double repl_abs;           // replacement when no reference magnitude exists (structurally zero diagonal)
 };
 
 struct TileTask { int blk, ti, tj, pad; };
@@ -47,7 +48,15 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ double fix_pivot(double d, int sign, double thr, double repl, bool& perturbed) {
+// Static pivoting rule.  Every pivot has a reference magnitude pref (|original diagonal entry|, refreshed for the dense
+// tail with the diagonal after the sparse head has been eliminated).  With the expected sign known (quasi-definite KKT
+// blocks: all contributions to a pivot carry its own sign until the dual-dual eliminations start) a pivot is accepted
+// iff sign*d > thr_rel*pref; otherwise it is replaced by sign*repl_rel*pref (repl_abs when pref == 0) and counted as
+// perturbed.  This is scale-invariant, unlike a threshold relative to max|K|: IPM diagonals span 1e-8..1e8.
+__device__ __forceinline__ double fix_pivot(double d, int sign, double pref, double thr_rel, double repl_rel,
+                                            double repl_abs, bool& perturbed) {
+   const double thr = thr_rel * pref;
+   const double repl = pref > 0.0 ? repl_rel * pref : repl_abs;
    perturbed = false;
    if (sign > 0) {
       if (!(d > thr)) { d = repl; perturbed = true; }
@@ -82,7 +91,29 @@ __global__ void k_tail_pad_diag(const BlkDesc* __restrict__ blks, double* __rest
    for (int t = bd.m + threadIdx.x; t < bd.m_pad; t += blockDim.x) arena[bd.T + t + (long long)t * bd.ldT] = 1.0;
 }
 
-// max |K| per block -> pivot thresholds
+// pivot reference magnitudes, permuted order, same layout as the work vectors (xw_off, length n_head + m_pad)
+__global__ void k_pref_init(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
+                            const long long* __restrict__ perm_off, const double* __restrict__ kval,
+                            const long long* __restrict__ kdiag, double* __restrict__ pref) {
+   const BlkDesc bd = blks[blockIdx.y];
+   const int* p = perm + perm_off[blockIdx.y];
+   const int len = bd.n_head + bd.m_pad;
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x)
+      pref[bd.xw_off + k] = k < bd.n ? fabs(kval[kdiag[bd.x_off + p[k]]]) : 1.0;
+}
+
+// tail columns: reference := max(reference, |diagonal after the head has been eliminated|)
+__global__ void k_pref_tail(const BlkDesc* __restrict__ blks, const double* __restrict__ arena, double* __restrict__ pref,
+                            int overwrite) {
+   const BlkDesc bd = blks[blockIdx.y];
+   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < bd.m_pad; t += gridDim.x * blockDim.x) {
+      const double v = fabs(arena[bd.T + t + (long long)t * bd.ldT]);
+      double* q = pref + bd.xw_off + bd.n_head + t;
+      *q = overwrite ? v : fmax(*q, v);
+   }
+}
+
+// max |K| per block -> fallback replacement magnitude
 __global__ void k_block_absmax(const double* __restrict__ kval, const long long* __restrict__ kptr, BlkDesc* blks,
                                double thr_rel, double repl_rel) {
    const int b = blockIdx.x;
@@ -97,8 +128,9 @@ __global__ void k_block_absmax(const double* __restrict__ kval, const long long*
    }
    if (threadIdx.x == 0) {
       const double a = red[0] > 0.0 ? red[0] : 1.0;
-      blks[b].thr = thr_rel * a;
-      blks[b].repl = repl_rel * a;
+      blks[b].thr_rel = thr_rel;
+      blks[b].repl_rel = repl_rel;
+      blks[b].repl_abs = repl_rel * a;
    }
 }
 
@@ -115,7 +147,8 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
                                                       const signed char* __restrict__ psign,
                                                       const long long* __restrict__ psign_off,
                                                       const int* __restrict__ bmap, double* __restrict__ arena,
-                                                      double* __restrict__ SC, int ldSC, int* __restrict__ inertia) {
+                                                      double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
+                                                      const double* __restrict__ pref) {
    __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w
    __shared__ double dk[WMAX];
    __shared__ double Ls[LCAP];
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
    for (int k = 0; k < w; ++k) {
       if (tid == 0) {
          bool pert;
-         const double d = fix_pivot(Ld[k + k * w], ps[k], bd.thr, bd.repl, pert);
+         const double d = fix_pivot(Ld[k + k * w], ps[k], pref[bd.xw_off + sn.c0 + k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
          dk[k] = d;
          if (pert) ++cnt[2]; else if (d > 0) ++cnt[0]; else ++cnt[1];
       }
@@ -417,12 +450,16 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int DLD = TILE + 1;
 
+// One workgroup per diagonal tile.  Right-looking LDL^T in LDS; the inverse X = L^-1 is accumulated on the fly by
+// applying every elimination step to an identity (X <- (I - l_k e_k^T) X), kept in the free upper triangle of the LDS
+// image (X[i][c], i > c, lives at As[i*DLD + c]).  All inner loops are data-parallel; one barrier pair per column.
 __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                   double* __restrict__ arena, double* __restrict__ dtail,
                                                   double* __restrict__ winv, const signed char* __restrict__ psign,
-                                                  const long long* __restrict__ psign_off, int* __restrict__ inertia) {
+                                                  const long long* __restrict__ psign_off, int* __restrict__ inertia,
+                                                  const double* __restrict__ pref) {
    extern __shared__ double As[];  // TILE * DLD doubles, As[col * DLD + row]
-   __shared__ double dcur;
+   __shared__ double dk[TILE];
    __shared__ int cnt[3];
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
@@ -430,56 +467,50 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
    const int tid = threadIdx.x, tj = task.tj, ld = bd.ldT;
    double* C = arena + bd.T + (long long)tj * TILE + (long long)tj * TILE * ld;
    const signed char* ps = psign + psign_off[task.blk] + bd.n_head + tj * TILE;
+   const double* pr = pref + bd.xw_off + bd.n_head + tj * TILE;
    if (tid < 3) cnt[tid] = 0;
    for (int idx = tid; idx < TILE * TILE; idx += 256) {
       const int rr = idx & (TILE - 1), cc = idx >> 7;
-      As[cc * DLD + rr] = C[rr + (long long)cc * ld];
+      As[cc * DLD + rr] = rr >= cc ? C[rr + (long long)cc * ld] : 0.0;
    }
    __syncthreads();
    const int tx = tid & 15, ty = tid >> 4;
    for (int k = 0; k < TILE; ++k) {
+      // every thread evaluates the (deterministic) pivot rule itself: no broadcast barrier
+      const int gk = tj * TILE + k;
+      bool pert;
+      const double d = fix_pivot(As[k * DLD + k], gk < bd.m ? (int)ps[k] : 1, pr[k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
       if (tid == 0) {
-         const int gk = tj * TILE + k;
-         const int sgn = gk < bd.m ? ps[k] : 1;
-         bool pert;
-         const double d = fix_pivot(As[k * DLD + k], sgn, bd.thr, bd.repl, pert);
-         dcur = d;
-         As[k * DLD + k] = d;
+         dk[k] = d;
          if (gk < bd.m) { if (pert) ++cnt[2]; else if (d > 0) ++cnt[0]; else ++cnt[1]; }
       }
-      __syncthreads();
-      const double dinv = 1.0 / dcur;
+      const double dinv = 1.0 / d;
+      // trailing update of A (lower triangle) with the unscaled column k
       for (int j = k + 1 + ty; j < TILE; j += 16) {
-         const double ajk = As[k * DLD + j] * dinv;
-         for (int i = j + tx; i < TILE; i += 16) As[j * DLD + i] -= As[k * DLD + i] * ajk;
+         const double ljk = As[k * DLD + j] * dinv;
+         for (int i = j + tx; i < TILE; i += 16) As[j * DLD + i] -= As[k * DLD + i] * ljk;
+      }
+      // X rows i > k:  X[i][c] -= l_ik X[k][c] (c < k),  X[i][k] = -l_ik
+      for (int i = k + 1 + ty; i < TILE; i += 16) {
+         const double lik = As[k * DLD + i] * dinv;
+         for (int c = tx; c < k; c += 16) As[i * DLD + c] -= lik * As[k * DLD + c];
+         if (tx == 0) As[i * DLD + k] = -lik;
       }
       __syncthreads();
-      for (int i = k + 1 + tid; i < TILE; i += 256) As[k * DLD + i] *= dinv;
-      __syncthreads();
    }
-   // store L (unit lower) and D
+   // store L (unit lower, scaled) and D
    for (int idx = tid; idx < TILE * TILE; idx += 256) {
       const int rr = idx & (TILE - 1), cc = idx >> 7;
-      if (rr >= cc) C[rr + (long long)cc * ld] = As[cc * DLD + rr];
+      if (rr > cc) C[rr + (long long)cc * ld] = As[cc * DLD + rr] / dk[cc];
+      else if (rr == cc) C[rr + (long long)cc * ld] = dk[cc];
    }
-   if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = As[tid * DLD + tid];
+   if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = dk[tid];
    if (tid == 0) {
       if (cnt[0]) atomicAdd(&inertia[3 * task.blk + 0], cnt[0]);
       if (cnt[1]) atomicAdd(&inertia[3 * task.blk + 1], cnt[1]);
       if (cnt[2]) atomicAdd(&inertia[3 * task.blk + 2], cnt[2]);
    }
-   __syncthreads();
-   // X = L^-1, column c by thread c:  X[i][c] (i > c) kept at As[i * DLD + c] (upper triangle of the LDS image)
-   if (tid < TILE) {
-      const int c = tid;
-      for (int i = c + 1; i < TILE; ++i) {
-         double s = As[c * DLD + i];  // L[i][c] * x_c, x_c = 1
-         for (int l = c + 1; l < i; ++l) s += As[l * DLD + i] * As[l * DLD + c];
-         As[i * DLD + c] = -s;
-      }
-   }
-   __syncthreads();
-   // Winv[n][k] = X[n][k] / d_n  (row-major in n: Winv stored column-major with row index n -> same layout as a panel)
+   // Winv[n][k] = X[n][k] / d_n
    double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
    for (int idx = tid; idx < TILE * TILE; idx += 256) {
       const int nn = idx & (TILE - 1), kk = idx >> 7;
@@ -487,7 +518,7 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
       if (nn == kk) x = 1.0;
       else if (nn > kk) x = As[nn * DLD + kk];
       else x = 0.0;
-      W[nn + (long long)kk * TILE] = x / As[nn * DLD + nn];
+      W[nn + (long long)kk * TILE] = x / dk[nn];
    }
 }
 
@@ -615,43 +646,60 @@ __global__ __launch_bounds__(128) void k_tail_fwd(const TileTask* __restrict__ t
    xt[ti * TILE + tid] = acc;
 }
 
+// out[c] = sum_r M[r + c*ldm] v[r] for a 128 x 128 column-major tile: the tile is staged through LDS in chunks of 32
+// columns with coalesced row-contiguous loads, then 8 threads reduce each column (rows part + 8k: bank-conflict-free at
+// the 136-double stride).  256 threads; v and out are LDS arrays of 128 doubles.
+constexpr int TG_LD = 136;
+__device__ __forceinline__ void tile_tgemv(const double* __restrict__ M, long long ldm, const double* v, double* out,
+                                           double* Ls, int tid) {
+   const int row = tid & 127, cg = tid >> 7;
+   const int col = tid >> 3, part = tid & 7;
+   for (int chunk = 0; chunk < 4; ++chunk) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+         const int c = cg * 16 + e;
+         Ls[c * TG_LD + row] = M[row + (long long)(chunk * 32 + c) * ldm];
+      }
+      __syncthreads();
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += Ls[col * TG_LD + part + 8 * k] * v[part + 8 * k];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      if (part == 0) out[chunk * 32 + col] = s;
+      __syncthreads();
+   }
+}
+
 // tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} (if i+1 < ntc) ; tile j == i: x_i = Winv_i^T (d_i z_i)
-__global__ __launch_bounds__(128) void k_tail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+__global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
                                                  const double* __restrict__ winv, double* __restrict__ xw, int i) {
+   __shared__ double Ls[32 * TG_LD];
    __shared__ double v[TILE];
-   __shared__ double part[2][TILE];
+   __shared__ double outp[TILE];
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
-   const int tid = threadIdx.x, tj = task.ti, ld = bd.ldT, lane = tid & 63, wave = tid >> 6;
+   const int tid = threadIdx.x, tj = task.ti, ld = bd.ldT;
    double* xt = xw + bd.xw_off + bd.n_head;
-   double acc = xt[tj * TILE + tid];
+   double acc = tid < TILE ? xt[tj * TILE + tid] : 0.0;
    if (i + 1 < bd.ntc) {
-      v[tid] = xt[(i + 1) * TILE + tid];
+      if (tid < TILE) v[tid] = xt[(i + 1) * TILE + tid];
       __syncthreads();
-      // out[c] = sum_r L[r][c] v[r]; each wave reduces 64 rows for every column, lanes along rows (coalesced)
-      const double* L = arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld;
-      for (int c = 0; c < TILE; ++c) {
-         double s = L[wave * 64 + lane + (long long)c * ld] * v[wave * 64 + lane];
-         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-         if (lane == 0) part[wave][c] = s;
-      }
-      __syncthreads();
-      acc -= part[0][tid] + part[1][tid];
+      tile_tgemv(arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, v, outp, Ls, tid);
+      if (tid < TILE) acc -= outp[tid];
    }
    if (tj == i) {
       __syncthreads();
-      v[tid] = acc * dtail[bd.dt_off + i * TILE + tid];
+      if (tid < TILE) v[tid] = acc * dtail[bd.dt_off + i * TILE + tid];
       __syncthreads();
-      // x[c] = sum_n Winv[n][c] v[n] : column c of Winv is contiguous in n
-      const double* W = winv + bd.winv_off + (long long)i * TILE * TILE + (long long)tid * TILE;
-      double x = 0.0;
-#pragma unroll 8
-      for (int nn = 0; nn < TILE; ++nn) x += W[nn] * v[nn];
-      acc = x;
+      // x[c] = sum_n Winv[n][c] v[n]
+      tile_tgemv(winv + bd.winv_off + (long long)i * TILE * TILE, TILE, v, outp, Ls, tid);
+      if (tid < TILE) acc = outp[tid];
    }
-   xt[tj * TILE + tid] = acc;
+   if (tid < TILE) xt[tj * TILE + tid] = acc;
 }
 
 // y = alpha * K x + beta-free accumulate (y must be initialised): symmetric lower CSR, one thread per row, atomics for
