@@ -165,7 +165,7 @@ struct TailCtx {
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
-   const size_t diag_lds = (size_t)TILE * DLD * sizeof(double);
+   const size_t diag_lds = 0;
    for (int j = 0; j < p.ntc_max; ++j) {
       if (p.upd[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 2);
@@ -217,8 +217,6 @@ static int tail_bwd(const TailCtx& c, double* xw) {
 static int ensure_diag_lds() {
    static bool done = false;
    if (done) return PIPS_OK;
-   HIP_TRY(hipFuncSetAttribute((const void*)k_tile_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)TILE * DLD * sizeof(double))));
    done = true;
    return PIPS_OK;
 }

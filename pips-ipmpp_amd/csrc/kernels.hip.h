@@ -448,77 +448,125 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict
 // ------------------------------------------------------------------------------------------------
 // diagonal tile: LDL^T of the 128 x 128 tile in LDS, then Winv = D^-1 L^-1 (built in the free upper triangle)
 // ------------------------------------------------------------------------------------------------
-constexpr int DLD = TILE + 1;
+constexpr int DLD = TILE + 1;   // (kept for the launch-side LDS size query; the register kernel needs no tile image)
 
-// One workgroup per diagonal tile.  Right-looking LDL^T in LDS; the inverse X = L^-1 is accumulated on the fly by
-// applying every elimination step to an identity (X <- (I - l_k e_k^T) X), kept in the free upper triangle of the LDS
-// image (X[i][c], i > c, lives at As[i*DLD + c]).  All inner loops are data-parallel; one barrier pair per column.
+struct DiagShared {
+   double colk[2][TILE];
+   double xrow[2][TILE];
+   double dk[TILE];
+   double prs[TILE];
+   int sgn[TILE];
+   int cnt[3];
+};
+
+// the 16 pivots k = 16 KB .. 16 KB + 15; KB is a template parameter so that every register-array index is a constant
+template <int KB>
+__device__ __forceinline__ void diag_block(double (&A)[8][8], double (&X)[8][8], DiagShared& sh, const BlkDesc& bd,
+                                           int tx, int ty, int tid, int gk0) {
+   for (int kt = 0; kt < 16; ++kt) {
+      const int k = KB * 16 + kt, buf = kt & 1;
+      if (ty == kt) {
+#pragma unroll
+         for (int a = KB; a < 8; ++a) sh.colk[buf][tx + 16 * a] = A[a][KB];   // A(i, k), i >= 16 KB
+      }
+      if (tx == kt) {
+#pragma unroll
+         for (int b = 0; b <= KB; ++b) sh.xrow[buf][ty + 16 * b] = X[KB][b];  // X(k, c), c < 16 (KB+1)
+      }
+      __syncthreads();
+      bool pert;
+      const double d = fix_pivot(sh.colk[buf][k], sh.sgn[k], sh.prs[k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
+      if (tid == 0) {
+         sh.dk[k] = d;
+         if (gk0 + k < bd.m) { if (pert) ++sh.cnt[2]; else if (d > 0) ++sh.cnt[0]; else ++sh.cnt[1]; }
+      }
+      const double dinv = 1.0 / d;
+      double li[8];
+#pragma unroll
+      for (int a = KB; a < 8; ++a) {
+         const int i = tx + 16 * a;
+         li[a] = i > k ? sh.colk[buf][i] * dinv : 0.0;   // l_ik, zero for rows that are not below the pivot
+      }
+      // A(i,j) -= l_ik a_jk  for i >= j > k
+#pragma unroll
+      for (int b = KB; b < 8; ++b) {
+         const int j = ty + 16 * b;
+         const double ajk = j > k ? sh.colk[buf][j] : 0.0;
+#pragma unroll
+         for (int a = KB; a < 8; ++a) A[a][b] -= li[a] * ajk;
+      }
+      // X(i,c) -= l_ik X(k,c) for c < k ;  X(i,k) = -l_ik
+#pragma unroll
+      for (int b = 0; b <= KB; ++b) {
+         const int c = ty + 16 * b;
+         const double xkc = c < k ? sh.xrow[buf][c] : (c == k ? 1.0 : 0.0);
+#pragma unroll
+         for (int a = KB; a < 8; ++a) X[a][b] -= li[a] * xkc;
+      }
+   }
+}
+
+// One workgroup per diagonal tile, the tile held in REGISTERS: thread (tx,ty) of the 16 x 16 thread grid owns the 8 x 8
+// elements A(tx+16a, ty+16b) of the 128 x 128 tile and the same elements of X = L^-1 (both lower triangular).  Per
+// pivot k the owners publish column k of A and row k of X through a double-buffered LDS line, everybody applies the
+// rank-1 update to its registers: one barrier per column, no LDS read-modify-write chains.  X is accumulated by
+// applying each elimination to an identity:  X <- (I - l_k e_k^T) X.
 __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                   double* __restrict__ arena, double* __restrict__ dtail,
                                                   double* __restrict__ winv, const signed char* __restrict__ psign,
                                                   const long long* __restrict__ psign_off, int* __restrict__ inertia,
                                                   const double* __restrict__ pref) {
-   extern __shared__ double As[];  // TILE * DLD doubles, As[col * DLD + row]
-   __shared__ double dk[TILE];
-   __shared__ int cnt[3];
+   __shared__ DiagShared sh;
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, tj = task.tj, ld = bd.ldT;
-   double* C = arena + bd.T + (long long)tj * TILE + (long long)tj * TILE * ld;
-   const signed char* ps = psign + psign_off[task.blk] + bd.n_head + tj * TILE;
-   const double* pr = pref + bd.xw_off + bd.n_head + tj * TILE;
-   if (tid < 3) cnt[tid] = 0;
-   for (int idx = tid; idx < TILE * TILE; idx += 256) {
-      const int rr = idx & (TILE - 1), cc = idx >> 7;
-      As[cc * DLD + rr] = rr >= cc ? C[rr + (long long)cc * ld] : 0.0;
-   }
-   __syncthreads();
    const int tx = tid & 15, ty = tid >> 4;
-   for (int k = 0; k < TILE; ++k) {
-      // every thread evaluates the (deterministic) pivot rule itself: no broadcast barrier
-      const int gk = tj * TILE + k;
-      bool pert;
-      const double d = fix_pivot(As[k * DLD + k], gk < bd.m ? (int)ps[k] : 1, pr[k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
-      if (tid == 0) {
-         dk[k] = d;
-         if (gk < bd.m) { if (pert) ++cnt[2]; else if (d > 0) ++cnt[0]; else ++cnt[1]; }
-      }
-      const double dinv = 1.0 / d;
-      // trailing update of A (lower triangle) with the unscaled column k
-      for (int j = k + 1 + ty; j < TILE; j += 16) {
-         const double ljk = As[k * DLD + j] * dinv;
-         for (int i = j + tx; i < TILE; i += 16) As[j * DLD + i] -= As[k * DLD + i] * ljk;
-      }
-      // X rows i > k:  X[i][c] -= l_ik X[k][c] (c < k),  X[i][k] = -l_ik
-      for (int i = k + 1 + ty; i < TILE; i += 16) {
-         const double lik = As[k * DLD + i] * dinv;
-         for (int c = tx; c < k; c += 16) As[i * DLD + c] -= lik * As[k * DLD + c];
-         if (tx == 0) As[i * DLD + k] = -lik;
-      }
-      __syncthreads();
+   double* C = arena + bd.T + (long long)tj * TILE + (long long)tj * TILE * ld;
+   if (tid < 3) sh.cnt[tid] = 0;
+   if (tid < TILE) {
+      sh.prs[tid] = pref[bd.xw_off + bd.n_head + tj * TILE + tid];
+      sh.sgn[tid] = tj * TILE + tid < bd.m ? (int)psign[psign_off[task.blk] + bd.n_head + tj * TILE + tid] : 1;
    }
-   // store L (unit lower, scaled) and D
-   for (int idx = tid; idx < TILE * TILE; idx += 256) {
-      const int rr = idx & (TILE - 1), cc = idx >> 7;
-      if (rr > cc) C[rr + (long long)cc * ld] = As[cc * DLD + rr] / dk[cc];
-      else if (rr == cc) C[rr + (long long)cc * ld] = dk[cc];
-   }
+   double A[8][8], X[8][8];
+#pragma unroll
+   for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+         const int i = tx + 16 * a, j = ty + 16 * b;
+         A[a][b] = i >= j ? C[i + (long long)j * ld] : 0.0;
+         X[a][b] = 0.0;
+      }
+   __syncthreads();
+   const int gk0 = tj * TILE;
+   diag_block<0>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<1>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<2>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<3>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<4>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<5>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<6>(A, X, sh, bd, tx, ty, tid, gk0);
+   diag_block<7>(A, X, sh, bd, tx, ty, tid, gk0);
+   double* dk = sh.dk;
+   int* cnt = sh.cnt;
+   __syncthreads();
+   // store L (unit lower, scaled), D, and Winv[n][k] = X[n][k] / d_n
+   double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
+#pragma unroll
+   for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+         const int i = tx + 16 * a, j = ty + 16 * b;
+         if (i > j) C[i + (long long)j * ld] = A[a][b] / dk[j];
+         else if (i == j) C[i + (long long)j * ld] = dk[j];
+         const double x = i == j ? 1.0 : (i > j ? X[a][b] : 0.0);
+         W[i + (long long)j * TILE] = x / dk[i];
+      }
    if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = dk[tid];
    if (tid == 0) {
       if (cnt[0]) atomicAdd(&inertia[3 * task.blk + 0], cnt[0]);
       if (cnt[1]) atomicAdd(&inertia[3 * task.blk + 1], cnt[1]);
       if (cnt[2]) atomicAdd(&inertia[3 * task.blk + 2], cnt[2]);
-   }
-   // Winv[n][k] = X[n][k] / d_n
-   double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
-   for (int idx = tid; idx < TILE * TILE; idx += 256) {
-      const int nn = idx & (TILE - 1), kk = idx >> 7;
-      double x;
-      if (nn == kk) x = 1.0;
-      else if (nn > kk) x = As[nn * DLD + kk];
-      else x = 0.0;
-      W[nn + (long long)kk * TILE] = x / dk[nn];
    }
 }
 
