@@ -324,13 +324,23 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
 // produces a 16 x 4 sub-tile: the row-panel fragment is the plain [k][row] LDS image (one ds_read_b64, 16 rows x 4 k),
 // the column-panel fragment is 4 columns x 4 k broadcast to the four blocks (LDS broadcast read, no conflict).
 // ------------------------------------------------------------------------------------------------
+// 16-byte-per-lane LDS-DMA: the wave writes 1 KiB contiguously at lds_base (wave-uniform) + 16 * lane
+__device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base) {
+   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr_lane,
+                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// Staging: both panels are column-major with the tile's 128 rows contiguous, so one LDS-DMA wave-instruction moves one
+// k-column (1 KiB) straight into the [k][row] LDS image (no VGPR round trip, no ds_write).  Two LDS buffers: the DMA of
+// stage s+1 is in flight while stage s is multiplied; one barrier per stage.  The diagonal scaling d_k of the update is
+// applied to the column-panel fragment after the LDS read (one v_mul_f64 per fragment, hidden beside the MFMAs).
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
                                                      const BlkDesc* __restrict__ blks, double* __restrict__ arena,
                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
                                                      const int* __restrict__ bmap, double* __restrict__ SC, int ldSC) {
-   __shared__ double As[KB * LDSW];
-   __shared__ double Bs[KB * LDSW];
+   __shared__ __attribute__((aligned(16))) double As[2][KB * LDSW];
+   __shared__ __attribute__((aligned(16))) double Bs[2][KB * LDSW];
 
    // XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
    // slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict
    const TileTask task = tasks[tix];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int wr = wave & 1, wc = wave >> 1;
    const int ld = bd.ldT;
    double* T = arena + bd.T;
@@ -375,49 +385,77 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict
 #pragma unroll
       for (int c = 0; c < 16; ++c) acc[i][c] = 0.0;
 
-   // staging: thread -> row (tid & 127), k-group (tid >> 7) of 8 consecutive k
-   const int srow = tid & 127, sk = (tid >> 7) * 8;
-   double ra[8], rb[8];
-   auto prefetch = [&](int k0) {
+   const int nst = K / KB;
+   const double* Al = Ap + 2 * lane;
+   const double* Bl = Bp + 2 * lane;
+   auto issue = [&](int st, int buf) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-         const int k = k0 + sk + e;
-         ra[e] = Ap[srow + (long long)k * ld];
-         double v = Bp[srow + (long long)k * ldb];
-         if (MODE != 1) v *= dv[k];
-         rb[e] = v;
+      for (int q = 0; q < 4; ++q) {
+         const int k = wave + 4 * q;   // this wave's four k-columns of the stage
+         glds16(Al + (long long)(st * KB + k) * ld, &As[buf][k * LDSW]);
+         glds16(Bl + (long long)(st * KB + k) * ldb, &Bs[buf][k * LDSW]);
       }
    };
-   if (K > 0) prefetch(0);
+   double dn[4] = {1.0, 1.0, 1.0, 1.0};
+   auto load_d = [&](int st) {
+      if (MODE != 1) {
+#pragma unroll
+         for (int q = 0; q < 4; ++q) dn[q] = dv[st * KB + 4 * q + (lane >> 4)];
+      }
+   };
+   if (nst > 0) { issue(0, 0); load_d(0); }
    const int rlane = wr * 64 + (lane & 15);   // row-panel fragment offset
    const int clane = wc * 64 + (lane & 3);    // column-panel fragment offset (broadcast over the 4 blocks)
-   for (int k0 = 0; k0 < K; k0 += KB) {
+   for (int st = 0; st < nst; ++st) {
+      const int buf = st & 1;
+#if !defined(PIPS_EXPERIMENT_NO_BARRIER)
+      __syncthreads();   // own DMA retired (vmcnt(0)) + everybody's DMA of this stage visible + buffer buf^1 free again
+#endif
+      double dc[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-         As[(sk + e) * LDSW + srow] = ra[e];
-         Bs[(sk + e) * LDSW + srow] = rb[e];
-      }
-      __syncthreads();
-      if (k0 + KB < K) prefetch(k0 + KB);
+      for (int q = 0; q < 4; ++q) dc[q] = dn[q];
+#if !defined(PIPS_EXPERIMENT_NO_DMA)
+      if (st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
+#endif
+      const double* Ab = As[buf] + (lane >> 4) * LDSW + rlane;
+      const double* Bb = Bs[buf] + (lane >> 4) * LDSW + clane;
+      // register double-buffered fragments: the LDS reads of k-step q+1 are issued between the MFMAs of k-step q
+      double fr[2][4], fc[2][16];
 #pragma unroll
-      for (int kk = 0; kk < KB; kk += 4) {
-         const int kl = (kk + (lane >> 4)) * LDSW;
-         double fr[4];
+      for (int i = 0; i < 4; ++i) fr[0][i] = Ab[i * 16];
 #pragma unroll
-         for (int i = 0; i < 4; ++i) fr[i] = As[kl + rlane + i * 16];
+      for (int c = 0; c < 16; ++c) fc[0][c] = Bb[c * 4];
 #pragma unroll
-         for (int h = 0; h < 2; ++h) {   // two halves of the column fragments keep the live registers under the 256 cap
-            double fc[8];
+      for (int q = 0; q < 4; ++q) {
+         const int cur = q & 1, nxt = cur ^ 1;
+         if (q < 3) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) fc[c] = Bs[kl + clane + (h * 8 + c) * 4];
+            for (int i = 0; i < 4; ++i) fr[nxt][i] = Ab[(4 * (q + 1)) * LDSW + i * 16];
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 16; ++c) fc[nxt][c] = Bb[(4 * (q + 1)) * LDSW + c * 4];
+         }
+         if (MODE != 1) {
 #pragma unroll
-               for (int i = 0; i < 4; ++i)
-                  acc[i][h * 8 + c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], fr[i], acc[i][h * 8 + c], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) fr[cur][i] *= dc[q];   // A diag(d) B^T: scale the 4 row fragments, not the 16 column ones
+         }
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+               acc[i][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[cur][c], fr[cur][i], acc[i][c], 0, 0, 0);
+         // interleave: 4 VALU (scaling) first, then {3 MFMA, 1 DS read} x 20, then the remaining 4 MFMA
+         if (MODE != 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+         if (q < 3) {
+#pragma unroll
+            for (int g = 0; g < 20; ++g) {
+               __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+         } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
          }
       }
-      __syncthreads();
    }
 
    // epilogue: lane holds C(row = wr*64 + 16 i + (lane&15), col = wc*64 + 4 c + (lane>>4))
