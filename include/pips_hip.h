@@ -169,6 +169,8 @@ int pips_border_assemble(int nx, int my, int mz, int n0, int n_empty, int myl, i
                          const double* A_val, const int* C_rowptr, const int* C_colidx, const double* C_val,
                          const int* F_rowptr, const int* F_colidx, const double* F_val, const int* G_rowptr,
                          const int* G_colidx, const double* G_val, int* Bt_rowptr, int* Bt_colidx, double* Bt_val);
+/* block -> rank map (DistributedTree::assignProcesses, DistributedTree.C:35-90): contiguous, monotone, balanced */
+int pips_map_children_to_ranks(int n_children, int n_ranks, int* map);
 /* symbolic analysis only (CPU): fills what[] like pips_hip_ldl_info and optionally perm/colcount (may be NULL) */
 int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, int S, const int* Bt_rowptr,
                         const int* Bt_colidx, int force_n_head, int64_t* what, int n_what, int* perm, int* colcount);

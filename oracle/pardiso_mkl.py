@@ -21,6 +21,9 @@ def available():
     global _mkl
     if _mkl is not None:
         return _mkl is not False
+    # MKL's default Intel threading layer needs libiomp5, which this image lacks: with it every multi-threaded PARDISO
+    # call fails with error -2/-3.  The GNU layer (libgomp) works.
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
     for c in _CANDIDATES:
         try:
             _mkl = C.CDLL(c, mode=C.RTLD_GLOBAL)

@@ -206,4 +206,18 @@ int pips_border_assemble(int nx, int my, int mz, int n0, int n_empty, int myl, i
    return 0;
 }
 
+// Contiguous, monotone, balanced (+-1) mapping of the root's children (scenario blocks) to ranks/GPUs — the contract
+// DistributedTree::assignProcesses asserts for mapChildrenToNSubTrees (Readers/Distributed/DistributedTree.C:35-90,437+):
+// map[i] <= map[i+1], loads differ by at most one, leftovers spread over the ranks.  n_ranks > n_children is an error
+// there (":57-60 too many MPI processes") and here.
+int pips_map_children_to_ranks(int n_children, int n_ranks, int* map) {
+   if (n_children < 0 || n_ranks <= 0 || n_ranks > n_children || !map)
+      PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_map_children_to_ranks: need 0 < n_ranks <= n_children (got %d ranks, %d children)", n_ranks, n_children);
+   for (int r = 0; r < n_ranks; ++r) {
+      const long long b = (long long)r * n_children / n_ranks, e = (long long)(r + 1) * n_children / n_ranks;
+      for (long long i = b; i < e; ++i) map[i] = r;
+   }
+   return 0;
+}
+
 }  // extern "C"

@@ -59,7 +59,7 @@ SYMBOLS = [
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
-    "pips_border_assemble", "pips_symbolic_probe",
+    "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
 ]
 
 
@@ -186,6 +186,13 @@ def border_assemble(nx, my, mz, n0, n_empty, R=None, A=None, Cm=None, F=None, G=
     val = np.zeros(nnz)
     _check(lib.pips_border_assemble(*args, _ptr(rowptr), _ptr(colidx), _ptr(val)), "pips_border_assemble")
     return Csr(S, nx + my + mz, rowptr, colidx, val)
+
+
+def map_children_to_ranks(n_children, n_ranks):
+    """Block -> rank map with the contract of DistributedTree::assignProcesses (contiguous, monotone, balanced)."""
+    m = np.zeros(max(n_children, 1), np.int32)
+    _check(lib.pips_map_children_to_ranks(C.c_int(n_children), C.c_int(n_ranks), _ptr(m)), "pips_map_children_to_ranks")
+    return m[:n_children]
 
 
 def symbolic_probe(K, n_primal=-1, Bt=None, force_n_head=-1, want_perm=False):

@@ -1,0 +1,103 @@
+"""Golden vectors (tests/golden/, made by tests/golden/make_golden.py): generator determinism, the oracle against the
+reference's third-party arithmetic (MKL PARDISO with the reference's iparm + LAPACK dsytrf), and — on the GPU — the
+HIP path against the same vectors."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import pips_ipmpp_amd as pa
+from oracle import oracle as orc
+from tests.golden.make_golden import digest
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_generator_is_bit_reproducible():
+    g = np.load(os.path.join(HERE, "generator_v1.npz"))
+    for (seed, blk, n_i, my_i, n0, myl, rho) in [(1, 1, 100, 50, 10, 8, 0.05), (20261002, 7, 1000, 500, 100, 100, 0.01),
+                                                  (42, 64, 10000, 5000, 1000, 1000, 1e-3)]:
+        W, T, F, c, xs = pa.gen_block(seed, blk, n_i, my_i, n0, myl, rho)
+        want = g[f"blk_{seed}_{blk}_{n_i}"]
+        assert digest(W.rowptr, W.colidx, W.val) == want[0]
+        assert digest(T.rowptr, T.colidx, T.val) == want[1]
+        assert digest(F.rowptr, F.colidx, F.val) == want[2]
+        assert digest(c, xs) == want[3]
+    F0, c0, x0 = pa.gen_root(42, 1000, 1000)
+    assert digest(F0.rowptr, F0.colidx, F0.val) == g["root_42"][0] and digest(c0, x0) == g["root_42"][1]
+    assert digest(pa.gen_diagonal(42, 3, 1000, -4, 4)) == g["diag_42_3"][0]
+
+
+def _load():
+    g = np.load(os.path.join(HERE, "arrowhead_small.npz"))
+    N, n_i, my_i, n0, myl = (int(g[k]) for k in ("N", "n_i", "my_i", "n0", "myl"))
+    n = n_i + my_i
+    Ks = [sp.csr_matrix((g[f"K{b}_val"], g[f"K{b}_colidx"], g[f"K{b}_rowptr"]), shape=(n, n)) for b in range(N)]
+    Bts = [sp.csr_matrix((g[f"Bt{b}_val"], g[f"Bt{b}_colidx"], g[f"Bt{b}_rowptr"]), shape=(n0 + myl, n)) for b in range(N)]
+    return g, N, n_i, my_i, n0, myl, Ks, Bts
+
+
+def test_oracle_reproduces_third_party_golden_vectors():
+    g, N, n_i, my_i, n0, myl, Ks, Bts = _load()
+    S = n0 + myl
+    SC = np.zeros((S, S))
+    solvers = []
+    for b in range(N):
+        s = orc.OracleLdl(Ks[b], n_primal=n_i)
+        s.matrixChanged()
+        solvers.append(s)
+        x = g[f"rhs{b}"].copy()
+        s.solve(x)
+        assert np.linalg.norm(x - g[f"x{b}"]) / np.linalg.norm(g[f"x{b}"]) < 1e-9
+        assert s.get_inertia()[:2] == tuple(g[f"inertia{b}"][:2])
+        orc.add_term_to_schur_compl_blocked(SC, s, Bts[b])
+    assert np.abs(np.tril(SC) - g["SC_assembled"]).max() / np.abs(g["SC_assembled"]).max() < 1e-9
+    F0 = sp.csr_matrix((g["F0_val"], g["F0_colidx"], g["F0_rowptr"]), shape=(myl, n0))
+    SCf = orc.finalize_kkt_dense(SC, n0, 0, myl, 0, g["x_diag0"], F0=F0)
+    assert np.abs(np.tril(SCf) - g["SC_finalized"]).max() / np.abs(g["SC_finalized"]).max() < 1e-9
+    root = orc.DenseRootSolver(S)
+    root.matrixChanged(np.tril(SCf))
+    x0 = g["b_root"].copy()
+    xs = [g[f"b{b}"].copy() for b in range(N)]
+    orc.solve_compressed(x0, xs, solvers, Bts, root, n0, 0, 0, myl, 0)
+    assert np.linalg.norm(x0 - g["sol_root"]) / np.linalg.norm(g["sol_root"]) < 1e-8
+    for b in range(N):
+        assert np.linalg.norm(xs[b] - g[f"sol{b}"]) / np.linalg.norm(g[f"sol{b}"]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_third_party_golden_vectors():
+    import torch
+    g, N, n_i, my_i, n0, myl, Ks, Bts = _load()
+    S = n0 + myl
+    bt = pa.LeafBatch(N, S)
+    for b in range(N):
+        bt.set_block(b, pa.Csr(Ks[b].shape[0], Ks[b].shape[1], Ks[b].indptr, Ks[b].indices, Ks[b].data), n_i,
+                     pa.Csr(S, Bts[b].shape[1], Bts[b].indptr, Bts[b].indices, Bts[b].data))
+    bt.analyze(2)
+    for b in range(N):
+        bt.set_values(b, Ks[b].data)
+    F0 = pa.Csr(myl, n0, g["F0_rowptr"], g["F0_colidx"], g["F0_val"])
+    kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0)
+    kkt.factorize(None, torch.tensor(g["x_diag0"], device="cuda"))
+    from tests.util import hip_lower_as_rowmajor
+    got = hip_lower_as_rowmajor(kkt.schur_to_host(), S)
+    assert np.abs(got - g["SC_finalized"]).max() / np.abs(g["SC_finalized"]).max() < 1e-9
+    for b in range(N):
+        assert bt.inertia(b)[:2] == tuple(g[f"inertia{b}"][:2])
+    assert kkt.root_inertia()[:2] == tuple(g["root_inertia"][:2])
+    rhs = np.concatenate([g[f"rhs{b}"] for b in range(N)])
+    x = torch.tensor(rhs, device="cuda")
+    bt.solve(x)
+    xs = x.cpu().numpy().reshape(N, -1)
+    for b in range(N):
+        assert np.linalg.norm(xs[b] - g[f"x{b}"]) / np.linalg.norm(g[f"x{b}"]) < 1e-9
+    b0 = torch.tensor(g["b_root"], device="cuda")
+    bl = torch.tensor(np.concatenate([g[f"b{b}"] for b in range(N)]), device="cuda")
+    kkt.solve_compressed(b0, bl)
+    bt.sync()
+    assert np.linalg.norm(b0.cpu().numpy() - g["sol_root"]) / np.linalg.norm(g["sol_root"]) < 1e-8
+    sol = bl.cpu().numpy().reshape(N, -1)
+    for b in range(N):
+        assert np.linalg.norm(sol[b] - g[f"sol{b}"]) / np.linalg.norm(g[f"sol{b}"]) < 1e-8

@@ -1,0 +1,58 @@
+"""Host-side symbolic analysis (constrained AMD, head/tail split, scatter maps) — runs without a GPU."""
+import numpy as np
+import pytest
+
+import pips_ipmpp_amd as pa
+from oracle import oracle as orc
+from tests.util import Problem
+
+
+@pytest.mark.parametrize("n_i,rho", [(40, 0.1), (300, 0.03), (2000, 0.005)])
+def test_permutation_is_valid_and_respects_dual_constraint(n_i, rho):
+    prob = Problem(3, 1, n_i, n_i // 2, 6, 6, rho)
+    K = prob.blocks[0]["K"]
+    info = pa.symbolic_probe(K, n_i, prob.blocks[0]["Bt"], want_perm=True)
+    perm = info["perm"]
+    n = K.nrows
+    assert sorted(perm.tolist()) == list(range(n))
+    # every dual row is eliminated after all its primal neighbours (static-pivot safety)
+    pos = np.empty(n, dtype=np.int64)
+    pos[perm] = np.arange(n)
+    W = prob.blocks[0]["W"].to_scipy().tocsr()
+    for r in range(W.shape[0]):
+        cols = W.indices[W.indptr[r]:W.indptr[r + 1]]
+        assert pos[n_i + r] > pos[cols].max()
+    assert info["n_head"] + info["m"] == n
+    assert info["nnzL"] >= K.nnz - n
+
+
+def test_fill_not_worse_than_natural_order():
+    prob = Problem(9, 1, 600, 300, 4, 4, 0.02)
+    K = prob.blocks[0]["K"]
+    info = pa.symbolic_probe(K, 600, want_perm=True, force_n_head=K.nrows)
+    o_nat = orc.OracleLdl(prob.K_scipy(0))
+    o_amd = orc.OracleLdl(prob.K_scipy(0), perm=info["perm"])
+    assert o_amd.nnzL() <= o_nat.nnzL()
+    # with everything in the head the stored factor equals the exact symbolic count of the oracle
+    assert info["nnzL"] - K.nrows == o_amd.nnzL()
+
+
+def test_cut_override_and_padding():
+    prob = Problem(9, 1, 500, 250, 4, 4, 0.03)
+    K = prob.blocks[0]["K"]
+    all_tail = pa.symbolic_probe(K, 500, force_n_head=0)
+    assert all_tail["n_head"] == 0 and all_tail["m"] == K.nrows and all_tail["ntc"] == (K.nrows + 127) // 128
+    all_head = pa.symbolic_probe(K, 500, force_n_head=K.nrows)
+    assert all_head["m"] == 0 and all_head["ntc"] == 0
+
+
+def test_unconstrained_ordering_without_hint():
+    prob = Problem(9, 1, 300, 150, 4, 4, 0.03)
+    info = pa.symbolic_probe(prob.blocks[0]["K"], -1, want_perm=True)
+    assert sorted(info["perm"].tolist()) == list(range(450))
+
+
+def test_rejects_upper_triangular_input():
+    K = pa.Csr(2, 2, [0, 2, 3], [0, 1, 1], [1.0, 2.0, 3.0])
+    with pytest.raises(pa.capi.PipsHipError):
+        pa.symbolic_probe(K)
