@@ -42,6 +42,18 @@ def update_kernel_algorithmic_flops(m, nb):
     return fl
 
 
+def update_kernel_traffic(n_blocks, n_i, S, world):
+    """HBM bytes of the update kernel per factorize from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes over this very command, FETCH_SIZE doubled per MI355X_MICROARCH.md); only valid for the profiled workload."""
+    path = os.path.join(ROOT, "profiles", "r1_bench_update_traffic.json")
+    if world != 1 or n_blocks != 64 or n_i != 10000 or S != 2000 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["hbm_bytes_per_factorize"]
+    except Exception:
+        return None
+
+
 def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
     S = n0 + myl
     bt = pa.LeafBatch(len(blocks), S, device=device)
@@ -56,6 +68,8 @@ def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
         vals.append(K.val)
         diags.append(diag)
     bt.analyze(min(16, os.cpu_count() or 8))
+    # PARDISO-style adaptive iterative refinement (iparm[7]=2 in the reference): up to 2 steps, stop at 1e-10 relative residual
+    bt.set_refinement(2, 1e-10)
     for i in range(len(blocks)):
         bt.set_values(i, vals[i])
     return bt, np.concatenate(diags)
@@ -206,7 +220,7 @@ def main():
     roofline = {
         "kernel": "k_tile_gemm<0> (tail update, v_mfma_f64_4x4x4_4b_f64)", "bound": "mfma", "achieved": round(achieved, 2),
         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
-        "traffic": None, "launches_per_factorize": upd_launches, "ms_per_factorize": round(upd_ms, 3),
+        "traffic": update_kernel_traffic(n_blocks_total, n_i, S, world), "launches_per_factorize": upd_launches, "ms_per_factorize": round(upd_ms, 3),
         "algorithmic_flops_per_factorize": alg_flops,
         "phase_ms": {k: round(v[0], 3) for k, v in tm.items()},
     }

@@ -32,8 +32,9 @@ int pips_hip_ldl_create(void** handle, int n, const int* krow, const int* jcol, 
 int pips_hip_ldl_set_inertia_hint(void* handle, int n_primal);
 /* relative pivot threshold / replacement (times max|K|); PARDISO's counterpart is the 1e-8 pivot perturbation */
 int pips_hip_ldl_set_pivot_rule(void* handle, double thr_rel, double repl_rel);
-/* iterative-refinement steps applied by every solve (PardisoProjectSolver.C:72 uses iparm[7]=2) */
-int pips_hip_ldl_set_refinement(void* handle, int steps);
+/* iterative refinement of every solve: at most max_steps steps; tol > 0 stops as soon as ||r||inf <= tol*||rhs||inf
+ * (PARDISO: iparm[7]=2, PardisoProjectSolver.C:72), tol = 0 always does max_steps steps.  Default (1, 0). */
+int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol);
 /* symbolic phase (ordering, supernodes, device allocation); pattern-only, done once */
 int pips_hip_ldl_analyze(void* handle);
 /* = DoubleLinearSolver::matrixChanged(): numeric LDL^T of the current values (host array of length nnz, CSR order) */
@@ -79,6 +80,10 @@ int pips_hip_batch_create(void** handle, int n_blocks, int S, int device, void* 
 int pips_hip_batch_set_block(void* handle, int b, int n, int n_primal, const int* K_rowptr, const int* K_colidx,
                              const int* Bt_rowptr, const int* Bt_colidx, const double* Bt_val);
 int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps, double thr_rel, double repl_rel);
+/* iterative refinement policy of pips_hip_batch_solve* (see pips_hip_ldl_set_refinement); default (1, 0) */
+int pips_hip_batch_set_refinement(void* handle, int max_steps, double tol);
+/* refinement steps the last solve actually took */
+int pips_hip_batch_last_refinement_steps(void* handle);
 /* symbolic phase for all blocks (n_threads host threads) + device setup */
 int pips_hip_batch_analyze(void* handle, int n_threads);
 /* upload all values of K_b (CSR order, host) — needed once; afterwards only diagonals change (a2) */
@@ -149,6 +154,55 @@ int pips_hip_comm_unique_id(void* id128);                 /* 128-byte ncclUnique
 int pips_hip_comm_create(void** comm, const void* id128, int n_ranks, int rank, int device);
 int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
 void pips_hip_comm_destroy(void* comm);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 4b. Flat-arena vector kernels: DistributedVector<T>/DenseVector<T> operations used around the path
+ *     (DistributedVector.C:406-460,1160-1340; DenseVector.cpp:281-516).  n = arena length; skip_root = number of leading
+ *     (replicated root) entries a non-special rank must not count in sums (iAmSpecial, DistributedVector.C:1293-1303).
+ *     Reductions return one host scalar (the caller all-reduces it across ranks where the reference does).
+ * ------------------------------------------------------------------------------------------------------------- */
+int pips_hip_vec_axpy(long long n, double a, const double* x_dev, double* y_dev, void* stream);           /* add            */
+int pips_hip_vec_axpby(long long n, double a, const double* x_dev, double b, double* y_dev, void* stream);
+int pips_hip_vec_scale(long long n, double a, double* y_dev, void* stream);                               /* scale / negate */
+int pips_hip_vec_copy(long long n, const double* x_dev, double* y_dev, void* stream);                     /* copyFrom       */
+int pips_hip_vec_set(long long n, double a, double* y_dev, void* stream);                                 /* setToConstant  */
+int pips_hip_vec_add_const(long long n, double a, double* y_dev, void* stream);                           /* add_constant   */
+int pips_hip_vec_mul(long long n, const double* x_dev, double* y_dev, void* stream);                      /* componentMult  */
+int pips_hip_vec_div(long long n, const double* x_dev, double* y_dev, void* stream);                      /* componentDiv   */
+int pips_hip_vec_add_product(long long n, double a, const double* x_dev, const double* z_dev, double* y_dev, void* stream);
+int pips_hip_vec_add_quotient(long long n, double a, const double* x_dev, const double* z_dev, const double* mask_dev,
+                              double* y_dev, void* stream);
+int pips_hip_vec_divide_some(long long n, const double* x_dev, const double* mask_dev, double* y_dev, void* stream);
+int pips_hip_vec_select_nonzeros(long long n, const double* mask_dev, double* y_dev, void* stream);
+int pips_hip_vec_safe_invert(long long n, double* y_dev, void* stream);
+int pips_hip_vec_dot(long long n, long long skip_root, const double* x_dev, const double* y_dev, double* result, void* stream);
+int pips_hip_vec_one_norm(long long n, long long skip_root, const double* x_dev, double* result, void* stream);
+int pips_hip_vec_inf_norm(long long n, const double* x_dev, double* result, void* stream);
+int pips_hip_vec_min(long long n, const double* x_dev, double* result, void* stream);
+/* two_norm = s*sqrt(sum (x/s)^2) with s = inf_norm (DistributedVector.C:424-437): returns sum (x*scale_inv)^2 */
+int pips_hip_vec_sumsq_scaled(long long n, long long skip_root, double scale_inv, const double* x_dev, double* result, void* stream);
+/* min over {dx_i < 0, mask_i != 0} of -x_i/dx_i (fraction_to_boundary / stepbound, Variables.C:191-225) */
+int pips_hip_vec_stepbound(long long n, const double* x_dev, const double* dx_dev, const double* mask_dev, double* result, void* stream);
+/* sum (x + a dx)(y + b dy)  (mustep_pd, Variables.C:109) */
+int pips_hip_vec_dot_shifted(long long n, long long skip_root, const double* x_dev, double a, const double* dx_dev,
+                             const double* y_dev, double b, const double* dy_dev, double* result, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 4c. Host harness: Mehrotra predictor-corrector IPM for  min c^T x, A x = b, x >= 0  with block-angular A, driving the
+ *     fused KKT path (counterpart of PIPSIPMppSolver::solve / InteriorPointMethod / LinearSystem::solve /
+ *     Residuals::evaluate for this problem class).  Single rank.
+ *     Block data are concatenated: W/T/F rowptr arrays hold N block-local row pointers (each starting at 0) back to back.
+ *     x order [x_0 | x_1 .. x_N], b/y order [linking rows | block 1 rows .. block N rows].
+ * ------------------------------------------------------------------------------------------------------------- */
+int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const int* my_i, const int* W_rowptr,
+                    const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
+                    const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
+                    const double* F0_val, const double* c, const double* b, double dual_reg, int device);
+/* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown)
+ * [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
+int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7);
+int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
+void pips_ipm_destroy(void* handle);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 5. Host harness helpers (no GPU needed): synthetic arrowhead LP of SURVEY.md §8d, leaf KKT / border assembly.

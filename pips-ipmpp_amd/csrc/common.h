@@ -93,8 +93,8 @@ struct AnalyzeOptions {
    int max_sn_width = 32;     // head supernode width cap
    int min_tail = 256;        // do not open a dense tail smaller than this
    int force_n_head = -1;     // >=0: override the cost model (tests)
-   double head_cost = 1.0e-11;  // seconds per scattered update entry (cost model)
-   double mfma_rate = 4.0e13;   // sustained dense FP64 flop/s (cost model)
+   double head_cost = 8.0e-11;  // seconds per scattered update entry (cost model; measured optimum on MI355X, config 2)
+   double mfma_rate = 5.0e13;   // sustained dense FP64 flop/s of the tile kernels (cost model)
 };
 
 // K: lower-triangular CSR pattern of K_i (n x n).  border: CSR with S rows (Schur column ids) over the n rows of K_i,

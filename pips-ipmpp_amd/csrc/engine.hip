@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -238,7 +239,11 @@ struct Engine {
    hipStream_t stream = nullptr;
    int nblk = 0, S = 0;
    bool analyzed = false, factored = false;
-   int refine_steps = 1;
+   int refine_steps = 1;       // maximum number of iterative-refinement steps per solve
+   double refine_tol = 0.0;    // > 0: stop as soon as max_b ||r_b||inf / ||rhs_b||inf <= tol (PARDISO-style adaptive refinement)
+   double* d_norms = nullptr;  // 2 * nblk
+   double* h_norms = nullptr;  // pinned
+   int last_refine_steps = 0;
    double thr_rel = 1e-13, repl_rel = 1e-8;
    AnalyzeOptions opt;
    std::vector<BlockInput> in;
@@ -265,12 +270,14 @@ struct Engine {
 
    ~Engine() { release(); }
    void release() {
-      void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_kdst, d_bdst, d_kdiag, d_kptr,
+      void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_sncol, d_bmap, d_perm,
                       d_inertia, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
-      d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = d_pref = nullptr;
+      d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = d_pref = d_norms = nullptr;
+      if (h_norms) (void)hipHostFree(h_norms);
+      h_norms = nullptr;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_rowidx = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
@@ -311,6 +318,8 @@ struct Engine {
          if (in[b].n <= 0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_analyze: block %d was never set", b);
       opt.tile = TILE;
       opt.max_sn_width = HEAD_WMAX;
+      if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);   // cost-model tuning knob (seconds per scattered update)
+      if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
       int rc = analyze_host(n_threads);
       if (rc) return rc;
       HIP_TRY(hipSetDevice(device));
@@ -442,6 +451,8 @@ struct Engine {
       HIP_TRY(hipMalloc((void**)&d_rhs, std::max<long long>(n_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_res, std::max<long long>(n_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_stage, std::max<long long>(n_total, 1) * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_norms, (size_t)2 * nblk * sizeof(double)));
+      HIP_TRY(hipHostMalloc((void**)&h_norms, (size_t)2 * nblk * sizeof(double), hipHostMallocDefault));
       HIP_TRY(hipMalloc((void**)&d_inertia, (size_t)3 * nblk * sizeof(int)));
       HIP_TRY(hipMemset(d_inertia, 0, (size_t)3 * nblk * sizeof(int)));
       if ((rc = dev_upload(&d_bval, h_bval, stream))) return rc;
@@ -541,22 +552,36 @@ struct Engine {
       return PIPS_OK;
    }
 
-   // x := K^-1 x with refine_steps steps of iterative refinement against the CSR values on the device
+   // x := K^-1 x with up to refine_steps steps of iterative refinement against the CSR values on the device.
+   // refine_tol > 0 makes it adaptive like PARDISO's iparm[7] (PardisoProjectSolver.C:72): after every solve the residual
+   // is formed and the loop stops once max_b ||r_b||inf / ||rhs_b||inf <= refine_tol (one small D2H copy + stream sync).
    int solve(double* x_dev) {
       if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
       HIP_TRY(hipSetDevice(device));
+      last_refine_steps = 0;
       if (refine_steps <= 0) return solve_once(x_dev);
       const size_t bytes = (size_t)n_total * sizeof(double);
       HIP_TRY(hipMemcpyAsync(d_rhs, x_dev, bytes, hipMemcpyDeviceToDevice, stream));
+      if (refine_tol > 0.0)
+         hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_rhs, d_blks, d_norms + nblk);
       int rc = solve_once(x_dev);
       if (rc) return rc;
       for (int it = 0; it < refine_steps; ++it) {
          HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
          hipLaunchKernelGGL(k_sym_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_krowptr, d_kcolidx, d_kval,
                             x_dev, d_res, n_total, d_rowbase);
+         if (refine_tol > 0.0) {
+            hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
+            HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)2 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            bool ok = true;
+            for (int b = 0; b < nblk && ok; ++b) ok = h_norms[b] <= refine_tol * h_norms[nblk + b] || h_norms[nblk + b] == 0.0;
+            if (ok) break;
+         }
          rc = solve_once(d_res);
          if (rc) return rc;
          hipLaunchKernelGGL(k_axpy, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, x_dev, d_res, 1.0, n_total);
+         ++last_refine_steps;
       }
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
@@ -747,6 +772,19 @@ int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps,
    return PIPS_OK;
 }
 
+int pips_hip_batch_set_refinement(void* handle, int max_steps, double tol) {
+   Engine* e = (Engine*)handle;
+   if (!e || max_steps < 0 || tol < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_batch_set_refinement: bad arguments");
+   e->refine_steps = max_steps;
+   e->refine_tol = tol;
+   return PIPS_OK;
+}
+
+int pips_hip_batch_last_refinement_steps(void* handle) {
+   Engine* e = (Engine*)handle;
+   return e ? e->last_refine_steps : -1;
+}
+
 int pips_hip_batch_analyze(void* handle, int n_threads) {
    Engine* e = (Engine*)handle;
    if (!e) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
@@ -932,10 +970,11 @@ int pips_hip_ldl_set_pivot_rule(void* handle, double thr_rel, double repl_rel) {
    return PIPS_OK;
 }
 
-int pips_hip_ldl_set_refinement(void* handle, int steps) {
+int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
-   h->eng.refine_steps = steps;
+   h->eng.refine_steps = max_steps;
+   h->eng.refine_tol = tol;
    return PIPS_OK;
 }
 

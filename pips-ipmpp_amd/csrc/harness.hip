@@ -1,0 +1,446 @@
+// Host harness: a Mehrotra predictor-corrector interior-point loop for the synthetic arrowhead LPs, driving the device
+// KKT path end to end.  This is the build's own counterpart of the reference callers that do not travel to the GPU box
+// (SURVEY.md §8 a18):
+//   PIPSIPMppSolver::solve            (InteriorPointMethod/PIPSIPMppSolver.cpp:29-83)   start point, loop, termination
+//   Solver::solve_linear_system       (InteriorPointMethod/Solver.cpp:19-31)            initial affine solve + shift
+//   InteriorPointMethod predictor/corrector (InteriorPointMethod.cpp:68-90,178-234)     sigma = (mu_aff/mu)^3
+//   LinearSystem::computeDiagonals / solve / solveXYZS (LinearSystem.C:262-294,327-447,449-548)  rhs reduction, recovery
+//   Residuals::evaluate / set_complementarity_residual (Residuals.cpp:58-171,220-256)
+// restricted to the problem class of the generator: min c^T x, A x = b, x >= 0 (ixlow = 1, no upper bounds, no
+// inequality rows), A block-angular.  Not reproduced: Gondzio correctors, Mehrotra's step-length heuristic, the filter
+// line search, the outer BiCGStab (the fused solveCompressed with iterative refinement is used directly).
+// Single rank.  Everything numeric runs on the device; the host sees scalars only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "pips_hip.h"
+
+// vector layer (vecops.hip)
+extern "C" {
+int pips_hip_vec_axpy(long long, double, const double*, double*, void*);
+int pips_hip_vec_copy(long long, const double*, double*, void*);
+int pips_hip_vec_set(long long, double, double*, void*);
+int pips_hip_vec_scale(long long, double, double*, void*);
+int pips_hip_vec_add_const(long long, double, double*, void*);
+int pips_hip_vec_mul(long long, const double*, double*, void*);
+int pips_hip_vec_div(long long, const double*, double*, void*);
+int pips_hip_vec_add_product(long long, double, const double*, const double*, double*, void*);
+int pips_hip_vec_add_quotient(long long, double, const double*, const double*, const double*, double*, void*);
+int pips_hip_vec_dot(long long, long long, const double*, const double*, double*, void*);
+int pips_hip_vec_inf_norm(long long, const double*, double*, void*);
+int pips_hip_vec_min(long long, const double*, double*, void*);
+int pips_hip_vec_stepbound(long long, const double*, const double*, const double*, double*, void*);
+int pips_hip_vec_dot_shifted(long long, long long, const double*, double, const double*, const double*, double, const double*,
+                             double*, void*);
+}
+
+namespace pips {
+
+#define HIP_TRYH(expr)                                                                                   \
+   do {                                                                                                  \
+      hipError_t _e = (expr);                                                                            \
+      if (_e != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+   } while (0)
+#define TRY(expr)                \
+   do {                          \
+      int _rc = (expr);          \
+      if (_rc) return _rc;       \
+   } while (0)
+
+// y = alpha * A x + beta * y, CSR, one thread per row (SparseStorage::mult, SparseStorage.C:818-845; the rows have ~10 entries)
+__global__ void k_csr_mult(int nrows, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                           const double* __restrict__ x, double alpha, double beta, double* __restrict__ y) {
+   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+      double s = 0.0;
+      for (int p = rp[r]; p < rp[r + 1]; ++p) s += v[p] * x[ci[p]];
+      y[r] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[r]);
+   }
+}
+
+// pack (rx, ry) into the KKT right-hand sides: b0 = [rx_0 | ry_link], leaf block i = [rx_i | ry_i]; unpack is the inverse
+__global__ void k_kkt_pack(int N, int n0, int myl, const int* __restrict__ xoff, const int* __restrict__ yoff,
+                           const long long* __restrict__ koff, const double* __restrict__ rx, const double* __restrict__ ry,
+                           double* __restrict__ b0, double* __restrict__ bl, int unpack) {
+   const int b = blockIdx.y;   // 0 = root, 1..N = leaves
+   const int nx = b == 0 ? n0 : xoff[b + 1] - xoff[b];
+   const int ny = b == 0 ? myl : yoff[b + 1] - yoff[b];
+   const int x0 = b == 0 ? 0 : xoff[b];
+   const int y0 = b == 0 ? 0 : yoff[b];
+   double* dst = b == 0 ? b0 : bl + koff[b];
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx + ny; i += gridDim.x * blockDim.x) {
+      double* vec = const_cast<double*>(i < nx ? rx + x0 + i : ry + y0 + (i - nx));
+      if (unpack) *vec = dst[i]; else dst[i] = *vec;
+   }
+}
+
+// K diagonals from the primal diagonal dd = gamma/v (computeDiagonals) and the dual regularisation (clear_dual_equality_diagonal)
+__global__ void k_leaf_diag(int N, const int* __restrict__ xoff, const int* __restrict__ yoff, const long long* __restrict__ koff,
+                            const double* __restrict__ dd, double dual_reg, double* __restrict__ leaf_diag) {
+   const int b = blockIdx.y + 1;
+   const int nx = xoff[b + 1] - xoff[b], ny = yoff[b + 1] - yoff[b];
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx + ny; i += gridDim.x * blockDim.x)
+      leaf_diag[koff[b] + i] = i < nx ? dd[xoff[b] + i] : -dual_reg;
+}
+
+struct Ipm {
+   int device = 0;
+   hipStream_t stream = nullptr;
+   int N = 0, n0 = 0, myl = 0, nx = 0, ny = 0;
+   long long nleaf = 0;
+   double dnorm = 1.0, dual_reg = 0.0;
+   void* batch = nullptr;
+   void* kkt = nullptr;
+   // global A (rows: [link | blocks], cols: [x0 | x_1..x_N]) and its transpose, CSR
+   int *A_rp = nullptr, *A_ci = nullptr, *At_rp = nullptr, *At_ci = nullptr, *d_xoff = nullptr, *d_yoff = nullptr;
+   long long* d_koff = nullptr;
+   double *A_v = nullptr, *At_v = nullptr;
+   // vectors
+   double *c = nullptr, *b = nullptr, *x = nullptr, *y = nullptr, *v = nullptr, *g = nullptr;
+   double *rQ = nullptr, *rA = nullptr, *rv = nullptr, *rg = nullptr, *dd = nullptr;
+   double *dx = nullptr, *dy = nullptr, *dv = nullptr, *dg = nullptr, *cx = nullptr, *cy = nullptr, *cv = nullptr, *cg = nullptr;
+   double *tx = nullptr, *ty = nullptr, *b0 = nullptr, *bl = nullptr, *leaf_diag = nullptr, *zx = nullptr, *zy = nullptr;
+   double *ex = nullptr, *ey = nullptr, *bx = nullptr, *by = nullptr;
+   int outer_max = 10, last_outer_steps = 0, total_outer_steps = 0;
+   double outer_tol = 1e-10, last_outer_res = 0.0;
+   std::vector<void*> owned;
+   double last[8] = {0};
+
+   ~Ipm() {
+      if (kkt) pips_hip_kkt_destroy(kkt);
+      if (batch) pips_hip_batch_destroy(batch);
+      for (void* p : owned)
+         if (p) (void)hipFree(p);
+   }
+   template <class T>
+   int up(T** d, const std::vector<T>& h) {
+      HIP_TRYH(hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * sizeof(T)));
+      owned.push_back(*d);
+      if (!h.empty()) HIP_TRYH(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+      return PIPS_OK;
+   }
+   int alloc(double** d, long long n) {
+      HIP_TRYH(hipMalloc((void**)d, std::max<long long>(n, 1) * sizeof(double)));
+      HIP_TRYH(hipMemset(*d, 0, std::max<long long>(n, 1) * sizeof(double)));
+      owned.push_back(*d);
+      return PIPS_OK;
+   }
+   void mult(const int* rp, const int* ci, const double* vals, int nrows, const double* xin, double alpha, double beta, double* yout) {
+      const int g = std::min(2048, (nrows + 255) / 256 > 0 ? (nrows + 255) / 256 : 1);
+      hipLaunchKernelGGL(k_csr_mult, dim3(g), dim3(256), 0, stream, nrows, rp, ci, vals, xin, alpha, beta, yout);
+   }
+   void Amult(const double* xin, double alpha, double beta, double* yout) { mult(A_rp, A_ci, A_v, ny, xin, alpha, beta, yout); }
+   void ATmult(const double* yin, double alpha, double beta, double* xout) { mult(At_rp, At_ci, At_v, nx, yin, alpha, beta, xout); }
+
+   // Residuals::evaluate for this problem class: rQ = c - A^T y - gamma, rA = A x - b, rv = x - v; returns the inf-norm
+   int residuals(double* rnorm, double* pobj, double* dobj) {
+      TRY(pips_hip_vec_copy(nx, c, rQ, stream));
+      ATmult(y, -1.0, 1.0, rQ);
+      TRY(pips_hip_vec_axpy(nx, -1.0, g, rQ, stream));
+      TRY(pips_hip_vec_copy(ny, b, rA, stream));
+      Amult(x, 1.0, -1.0, rA);
+      TRY(pips_hip_vec_copy(nx, x, rv, stream));
+      TRY(pips_hip_vec_axpy(nx, -1.0, v, rv, stream));
+      double a1, a2, a3;
+      TRY(pips_hip_vec_inf_norm(nx, rQ, &a1, stream));
+      TRY(pips_hip_vec_inf_norm(ny, rA, &a2, stream));
+      TRY(pips_hip_vec_inf_norm(nx, rv, &a3, stream));
+      *rnorm = std::max(a1, std::max(a2, a3));
+      TRY(pips_hip_vec_dot(nx, 0, c, x, pobj, stream));
+      TRY(pips_hip_vec_dot(ny, 0, b, y, dobj, stream));
+      return PIPS_OK;
+   }
+   int mu(double* out) {
+      double s;
+      TRY(pips_hip_vec_dot(nx, 0, v, g, &s, stream));
+      *out = s / nx;
+      return PIPS_OK;
+   }
+   // LinearSystem::factorize: dd = gamma / v, K diagonals, factor2 of the two-level system
+   int factorize() {
+      TRY(pips_hip_vec_copy(nx, g, dd, stream));
+      TRY(pips_hip_vec_div(nx, v, dd, stream));
+      hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, dual_reg, leaf_diag);
+      return pips_hip_kkt_factorize(kkt, leaf_diag, dd, nullptr);
+   }
+   // LinearSystem::solve + step.negate(): (sx, sy, sv, sg) := -solution for the residual set (rQ_, rA_, rv_, rg_)
+   int solve(const double* rQ_, const double* rA_, const double* rv_, const double* rg_, double* sx, double* sy, double* sv, double* sg) {
+      // rx = rQ + Gamma/V rv + rgamma/V ; ry = rA
+      TRY(pips_hip_vec_copy(nx, rQ_, tx, stream));
+      TRY(pips_hip_vec_add_product(nx, 1.0, dd, rv_, tx, stream));
+      TRY(pips_hip_vec_add_quotient(nx, 1.0, rg_, v, nullptr, tx, stream));
+      TRY(pips_hip_vec_copy(ny, rA_, ty, stream));
+      // outer iterative refinement on the ORIGINAL (unregularised) system [dd A^T; A 0], preconditioned by solveCompressed
+      // (LinearSystem::solveCompressedIterRefin, LinearSystem.C:877-966 = OUTER_SOLVE 1; the reference's default wraps the
+      // same preconditioner in BiCGStab, :550-798).  Stops at outer_tol * ||rhs||inf or after outer_max steps.
+      double bnorm_x, bnorm_y;
+      TRY(pips_hip_vec_inf_norm(nx, tx, &bnorm_x, stream));
+      TRY(pips_hip_vec_inf_norm(ny, ty, &bnorm_y, stream));
+      const double bnorm = std::max(std::max(bnorm_x, bnorm_y), 1e-300);
+      TRY(pips_hip_vec_set(nx, 0.0, sx, stream));
+      TRY(pips_hip_vec_set(ny, 0.0, sy, stream));
+      TRY(pips_hip_vec_copy(nx, tx, ex, stream));   // e = rhs - K * 0
+      TRY(pips_hip_vec_copy(ny, ty, ey, stream));
+      last_outer_steps = 0;
+      double best = INFINITY;
+      for (int it = 0; it <= outer_max; ++it) {
+         hipLaunchKernelGGL(k_kkt_pack, dim3(32, N + 1), dim3(256), 0, stream, N, n0, myl, d_xoff, d_yoff, d_koff, ex, ey, b0, bl, 0);
+         TRY(pips_hip_kkt_solve_compressed(kkt, b0, bl));
+         hipLaunchKernelGGL(k_kkt_pack, dim3(32, N + 1), dim3(256), 0, stream, N, n0, myl, d_xoff, d_yoff, d_koff, ex, ey, b0, bl, 1);
+         TRY(pips_hip_vec_axpy(nx, 1.0, ex, sx, stream));
+         TRY(pips_hip_vec_axpy(ny, 1.0, ey, sy, stream));
+         // e = rhs - [dd sx + A^T sy ; A sx]
+         TRY(pips_hip_vec_copy(nx, tx, ex, stream));
+         TRY(pips_hip_vec_add_product(nx, -1.0, dd, sx, ex, stream));
+         ATmult(sy, -1.0, 1.0, ex);
+         TRY(pips_hip_vec_copy(ny, ty, ey, stream));
+         Amult(sx, -1.0, 1.0, ey);
+         double e1, e2;
+         TRY(pips_hip_vec_inf_norm(nx, ex, &e1, stream));
+         TRY(pips_hip_vec_inf_norm(ny, ey, &e2, stream));
+         const double res = std::max(e1, e2) / bnorm;
+         if (!(res < best)) {
+            // the correction made things worse (preconditioner too inaccurate at this conditioning): keep the best iterate
+            TRY(pips_hip_vec_copy(nx, bx, sx, stream));
+            TRY(pips_hip_vec_copy(ny, by, sy, stream));
+            break;
+         }
+         best = res;
+         last_outer_res = res;
+         TRY(pips_hip_vec_copy(nx, sx, bx, stream));
+         TRY(pips_hip_vec_copy(ny, sy, by, stream));
+         if (res <= outer_tol) break;
+         ++last_outer_steps;
+      }
+      // solveXYZS: stepy.negate()
+      TRY(pips_hip_vec_scale(ny, -1.0, sy, stream));
+      // Dv = Dx - rv ; Dgamma = (rgamma - Gamma Dv) / V
+      TRY(pips_hip_vec_copy(nx, sx, sv, stream));
+      TRY(pips_hip_vec_axpy(nx, -1.0, rv_, sv, stream));
+      TRY(pips_hip_vec_copy(nx, rg_, sg, stream));
+      TRY(pips_hip_vec_add_product(nx, -1.0, g, sv, sg, stream));
+      TRY(pips_hip_vec_div(nx, v, sg, stream));
+      // step.negate()
+      TRY(pips_hip_vec_scale(nx, -1.0, sx, stream));
+      TRY(pips_hip_vec_scale(ny, -1.0, sy, stream));
+      TRY(pips_hip_vec_scale(nx, -1.0, sv, stream));
+      TRY(pips_hip_vec_scale(nx, -1.0, sg, stream));
+      return PIPS_OK;
+   }
+   int step_lengths(const double* sv, const double* sg, double tau, double* ap, double* ad) {
+      double bp, bd;
+      TRY(pips_hip_vec_stepbound(nx, v, sv, nullptr, &bp, stream));
+      TRY(pips_hip_vec_stepbound(nx, g, sg, nullptr, &bd, stream));
+      *ap = std::min(1.0, tau * bp);
+      *ad = std::min(1.0, tau * bd);
+      return PIPS_OK;
+   }
+
+   int run(int max_iter, double mutol, double artol, int verbose, double* result) {
+      HIP_TRYH(hipSetDevice(device));
+      // ---- start point: push_to_interior(sqrt(dnorm)), one affine solve, full step, shift (PIPSIPMppSolver.cpp:36-42, Solver.cpp:19-31)
+      const double s0 = std::sqrt(dnorm);
+      TRY(pips_hip_vec_set(nx, 0.0, x, stream));
+      TRY(pips_hip_vec_set(ny, 0.0, y, stream));
+      TRY(pips_hip_vec_set(nx, s0, v, stream));
+      TRY(pips_hip_vec_set(nx, s0, g, stream));
+      double rnorm, pobj, dobj, m;
+      TRY(residuals(&rnorm, &pobj, &dobj));
+      TRY(pips_hip_vec_copy(nx, v, rg, stream));
+      TRY(pips_hip_vec_mul(nx, g, rg, stream));
+      TRY(factorize());
+      TRY(solve(rQ, rA, rv, rg, dx, dy, dv, dg));
+      TRY(pips_hip_vec_axpy(nx, 1.0, dx, x, stream));
+      TRY(pips_hip_vec_axpy(ny, 1.0, dy, y, stream));
+      TRY(pips_hip_vec_axpy(nx, 1.0, dv, v, stream));
+      TRY(pips_hip_vec_axpy(nx, 1.0, dg, g, stream));
+      double vmin, gmin;
+      TRY(pips_hip_vec_min(nx, v, &vmin, stream));
+      TRY(pips_hip_vec_min(nx, g, &gmin, stream));
+      const double viol = std::max(0.0, std::max(-vmin, -gmin));
+      const double shift = 1e3 + 2.0 * viol;
+      TRY(pips_hip_vec_add_const(nx, shift, v, stream));
+      TRY(pips_hip_vec_add_const(nx, shift, g, stream));
+
+      int it = 0, status = 1;  // 1 = max iterations
+      for (; it < max_iter; ++it) {
+         TRY(residuals(&rnorm, &pobj, &dobj));
+         TRY(mu(&m));
+         if (verbose)
+            printf("ipm it %3d  mu %.3e  ||r||inf %.3e  pobj %.10e  dobj %.10e  (last solve: %d outer steps, res %.1e)\n", it, m, rnorm, pobj,
+                   dobj, last_outer_steps, last_outer_res);
+         if (!(m == m) || !(rnorm == rnorm)) { status = 2; break; }         // numerical breakdown (NaN)
+         if (m <= mutol && rnorm <= artol * dnorm) { status = 0; break; }   // PIPSIPMppSolver.cpp:143-149
+         // ---- predictor (affine scaling): rgamma = V Gamma e
+         TRY(pips_hip_vec_copy(nx, v, rg, stream));
+         TRY(pips_hip_vec_mul(nx, g, rg, stream));
+         TRY(factorize());
+         TRY(solve(rQ, rA, rv, rg, dx, dy, dv, dg));
+         double ap, ad;
+         TRY(step_lengths(dv, dg, 1.0, &ap, &ad));
+         double maff;
+         TRY(pips_hip_vec_dot_shifted(nx, 0, v, ap, dv, g, ad, dg, &maff, stream));
+         maff /= nx;
+         const double sigma = std::pow(maff / m, 3.0);
+         // ---- corrector: linear residuals cleared, rgamma = dV_aff dGamma_aff - sigma mu  (set_complementarity_residual(step, -sigma mu))
+         TRY(pips_hip_vec_copy(nx, dv, rg, stream));
+         TRY(pips_hip_vec_mul(nx, dg, rg, stream));
+         TRY(pips_hip_vec_add_const(nx, -sigma * m, rg, stream));
+         TRY(solve(zx, zy, zx, rg, cx, cy, cv, cg));   // zx / zy: constant zero vectors (clear_linear_residuals)
+         TRY(pips_hip_vec_axpy(nx, 1.0, cx, dx, stream));
+         TRY(pips_hip_vec_axpy(ny, 1.0, cy, dy, stream));
+         TRY(pips_hip_vec_axpy(nx, 1.0, cv, dv, stream));
+         TRY(pips_hip_vec_axpy(nx, 1.0, cg, dg, stream));
+         const double tau = std::max(0.99, 1.0 - m);
+         TRY(step_lengths(dv, dg, tau, &ap, &ad));
+         TRY(pips_hip_vec_axpy(nx, ap, dx, x, stream));
+         TRY(pips_hip_vec_axpy(nx, ap, dv, v, stream));
+         TRY(pips_hip_vec_axpy(ny, ad, dy, y, stream));
+         TRY(pips_hip_vec_axpy(nx, ad, dg, g, stream));
+      }
+      last[0] = pobj; last[1] = it; last[2] = m; last[3] = rnorm; last[4] = status; last[5] = dobj; last[6] = dnorm;
+      if (result)
+         for (int i = 0; i < 7; ++i) result[i] = last[i];
+      return PIPS_OK;
+   }
+};
+
+}  // namespace pips
+
+using namespace pips;
+
+extern "C" {
+
+int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const int* my_i, const int* W_rowptr,
+                    const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
+                    const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
+                    const double* F0_val, const double* c, const double* b, double dual_reg, int device) {
+   if (!handle || N <= 0 || n0 < 0 || myl < 0 || !n_i || !my_i) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_create: bad arguments");
+   auto p = std::make_unique<Ipm>();
+   p->N = N; p->n0 = n0; p->myl = myl; p->dual_reg = dual_reg;
+   std::vector<int> xoff(N + 2, 0), yoff(N + 2, 0);
+   std::vector<long long> koff(N + 2, 0);
+   xoff[1] = n0; yoff[1] = myl;
+   for (int i = 1; i <= N; ++i) {
+      xoff[i + 1] = xoff[i] + n_i[i - 1];
+      yoff[i + 1] = yoff[i] + my_i[i - 1];
+      koff[i + 1] = koff[i] + n_i[i - 1] + my_i[i - 1];
+   }
+   p->nx = xoff[N + 1]; p->ny = yoff[N + 1]; p->nleaf = koff[N + 1];
+   const int S = n0 + myl;
+   int rc = pips_hip_batch_create(&p->batch, N, S, device, nullptr);
+   if (rc) return rc;
+   // ---- per block: K_i pattern/values, border, and rows of the global A
+   std::vector<std::vector<std::pair<int, double>>> Arows(p->ny);
+   double dn = 0.0;
+   long long wp = 0, tp = 0, fp = 0;   // running offsets into the concatenated CSR arrays
+   long long wr = 0, tr = 0, fr = 0;   // running row-pointer offsets
+   std::vector<std::vector<double>> kvals(N);
+   for (int i = 0; i < N; ++i) {
+      const int nxi = n_i[i], myi = my_i[i];
+      const int* Wrp = W_rowptr + wr; const int* Trp = T_rowptr ? T_rowptr + tr : nullptr; const int* Frp = F_rowptr ? F_rowptr + fr : nullptr;
+      const int* Wci = W_colidx + wp; const double* Wv = W_val + wp;
+      const int* Tci = T_colidx ? T_colidx + tp : nullptr; const double* Tv = T_val ? T_val + tp : nullptr;
+      const int* Fci = F_colidx ? F_colidx + fp : nullptr; const double* Fv = F_val ? F_val + fp : nullptr;
+      std::vector<int> Krp(nxi + myi + 1), dpos(nxi + myi);
+      rc = pips_kkt_leaf_assemble(nxi, myi, 0, nullptr, nullptr, nullptr, Wrp, Wci, Wv, nullptr, nullptr, nullptr, Krp.data(), nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      std::vector<int> Kci(Krp[nxi + myi]);
+      kvals[i].assign(Krp[nxi + myi], 0.0);
+      rc = pips_kkt_leaf_assemble(nxi, myi, 0, nullptr, nullptr, nullptr, Wrp, Wci, Wv, nullptr, nullptr, nullptr, Krp.data(), Kci.data(), kvals[i].data(), dpos.data());
+      if (rc) return rc;
+      std::vector<int> Brp(S + 1);
+      rc = pips_border_assemble(nxi, myi, 0, n0, 0, myl, 0, nullptr, nullptr, nullptr, Trp, Tci, Tv, nullptr, nullptr, nullptr, Frp, Fci, Fv, nullptr, nullptr, nullptr, Brp.data(), nullptr, nullptr);
+      if (rc) return rc;
+      std::vector<int> Bci(Brp[S]);
+      std::vector<double> Bv(Brp[S]);
+      rc = pips_border_assemble(nxi, myi, 0, n0, 0, myl, 0, nullptr, nullptr, nullptr, Trp, Tci, Tv, nullptr, nullptr, nullptr, Frp, Fci, Fv, nullptr, nullptr, nullptr, Brp.data(), Bci.data(), Bv.data());
+      if (rc) return rc;
+      rc = pips_hip_batch_set_block(p->batch, i, nxi + myi, nxi, Krp.data(), Kci.data(), Brp.data(), Bci.data(), Bv.data());
+      if (rc) return rc;
+      for (int r = 0; r < myi; ++r) {
+         auto& row = Arows[yoff[i + 1] + r];
+         if (Trp) for (int q = Trp[r] - Trp[0]; q < Trp[r + 1] - Trp[0]; ++q) { row.push_back({Tci[q], Tv[q]}); dn = std::max(dn, std::fabs(Tv[q])); }
+         for (int q = Wrp[r] - Wrp[0]; q < Wrp[r + 1] - Wrp[0]; ++q) { row.push_back({xoff[i + 1] + Wci[q], Wv[q]}); dn = std::max(dn, std::fabs(Wv[q])); }
+      }
+      if (Frp)
+         for (int l = 0; l < myl; ++l)
+            for (int q = Frp[l] - Frp[0]; q < Frp[l + 1] - Frp[0]; ++q) { Arows[l].push_back({xoff[i + 1] + Fci[q], Fv[q]}); dn = std::max(dn, std::fabs(Fv[q])); }
+      wp += Wrp[myi] - Wrp[0]; wr += myi + 1;
+      if (Trp) { tp += Trp[myi] - Trp[0]; tr += myi + 1; }
+      if (Frp) { fp += Frp[myl] - Frp[0]; fr += myl + 1; }
+   }
+   if (F0_rowptr)
+      for (int l = 0; l < myl; ++l)
+         for (int q = F0_rowptr[l]; q < F0_rowptr[l + 1]; ++q) { Arows[l].push_back({F0_colidx[q], F0_val[q]}); dn = std::max(dn, std::fabs(F0_val[q])); }
+   for (int j = 0; j < p->nx; ++j) dn = std::max(dn, std::fabs(c[j]));
+   for (int r = 0; r < p->ny; ++r) dn = std::max(dn, std::fabs(b[r]));
+   p->dnorm = dn > 0 ? dn : 1.0;
+   // CSR of A and A^T
+   std::vector<int> Arp(p->ny + 1, 0), Atrp(p->nx + 1, 0);
+   for (int r = 0; r < p->ny; ++r) {
+      std::sort(Arows[r].begin(), Arows[r].end());
+      Arp[r + 1] = Arp[r] + (int)Arows[r].size();
+      for (auto& e : Arows[r]) ++Atrp[e.first + 1];
+   }
+   std::vector<int> Aci(Arp[p->ny]), Atci(Arp[p->ny]);
+   std::vector<double> Av(Arp[p->ny]), Atv(Arp[p->ny]);
+   for (int j = 0; j < p->nx; ++j) Atrp[j + 1] += Atrp[j];
+   {
+      std::vector<int> fill(Atrp.begin(), Atrp.end() - 1);
+      for (int r = 0; r < p->ny; ++r) {
+         int q = Arp[r];
+         for (auto& e : Arows[r]) {
+            Aci[q] = e.first; Av[q] = e.second; ++q;
+            const int t = fill[e.first]++;
+            Atci[t] = r; Atv[t] = e.second;
+         }
+      }
+   }
+   rc = pips_hip_batch_analyze(p->batch, 16);
+   if (rc) return rc;
+   for (int i = 0; i < N; ++i)
+      if ((rc = pips_hip_batch_set_values(p->batch, i, kvals[i].data()))) return rc;
+   if ((rc = pips_hip_batch_set_refinement(p->batch, 2, 1e-12))) return rc;
+   rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr, nullptr, nullptr, 0, 1);
+   if (rc) return rc;
+   HIP_TRYH(hipGetDevice(&p->device));
+   if ((rc = p->up(&p->A_rp, Arp)) || (rc = p->up(&p->A_ci, Aci)) || (rc = p->up(&p->A_v, Av)) || (rc = p->up(&p->At_rp, Atrp)) ||
+       (rc = p->up(&p->At_ci, Atci)) || (rc = p->up(&p->At_v, Atv)) || (rc = p->up(&p->d_xoff, xoff)) || (rc = p->up(&p->d_yoff, yoff)) ||
+       (rc = p->up(&p->d_koff, koff)))
+      return rc;
+   std::vector<double> hc(c, c + p->nx), hb(b, b + p->ny);
+   if ((rc = p->up(&p->c, hc)) || (rc = p->up(&p->b, hb))) return rc;
+   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx, &p->ex, &p->bx};
+   for (auto d : xs)
+      if ((rc = p->alloc(d, p->nx))) return rc;
+   double** ys[] = {&p->y, &p->rA, &p->dy, &p->cy, &p->ty, &p->zy, &p->ey, &p->by};
+   for (auto d : ys)
+      if ((rc = p->alloc(d, p->ny))) return rc;
+   if ((rc = p->alloc(&p->b0, S)) || (rc = p->alloc(&p->bl, p->nleaf)) || (rc = p->alloc(&p->leaf_diag, p->nleaf))) return rc;
+   *handle = p.release();
+   return PIPS_OK;
+}
+
+int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7) {
+   Ipm* p = (Ipm*)handle;
+   if (!p) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   return p->run(max_iter, mutol, artol, verbose, result7);
+}
+
+int pips_ipm_get_solution(void* handle, double* x_host, double* y_host) {
+   Ipm* p = (Ipm*)handle;
+   if (!p) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (x_host) HIP_TRYH(hipMemcpy(x_host, p->x, (size_t)p->nx * sizeof(double), hipMemcpyDeviceToHost));
+   if (y_host) HIP_TRYH(hipMemcpy(y_host, p->y, (size_t)p->ny * sizeof(double), hipMemcpyDeviceToHost));
+   return PIPS_OK;
+}
+
+void pips_ipm_destroy(void* handle) { delete (Ipm*)handle; }
+
+}  // extern "C"

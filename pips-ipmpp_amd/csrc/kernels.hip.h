@@ -113,6 +113,21 @@ __global__ void k_pref_tail(const BlkDesc* __restrict__ blks, const double* __re
    }
 }
 
+// out[b] = max |v| over the rows of block b (flat block-after-block vector); one workgroup per block
+__global__ void k_vec_block_absmax(const double* __restrict__ v, const BlkDesc* __restrict__ blks, double* __restrict__ out) {
+   const BlkDesc bd = blks[blockIdx.x];
+   double mx = 0.0;
+   for (int i = threadIdx.x; i < bd.n; i += blockDim.x) mx = fmax(mx, fabs(v[bd.x_off + i]));
+   __shared__ double red[256];
+   red[threadIdx.x] = mx;
+   __syncthreads();
+   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
 // max |K| per block -> fallback replacement magnitude
 __global__ void k_block_absmax(const double* __restrict__ kval, const long long* __restrict__ kptr, BlkDesc* blks,
                                double thr_rel, double repl_rel) {

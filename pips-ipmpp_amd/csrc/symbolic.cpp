@@ -73,8 +73,9 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       }
       double best = head[n];
       for (int k = 0; k <= n; ++k) {
-         const double m = n - k;
-         if (m < opt.min_tail) break;
+         if (n - k < opt.min_tail) break;
+         // the tail is processed in full tiles: price the padded dimension, so the cut lands just below a tile boundary
+         const double m = round_up(n - k, opt.tile);
          const double tail = (m * m * m / 3.0 + (double)nb * m * m + (double)nb * nb * m) / opt.mfma_rate;
          if (head[k] + tail < best) { best = head[k] + tail; n_head = k; }
       }

@@ -1,0 +1,249 @@
+// Flat-arena vector kernels: the DistributedVector<T> / DenseVector<T> operations the IPM uses around the KKT path
+// (LinearAlgebra/Distributed/DistributedVector.C:406-460,1160-1340; LinearAlgebra/Dense/DenseVector.cpp:281-516).
+// A vector tree {first, children...} is one contiguous device array (root part first, then the leaves of this rank);
+// element-wise kernels run over the whole arena in one launch, reductions are two-stage (per-workgroup partials, then
+// one workgroup) and return ONE scalar to the host — the reference does one MPI_Allreduce per reduction at the same
+// point (DistributedVector.C:421,456,1306).  Replicated root entries are counted once by giving `root_len` entries the
+// weight 0 on every rank but the "special" one (iAmSpecial, DistributedVector.C:1293-1303): pass count_root = 0 there.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "common.h"
+#include "pips_hip.h"
+
+namespace pips {
+
+#define HIP_TRYV(expr)                                                                                   \
+   do {                                                                                                  \
+      hipError_t _e = (expr);                                                                            \
+      if (_e != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+   } while (0)
+
+static inline int vgrid(long long n) {
+   long long g = (n + 255) / 256;
+   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+enum VecOp : int {
+   OP_AXPY = 0,      // y += a x
+   OP_SCALE,         // y *= a
+   OP_COPY,          // y = x
+   OP_SET,           // y = a
+   OP_MUL,           // y *= x             (componentMult)
+   OP_DIV,           // y /= x             (componentDiv)
+   OP_ADD_PRODUCT,   // y += a x z         (add_product)
+   OP_ADD_QUOTIENT,  // y += a x / z  where mask != 0   (add_quotient with index vector)
+   OP_DIVIDE_SOME,   // y /= x where mask != 0          (divideSome)
+   OP_SELECT,        // y = mask != 0 ? y : 0           (selectNonZeros)
+   OP_SAFE_INVERT,   // y = y != 0 ? 1/y : 0            (safe_invert)
+   OP_ADD_CONST,     // y += a
+   OP_AXPBY,         // y = a x + b y
+};
+
+__global__ void k_vec_op(int op, long long n, double a, double b, const double* __restrict__ x, const double* __restrict__ z,
+                         const double* __restrict__ mask, double* __restrict__ y) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+      const bool on = mask == nullptr || mask[i] != 0.0;
+      double v = y[i];
+      switch (op) {
+         case OP_AXPY: v += a * x[i]; break;
+         case OP_SCALE: v *= a; break;
+         case OP_COPY: v = x[i]; break;
+         case OP_SET: v = a; break;
+         case OP_MUL: v *= x[i]; break;
+         case OP_DIV: v /= x[i]; break;
+         case OP_ADD_PRODUCT: v += a * x[i] * z[i]; break;
+         case OP_ADD_QUOTIENT: if (on) v += a * x[i] / z[i]; break;
+         case OP_DIVIDE_SOME: if (on) v /= x[i]; break;
+         case OP_SELECT: if (!on) v = 0.0; break;
+         case OP_SAFE_INVERT: v = v != 0.0 ? 1.0 / v : 0.0; break;
+         case OP_ADD_CONST: v += a; break;
+         case OP_AXPBY: v = a * x[i] + b * v; break;
+      }
+      y[i] = v;
+   }
+}
+
+enum RedOp : int {
+   RED_DOT = 0,     // sum x y
+   RED_SUM_ABS,     // sum |x|            (one_norm)
+   RED_MAX_ABS,     // max |x|            (inf_norm)
+   RED_SUMSQ_SCALED,// sum (x/s)^2        (two_norm = s sqrt(.), s = inf_norm; DistributedVector.C:424-437)
+   RED_MIN,         // min x
+   RED_STEPBOUND,   // min over {i : dx_i < 0, mask_i != 0} of -x_i/dx_i      (fraction_to_boundary / stepbound, Variables.C:191-225)
+   RED_DOT_SHIFTED, // sum (x + a dx)(y + b dy)                                (mustep_pd, Variables.C:109)
+};
+
+__device__ __forceinline__ double red_combine(int op, double u, double v) {
+   switch (op) {
+      case RED_MAX_ABS: return fmax(u, v);
+      case RED_MIN:
+      case RED_STEPBOUND: return fmin(u, v);
+      default: return u + v;
+   }
+}
+
+__device__ __forceinline__ double red_identity(int op) {
+   switch (op) {
+      case RED_MIN:
+      case RED_STEPBOUND: return INFINITY;
+      default: return 0.0;
+   }
+}
+
+// skip: the first `skip` entries (replicated root part) are ignored on non-special ranks
+__global__ void k_vec_reduce(int op, long long n, long long skip, double a, double b, const double* __restrict__ x,
+                             const double* __restrict__ y, const double* __restrict__ dx, const double* __restrict__ dy,
+                             const double* __restrict__ mask, double* __restrict__ partial) {
+   double acc = red_identity(op);
+   for (long long i = skip + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+      double t;
+      switch (op) {
+         case RED_DOT: t = x[i] * y[i]; break;
+         case RED_SUM_ABS: t = fabs(x[i]); break;
+         case RED_MAX_ABS: t = fabs(x[i]); break;
+         case RED_SUMSQ_SCALED: { const double q = x[i] * a; t = q * q; break; }
+         case RED_MIN: t = x[i]; break;
+         case RED_STEPBOUND: t = (dx[i] < 0.0 && (mask == nullptr || mask[i] != 0.0)) ? -x[i] / dx[i] : INFINITY; break;
+         default: t = (x[i] + a * dx[i]) * (y[i] + b * dy[i]); break;
+      }
+      acc = red_combine(op, acc, t);
+   }
+   __shared__ double red[256];
+   red[threadIdx.x] = acc;
+   __syncthreads();
+   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = red_combine(op, red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void k_vec_reduce_final(int op, int n, const double* __restrict__ partial, double* __restrict__ out) {
+   double acc = red_identity(op);
+   for (int i = threadIdx.x; i < n; i += blockDim.x) acc = red_combine(op, acc, partial[i]);
+   __shared__ double red[256];
+   red[threadIdx.x] = acc;
+   __syncthreads();
+   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] = red_combine(op, red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) out[0] = red[0];
+}
+
+static double red_identity_host(int op) { return (op == RED_MIN || op == RED_STEPBOUND) ? INFINITY : 0.0; }
+
+struct VecWorkspace {
+   double* d_partial = nullptr;  // 2048 partials + 8 result slots
+   double* h_out = nullptr;      // pinned
+   int init() {
+      if (d_partial) return PIPS_OK;
+      HIP_TRYV(hipMalloc((void**)&d_partial, (2048 + 8) * sizeof(double)));
+      HIP_TRYV(hipHostMalloc((void**)&h_out, 8 * sizeof(double), hipHostMallocDefault));
+      return PIPS_OK;
+   }
+};
+static thread_local VecWorkspace g_ws;
+
+int vec_apply(int op, long long n, double a, double b, const double* x, const double* z, const double* mask, double* y,
+              hipStream_t s) {
+   if (n <= 0) return PIPS_OK;
+   hipLaunchKernelGGL(k_vec_op, dim3(vgrid(n)), dim3(256), 0, s, op, n, a, b, x, z, mask, y);
+   HIP_TRYV(hipGetLastError());
+   return PIPS_OK;
+}
+
+int vec_reduce(int op, long long n, long long skip, double a, double b, const double* x, const double* y, const double* dx,
+               const double* dy, const double* mask, double* result, hipStream_t s) {
+   int rc = g_ws.init();
+   if (rc) return rc;
+   if (n - skip <= 0) {
+      *result = red_identity_host(op);
+      return PIPS_OK;
+   }
+   const int g = vgrid(n - skip);
+   hipLaunchKernelGGL(k_vec_reduce, dim3(g), dim3(256), 0, s, op, n, skip, a, b, x, y, dx, dy, mask, g_ws.d_partial);
+   hipLaunchKernelGGL(k_vec_reduce_final, dim3(1), dim3(256), 0, s, op, g, g_ws.d_partial, g_ws.d_partial + 2048);
+   HIP_TRYV(hipMemcpyAsync(g_ws.h_out, g_ws.d_partial + 2048, sizeof(double), hipMemcpyDeviceToHost, s));
+   HIP_TRYV(hipStreamSynchronize(s));
+   *result = g_ws.h_out[0];
+   return PIPS_OK;
+}
+
+}  // namespace pips
+
+using namespace pips;
+
+extern "C" {
+
+int pips_hip_vec_axpy(long long n, double a, const double* x_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_AXPY, n, a, 0, x_dev, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_axpby(long long n, double a, const double* x_dev, double b, double* y_dev, void* stream) {
+   return vec_apply(OP_AXPBY, n, a, b, x_dev, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_scale(long long n, double a, double* y_dev, void* stream) {
+   return vec_apply(OP_SCALE, n, a, 0, nullptr, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_copy(long long n, const double* x_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_COPY, n, 0, 0, x_dev, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_set(long long n, double a, double* y_dev, void* stream) {
+   return vec_apply(OP_SET, n, a, 0, nullptr, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_add_const(long long n, double a, double* y_dev, void* stream) {
+   return vec_apply(OP_ADD_CONST, n, a, 0, nullptr, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_mul(long long n, const double* x_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_MUL, n, 0, 0, x_dev, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_div(long long n, const double* x_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_DIV, n, 0, 0, x_dev, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_add_product(long long n, double a, const double* x_dev, const double* z_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_ADD_PRODUCT, n, a, 0, x_dev, z_dev, nullptr, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_add_quotient(long long n, double a, const double* x_dev, const double* z_dev, const double* mask_dev,
+                              double* y_dev, void* stream) {
+   return vec_apply(OP_ADD_QUOTIENT, n, a, 0, x_dev, z_dev, mask_dev, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_divide_some(long long n, const double* x_dev, const double* mask_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_DIVIDE_SOME, n, 0, 0, x_dev, nullptr, mask_dev, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_select_nonzeros(long long n, const double* mask_dev, double* y_dev, void* stream) {
+   return vec_apply(OP_SELECT, n, 0, 0, nullptr, nullptr, mask_dev, y_dev, (hipStream_t)stream);
+}
+int pips_hip_vec_safe_invert(long long n, double* y_dev, void* stream) {
+   return vec_apply(OP_SAFE_INVERT, n, 0, 0, nullptr, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+
+int pips_hip_vec_dot(long long n, long long skip_root, const double* x_dev, const double* y_dev, double* result, void* stream) {
+   return vec_reduce(RED_DOT, n, skip_root, 0, 0, x_dev, y_dev, nullptr, nullptr, nullptr, result, (hipStream_t)stream);
+}
+int pips_hip_vec_one_norm(long long n, long long skip_root, const double* x_dev, double* result, void* stream) {
+   return vec_reduce(RED_SUM_ABS, n, skip_root, 0, 0, x_dev, nullptr, nullptr, nullptr, nullptr, result, (hipStream_t)stream);
+}
+int pips_hip_vec_inf_norm(long long n, const double* x_dev, double* result, void* stream) {
+   return vec_reduce(RED_MAX_ABS, n, 0, 0, 0, x_dev, nullptr, nullptr, nullptr, nullptr, result, (hipStream_t)stream);
+}
+int pips_hip_vec_min(long long n, const double* x_dev, double* result, void* stream) {
+   return vec_reduce(RED_MIN, n, 0, 0, 0, x_dev, nullptr, nullptr, nullptr, nullptr, result, (hipStream_t)stream);
+}
+/* two_norm = s * sqrt(sum (x/s)^2), s = inf_norm (DistributedVector.C:424-437): scale_inv = 1/s from a previous inf_norm
+ * (combined across ranks by the caller); returns the local sum of squares of the scaled entries */
+int pips_hip_vec_sumsq_scaled(long long n, long long skip_root, double scale_inv, const double* x_dev, double* result, void* stream) {
+   return vec_reduce(RED_SUMSQ_SCALED, n, skip_root, scale_inv, 0, x_dev, nullptr, nullptr, nullptr, nullptr, result, (hipStream_t)stream);
+}
+/* largest alpha in (0, +inf] with x + alpha dx >= 0 on the masked entries (min ratio test) */
+int pips_hip_vec_stepbound(long long n, const double* x_dev, const double* dx_dev, const double* mask_dev, double* result, void* stream) {
+   return vec_reduce(RED_STEPBOUND, n, 0, 0, 0, x_dev, nullptr, dx_dev, nullptr, mask_dev, result, (hipStream_t)stream);
+}
+/* sum (x + a dx)(y + b dy)  (complementarity after a trial step) */
+int pips_hip_vec_dot_shifted(long long n, long long skip_root, const double* x_dev, double a, const double* dx_dev,
+                             const double* y_dev, double b, const double* dy_dev, double* result, void* stream) {
+   return vec_reduce(RED_DOT_SHIFTED, n, skip_root, a, b, x_dev, y_dev, dx_dev, dy_dev, nullptr, result, (hipStream_t)stream);
+}
+
+}  // extern "C"

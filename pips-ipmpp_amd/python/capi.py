@@ -49,7 +49,8 @@ SYMBOLS = [
     "pips_hip_ldl_get_perm", "pips_hip_ldl_destroy",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
     "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_destroy",
-    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_analyze",
+    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_refinement",
+    "pips_hip_batch_last_refinement_steps", "pips_hip_batch_analyze",
     "pips_hip_batch_set_values", "pips_hip_batch_set_diagonals_dev", "pips_hip_batch_set_diagonals", "pips_hip_batch_factor",
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
@@ -58,6 +59,11 @@ SYMBOLS = [
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
+    "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
+    "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
+    "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_dot",
+    "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
+    "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_get_solution", "pips_ipm_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
 ]
@@ -223,7 +229,7 @@ class HipLdlSolver:
     SparseSymmetricMatrix (PardisoSolver.h:49-50): mutate `K.val` in place, then call matrixChanged().
     """
 
-    def __init__(self, K, n_primal=-1, device=-1, refine_steps=1):
+    def __init__(self, K, n_primal=-1, device=-1, refine_steps=1, refine_tol=0.0):
         self.K = K
         self.n = K.nrows
         self._h = C.c_void_p()
@@ -231,7 +237,8 @@ class HipLdlSolver:
                                        C.c_int(0)), "pips_hip_ldl_create")
         if n_primal >= 0:
             _check(lib.pips_hip_ldl_set_inertia_hint(self._h, C.c_int(n_primal)), "pips_hip_ldl_set_inertia_hint")
-        _check(lib.pips_hip_ldl_set_refinement(self._h, C.c_int(refine_steps)), "pips_hip_ldl_set_refinement")
+        _check(lib.pips_hip_ldl_set_refinement(self._h, C.c_int(refine_steps), C.c_double(refine_tol)),
+               "pips_hip_ldl_set_refinement")
 
     def set_pivot_rule(self, thr_rel, repl_rel):
         _check(lib.pips_hip_ldl_set_pivot_rule(self._h, C.c_double(thr_rel), C.c_double(repl_rel)), "set_pivot_rule")
@@ -344,6 +351,13 @@ class LeafBatch:
     def set_options(self, force_n_head=-1, refine_steps=-1, thr_rel=-1.0, repl_rel=-1.0):
         _check(lib.pips_hip_batch_set_options(self._h, C.c_int(force_n_head), C.c_int(refine_steps), C.c_double(thr_rel),
                                               C.c_double(repl_rel)), "pips_hip_batch_set_options")
+
+    def set_refinement(self, max_steps, tol):
+        """tol > 0: adaptive (stop once ||r||inf <= tol ||rhs||inf, at most max_steps steps); tol = 0: always max_steps."""
+        _check(lib.pips_hip_batch_set_refinement(self._h, C.c_int(max_steps), C.c_double(tol)), "pips_hip_batch_set_refinement")
+
+    def last_refinement_steps(self):
+        return int(lib.pips_hip_batch_last_refinement_steps(self._h))
 
     def analyze(self, n_threads=8):
         _check(lib.pips_hip_batch_analyze(self._h, C.c_int(n_threads)), "pips_hip_batch_analyze")
@@ -478,6 +492,153 @@ class KktSystem:
     def close(self):
         if self._h:
             lib.pips_hip_kkt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# flat-arena vector kernels (DistributedVector / DenseVector operations) on torch CUDA tensors
+# ----------------------------------------------------------------------------------------------------------------------
+class vec:
+    """Thin wrappers: every function takes float64 CUDA tensors of equal length and works in place on `y`."""
+
+    @staticmethod
+    def _n(t):
+        return C.c_longlong(t.numel())
+
+    @staticmethod
+    def axpy(a, x, y):
+        _check(lib.pips_hip_vec_axpy(vec._n(y), C.c_double(a), _ptr(x), _ptr(y), None), "vec_axpy")
+
+    @staticmethod
+    def axpby(a, x, b, y):
+        _check(lib.pips_hip_vec_axpby(vec._n(y), C.c_double(a), _ptr(x), C.c_double(b), _ptr(y), None), "vec_axpby")
+
+    @staticmethod
+    def scale(a, y):
+        _check(lib.pips_hip_vec_scale(vec._n(y), C.c_double(a), _ptr(y), None), "vec_scale")
+
+    @staticmethod
+    def add_const(a, y):
+        _check(lib.pips_hip_vec_add_const(vec._n(y), C.c_double(a), _ptr(y), None), "vec_add_const")
+
+    @staticmethod
+    def mul(x, y):
+        _check(lib.pips_hip_vec_mul(vec._n(y), _ptr(x), _ptr(y), None), "vec_mul")
+
+    @staticmethod
+    def div(x, y):
+        _check(lib.pips_hip_vec_div(vec._n(y), _ptr(x), _ptr(y), None), "vec_div")
+
+    @staticmethod
+    def add_product(a, x, z, y):
+        _check(lib.pips_hip_vec_add_product(vec._n(y), C.c_double(a), _ptr(x), _ptr(z), _ptr(y), None), "vec_add_product")
+
+    @staticmethod
+    def add_quotient(a, x, z, mask, y):
+        _check(lib.pips_hip_vec_add_quotient(vec._n(y), C.c_double(a), _ptr(x), _ptr(z), _ptr(mask), _ptr(y), None),
+               "vec_add_quotient")
+
+    @staticmethod
+    def divide_some(x, mask, y):
+        _check(lib.pips_hip_vec_divide_some(vec._n(y), _ptr(x), _ptr(mask), _ptr(y), None), "vec_divide_some")
+
+    @staticmethod
+    def select_nonzeros(mask, y):
+        _check(lib.pips_hip_vec_select_nonzeros(vec._n(y), _ptr(mask), _ptr(y), None), "vec_select_nonzeros")
+
+    @staticmethod
+    def safe_invert(y):
+        _check(lib.pips_hip_vec_safe_invert(vec._n(y), _ptr(y), None), "vec_safe_invert")
+
+    @staticmethod
+    def _red(fn, *args):
+        out = C.c_double()
+        _check(fn(*args, C.byref(out), None), fn.__name__)
+        return out.value
+
+    @staticmethod
+    def dot(x, y, skip_root=0):
+        return vec._red(lib.pips_hip_vec_dot, vec._n(x), C.c_longlong(skip_root), _ptr(x), _ptr(y))
+
+    @staticmethod
+    def one_norm(x, skip_root=0):
+        return vec._red(lib.pips_hip_vec_one_norm, vec._n(x), C.c_longlong(skip_root), _ptr(x))
+
+    @staticmethod
+    def inf_norm(x):
+        return vec._red(lib.pips_hip_vec_inf_norm, vec._n(x), _ptr(x))
+
+    @staticmethod
+    def min(x):
+        return vec._red(lib.pips_hip_vec_min, vec._n(x), _ptr(x))
+
+    @staticmethod
+    def two_norm(x):
+        """DistributedVector::two_norm (DistributedVector.C:424-437): s * sqrt(sum (x/s)^2), s = inf_norm."""
+        s = vec.inf_norm(x)
+        if s == 0.0:
+            return 0.0
+        q = vec._red(lib.pips_hip_vec_sumsq_scaled, vec._n(x), C.c_longlong(0), C.c_double(1.0 / s), _ptr(x))
+        return s * q ** 0.5
+
+    @staticmethod
+    def stepbound(x, dx, mask=None):
+        return vec._red(lib.pips_hip_vec_stepbound, vec._n(x), _ptr(x), _ptr(dx), _ptr(mask))
+
+    @staticmethod
+    def dot_shifted(x, a, dx, y, b, dy, skip_root=0):
+        return vec._red(lib.pips_hip_vec_dot_shifted, vec._n(x), C.c_longlong(skip_root), _ptr(x), C.c_double(a), _ptr(dx),
+                        _ptr(y), C.c_double(b), _ptr(dy))
+
+
+class IpmSolver:
+    """The host harness: Mehrotra predictor-corrector on the device for the generator's LP class."""
+
+    def __init__(self, n0, myl, blocks, F0, c, b, dual_reg=0.0, device=-1):
+        """blocks: list of (W, T, F) Csr triples; c: [x0 | x1..xN]; b: [link | block rows]."""
+        N = len(blocks)
+        n_i = _i32([w.ncols for (w, t, f) in blocks])
+        my_i = _i32([w.nrows for (w, t, f) in blocks])
+
+        def cat(ms):
+            return (_i32(np.concatenate([m.rowptr for m in ms])), _i32(np.concatenate([m.colidx for m in ms])),
+                    _f64(np.concatenate([m.val for m in ms])))
+
+        W = cat([w for (w, t, f) in blocks])
+        T = cat([t for (w, t, f) in blocks]) if n0 > 0 else (None, None, None)
+        F = cat([f for (w, t, f) in blocks]) if myl > 0 else (None, None, None)
+        self._keep = (n_i, my_i, W, T, F, _f64(c), _f64(b))
+        self.nx = n0 + int(n_i.sum())
+        self.ny = myl + int(my_i.sum())
+        self._h = C.c_void_p()
+        _check(lib.pips_ipm_create(C.byref(self._h), C.c_int(N), C.c_int(n0), C.c_int(myl), _ptr(n_i), _ptr(my_i),
+                                   *[_ptr(a) for a in W], *[_ptr(a) for a in T], *[_ptr(a) for a in F],
+                                   _ptr(F0.rowptr) if F0 is not None else None, _ptr(F0.colidx) if F0 is not None else None,
+                                   _ptr(F0.val) if F0 is not None else None, _ptr(self._keep[5]), _ptr(self._keep[6]),
+                                   C.c_double(dual_reg), C.c_int(device)), "pips_ipm_create")
+
+    def solve(self, max_iter=100, mutol=1e-6, artol=1e-4, verbose=False):
+        res = np.zeros(7)
+        _check(lib.pips_ipm_solve(self._h, C.c_int(max_iter), C.c_double(mutol), C.c_double(artol), C.c_int(1 if verbose else 0),
+                                  _ptr(res)), "pips_ipm_solve")
+        return dict(objective=res[0], iterations=int(res[1]), mu=res[2], rnorm=res[3], status=int(res[4]), dual_objective=res[5],
+                    dnorm=res[6])
+
+    def solution(self):
+        x = np.zeros(self.nx)
+        y = np.zeros(self.ny)
+        _check(lib.pips_ipm_get_solution(self._h, _ptr(x), _ptr(y)), "pips_ipm_get_solution")
+        return x, y
+
+    def close(self):
+        if self._h:
+            lib.pips_ipm_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -96,3 +96,29 @@ def test_solve_compressed_solves_the_full_arrowhead_system():
     xfull = spl.splu(Kbig).solve(np.concatenate(bs + [b0]))
     got = np.concatenate(xs + [x0])
     assert np.linalg.norm(got - xfull) / np.linalg.norm(xfull) < 1e-8
+
+
+def test_ipm_oracle_against_highs():
+    """The IPM restatement (oracle/ipm_oracle.py) reaches the optimum an independent LP solver finds."""
+    from scipy.optimize import linprog
+    from oracle import ipm_oracle as io
+    import pips_ipmpp_amd as pa
+    import scipy.sparse as sp
+    N, n_i, my_i, n0, myl, rho = 3, 60, 30, 6, 5, 0.1
+    F0, c0, x0s = pa.gen_root(2026, n0, myl)
+    blocks, cs, xs = [], [c0], [x0s]
+    for b in range(1, N + 1):
+        W, T, F, c, x = pa.gen_block(2026, b, n_i, my_i, n0, myl, rho)
+        blocks.append((W, T, F)); cs.append(c); xs.append(x)
+    rows = [[F0.to_scipy()] + [F.to_scipy() for (_, _, F) in blocks]]
+    for i, (W, T, F) in enumerate(blocks):
+        r = [T.to_scipy()] + [None] * N
+        r[1 + i] = W.to_scipy()
+        rows.append(r)
+    A = sp.bmat(rows, format="csr")
+    c = np.concatenate(cs)
+    b = A @ np.concatenate(xs)
+    o = io.solve_lp(A, b, c, 100, 1e-9, 1e-9)
+    ref = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
+    assert o["status"] == 0 and o["iterations"] <= 30
+    assert abs(o["objective"] - ref.fun) / abs(ref.fun) < 1e-9

@@ -1,0 +1,90 @@
+"""Flat-arena vector kernels (a15) against numpy on the same data: single-rounding ops bit-for-bit, multiply-add ops to
+2 ulp (the GPU contracts a*x+y into one FMA, numpy rounds twice), sums to 1e-12 of the absolute sum."""
+import numpy as np
+import pytest
+
+import pips_ipmpp_amd as pa
+
+pytestmark = pytest.mark.gpu
+N = 100003  # ragged on purpose
+
+
+def _mk(seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(N)
+    return a, torch.tensor(a, device="cuda")
+
+
+def _ulp_close(got, want, scale):
+    """|got - want| <= 2 ulp of the largest term that entered the result (FMA contraction vs two roundings)."""
+    return bool(np.all(np.abs(got - want) <= 4.5e-16 * scale))
+
+
+def test_elementwise_ops_match_numpy_exactly():
+    import torch
+    V = pa.capi.vec
+    x, xd = _mk(1)
+    z, zd = _mk(2)
+    y, yd = _mk(3)
+    mask = (np.random.default_rng(4).random(N) < 0.7).astype(np.float64)
+    md = torch.tensor(mask, device="cuda")
+    get = lambda: yd.cpu().numpy().copy()  # noqa: E731
+    V.axpy(0.37, xd, yd)
+    assert _ulp_close(get(), y + 0.37 * x, np.abs(y) + np.abs(0.37 * x))
+    y = get()
+    V.add_product(-1.5, xd, zd, yd)
+    assert _ulp_close(get(), y + (-1.5 * x) * z, np.abs(y) + np.abs(1.5 * x * z))
+    y = get()
+    V.add_quotient(2.0, xd, zd, md, yd)
+    assert _ulp_close(get(), np.where(mask != 0, y + 2.0 * x / z, y), np.abs(y) + np.abs(2.0 * x / z))
+    y = get()
+    V.divide_some(zd, md, yd)
+    y = np.where(mask != 0, y / z, y)
+    assert np.array_equal(get(), y)
+    V.select_nonzeros(md, yd)
+    y = np.where(mask != 0, y, 0.0)
+    assert np.array_equal(get(), y)
+    V.safe_invert(yd)
+    y = np.where(y != 0, 1.0 / np.where(y != 0, y, 1.0), 0.0)
+    assert np.array_equal(get(), y)
+    V.scale(-1.0, yd)
+    V.add_const(0.25, yd)
+    V.mul(xd, yd)
+    V.div(zd, yd)
+    y = ((-y + 0.25) * x) / z
+    assert np.array_equal(get(), y)
+    V.axpby(2.0, xd, -0.5, yd)
+    assert _ulp_close(get(), 2.0 * x + -0.5 * y, np.abs(2.0 * x) + np.abs(0.5 * y))
+
+
+def test_reductions_match_numpy():
+    V = pa.capi.vec
+    x, xd = _mk(5)
+    y, yd = _mk(6)
+    assert abs(V.dot(xd, yd) - x @ y) <= 1e-12 * np.abs(x * y).sum()
+    assert abs(V.dot(xd, yd, skip_root=1000) - x[1000:] @ y[1000:]) <= 1e-12 * np.abs(x * y).sum()
+    assert abs(V.one_norm(xd) - np.abs(x).sum()) <= 1e-12 * np.abs(x).sum()
+    assert V.inf_norm(xd) == np.abs(x).max()
+    assert V.min(xd) == x.min()
+    assert abs(V.two_norm(xd) - np.linalg.norm(x)) <= 1e-13 * np.linalg.norm(x)
+    # step bound: largest alpha with v + alpha dv >= 0
+    v = np.abs(x) + 0.1
+    import torch
+    vd = torch.tensor(v, device="cuda")
+    want = np.min(np.where(y < 0, -v / np.where(y < 0, y, -1.0), np.inf))
+    assert V.stepbound(vd, yd) == want
+    a, b = 0.3, 0.7
+    want = ((v + a * y) * (np.abs(y) + b * x)).sum()
+    wd = torch.tensor(np.abs(y), device="cuda")
+    got = V.dot_shifted(vd, a, yd, wd, b, xd)
+    assert abs(got - want) <= 1e-12 * np.abs((v + a * y) * (np.abs(y) + b * x)).sum()
+
+
+def test_empty_and_tiny_vectors():
+    import torch
+    V = pa.capi.vec
+    e = torch.zeros(0, dtype=torch.float64, device="cuda")
+    assert V.dot(e, e) == 0.0 and V.inf_norm(e) == 0.0 and V.min(e) == float("inf")
+    one = torch.tensor([-3.0], dtype=torch.float64, device="cuda")
+    assert V.inf_norm(one) == 3.0 and V.two_norm(one) == 3.0
