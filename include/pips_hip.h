@@ -80,6 +80,9 @@ int pips_hip_batch_create(void** handle, int n_blocks, int S, int device, void* 
 int pips_hip_batch_set_block(void* handle, int b, int n, int n_primal, const int* K_rowptr, const int* K_colidx,
                              const int* Bt_rowptr, const int* Bt_colidx, const double* Bt_val);
 int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps, double thr_rel, double repl_rel);
+/* add_regularization_local_kkt (DistributedLeafLinearSystem.C:108-143): K diagonal += primal on the leading n_primal rows
+ * of every block, -= dual on the remaining rows; used by the inertia-correcting loop (LinearSystem.C:296-325) */
+int pips_hip_batch_add_regularization(void* handle, double primal, double dual);
 /* iterative refinement policy of pips_hip_batch_solve* (see pips_hip_ldl_set_refinement); default (1, 0) */
 int pips_hip_batch_set_refinement(void* handle, int max_steps, double tol);
 /* refinement steps the last solve actually took */
@@ -132,7 +135,13 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
 /* leaf_diag_dev: flat K diagonals of this rank's blocks (NULL: keep); xdiag0_dev: n0 primal diagonal of the root
  * (xDiag); zdiag_link_dev: mzl entries or NULL.  Asynchronous on the batch's stream. */
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev);
-/* in place: b0 (S doubles, replicated on every rank) and the flat leaf vector of this rank's blocks */
+/* root inequality rows C0 (mz0 x n0, CSR): adds -C0^T diag(zdiag0)^-1 C0 to SC at every factorize (sLinsysRootAug.C:
+ * 1276-1338) and the z0 elimination to solve_compressed (:384-466); zdiag0 (< 0, = nOmegaInv of the root, caller-owned
+ * device vector of mz0 entries) must be set before pips_hip_kkt_factorize */
+int pips_hip_kkt_set_root_inequalities(void* handle, int mz0, const int* C0_rowptr, const int* C0_colidx, const double* C0_val);
+int pips_hip_kkt_set_zdiag0_dev(void* handle, const double* zdiag0_dev);
+/* in place: b0 (replicated on every rank; [x0 | y0 | ylink | zlink], or [x0 | y0 | z0 | ylink | zlink] when mz0 > 0) and
+ * the flat leaf vector of this rank's blocks */
 int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev);
 int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld);
 int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero);

@@ -263,7 +263,7 @@ struct Engine {
              *d_perm_off = nullptr, *d_rowbase = nullptr, *d_bt_xoff = nullptr;
    SnDesc* d_sns = nullptr;
    BlkDesc* d_blks = nullptr;
-   int *d_rowidx = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr;
+   int *d_rowidx = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr, *d_nprimal = nullptr;
    int *d_krowptr = nullptr, *d_kcolidx = nullptr, *d_bt_rowptr = nullptr, *d_bt_colidx = nullptr, *d_bt_rowsc = nullptr;
    signed char* d_psign = nullptr;
    std::vector<int> h_inertia;
@@ -272,7 +272,7 @@ struct Engine {
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_sncol, d_bmap, d_perm,
-                      d_inertia, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
+                      d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = d_pref = d_norms = nullptr;
@@ -280,6 +280,7 @@ struct Engine {
       h_norms = nullptr;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
+      d_nprimal = nullptr;
       d_rowidx = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
@@ -476,6 +477,11 @@ struct Engine {
       if ((rc = dev_upload(&d_bt_rowptr, h_bt_rowptr, stream))) return rc;
       if ((rc = dev_upload(&d_bt_colidx, h_bt_colidx, stream))) return rc;
       if ((rc = dev_upload(&d_bt_rowsc, h_bt_rowsc, stream))) return rc;
+      {
+         std::vector<int> np(nblk);
+         for (int b = 0; b < nblk; ++b) np[b] = in[b].n_primal;
+         if ((rc = dev_upload(&d_nprimal, np, stream))) return rc;
+      }
       if ((rc = plan.build(h_blks))) return rc;
       h_inertia.assign(3 * nblk, 0);
       analyzed = true;
@@ -687,15 +693,58 @@ struct KktSystem {
    int n0 = 0, my0 = 0, myl = 0, mzl = 0, S = 0;
    int rank = 0, n_ranks = 1;
    void* comm = nullptr;
-   double *d_SC = nullptr, *d_t = nullptr, *d_fin_val = nullptr;
+   double *d_SC = nullptr, *d_t = nullptr, *d_fin_val = nullptr, *d_c0_val = nullptr, *d_red = nullptr;
    long long* d_fin_idx = nullptr;
    long long n_fin = 0;
+   int mz0 = 0;
+   int *d_c0_rp = nullptr, *d_c0_ci = nullptr;
+   const double* d_zdiag0 = nullptr;   // caller-owned, set per iteration
    ~KktSystem() {
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
 };
+
+// SC[0:n0,0:n0] -= C0^T diag(zdiag)^-1 C0 (lower triangle; zdiag < 0): schur_complement_add_CTDC_block
+// (sLinsysRootAug.C:1276-1338, SparseStorage::matTransDinvMultMat SparseStorage.C:1257).  One thread per row of C0.
+__global__ void k_ctdc(int mz0, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                       const double* __restrict__ zdiag, double* __restrict__ SC, int ld) {
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mz0; k += gridDim.x * blockDim.x) {
+      const double dinv = 1.0 / zdiag[k];
+      for (int p = rp[k]; p < rp[k + 1]; ++p)
+         for (int q = rp[k]; q < rp[k + 1]; ++q) {
+            const int i = ci[p], j = ci[q];
+            if (i >= j) atomic_add_f64(SC + i + (long long)j * ld, -v[p] * v[q] * dinv);
+         }
+   }
+}
+
+// solveReducedLinkCons (sLinsysRootAug.C:384-466), z0 elimination: mode 0: t_k = b3_k / zdiag_k ; rhs1 -= C0^T t
+//                                                                     mode 1: b3_k = (b3_k - (C0 x1)_k) / zdiag_k
+__global__ void k_z0_elim(int mode, int mz0, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                          const double* __restrict__ zdiag, double* __restrict__ b3, double* __restrict__ x1) {
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mz0; k += gridDim.x * blockDim.x) {
+      if (mode == 0) {
+         const double t = b3[k] / zdiag[k];
+         for (int p = rp[k]; p < rp[k + 1]; ++p) atomic_add_f64(x1 + ci[p], -v[p] * t);
+      } else {
+         double s = b3[k];
+         for (int p = rp[k]; p < rp[k + 1]; ++p) s -= v[p] * x1[ci[p]];
+         b3[k] = s / zdiag[k];
+      }
+   }
+}
+
+// add_regularization_local_kkt (DistributedLeafLinearSystem.C:108-143): K diag += primal on the leading n_primal rows,
+// -= dual on the rest
+__global__ void k_add_regularization(const BlkDesc* __restrict__ blks, const int* __restrict__ n_primal,
+                                     const long long* __restrict__ kdiag, double* __restrict__ kval, double primal, double dual) {
+   const BlkDesc bd = blks[blockIdx.y];
+   const int np = n_primal[blockIdx.y];
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bd.n; i += gridDim.x * blockDim.x)
+      kval[kdiag[bd.x_off + i]] += (np < 0 || i < np) ? primal : -dual;
+}
 
 __global__ void k_add_diag(double* __restrict__ M, int ld, int off, const double* __restrict__ d, int n) {
    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -769,6 +818,16 @@ int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps,
    if (refine_steps >= 0) e->refine_steps = refine_steps;
    if (thr_rel >= 0) e->thr_rel = thr_rel;
    if (repl_rel > 0) e->repl_rel = repl_rel;
+   return PIPS_OK;
+}
+
+int pips_hip_batch_add_regularization(void* handle, double primal, double dual) {
+   Engine* e = (Engine*)handle;
+   if (!e || !e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_add_regularization: analyze first");
+   HIP_TRY(hipSetDevice(e->device));
+   hipLaunchKernelGGL(k_add_regularization, dim3(32, e->nblk), dim3(256), 0, e->stream, e->d_blks, e->d_nprimal, e->d_kdiag, e->d_kval,
+                      primal, dual);
+   HIP_TRY(hipGetLastError());
    return PIPS_OK;
 }
 
@@ -1201,6 +1260,11 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    if (k->n_fin > 0)
       hipLaunchKernelGGL(k_add_entries, dim3(grid_for(k->n_fin, 256)), dim3(256), 0, e->stream, k->d_SC, k->d_fin_idx,
                          k->d_fin_val, k->n_fin);
+   if (k->mz0 > 0) {
+      if (!k->d_zdiag0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: mz0 > 0 needs pips_hip_kkt_set_root_inequalities + a zdiag0 vector");
+      hipLaunchKernelGGL(k_ctdc, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val, k->d_zdiag0,
+                         k->d_SC, k->S);
+   }
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, k->d_SC, k->S,
                          k->n0 + k->my0 + k->myl, zdiag_link_dev, k->mzl);
@@ -1214,19 +1278,58 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    Engine* e = k->leaves;
    HIP_TRY(hipSetDevice(e->device));
    int rc;
+   // with mz0 > 0 the caller's vector is [x0 | y0 | z0 | ylink | zlink]; the Schur system lives on the reduced vector
+   // [x0 | y0 | ylink | zlink] (solveReducedLinkCons, sLinsysRootAug.C:397-433)
+   double* red = b0_dev;
+   const int head = k->n0 + k->my0, tailn = k->myl + k->mzl;
+   if (k->mz0 > 0) {
+      red = k->d_red;
+      HIP_TRY(hipMemcpyAsync(red, b0_dev, (size_t)head * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(red + head, b0_dev + head + k->mz0, (size_t)tailn * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+   }
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
-   if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(b0_dev, 0, (size_t)k->S * sizeof(double), e->stream));
+   if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
    if ((rc = e->solve(b_leaf_dev))) return rc;
-   if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, b0_dev, -1.0))) return rc;
-   if (k->n_ranks > 1 && (rc = pips_hip_allreduce_sum(k->comm, b0_dev, (size_t)k->S, e->stream))) return rc;
-   // Dsolve (mz0 = 0: no z0 elimination; solveReducedLinkCons :384-466 reduces to the plain SC solve)
-   if ((rc = k->root->solve_dev(b0_dev))) return rc;
+   if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
+   if (k->n_ranks > 1 && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream))) return rc;
+   // Dsolve: eliminate z0 through C0, solve with the Schur complement, recover z0 (solveReducedLinkCons :384-466)
+   if (k->mz0 > 0)
+      hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
+                         k->d_zdiag0, b0_dev + head, red);
+   if ((rc = k->root->solve_dev(red))) return rc;
+   if (k->mz0 > 0) {
+      hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 1, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
+                         k->d_zdiag0, b0_dev + head, red);
+      HIP_TRY(hipMemcpyAsync(b0_dev, red, (size_t)head * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(b0_dev + head + k->mz0, red + head, (size_t)tailn * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+   }
    // Ltsolve: b_i -= K_i^-1 Br_i x0 (LniTransMult, DistributedLinearSystem.C:430-483)
    HIP_TRY(hipMemsetAsync(k->d_t, 0, (size_t)e->n_total * sizeof(double), e->stream));
-   if ((rc = pips_hip_batch_border_mult_dev(e, b0_dev, k->d_t, 1.0))) return rc;
+   if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, 1.0))) return rc;
    if ((rc = e->solve(k->d_t))) return rc;
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    HIP_TRY(hipGetLastError());
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_set_root_inequalities(void* handle, int mz0, const int* C0_rowptr, const int* C0_colidx, const double* C0_val) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || mz0 < 0 || (mz0 > 0 && (!C0_rowptr || !C0_colidx || !C0_val))) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_root_inequalities: bad arguments");
+   HIP_TRY(hipSetDevice(k->leaves->device));
+   k->mz0 = mz0;
+   if (mz0 == 0) return PIPS_OK;
+   std::vector<int> rp(C0_rowptr, C0_rowptr + mz0 + 1), ci(C0_colidx, C0_colidx + C0_rowptr[mz0]);
+   std::vector<double> v(C0_val, C0_val + C0_rowptr[mz0]);
+   int rc;
+   if ((rc = dev_upload(&k->d_c0_rp, rp, nullptr)) || (rc = dev_upload(&k->d_c0_ci, ci, nullptr)) || (rc = dev_upload(&k->d_c0_val, v, nullptr))) return rc;
+   HIP_TRY(hipMalloc((void**)&k->d_red, (size_t)std::max(k->S, 1) * sizeof(double)));
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_set_zdiag0_dev(void* handle, const double* zdiag0_dev) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   k->d_zdiag0 = zdiag0_dev;
    return PIPS_OK;
 }
 

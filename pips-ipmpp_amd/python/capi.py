@@ -49,13 +49,14 @@ SYMBOLS = [
     "pips_hip_ldl_get_perm", "pips_hip_ldl_destroy",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
     "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_destroy",
-    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_refinement",
+    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
     "pips_hip_batch_last_refinement_steps", "pips_hip_batch_analyze",
     "pips_hip_batch_set_values", "pips_hip_batch_set_diagonals_dev", "pips_hip_batch_set_diagonals", "pips_hip_batch_factor",
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
     "pips_hip_kkt_create", "pips_hip_kkt_factorize", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
+    "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
@@ -352,6 +353,9 @@ class LeafBatch:
         _check(lib.pips_hip_batch_set_options(self._h, C.c_int(force_n_head), C.c_int(refine_steps), C.c_double(thr_rel),
                                               C.c_double(repl_rel)), "pips_hip_batch_set_options")
 
+    def add_regularization(self, primal, dual):
+        _check(lib.pips_hip_batch_add_regularization(self._h, C.c_double(primal), C.c_double(dual)), "add_regularization")
+
     def set_refinement(self, max_steps, tol):
         """tol > 0: adaptive (stop once ||r||inf <= tol ||rhs||inf, at most max_steps steps); tol = 0: always max_steps."""
         _check(lib.pips_hip_batch_set_refinement(self._h, C.c_int(max_steps), C.c_double(tol)), "pips_hip_batch_set_refinement")
@@ -463,6 +467,15 @@ class KktSystem:
         _check(lib.pips_hip_kkt_create(C.byref(self._h), batch._h, C.c_int(n0), C.c_int(my0), C.c_int(myl), C.c_int(mzl),
                                        *trip(A0), *trip(F0), *trip(G0), comm._h if comm is not None else None,
                                        C.c_int(rank), C.c_int(n_ranks)), "pips_hip_kkt_create")
+
+    def set_root_inequalities(self, C0):
+        self.mz0 = C0.nrows
+        _check(lib.pips_hip_kkt_set_root_inequalities(self._h, C.c_int(C0.nrows), _ptr(C0.rowptr), _ptr(C0.colidx), _ptr(C0.val)),
+               "pips_hip_kkt_set_root_inequalities")
+
+    def set_zdiag0(self, zdiag0_dev):
+        self._zdiag0 = zdiag0_dev   # keep alive: the library stores the pointer only
+        _check(lib.pips_hip_kkt_set_zdiag0_dev(self._h, _ptr(zdiag0_dev)), "pips_hip_kkt_set_zdiag0_dev")
 
     def factorize(self, leaf_diag_dev, xdiag0_dev, zdiag_link_dev=None):
         _check(lib.pips_hip_kkt_factorize(self._h, _ptr(leaf_diag_dev), _ptr(xdiag0_dev), _ptr(zdiag_link_dev)),

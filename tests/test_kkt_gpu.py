@@ -69,3 +69,16 @@ def test_factorize_and_solve_compressed(shape):
         num += ri @ ri
     num += res0 @ res0
     assert np.sqrt(num) / np.sqrt(b0 @ b0 + bl @ bl) < 1e-9
+
+
+def test_rccl_communicator_single_rank_roundtrip():
+    """dlopen'd RCCL: unique id, communicator of one rank, in-place all-reduce (the path bench.py uses for N > 1)."""
+    import torch
+    ident = pa.Comm.unique_id()
+    assert len(ident) == 128
+    comm = pa.Comm(ident, 1, 0, 0)
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.allreduce_sum(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    comm.close()
