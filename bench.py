@@ -68,8 +68,9 @@ def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
         vals.append(K.val)
         diags.append(diag)
     bt.analyze(min(16, os.cpu_count() or 8))
-    # PARDISO-style adaptive iterative refinement (iparm[7]=2 in the reference): up to 2 steps, stop at 1e-10 relative residual
-    bt.set_refinement(2, 1e-10)
+    # PARDISO-style adaptive iterative refinement (iparm[7]=2 in the reference, PardisoProjectSolver.C:72: at most 2 steps,
+    # stop when the backward error is satisfactory): normwise backward error <= 1e-15 for every block
+    bt.set_refinement_backward_error(2, 1e-15)
     for i in range(len(blocks)):
         bt.set_values(i, vals[i])
     return bt, np.concatenate(diags)
@@ -234,7 +235,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""),
-                       "solves_per_unit": R_SOLVES, "iter_per_s": round(a.steps / dt, 4),
+                       "solves_per_unit": R_SOLVES, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(), "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},
             "roofline": roofline,

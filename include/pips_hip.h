@@ -85,6 +85,12 @@ int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps,
 int pips_hip_batch_add_regularization(void* handle, double primal, double dual);
 /* iterative refinement policy of pips_hip_batch_solve* (see pips_hip_ldl_set_refinement); default (1, 0) */
 int pips_hip_batch_set_refinement(void* handle, int max_steps, double tol);
+/* same, but the stopping test is the normwise backward error  ||r_b||inf / (max|K_b| ||x_b||inf + ||rhs_b||inf) <= tol
+ * for every block b — the criterion PARDISO's iparm[7] refinement uses ("stops if a satisfactory level of accuracy of the
+ * solution in terms of backward error is achieved") */
+int pips_hip_batch_set_refinement_backward_error(void* handle, int max_steps, double tol);
+/* error measure the last adaptive solve saw at its final check */
+double pips_hip_batch_last_refinement_measure(void* handle);
 /* refinement steps the last solve actually took */
 int pips_hip_batch_last_refinement_steps(void* handle);
 /* symbolic phase for all blocks (n_threads host threads) + device setup */

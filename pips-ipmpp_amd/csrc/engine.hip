@@ -240,8 +240,10 @@ struct Engine {
    int nblk = 0, S = 0;
    bool analyzed = false, factored = false;
    int refine_steps = 1;       // maximum number of iterative-refinement steps per solve
-   double refine_tol = 0.0;    // > 0: stop as soon as max_b ||r_b||inf / ||rhs_b||inf <= tol (PARDISO-style adaptive refinement)
-   double* d_norms = nullptr;  // 2 * nblk
+   double refine_tol = 0.0;    // > 0: adaptive refinement, stop as soon as the error measure of every block is <= tol
+   int refine_mode = 0;        // 0: ||r_b||inf / ||rhs_b||inf ; 1: normwise backward error ||r_b||inf / (max|K_b| ||x_b||inf + ||rhs_b||inf)
+   double last_refine_measure = 0.0;
+   double* d_norms = nullptr;  // 3 * nblk: ||r||, ||rhs||, ||x|| per block
    double* h_norms = nullptr;  // pinned
    int last_refine_steps = 0;
    double thr_rel = 1e-13, repl_rel = 1e-8;
@@ -267,6 +269,7 @@ struct Engine {
    int *d_krowptr = nullptr, *d_kcolidx = nullptr, *d_bt_rowptr = nullptr, *d_bt_colidx = nullptr, *d_bt_rowsc = nullptr;
    signed char* d_psign = nullptr;
    std::vector<int> h_inertia;
+   std::vector<double> h_amax;   // max|K_b| of the current factorisation (backward-error refinement criterion)
 
    ~Engine() { release(); }
    void release() {
@@ -452,8 +455,8 @@ struct Engine {
       HIP_TRY(hipMalloc((void**)&d_rhs, std::max<long long>(n_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_res, std::max<long long>(n_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_stage, std::max<long long>(n_total, 1) * sizeof(double)));
-      HIP_TRY(hipMalloc((void**)&d_norms, (size_t)2 * nblk * sizeof(double)));
-      HIP_TRY(hipHostMalloc((void**)&h_norms, (size_t)2 * nblk * sizeof(double), hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void**)&d_norms, (size_t)3 * nblk * sizeof(double)));
+      HIP_TRY(hipHostMalloc((void**)&h_norms, (size_t)3 * nblk * sizeof(double), hipHostMallocDefault));
       HIP_TRY(hipMalloc((void**)&d_inertia, (size_t)3 * nblk * sizeof(int)));
       HIP_TRY(hipMemset(d_inertia, 0, (size_t)3 * nblk * sizeof(int)));
       if ((rc = dev_upload(&d_bval, h_bval, stream))) return rc;
@@ -524,6 +527,7 @@ struct Engine {
       int rc = tail_factor(c, SC, ldSC);
       if (rc) return rc;
       if (timer.on) (void)hipEventRecord(timer.recs[total_rec].b, stream);
+      h_amax.clear();
       factored = true;
       return PIPS_OK;
    }
@@ -578,11 +582,24 @@ struct Engine {
                             x_dev, d_res, n_total, d_rowbase);
          if (refine_tol > 0.0) {
             hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
-            HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)2 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
+            if (refine_mode == 1)
+               hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, x_dev, d_blks, d_norms + 2 * nblk);
+            HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)3 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
+            if (refine_mode == 1 && h_amax.empty()) {
+               h_amax.resize(nblk);
+               std::vector<BlkDesc> tmp(nblk);
+               HIP_TRY(hipMemcpyAsync(tmp.data(), d_blks, (size_t)nblk * sizeof(BlkDesc), hipMemcpyDeviceToHost, stream));
+               HIP_TRY(hipStreamSynchronize(stream));
+               for (int b = 0; b < nblk; ++b) h_amax[b] = tmp[b].repl_abs / (repl_rel > 0 ? repl_rel : 1.0);   // = max|K_b| (k_block_absmax)
+            }
             HIP_TRY(hipStreamSynchronize(stream));
-            bool ok = true;
-            for (int b = 0; b < nblk && ok; ++b) ok = h_norms[b] <= refine_tol * h_norms[nblk + b] || h_norms[nblk + b] == 0.0;
-            if (ok) break;
+            double worst = 0.0;
+            for (int b = 0; b < nblk; ++b) {
+               const double den = refine_mode == 1 ? h_amax[b] * h_norms[2 * nblk + b] + h_norms[nblk + b] : h_norms[nblk + b];
+               if (den > 0.0) worst = std::max(worst, h_norms[b] / den);
+            }
+            last_refine_measure = worst;
+            if (worst <= refine_tol) break;
          }
          rc = solve_once(d_res);
          if (rc) return rc;
@@ -836,7 +853,22 @@ int pips_hip_batch_set_refinement(void* handle, int max_steps, double tol) {
    if (!e || max_steps < 0 || tol < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_batch_set_refinement: bad arguments");
    e->refine_steps = max_steps;
    e->refine_tol = tol;
+   e->refine_mode = 0;
    return PIPS_OK;
+}
+
+int pips_hip_batch_set_refinement_backward_error(void* handle, int max_steps, double tol) {
+   Engine* e = (Engine*)handle;
+   if (!e || max_steps < 0 || tol < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_batch_set_refinement_backward_error: bad arguments");
+   e->refine_steps = max_steps;
+   e->refine_tol = tol;
+   e->refine_mode = 1;
+   return PIPS_OK;
+}
+
+double pips_hip_batch_last_refinement_measure(void* handle) {
+   Engine* e = (Engine*)handle;
+   return e ? e->last_refine_measure : -1.0;
 }
 
 int pips_hip_batch_last_refinement_steps(void* handle) {

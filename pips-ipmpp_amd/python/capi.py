@@ -50,7 +50,8 @@ SYMBOLS = [
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
     "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_destroy",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
-    "pips_hip_batch_last_refinement_steps", "pips_hip_batch_analyze",
+    "pips_hip_batch_last_refinement_steps", "pips_hip_batch_set_refinement_backward_error",
+    "pips_hip_batch_last_refinement_measure", "pips_hip_batch_analyze",
     "pips_hip_batch_set_values", "pips_hip_batch_set_diagonals_dev", "pips_hip_batch_set_diagonals", "pips_hip_batch_factor",
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
@@ -359,6 +360,14 @@ class LeafBatch:
     def set_refinement(self, max_steps, tol):
         """tol > 0: adaptive (stop once ||r||inf <= tol ||rhs||inf, at most max_steps steps); tol = 0: always max_steps."""
         _check(lib.pips_hip_batch_set_refinement(self._h, C.c_int(max_steps), C.c_double(tol)), "pips_hip_batch_set_refinement")
+
+    def set_refinement_backward_error(self, max_steps, tol):
+        _check(lib.pips_hip_batch_set_refinement_backward_error(self._h, C.c_int(max_steps), C.c_double(tol)),
+               "pips_hip_batch_set_refinement_backward_error")
+
+    def last_refinement_measure(self):
+        lib.pips_hip_batch_last_refinement_measure.restype = C.c_double
+        return float(lib.pips_hip_batch_last_refinement_measure(self._h))
 
     def last_refinement_steps(self):
         return int(lib.pips_hip_batch_last_refinement_steps(self._h))

@@ -12,8 +12,8 @@ for b in range(N):
 bt.analyze(16)
 for b in range(N): bt.set_values(b, vals[b])
 bt.factor()
-for tol in (0.0, 1e-10, 1e-9, 1e-8):
-    bt.set_refinement(2, tol)
+for tol in (1e-30, 1e-16, 1e-15, 1e-14):
+    bt.set_refinement_backward_error(2, tol)
     x = torch.randn(N * 15000, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize(); t0 = time.time(); bt.solve(x); bt.sync(); dt = time.time() - t0
-    print(f"tol {tol:g}: refinement steps taken {bt.last_refinement_steps()}  {dt*1e3:.2f} ms")
+    print(f"backward-error tol {tol:g}: refinement steps taken {bt.last_refinement_steps()} last measure {bt.last_refinement_measure():.2e}  {dt*1e3:.2f} ms")
