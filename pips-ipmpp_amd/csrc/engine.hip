@@ -170,7 +170,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    for (int j = 0; j < p.ntc_max; ++j) {
       if (p.upd[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 2);
-         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((p.upd[j].cnt + 7) / 8 * 8), dim3(256), 0, c.stream, p.d_tasks + p.upd[j].off, p.upd[j].cnt, c.d_blks,
+         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((p.upd[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.upd[j].off, p.upd[j].cnt, c.d_blks,
                             c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
          if (c.timer) c.timer->end(c.stream);
       }
@@ -180,14 +180,14 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       if (c.timer) c.timer->end(c.stream);
       if (p.trsm[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 4);
-         hipLaunchKernelGGL(k_tile_gemm<1>, dim3((p.trsm[j].cnt + 7) / 8 * 8), dim3(256), 0, c.stream, p.d_tasks + p.trsm[j].off, p.trsm[j].cnt,
+         hipLaunchKernelGGL(k_tile_gemm<1>, dim3((p.trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trsm[j].off, p.trsm[j].cnt,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
          if (c.timer) c.timer->end(c.stream);
       }
    }
    if (SC && p.schur.cnt > 0) {
       if (c.timer) c.timer->begin(c.stream, 5);
-      hipLaunchKernelGGL(k_tile_gemm<2>, dim3((p.schur.cnt + 7) / 8 * 8), dim3(256), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
+      hipLaunchKernelGGL(k_tile_gemm<2>, dim3((p.schur.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
                          c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC);
       if (c.timer) c.timer->end(c.stream);
    }

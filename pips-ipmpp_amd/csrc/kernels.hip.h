@@ -329,7 +329,8 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
 //   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
 //   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
 //   MODE 2 (schur) : SC[bmap(ti), bmap(tj)] -= A(ti,0:K) diag(d) B(tj,0:K)^T   ti,tj border tile rows, K = m_pad
-// 256 threads = 4 waves in a 2 x 2 grid, each wave owns a 64 x 64 sub-tile.
+// 512 threads = 8 waves in a 2 x 4 grid, each wave owns a 64 x 32 sub-tile (32 accumulators): ~110 VGPRs, so four
+// waves share a SIMD and hide each other's LDS / barrier / DMA-issue stalls (two 256-thread workgroups per CU).
 //
 // Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction).  Measured on MI355X
 // (tools/mb2.hip, profiles/r1_fp64_issue_rates.txt) it sustains 72.6 TFLOP/s (17 cycles/instruction/SIMD) whereas
@@ -350,12 +351,13 @@ __device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base
 // stage s+1 is in flight while stage s is multiplied; one barrier per stage.  The diagonal scaling d_k of the update is
 // applied to the column-panel fragment after the LDS read (one v_mul_f64 per fragment, hidden beside the MFMAs).
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
+__global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
                                                      const BlkDesc* __restrict__ blks, double* __restrict__ arena,
                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
                                                      const int* __restrict__ bmap, double* __restrict__ SC, int ldSC) {
    __shared__ __attribute__((aligned(16))) double As[2][KB * LDSW];
    __shared__ __attribute__((aligned(16))) double Bs[2][KB * LDSW];
+   __shared__ double Ds[2][KB];   // diagonal scaling d_k of the stage
 
    // XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
    // slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const int wr = wave & 1, wc = wave >> 1;
+   const int wr = wave & 1, wc = wave >> 1;   // 8 waves: 2 (rows) x 4 (cols), each 64 rows x 32 columns
    const int ld = bd.ldT;
    double* T = arena + bd.T;
 
@@ -394,92 +396,82 @@ __global__ __launch_bounds__(256, 2) void k_tile_gemm(const TileTask* __restrict
       dv = dtail + bd.dt_off;
    }
 
-   double acc[4][16];
+   double acc[4][8];
 #pragma unroll
    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) acc[i][c] = 0.0;
+      for (int c = 0; c < 8; ++c) acc[i][c] = 0.0;
 
+#if defined(PIPS_EXPERIMENT_CLOCK)
+   const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
    const int nst = K / KB;
    const double* Al = Ap + 2 * lane;
    const double* Bl = Bp + 2 * lane;
    auto issue = [&](int st, int buf) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-         const int k = wave + 4 * q;   // this wave's four k-columns of the stage
+      for (int q = 0; q < 2; ++q) {
+         const int k = wave + 8 * q;   // this wave's two k-columns of the stage
          glds16(Al + (long long)(st * KB + k) * ld, &As[buf][k * LDSW]);
          glds16(Bl + (long long)(st * KB + k) * ldb, &Bs[buf][k * LDSW]);
       }
    };
-   double dn[4] = {1.0, 1.0, 1.0, 1.0};
+   // the 16 scaling factors of a stage travel through one register of the first 16 threads into LDS
+   double dreg = 1.0;
    auto load_d = [&](int st) {
-      if (MODE != 1) {
-#pragma unroll
-         for (int q = 0; q < 4; ++q) dn[q] = dv[st * KB + 4 * q + (lane >> 4)];
-      }
+      if (MODE != 1 && tid < KB) dreg = dv[st * KB + tid];
    };
-   if (nst > 0) { issue(0, 0); load_d(0); }
+   if (nst > 0) {
+      issue(0, 0);
+      load_d(0);
+      if (tid < KB) Ds[0][tid] = dreg;
+   }
    const int rlane = wr * 64 + (lane & 15);   // row-panel fragment offset
-   const int clane = wc * 64 + (lane & 3);    // column-panel fragment offset (broadcast over the 4 blocks)
+   const int clane = wc * 32 + (lane & 3);    // column-panel fragment offset (broadcast over the 4 blocks)
    for (int st = 0; st < nst; ++st) {
       const int buf = st & 1;
 #if !defined(PIPS_EXPERIMENT_NO_BARRIER)
       __syncthreads();   // own DMA retired (vmcnt(0)) + everybody's DMA of this stage visible + buffer buf^1 free again
 #endif
-      double dc[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dc[q] = dn[q];
 #if !defined(PIPS_EXPERIMENT_NO_DMA)
       if (st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
 #endif
       const double* Ab = As[buf] + (lane >> 4) * LDSW + rlane;
       const double* Bb = Bs[buf] + (lane >> 4) * LDSW + clane;
-      // register double-buffered fragments: the LDS reads of k-step q+1 are issued between the MFMAs of k-step q
-      double fr[2][4], fc[2][16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fr[0][i] = Ab[i * 16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) fc[0][c] = Bb[c * 4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-         const int cur = q & 1, nxt = cur ^ 1;
-         if (q < 3) {
+         double fr[4], fc[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fr[nxt][i] = Ab[(4 * (q + 1)) * LDSW + i * 16];
+         for (int i = 0; i < 4; ++i) fr[i] = Ab[(4 * q) * LDSW + i * 16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) fc[nxt][c] = Bb[(4 * (q + 1)) * LDSW + c * 4];
-         }
+         for (int c = 0; c < 8; ++c) fc[c] = Bb[(4 * q) * LDSW + c * 4];
          if (MODE != 1) {
+            const double dq = Ds[buf][4 * q + (lane >> 4)];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fr[cur][i] *= dc[q];   // A diag(d) B^T: scale the 4 row fragments, not the 16 column ones
+            for (int i = 0; i < 4; ++i) fr[i] *= dq;   // A diag(d) B^T: scale the 4 row fragments, not the column ones
          }
 #pragma unroll
-         for (int c = 0; c < 16; ++c)
+         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-               acc[i][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[cur][c], fr[cur][i], acc[i][c], 0, 0, 0);
-         // interleave: 4 VALU (scaling) first, then {3 MFMA, 1 DS read} x 20, then the remaining 4 MFMA
-         if (MODE != 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-         if (q < 3) {
-#pragma unroll
-            for (int g = 0; g < 20; ++g) {
-               __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
-         }
+            for (int c = 0; c < 8; ++c)
+               acc[i][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], fr[i], acc[i][c], 0, 0, 0);
       }
+      if (MODE != 1 && st + 1 < nst && tid < KB) Ds[buf ^ 1][tid] = dreg;   // visible after the next barrier
    }
 
-   // epilogue: lane holds C(row = wr*64 + 16 i + (lane&15), col = wc*64 + 4 c + (lane>>4))
+#if defined(PIPS_EXPERIMENT_CLOCK)
+   if (tid == 0 && SC) {   // diagnostic build only: shader cycles and 100 MHz ticks of the main loop into a debug buffer
+      SC[2 * tix] = (double)(__builtin_amdgcn_s_memtime() - t0_);
+      SC[2 * tix + 1] = (double)(__builtin_amdgcn_s_memrealtime() - r0_);
+   }
+#endif
+   // epilogue: lane holds C(row = wr*64 + 16 i + (lane&15), col = wc*32 + 4 c + (lane>>4))
 #pragma unroll
    for (int i = 0; i < 4; ++i) {
       const int row = wr * 64 + i * 16 + (lane & 15);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-         const int col = wc * 64 + c * 4 + (lane >> 4);
+      for (int c = 0; c < 8; ++c) {
+         const int col = wc * 32 + c * 4 + (lane >> 4);
          const double v = acc[i][c];
          if (MODE == 0) {
             double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;

@@ -53,13 +53,26 @@ int main(int argc, char** argv) {
    CK(hipMalloc(&dbd, sizeof(BlkDesc))); CK(hipMemcpy(dbd, &bd, sizeof(BlkDesc), hipMemcpyHostToDevice));
    std::vector<TileTask> tk; for (int r = 0; r < rows; ++r) tk.push_back({0, nt + r, nt - 1, 0});
    CK(hipMalloc(&dtk, tk.size() * sizeof(TileTask))); CK(hipMemcpy(dtk, tk.data(), tk.size() * sizeof(TileTask), hipMemcpyHostToDevice));
+   double* dbg = nullptr;
+#if defined(PIPS_EXPERIMENT_CLOCK)
+   CK(hipMalloc(&dbg, tk.size() * 2 * sizeof(double)));
+#endif
    for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(k_tile_gemm<0>, dim3((unsigned)tk.size()), dim3(256), 0, 0, dtk, (int)tk.size(), dbd, T, dt, (const double*)nullptr, (const int*)nullptr, (double*)nullptr, 0);
+      hipLaunchKernelGGL(k_tile_gemm<0>, dim3((unsigned)tk.size()), dim3(512), 0, 0, dtk, (int)tk.size(), dbd, T, dt, (const double*)nullptr, (const int*)nullptr, dbg, 0);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double fl = (double)tk.size() * 2.0 * TILE * TILE * (nt - 1) * TILE;
       printf("k_tile_gemm<0>: %zu tiles K=%d: %.3f ms  %.2f TFLOP/s\n", tk.size(), (nt - 1) * TILE, ms, fl / ms / 1e9);
    }
+#if defined(PIPS_EXPERIMENT_CLOCK)
+   {
+      std::vector<double> hd(tk.size() * 2);
+      CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+      double cyc = 0, tick = 0;
+      for (size_t i = 0; i < tk.size(); ++i) { cyc += hd[2 * i]; tick += hd[2 * i + 1]; }
+      printf("in-kernel clock: %.0f MHz; mean main-loop cycles per workgroup %.0f (MFMA-bound floor %d)\n", cyc / tick * 100.0, cyc / tk.size(), (nt - 1) * TILE / 4 * 32 * 17 * 2);
+   }
+#endif
    return 0;
 }
