@@ -199,7 +199,7 @@ static int tail_fwd(const TailCtx& c, double* xw) {
    const TailPlan& p = *c.plan;
    for (int j = 0; j < p.ntc_max; ++j)
       if (p.fwd[j].cnt > 0)
-         hipLaunchKernelGGL(k_tail_fwd, dim3(p.fwd[j].cnt), dim3(128), 0, c.stream, p.d_tasks + p.fwd[j].off, c.d_blks,
+         hipLaunchKernelGGL(k_tail_fwd, dim3(p.fwd[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.fwd[j].off, c.d_blks,
                             c.d_arena, c.d_dtail, c.d_winv, xw, j);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;

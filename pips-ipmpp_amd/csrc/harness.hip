@@ -7,8 +7,9 @@
 //   LinearSystem::computeDiagonals / solve / solveXYZS (LinearSystem.C:262-294,327-447,449-548)  rhs reduction, recovery
 //   Residuals::evaluate / set_complementarity_residual (Residuals.cpp:58-171,220-256)
 // restricted to the problem class of the generator: min c^T x, A x = b, x >= 0 (ixlow = 1, no upper bounds, no
-// inequality rows), A block-angular.  Not reproduced: Gondzio correctors, Mehrotra's step-length heuristic, the filter
-// line search, the outer BiCGStab (the fused solveCompressed with iterative refinement is used directly).
+// inequality rows), A block-angular.  The outer Krylov wrapper of the reference (solveCompressedBiCGStab, OUTER_SOLVE 2,
+// LinearSystem.C:550-798) is reproduced with solveCompressed as the preconditioner; OUTER_SOLVE 1 (iterative refinement,
+// :877-966) is available too.  Not reproduced: Gondzio correctors, Mehrotra's step-length heuristic, the filter line search.
 // Single rank.  Everything numeric runs on the device; the host sees scalars only.
 #include <hip/hip_runtime.h>
 
@@ -24,6 +25,8 @@
 // vector layer (vecops.hip)
 extern "C" {
 int pips_hip_vec_axpy(long long, double, const double*, double*, void*);
+int pips_hip_vec_axpby(long long, double, const double*, double, double*, void*);
+int pips_hip_vec_sumsq_scaled(long long, long long, double, const double*, double*, void*);
 int pips_hip_vec_copy(long long, const double*, double*, void*);
 int pips_hip_vec_set(long long, double, double*, void*);
 int pips_hip_vec_scale(long long, double, double*, void*);
@@ -105,8 +108,11 @@ struct Ipm {
    double *rQ = nullptr, *rA = nullptr, *rv = nullptr, *rg = nullptr, *dd = nullptr;
    double *dx = nullptr, *dy = nullptr, *dv = nullptr, *dg = nullptr, *cx = nullptr, *cy = nullptr, *cv = nullptr, *cg = nullptr;
    double *tx = nullptr, *ty = nullptr, *b0 = nullptr, *bl = nullptr, *leaf_diag = nullptr, *zx = nullptr, *zy = nullptr;
-   double *ex = nullptr, *ey = nullptr, *bx = nullptr, *by = nullptr;
-   int outer_max = 10, last_outer_steps = 0, total_outer_steps = 0;
+   double *bz = nullptr, *xz = nullptr, *w_r = nullptr, *w_r0 = nullptr, *w_best = nullptr, *w_v = nullptr, *w_t = nullptr, *w_p = nullptr,
+          *w_dx = nullptr;
+   int outer_mode = 2;   // 1 = iterative refinement, 2 = BiCGStab (the reference's OUTER_SOLVE default)
+   int outer_max = 10, last_outer_steps = 0;
+   long long n_precond = 0;
    double outer_tol = 1e-10, last_outer_res = 0.0;
    std::vector<void*> owned;
    double last[8] = {0};
@@ -168,6 +174,141 @@ struct Ipm {
       hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, dual_reg, leaf_diag);
       return pips_hip_kkt_factorize(kkt, leaf_diag, dd, nullptr);
    }
+   // ---- outer solve machinery on concatenated vectors z = [x | y] of length nz = nx + ny ------------------------------
+   // z := M^-1 z with M^-1 = solveCompressed (the Schur-complement decomposition as preconditioner)
+   int precond(double* z) {
+      hipLaunchKernelGGL(k_kkt_pack, dim3(32, N + 1), dim3(256), 0, stream, N, n0, myl, d_xoff, d_yoff, d_koff, z, z + nx, b0, bl, 0);
+      TRY(pips_hip_kkt_solve_compressed(kkt, b0, bl));
+      hipLaunchKernelGGL(k_kkt_pack, dim3(32, N + 1), dim3(256), 0, stream, N, n0, myl, d_xoff, d_yoff, d_koff, z, z + nx, b0, bl, 1);
+      ++n_precond;
+      return PIPS_OK;
+   }
+   // out = K z, K = [dd A^T; A 0]  (LinearSystem::system_mult, LinearSystem.C:808-844, for this problem class)
+   int kmult(const double* z, double* out) {
+      TRY(pips_hip_vec_set(nx, 0.0, out, stream));
+      TRY(pips_hip_vec_add_product(nx, 1.0, dd, z, out, stream));
+      ATmult(z + nx, 1.0, 1.0, out);
+      Amult(z, 1.0, 0.0, out + nx);
+      return PIPS_OK;
+   }
+   int residual(const double* rhs, const double* z, double* r, double* nrm) {   // r = rhs - K z, two-norm
+      TRY(kmult(z, r));
+      TRY(pips_hip_vec_axpby(nz(), 1.0, rhs, -1.0, r, stream));
+      return two_norm(r, nrm);
+   }
+   long long nz() const { return (long long)nx + ny; }
+   int two_norm(const double* z, double* out) {   // DistributedVector::two_norm: s * sqrt(sum (z/s)^2), s = inf_norm
+      double s, q;
+      TRY(pips_hip_vec_inf_norm(nz(), z, &s, stream));
+      if (s == 0.0) { *out = 0.0; return PIPS_OK; }
+      TRY(pips_hip_vec_sumsq_scaled(nz(), 0, 1.0 / s, z, &q, stream));
+      *out = s * std::sqrt(q);
+      return PIPS_OK;
+   }
+   // OUTER_SOLVE 1 (solveCompressedIterRefin, LinearSystem.C:877-966): x += M^-1 (b - K x) while the residual decreases
+   int iter_refine(const double* b_, double* x_) {
+      double bn, rn, best = INFINITY;
+      TRY(two_norm(b_, &bn));
+      const double target = std::max(bn * outer_tol, 1e-15);
+      TRY(pips_hip_vec_set(nz(), 0.0, x_, stream));
+      TRY(pips_hip_vec_copy(nz(), b_, w_r, stream));
+      last_outer_steps = 0;
+      for (int it = 0; it <= outer_max; ++it) {
+         TRY(precond(w_r));
+         TRY(pips_hip_vec_axpy(nz(), 1.0, w_r, x_, stream));
+         TRY(residual(b_, x_, w_r, &rn));
+         if (!(rn < best)) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); break; }
+         best = rn;
+         last_outer_res = bn > 0 ? rn / bn : rn;
+         TRY(pips_hip_vec_copy(nz(), x_, w_best, stream));
+         if (rn <= target) break;
+         ++last_outer_steps;
+      }
+      return PIPS_OK;
+   }
+   // OUTER_SOLVE 2, the reference's default: BiCGStab right-preconditioned by solveCompressed
+   // (LinearSystem::solveCompressedBiCGStab, LinearSystem.C:550-798): same half-step structure, best-iterate rollback,
+   // divergence (4) and stagnation (4) counters, <= 75 iterations, tolerance max(tol ||b||_2, 1e-15).
+   int bicgstab(const double* b_, double* x_) {
+      const double eps = 1e-15;
+      double bn, rn;
+      TRY(two_norm(b_, &bn));
+      const double target = std::max(bn * outer_tol, eps);
+      TRY(pips_hip_vec_copy(nz(), b_, x_, stream));
+      TRY(precond(x_));
+      TRY(residual(b_, x_, w_r, &rn));
+      double min_rn = rn;
+      TRY(pips_hip_vec_copy(nz(), x_, w_best, stream));
+      last_outer_steps = 0;
+      last_outer_res = bn > 0 ? rn / bn : rn;
+      if (rn <= target) return PIPS_OK;                      // "skipped": the common case (LinearSystem.C:591-600)
+      TRY(pips_hip_vec_copy(nz(), w_r, w_r0, stream));
+      TRY(pips_hip_vec_scale(nz(), 1.0 / rn, w_r0, stream));
+      double rho = 1.0, omega = 1.0, alpha = 1.0;
+      int ndiv = 0, nstag = 0;
+      auto is_zero = [](double v) { return std::fabs(v) < 1e-40; };   // PIPSisZero with pips_eps0 (pipsdef.h:35,108)
+      auto stagn = [&](double step, double step_norm, double xn) { if (std::fabs(step) * step_norm <= eps * xn) ++nstag; else nstag = 0; };
+      int it = 0;
+      for (; it < 75; ++it) {
+         const double rho_last = rho;
+         TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_r, &rho, stream));
+         if (is_zero(rho)) break;
+         if (it == 0) TRY(pips_hip_vec_copy(nz(), w_r, w_p, stream));
+         else {
+            const double beta = (rho / rho_last) * (alpha / omega);
+            if (is_zero(beta)) break;
+            TRY(pips_hip_vec_axpy(nz(), -omega, w_v, w_p, stream));
+            TRY(pips_hip_vec_axpby(nz(), 1.0, w_r, beta, w_p, stream));
+         }
+         TRY(pips_hip_vec_copy(nz(), w_p, w_dx, stream));
+         TRY(precond(w_dx));
+         TRY(kmult(w_dx, w_v));
+         double rtv, dxn, xn;
+         TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_v, &rtv, stream));
+         if (is_zero(rtv)) break;
+         alpha = rho / rtv;
+         TRY(two_norm(w_dx, &dxn));
+         TRY(two_norm(x_, &xn));
+         stagn(alpha, dxn, xn);
+         TRY(pips_hip_vec_axpy(nz(), alpha, w_dx, x_, stream));   // half-way iterate
+         TRY(pips_hip_vec_axpy(nz(), -alpha, w_v, w_r, stream));
+         TRY(two_norm(w_r, &rn));
+         if (rn <= target) {
+            TRY(residual(b_, x_, w_r, &rn));
+            if (rn <= target) break;
+         }
+         if (rn < min_rn) { min_rn = rn; TRY(pips_hip_vec_copy(nz(), x_, w_best, stream)); }
+         TRY(pips_hip_vec_copy(nz(), w_r, w_dx, stream));
+         TRY(precond(w_dx));
+         TRY(kmult(w_dx, w_t));
+         double tt, tr;
+         TRY(pips_hip_vec_dot(nz(), 0, w_t, w_t, &tt, stream));
+         if (is_zero(tt)) break;
+         TRY(pips_hip_vec_dot(nz(), 0, w_t, w_r, &tr, stream));
+         omega = tr / tt;
+         TRY(two_norm(w_dx, &dxn));
+         TRY(two_norm(x_, &xn));
+         stagn(omega, dxn, xn);
+         TRY(pips_hip_vec_axpy(nz(), omega, w_dx, x_, stream));
+         TRY(pips_hip_vec_axpy(nz(), -omega, w_t, w_r, stream));
+         TRY(two_norm(w_r, &rn));
+         if (rn <= target || nstag >= 4) {
+            TRY(residual(b_, x_, w_r, &rn));
+            if (rn <= target) break;
+         } else {
+            if (rn >= min_rn) ++ndiv; else ndiv = 0;
+            if (ndiv > 4) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; break; }   // diverged: roll back
+         }
+         if (rn < min_rn) { min_rn = rn; TRY(pips_hip_vec_copy(nz(), x_, w_best, stream)); }
+         if (nstag >= 4) { if (min_rn < rn) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; } break; }
+         if (is_zero(omega)) break;
+      }
+      if (min_rn < rn) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; }
+      last_outer_steps = it + 1;
+      last_outer_res = bn > 0 ? rn / bn : rn;
+      return PIPS_OK;
+   }
+
    // LinearSystem::solve + step.negate(): (sx, sy, sv, sg) := -solution for the residual set (rQ_, rA_, rv_, rg_)
    int solve(const double* rQ_, const double* rA_, const double* rv_, const double* rg_, double* sx, double* sy, double* sv, double* sg) {
       // rx = rQ + Gamma/V rv + rgamma/V ; ry = rA
@@ -175,48 +316,13 @@ struct Ipm {
       TRY(pips_hip_vec_add_product(nx, 1.0, dd, rv_, tx, stream));
       TRY(pips_hip_vec_add_quotient(nx, 1.0, rg_, v, nullptr, tx, stream));
       TRY(pips_hip_vec_copy(ny, rA_, ty, stream));
-      // outer iterative refinement on the ORIGINAL (unregularised) system [dd A^T; A 0], preconditioned by solveCompressed
-      // (LinearSystem::solveCompressedIterRefin, LinearSystem.C:877-966 = OUTER_SOLVE 1; the reference's default wraps the
-      // same preconditioner in BiCGStab, :550-798).  Stops at outer_tol * ||rhs||inf or after outer_max steps.
-      double bnorm_x, bnorm_y;
-      TRY(pips_hip_vec_inf_norm(nx, tx, &bnorm_x, stream));
-      TRY(pips_hip_vec_inf_norm(ny, ty, &bnorm_y, stream));
-      const double bnorm = std::max(std::max(bnorm_x, bnorm_y), 1e-300);
-      TRY(pips_hip_vec_set(nx, 0.0, sx, stream));
-      TRY(pips_hip_vec_set(ny, 0.0, sy, stream));
-      TRY(pips_hip_vec_copy(nx, tx, ex, stream));   // e = rhs - K * 0
-      TRY(pips_hip_vec_copy(ny, ty, ey, stream));
-      last_outer_steps = 0;
-      double best = INFINITY;
-      for (int it = 0; it <= outer_max; ++it) {
-         hipLaunchKernelGGL(k_kkt_pack, dim3(32, N + 1), dim3(256), 0, stream, N, n0, myl, d_xoff, d_yoff, d_koff, ex, ey, b0, bl, 0);
-         TRY(pips_hip_kkt_solve_compressed(kkt, b0, bl));
-         hipLaunchKernelGGL(k_kkt_pack, dim3(32, N + 1), dim3(256), 0, stream, N, n0, myl, d_xoff, d_yoff, d_koff, ex, ey, b0, bl, 1);
-         TRY(pips_hip_vec_axpy(nx, 1.0, ex, sx, stream));
-         TRY(pips_hip_vec_axpy(ny, 1.0, ey, sy, stream));
-         // e = rhs - [dd sx + A^T sy ; A sx]
-         TRY(pips_hip_vec_copy(nx, tx, ex, stream));
-         TRY(pips_hip_vec_add_product(nx, -1.0, dd, sx, ex, stream));
-         ATmult(sy, -1.0, 1.0, ex);
-         TRY(pips_hip_vec_copy(ny, ty, ey, stream));
-         Amult(sx, -1.0, 1.0, ey);
-         double e1, e2;
-         TRY(pips_hip_vec_inf_norm(nx, ex, &e1, stream));
-         TRY(pips_hip_vec_inf_norm(ny, ey, &e2, stream));
-         const double res = std::max(e1, e2) / bnorm;
-         if (!(res < best)) {
-            // the correction made things worse (preconditioner too inaccurate at this conditioning): keep the best iterate
-            TRY(pips_hip_vec_copy(nx, bx, sx, stream));
-            TRY(pips_hip_vec_copy(ny, by, sy, stream));
-            break;
-         }
-         best = res;
-         last_outer_res = res;
-         TRY(pips_hip_vec_copy(nx, sx, bx, stream));
-         TRY(pips_hip_vec_copy(ny, sy, by, stream));
-         if (res <= outer_tol) break;
-         ++last_outer_steps;
-      }
+      // joinRHS: z = [rx | ry]; outer solve on the ORIGINAL system [dd A^T; A 0] preconditioned by solveCompressed
+      TRY(pips_hip_vec_copy(nx, tx, bz, stream));
+      TRY(pips_hip_vec_copy(ny, ty, bz + nx, stream));
+      if (outer_mode == 2) TRY(bicgstab(bz, xz));
+      else TRY(iter_refine(bz, xz));
+      TRY(pips_hip_vec_copy(nx, xz, sx, stream));       // separateVars
+      TRY(pips_hip_vec_copy(ny, xz + nx, sy, stream));
       // solveXYZS: stepy.negate()
       TRY(pips_hip_vec_scale(ny, -1.0, sy, stream));
       // Dv = Dx - rv ; Dgamma = (rgamma - Gamma Dv) / V
@@ -272,10 +378,12 @@ struct Ipm {
          TRY(residuals(&rnorm, &pobj, &dobj));
          TRY(mu(&m));
          if (verbose)
-            printf("ipm it %3d  mu %.3e  ||r||inf %.3e  pobj %.10e  dobj %.10e  (last solve: %d outer steps, res %.1e)\n", it, m, rnorm, pobj,
+            printf("ipm it %3d  mu %.3e  ||r||inf %.3e  pobj %.10e  dobj %.10e  (last solve: %d outer its, rel.res %.1e)\n", it, m, rnorm, pobj,
                    dobj, last_outer_steps, last_outer_res);
          if (!(m == m) || !(rnorm == rnorm)) { status = 2; break; }         // numerical breakdown (NaN)
          if (m <= mutol && rnorm <= artol * dnorm) { status = 0; break; }   // PIPSIPMppSolver.cpp:143-149
+         // outer tolerance schedule (InteriorPointMethod.cpp:655-669): 1e-8 up to iteration 3, 1e-9 up to 7, then 1e-10
+         outer_tol = it <= 3 ? 1e-8 : (it <= 7 ? 1e-9 : 1e-10);
          // ---- predictor (affine scaling): rgamma = V Gamma e
          TRY(pips_hip_vec_copy(nx, v, rg, stream));
          TRY(pips_hip_vec_mul(nx, g, rg, stream));
@@ -416,12 +524,15 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
       return rc;
    std::vector<double> hc(c, c + p->nx), hb(b, b + p->ny);
    if ((rc = p->up(&p->c, hc)) || (rc = p->up(&p->b, hb))) return rc;
-   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx, &p->ex, &p->bx};
+   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx};
    for (auto d : xs)
       if ((rc = p->alloc(d, p->nx))) return rc;
-   double** ys[] = {&p->y, &p->rA, &p->dy, &p->cy, &p->ty, &p->zy, &p->ey, &p->by};
+   double** ys[] = {&p->y, &p->rA, &p->dy, &p->cy, &p->ty, &p->zy};
    for (auto d : ys)
       if ((rc = p->alloc(d, p->ny))) return rc;
+   double** zs[] = {&p->bz, &p->xz, &p->w_r, &p->w_r0, &p->w_best, &p->w_v, &p->w_t, &p->w_p, &p->w_dx};
+   for (auto d : zs)
+      if ((rc = p->alloc(d, (long long)p->nx + p->ny))) return rc;
    if ((rc = p->alloc(&p->b0, S)) || (rc = p->alloc(&p->bl, p->nleaf)) || (rc = p->alloc(&p->leaf_diag, p->nleaf))) return rc;
    *handle = p.release();
    return PIPS_OK;

@@ -709,34 +709,47 @@ __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns,
 }
 
 // tail forward step j: tiles i >= j of block b:  b_i -= L(i,j-1) (d z)_{j-1}  (j >= 1) ; tile i == j: z_j = Winv_j b_j
-__global__ __launch_bounds__(128) void k_tail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+// 256 threads: thread (row, half) accumulates 64 of the 128 columns with all its loads issued up front (the launch is
+// latency-bound for the late, small tile columns: one HBM round trip instead of sixteen), halves combined through LDS.
+__device__ __forceinline__ double tile_gemv_half(const double* __restrict__ M, long long ldm, const double* v, int row, int half) {
+   double m[64];
+#pragma unroll
+   for (int c = 0; c < 64; ++c) m[c] = M[row + (long long)(half * 64 + c) * ldm];
+   double s = 0.0;
+#pragma unroll
+   for (int c = 0; c < 64; ++c) s += m[c] * v[half * 64 + c];
+   return s;
+}
+
+__global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
                                                  const double* __restrict__ winv, double* __restrict__ xw, int j) {
    __shared__ double v[TILE];
+   __shared__ double part[TILE];
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
-   const int tid = threadIdx.x, ti = task.ti, ld = bd.ldT;
+   const int tid = threadIdx.x, row = tid & 127, half = tid >> 7, ti = task.ti, ld = bd.ldT;
    double* xt = xw + bd.xw_off + bd.n_head;
-   double acc = xt[ti * TILE + tid];
+   double acc = xt[ti * TILE + row];
    if (j >= 1) {
-      v[tid] = xt[(j - 1) * TILE + tid] * dtail[bd.dt_off + (j - 1) * TILE + tid];
+      if (tid < TILE) v[tid] = xt[(j - 1) * TILE + tid] * dtail[bd.dt_off + (j - 1) * TILE + tid];
       __syncthreads();
-      const double* L = arena + bd.T + (long long)ti * TILE + tid + (long long)(j - 1) * TILE * ld;
-#pragma unroll 8
-      for (int c = 0; c < TILE; ++c) acc -= L[(long long)c * ld] * v[c];
+      const double s = tile_gemv_half(arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, v, row, half);
+      if (half == 1) part[row] = s;
+      __syncthreads();
+      if (half == 0) acc -= s + part[row];
       __syncthreads();
    }
    if (ti == j) {
-      v[tid] = acc;
+      if (half == 0) v[row] = acc;
       __syncthreads();
-      const double* W = winv + bd.winv_off + (long long)j * TILE * TILE + tid;
-      double z = 0.0;
-#pragma unroll 8
-      for (int c = 0; c < TILE; ++c) z += W[(long long)c * TILE] * v[c];
-      acc = z;
+      const double s = tile_gemv_half(winv + bd.winv_off + (long long)j * TILE * TILE, TILE, v, row, half);
+      if (half == 1) part[row] = s;
+      __syncthreads();
+      if (half == 0) acc = s + part[row];
    }
-   xt[ti * TILE + tid] = acc;
+   if (half == 0) xt[ti * TILE + row] = acc;
 }
 
 // out[c] = sum_r M[r + c*ldm] v[r] for a 128 x 128 column-major tile: the tile is staged through LDS in chunks of 32
@@ -747,12 +760,16 @@ __device__ __forceinline__ void tile_tgemv(const double* __restrict__ M, long lo
                                            double* Ls, int tid) {
    const int row = tid & 127, cg = tid >> 7;
    const int col = tid >> 3, part = tid & 7;
+   // issue the loads of all four 32-column chunks first (64 per thread in flight): one HBM round trip per tile
+   double m[4][16];
+#pragma unroll
+   for (int chunk = 0; chunk < 4; ++chunk)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m[chunk][e] = M[row + (long long)(chunk * 32 + cg * 16 + e) * ldm];
+#pragma unroll
    for (int chunk = 0; chunk < 4; ++chunk) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-         const int c = cg * 16 + e;
-         Ls[c * TG_LD + row] = M[row + (long long)(chunk * 32 + c) * ldm];
-      }
+      for (int e = 0; e < 16; ++e) Ls[(cg * 16 + e) * TG_LD + row] = m[chunk][e];
       __syncthreads();
       double s = 0.0;
 #pragma unroll
