@@ -514,7 +514,7 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
    if (rc) return rc;
    for (int i = 0; i < N; ++i)
       if ((rc = pips_hip_batch_set_values(p->batch, i, kvals[i].data()))) return rc;
-   if ((rc = pips_hip_batch_set_refinement(p->batch, 2, 1e-12))) return rc;
+   if ((rc = pips_hip_batch_set_refinement_backward_error(p->batch, 2, 1e-15))) return rc;   // PARDISO iparm[7]=2 semantics
    rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr, nullptr, nullptr, 0, 1);
    if (rc) return rc;
    HIP_TRYH(hipGetDevice(&p->device));

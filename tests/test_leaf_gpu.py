@@ -183,3 +183,52 @@ def test_dense_root_matches_lapack(n, n_primal):
     assert np.linalg.norm(M @ xh - rhs) / np.linalg.norm(rhs) < 1e-10
     assert h.get_inertia() == (n_primal, m, 0)
     assert o.get_inertia()[:2] == (n_primal, m)
+
+
+def test_heterogeneous_blocks_in_one_batch():
+    """Blocks of different sizes and different head/tail splits (some without a dense tail) share every launch."""
+    import torch
+    shapes = [(40, 0.15), (700, 0.012), (150, 0.05), (1200, 0.008)]
+    S = 24
+    n0, myl = 14, 10
+    probs = [Problem(50 + i, 1, n_i, n_i // 2, n0, myl, rho) for i, (n_i, rho) in enumerate(shapes)]
+    bt = pa.LeafBatch(len(probs), S)
+    for i, pr in enumerate(probs):
+        bt.set_block(i, pr.blocks[0]["K"], pr.n_i, pr.blocks[0]["Bt"])
+    bt.analyze(4)
+    for i, pr in enumerate(probs):
+        bt.set_values(i, pr.blocks[0]["K"].val)
+    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
+    bt.factor(SC, S)
+    bt.sync()
+    want = np.zeros((S, S))
+    for pr in probs:
+        want += pr.oracle_schur()
+    got = hip_lower_as_rowmajor(SC.cpu().numpy(), S)
+    assert np.abs(got - np.tril(want)).max() / np.abs(want).max() < RTOL_SC, bt.info()
+    rhs = np.concatenate([np.random.default_rng(i).standard_normal(pr.n_leaf) for i, pr in enumerate(probs)])
+    x = rhs.copy()
+    bt.solve(x)
+    off = 0
+    for i, pr in enumerate(probs):
+        xi, ri = x[off:off + pr.n_leaf], rhs[off:off + pr.n_leaf]
+        assert np.linalg.norm(pr.K_full(0) @ xi - ri) / np.linalg.norm(ri) < 1e-10
+        assert bt.inertia(i) == (pr.n_i, pr.my_i, 0)
+        off += pr.n_leaf
+
+
+def test_block_without_border_and_zero_schur_dim():
+    prob = Problem(8, 2, 300, 150, 0, 0, 0.03)
+    bt = pa.LeafBatch(2, 0)
+    for b in range(2):
+        bt.set_block(b, prob.blocks[b]["K"], prob.n_i)
+    bt.analyze(2)
+    for b in range(2):
+        bt.set_values(b, prob.blocks[b]["K"].val)
+    bt.factor()
+    rhs = np.random.default_rng(3).standard_normal(2 * prob.n_leaf)
+    x = rhs.copy()
+    bt.solve(x)
+    for b in range(2):
+        r = rhs.reshape(2, -1)[b]
+        assert np.linalg.norm(prob.K_full(b) @ x.reshape(2, -1)[b] - r) / np.linalg.norm(r) < 1e-10
