@@ -710,14 +710,14 @@ struct KktSystem {
    int n0 = 0, my0 = 0, myl = 0, mzl = 0, S = 0;
    int rank = 0, n_ranks = 1;
    void* comm = nullptr;
-   double *d_SC = nullptr, *d_t = nullptr, *d_fin_val = nullptr, *d_c0_val = nullptr, *d_red = nullptr;
+   double *d_SC = nullptr, *d_t = nullptr, *d_fin_val = nullptr, *d_c0_val = nullptr, *d_red = nullptr, *d_packed = nullptr;
    long long* d_fin_idx = nullptr;
    long long n_fin = 0;
    int mz0 = 0;
    int *d_c0_rp = nullptr, *d_c0_ci = nullptr;
    const double* d_zdiag0 = nullptr;   // caller-owned, set per iteration
    ~KktSystem() {
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
@@ -761,6 +761,18 @@ __global__ void k_add_regularization(const BlkDesc* __restrict__ blks, const int
    const int np = n_primal[blockIdx.y];
    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bd.n; i += gridDim.x * blockDim.x)
       kval[kdiag[bd.x_off + i]] += (np < 0 || i < np) ? primal : -dual;
+}
+
+// pack / unpack the lower triangle of the column-major S x S Schur complement (column c holds S - c entries):
+// the reference reduces packed triangles too (submatrixAllReduceDiagLower, DistributedRootLinearSystem.C:1661-1707)
+__global__ void k_pack_lower(const double* __restrict__ M, int ld, int S, double* __restrict__ packed, int unpack) {
+   const int c = blockIdx.y;
+   const long long base = (long long)c * S - (long long)c * (c - 1) / 2;
+   double* col = const_cast<double*>(M) + (long long)c * ld;
+   for (int r = c + blockIdx.x * blockDim.x + threadIdx.x; r < S; r += gridDim.x * blockDim.x) {
+      if (unpack) col[r] = packed[base + (r - c)];
+      else packed[base + (r - c)] = col[r];
+   }
 }
 
 __global__ void k_add_diag(double* __restrict__ M, int ld, int off, const double* __restrict__ d, int n) {
@@ -1282,9 +1294,17 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    const size_t n = (size_t)k->S * k->S;
    HIP_TRY(hipMemsetAsync(k->d_SC, 0, n * sizeof(double), e->stream));            // initializeKKT (:840-847)
    if ((rc = e->factor(k->d_SC, k->S))) return rc;                               // children factor2 + assembleLocalKKT
-   if (k->n_ranks > 1) {                                                          // reduceKKT (:860-881)
+   // reduceKKT (:860-881).  PIPS_HIP_FORCE_REDUCE exercises the reduction path with a one-rank communicator (tests).
+   const bool reduce = k->n_ranks > 1 || (k->comm && getenv("PIPS_HIP_FORCE_REDUCE"));
+   if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
-      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_SC, n, e->stream))) return rc;
+      // only the lower triangle is authoritative: reduce S(S+1)/2 packed doubles instead of S^2
+      const size_t np = (size_t)k->S * (k->S + 1) / 2;
+      if (!k->d_packed) HIP_TRY(hipMalloc((void**)&k->d_packed, np * sizeof(double)));
+      const dim3 pg(std::max(1, std::min(64, (k->S + 255) / 256)), k->S);
+      hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 0);
+      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_packed, np, e->stream))) return rc;
+      hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 1);
    }
    // finalizeKKTdense
    if (xdiag0_dev && k->n0 > 0)
@@ -1323,7 +1343,8 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
    if ((rc = e->solve(b_leaf_dev))) return rc;
    if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
-   if (k->n_ranks > 1 && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream))) return rc;
+   if ((k->n_ranks > 1 || (k->comm && getenv("PIPS_HIP_FORCE_REDUCE"))) && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream)))
+      return rc;
    // Dsolve: eliminate z0 through C0, solve with the Schur complement, recover z0 (solveReducedLinkCons :384-466)
    if (k->mz0 > 0)
       hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,

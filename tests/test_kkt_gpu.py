@@ -82,3 +82,30 @@ def test_rccl_communicator_single_rank_roundtrip():
     torch.cuda.synchronize()
     assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
     comm.close()
+
+
+def test_reduction_path_with_one_rank_communicator(monkeypatch):
+    """pack lower triangle -> RCCL all-reduce -> unpack, and the b0 all-reduce, driven on one GPU: results must not change."""
+    import torch
+    monkeypatch.setenv("PIPS_HIP_FORCE_REDUCE", "1")
+    prob = Problem(78, 3, 200, 100, 24, 16, 0.04)
+    comm = pa.Comm(pa.Comm.unique_id(), 1, 0, 0)
+    bt, kkt = build_system(prob, comm=comm, rank=0, n_ranks=1)
+    diag = torch.tensor(np.concatenate([b["diag"] for b in prob.blocks]), device="cuda")
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    got = hip_lower_as_rowmajor(kkt.schur_to_host(), prob.S)
+    want = np.tril(prob.oracle_finalize(prob.oracle_schur()))
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9
+    rng = np.random.default_rng(5)
+    b0, bl = rng.standard_normal(prob.S), rng.standard_normal(prob.N * prob.n_leaf)
+    b0_d, bl_d = torch.tensor(b0, device="cuda"), torch.tensor(bl, device="cuda")
+    kkt.solve_compressed(b0_d, bl_d)
+    bt.sync()
+    root = orc.DenseRootSolver(prob.S)
+    root.matrixChanged(want)
+    bs_o = [bl.reshape(prob.N, -1)[b].copy() for b in range(prob.N)]
+    b0_o = b0.copy()
+    orc.solve_compressed(b0_o, bs_o, [prob.oracle_leaf(b) for b in range(prob.N)], [prob.Bt_scipy(b) for b in range(prob.N)], root,
+                         prob.n0, 0, 0, prob.myl, 0)
+    assert np.linalg.norm(b0_d.cpu().numpy() - b0_o) / np.linalg.norm(b0_o) < 1e-8
+    comm.close()
