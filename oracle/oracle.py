@@ -114,6 +114,7 @@ class OracleLdl:
         self.krow = np.ascontiguousarray(K.indptr, dtype=np.int32)
         self.jcol = np.ascontiguousarray(K.indices, dtype=np.int32)
         self.perm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        self.n_primal = n_primal
         self.psign = None
         if n_primal >= 0:
             self.psign = np.where(np.arange(self.n) < n_primal, 1, -1).astype(np.int8)
@@ -129,7 +130,21 @@ class OracleLdl:
         amax = float(np.abs(self.vals).max()) if self.vals.size else 1.0
         amax = amax if amax > 0 else 1.0
         lib().oracle_ldl_factor(self._f, _p(self.vals), _p(self.psign), C.c_double(self.thr_rel), C.c_double(self.repl_rel),
-                                C.c_double(self.repl_rel * amax))
+                                C.c_double(self.repl_rel * amax), _p(self._pivot_reference()))
+
+    def _pivot_reference(self):
+        """|a_kk| for primal rows, |a_kk| + sum_j K_kj^2/|K_jj| over the primal neighbours for dual rows (the magnitude of the
+        normal-equation diagonal the pivot is built from)."""
+        K = self.K
+        diag = np.abs(K.diagonal())
+        pref = diag.copy()
+        if self.n_primal >= 0:
+            for i in range(self.n_primal, self.n):
+                s, e = K.indptr[i], K.indptr[i + 1]
+                cols, vals = K.indices[s:e], K.data[s:e]
+                m = (cols < self.n_primal) & (diag[cols] > 0)
+                pref[i] += np.sum(vals[m] ** 2 / diag[cols[m]])
+        return np.ascontiguousarray(pref)
 
     def _solve_raw(self, x):
         nrhs = 1 if x.ndim == 1 else x.shape[0]

@@ -104,9 +104,11 @@ long oracle_ldl_nnzL(const oracle_ldl* f) { return f->Lp[f->n]; }
 
 /* numeric phase.  psign (original order, may be NULL): expected pivot sign +1/-1/0.  Static pivoting rule: with
  * pref = |original diagonal entry| a pivot d is accepted iff sign*d > thr_rel*pref (|d| > thr_rel*pref when the sign is
- * unknown); otherwise it is replaced by sign*repl_rel*pref (repl_abs if pref == 0) and counted in inertia[2]. */
+ * unknown); otherwise it is replaced by sign*repl_rel*pref (repl_abs if pref == 0) and counted in inertia[2].
+ * pref_in (original order, may be NULL): caller-supplied reference magnitudes (oracle.py passes |a_kk| + sum_j K_kj^2/|K_jj|
+ * for dual rows, the normal-equation diagonal, so that a rank-deficient pivot is caught whatever sign its noise has). */
 int oracle_ldl_factor(oracle_ldl* f, const double* val, const signed char* psign, double thr_rel, double repl_rel,
-                      double repl_abs) {
+                      double repl_abs, const double* pref_in) {
    const int n = f->n;
    double* Ux = (double*)xmalloc(sizeof(double) * f->nnz);
    for (int p = 0; p < f->nnz; ++p) Ux[f->Umap[p]] = val[p];
@@ -130,7 +132,7 @@ int oracle_ldl_factor(oracle_ldl* f, const double* val, const signed char* psign
          while (len > 0) pattern[--top] = pattern[--len];
       }
       double d = Y[k];
-      const double pref = fabs(d);
+      const double pref = pref_in ? pref_in[f->perm[k]] : fabs(d);
       const double thr = thr_rel * pref, repl = pref > 0.0 ? repl_rel * pref : repl_abs;
       Y[k] = 0.0;
       for (; top < n; ++top) {

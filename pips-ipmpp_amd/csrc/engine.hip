@@ -195,22 +195,22 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    return PIPS_OK;
 }
 
-static int tail_fwd(const TailCtx& c, double* xw) {
+static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
    for (int j = 0; j < p.ntc_max; ++j)
       if (p.fwd[j].cnt > 0)
-         hipLaunchKernelGGL(k_tail_fwd, dim3(p.fwd[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.fwd[j].off, c.d_blks,
-                            c.d_arena, c.d_dtail, c.d_winv, xw, j);
+         hipLaunchKernelGGL(k_tail_fwd, dim3(p.fwd[j].cnt, nrhs), dim3(256), 0, c.stream, p.d_tasks + p.fwd[j].off, c.d_blks,
+                            c.d_arena, c.d_dtail, c.d_winv, xw, j, xw_stride);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;
 }
 
-static int tail_bwd(const TailCtx& c, double* xw) {
+static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
    for (int i = p.ntc_max - 1; i >= 0; --i)
       if (p.bwd[i].cnt > 0)
-         hipLaunchKernelGGL(k_tail_bwd, dim3(p.bwd[i].cnt), dim3(256), 0, c.stream, p.d_tasks + p.bwd[i].off, c.d_blks,
-                            c.d_arena, c.d_dtail, c.d_winv, xw, i);
+         hipLaunchKernelGGL(k_tail_bwd, dim3(p.bwd[i].cnt, nrhs), dim3(256), 0, c.stream, p.d_tasks + p.bwd[i].off, c.d_blks,
+                            c.d_arena, c.d_dtail, c.d_winv, xw, i, xw_stride);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;
 }
@@ -281,6 +281,8 @@ struct Engine {
       d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = d_pref = d_norms = nullptr;
       if (h_norms) (void)hipHostFree(h_norms);
       h_norms = nullptr;
+      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      mx_cap = 0;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
@@ -506,7 +508,8 @@ struct Engine {
       if (nnzB_total > 0)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzB_total, 256)), dim3(256), 0, stream, d_bdst, d_bval, d_arena, nnzB_total);
       hipLaunchKernelGGL(k_tail_pad_diag, dim3(nblk), dim3(128), 0, stream, d_blks, d_arena, nblk);
-      hipLaunchKernelGGL(k_pref_init, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, d_kval, d_kdiag, d_pref);
+      hipLaunchKernelGGL(k_pref_init, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, d_kval, d_kdiag, d_pref, d_nprimal,
+                         d_krowptr, d_kcolidx);
       if (timer.on) timer.end(stream);
       // the whole-factor record (phase 6) was pushed first; close it at the end
       const size_t total_rec = 0;
@@ -532,32 +535,77 @@ struct Engine {
       return PIPS_OK;
    }
 
-   int solve_once(double* x_dev) {
-      const dim3 pg(64, nblk);
-      hipLaunchKernelGGL(k_permute_in, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, 0LL, d_xw, nblk);
+   // nrhs right-hand sides at x_dev + r * x_stride (flat over all blocks each); work vectors at xw + r * xw_total
+   int solve_once(double* x_dev, int nrhs = 1, long long x_stride = 0, double* xw = nullptr) {
+      if (!xw) xw = d_xw;
+      const long long xws = nrhs > 1 ? xw_total : 0;
+      const dim3 pg(64, nblk, nrhs);
+      hipLaunchKernelGGL(k_permute_in, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
       for (const LevelRange& L : levels) {
          // small and large supernodes of one level are contiguous in d_sns
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
          if (cnt > 0)
-            hipLaunchKernelGGL(k_head_fwd, dim3(cnt), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw);
+            hipLaunchKernelGGL(k_head_fwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
       TailCtx c = ctx();
-      int rc = tail_fwd(c, d_xw);
+      int rc = tail_fwd(c, xw, nrhs, xws);
       if (rc) return rc;
       if (nsn_total > 0)
-         hipLaunchKernelGGL(k_head_dscale, dim3(grid_for(nsn_total, 256)), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
-                            d_arena, d_xw);
-      rc = tail_bwd(c, d_xw);
+         hipLaunchKernelGGL(k_head_dscale, dim3(grid_for(nsn_total, 256), nrhs), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
+                            d_arena, xw, xws);
+      rc = tail_bwd(c, xw, nrhs, xws);
       if (rc) return rc;
       for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
          if (cnt > 0)
-            hipLaunchKernelGGL(k_head_bwd, dim3(cnt), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw);
+            hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
-      hipLaunchKernelGGL(k_permute_out, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, 0LL, d_xw, nblk);
+      hipLaunchKernelGGL(k_permute_out, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
+
+   // multi-RHS solve (DoubleLinearSolver::solve(int nrhss, double* rhss, int*), PardisoSolver.C:276-352): all right-hand
+   // sides share every launch (grid.y/z = rhs index); refine_steps unconditional refinement steps.  X_dev: nrhs vectors of
+   // length n_total at distance x_stride.
+   double *d_mx_xw = nullptr, *d_mx_rhs = nullptr, *d_mx_res = nullptr;
+   int mx_cap = 0;
+   int solve_multi(double* X_dev, int nrhs, long long x_stride) {
+      if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
+      HIP_TRY(hipSetDevice(device));
+      const int chunk_max = 32;
+      if (mx_cap == 0) {
+         HIP_TRY(hipMalloc((void**)&d_mx_xw, (size_t)chunk_max * std::max<long long>(xw_total, 1) * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_mx_rhs, (size_t)chunk_max * std::max<long long>(n_total, 1) * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_mx_res, (size_t)chunk_max * std::max<long long>(n_total, 1) * sizeof(double)));
+         mx_cap = chunk_max;
+      }
+      for (int r0 = 0; r0 < nrhs; r0 += chunk_max) {
+         const int nr = std::min(chunk_max, nrhs - r0);
+         double* X = X_dev + (long long)r0 * x_stride;
+         if (refine_steps > 0)
+            HIP_TRY(hipMemcpy2DAsync(d_mx_rhs, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
+                                     (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
+         int rc = solve_once(X, nr, x_stride, d_mx_xw);
+         if (rc) return rc;
+         for (int it = 0; it < refine_steps; ++it) {
+            HIP_TRY(hipMemcpyAsync(d_mx_res, d_mx_rhs, (size_t)nr * n_total * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            // r = rhs - K x for every right-hand side: x at stride x_stride, r contiguous -> copy x into a contiguous view first
+            HIP_TRY(hipMemcpy2DAsync(d_mx_xw, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
+                                     (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
+            // (d_mx_xw is free between solves; it is at least nr * n_total long because xw_total >= n_total)
+            hipLaunchKernelGGL(k_sym_spmv_sub, dim3(grid_for(n_total, 256), nr), dim3(256), 0, stream, d_krowptr, d_kcolidx, d_kval,
+                               d_mx_xw, d_mx_res, n_total, d_rowbase, n_total);
+            rc = solve_once(d_mx_res, nr, n_total, d_mx_xw);
+            if (rc) return rc;
+            for (int r = 0; r < nr; ++r)
+               hipLaunchKernelGGL(k_axpy, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, X + (long long)r * x_stride,
+                                  d_mx_res + (long long)r * n_total, 1.0, n_total);
+         }
+      }
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
@@ -579,7 +627,7 @@ struct Engine {
       for (int it = 0; it < refine_steps; ++it) {
          HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
          hipLaunchKernelGGL(k_sym_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_krowptr, d_kcolidx, d_kval,
-                            x_dev, d_res, n_total, d_rowbase);
+                            x_dev, d_res, n_total, d_rowbase, 0LL);
          if (refine_tol > 0.0) {
             hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
             if (refine_mode == 1)
@@ -1108,15 +1156,25 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    Engine& e = h->eng;
    if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve: factor first");
    HIP_TRY(hipSetDevice(e.device));
-   const size_t bytes = (size_t)e.n_total * sizeof(double);
-   for (int k = 0; k < nrhs; ++k) {
-      double* x = rhs + (size_t)k * ld;
-      HIP_TRY(hipMemcpyAsync(e.d_stage, x, bytes, hipMemcpyHostToDevice, e.stream));
+   const size_t row = (size_t)e.n_total * sizeof(double);
+   if (nrhs == 1) {
+      HIP_TRY(hipMemcpyAsync(e.d_stage, rhs, row, hipMemcpyHostToDevice, e.stream));
       int rc = e.solve(e.d_stage);
       if (rc) return rc;
-      HIP_TRY(hipMemcpyAsync(x, e.d_stage, bytes, hipMemcpyDeviceToHost, e.stream));
+      HIP_TRY(hipMemcpyAsync(rhs, e.d_stage, row, hipMemcpyDeviceToHost, e.stream));
       HIP_TRY(hipStreamSynchronize(e.stream));
+      return PIPS_OK;
    }
+   // all right-hand sides in one pass (one RHS per row of length ld, PardisoSolver.C:276-352)
+   double* d_X = nullptr;
+   HIP_TRY(hipMalloc((void**)&d_X, (size_t)nrhs * row));
+   hipError_t err = hipMemcpy2DAsync(d_X, row, rhs, (size_t)ld * sizeof(double), row, nrhs, hipMemcpyHostToDevice, e.stream);
+   int rc = err == hipSuccess ? e.solve_multi(d_X, nrhs, e.n_total) : PIPS_ERR_HIP;
+   if (!rc) err = hipMemcpy2DAsync(rhs, (size_t)ld * sizeof(double), d_X, row, row, nrhs, hipMemcpyDeviceToHost, e.stream);
+   if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+   (void)hipFree(d_X);
+   if (rc) return rc;
+   if (err != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_ldl_solve: %s", hipGetErrorString(err));
    return PIPS_OK;
 }
 

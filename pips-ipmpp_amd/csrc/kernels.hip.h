@@ -94,12 +94,32 @@ __global__ void k_tail_pad_diag(const BlkDesc* __restrict__ blks, double* __rest
 // pivot reference magnitudes, permuted order, same layout as the work vectors (xw_off, length n_head + m_pad)
 __global__ void k_pref_init(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
                             const long long* __restrict__ perm_off, const double* __restrict__ kval,
-                            const long long* __restrict__ kdiag, double* __restrict__ pref) {
+                            const long long* __restrict__ kdiag, double* __restrict__ pref, const int* __restrict__ n_primal,
+                            const int* __restrict__ krowptr, const int* __restrict__ kcolidx) {
+   // primal row: |a_kk|.  dual row: |a_kk| + sum_j K_kj^2 / |K_jj| over its primal neighbours j, i.e. the magnitude of the
+   // normal-equation diagonal (W D^-1 W^T)_kk the pivot is built from - so that a pivot which cancels to rounding noise
+   // (rank-deficient W) is recognised whatever sign the noise has, also when the dual diagonal itself is zero.
    const BlkDesc bd = blks[blockIdx.y];
    const int* p = perm + perm_off[blockIdx.y];
+   const int np = n_primal[blockIdx.y];
    const int len = bd.n_head + bd.m_pad;
-   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x)
-      pref[bd.xw_off + k] = k < bd.n ? fabs(kval[kdiag[bd.x_off + p[k]]]) : 1.0;
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x) {
+      double v = 1.0;
+      if (k < bd.n) {
+         const int i = p[k];
+         v = fabs(kval[kdiag[bd.x_off + i]]);
+         if (np >= 0 && i >= np) {
+            for (int q = krowptr[bd.x_off + i]; q < krowptr[bd.x_off + i + 1]; ++q) {
+               const int j = kcolidx[q];
+               if (j < np) {
+                  const double dj = fabs(kval[kdiag[bd.x_off + j]]);
+                  if (dj > 0.0) v += kval[q] * kval[q] / dj;
+               }
+            }
+         }
+      }
+      pref[bd.xw_off + k] = v;
+   }
 }
 
 // tail columns: reference := max(reference, |diagonal after the head has been eliminated|)
@@ -620,36 +640,41 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // gather/scatter between original-order flat vectors and the permuted work vectors
 __global__ void k_permute_in(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
-                             const long long* __restrict__ perm_off, const double* __restrict__ x, long long x_stride_off,
-                             double* __restrict__ xw, int nblk) {
+                             const long long* __restrict__ perm_off, const double* __restrict__ x, long long x_stride,
+                             double* __restrict__ xw, long long xw_stride) {
+   // blockIdx.y = block, blockIdx.z = right-hand side (rhs r lives at x + r*x_stride, its work vector at xw + r*xw_stride)
    const int b = blockIdx.y;
    const BlkDesc bd = blks[b];
    const int* p = perm + perm_off[b];
    const int len = bd.n_head + bd.m_pad;
+   x += x_stride * blockIdx.z;
+   xw += xw_stride * blockIdx.z;
    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x)
-      xw[bd.xw_off + k] = k < bd.n ? x[x_stride_off + bd.x_off + p[k]] : 0.0;
+      xw[bd.xw_off + k] = k < bd.n ? x[bd.x_off + p[k]] : 0.0;
 }
 
 __global__ void k_permute_out(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
-                              const long long* __restrict__ perm_off, double* __restrict__ x, long long x_stride_off,
-                              const double* __restrict__ xw, int nblk) {
+                              const long long* __restrict__ perm_off, double* __restrict__ x, long long x_stride,
+                              const double* __restrict__ xw, long long xw_stride) {
    const int b = blockIdx.y;
    const BlkDesc bd = blks[b];
    const int* p = perm + perm_off[b];
+   x += x_stride * blockIdx.z;
+   xw += xw_stride * blockIdx.z;
    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < bd.n; k += gridDim.x * blockDim.x)
-      x[x_stride_off + bd.x_off + p[k]] = xw[bd.xw_off + k];
+      x[bd.x_off + p[k]] = xw[bd.xw_off + k];
 }
 
 // head forward: y_J = L11^-1 b_J ; b[rows] -= L21 y_J (atomics) ; one wave per supernode
 __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw) {
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
    __shared__ double y[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
    const double* P = arena + sn.panel;
-   double* xb = xw + bd.xw_off;
+   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;   // blockIdx.y = right-hand side
    if (tid < w) y[tid] = xb[sn.c0 + tid];
    __syncthreads();
    for (int k = 0; k < w; ++k) {
@@ -670,7 +695,8 @@ __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns,
 
 // head diagonal scaling: z = D^-1 y for the head columns
 __global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
-                              const double* __restrict__ arena, double* __restrict__ xw) {
+                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+   xw += xw_stride * blockIdx.y;
    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsn; s += gridDim.x * blockDim.x) {
       const SnDesc sn = sns[s];
       const BlkDesc bd = blks[sn.blk];
@@ -682,13 +708,13 @@ __global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const Blk
 // head backward: x_J = L11^-T (z_J - L21^T x_below)
 __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw) {
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
    __shared__ double y[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
    const double* P = arena + sn.panel;
-   double* xb = xw + bd.xw_off;
+   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
    const int* rows = rowidx + sn.rows;
    for (int k = 0; k < w; ++k) {
       double s = 0.0;
@@ -723,9 +749,11 @@ __device__ __forceinline__ double tile_gemv_half(const double* __restrict__ M, l
 
 __global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
-                                                 const double* __restrict__ winv, double* __restrict__ xw, int j) {
+                                                 const double* __restrict__ winv, double* __restrict__ xw, int j,
+                                                 long long xw_stride) {
    __shared__ double v[TILE];
    __shared__ double part[TILE];
+   xw += xw_stride * blockIdx.y;   // blockIdx.y = right-hand side
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
@@ -785,7 +813,9 @@ __device__ __forceinline__ void tile_tgemv(const double* __restrict__ M, long lo
 // tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} (if i+1 < ntc) ; tile j == i: x_i = Winv_i^T (d_i z_i)
 __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
-                                                 const double* __restrict__ winv, double* __restrict__ xw, int i) {
+                                                 const double* __restrict__ winv, double* __restrict__ xw, int i,
+                                                 long long xw_stride) {
+   xw += xw_stride * blockIdx.y;
    __shared__ double Ls[32 * TG_LD];
    __shared__ double v[TILE];
    __shared__ double outp[TILE];
@@ -816,7 +846,9 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ t
 // the transposed part.  Used by iterative refinement:  r = b - K x.
 __global__ void k_sym_spmv_sub(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
-                               long long nrows_total, const long long* __restrict__ row_blk_base) {
+                               long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride) {
+   x += vec_stride * blockIdx.y;   // blockIdx.y = right-hand side
+   y += vec_stride * blockIdx.y;
    // rowptr is global over all blocks (entries index kval), colidx is block-local; row_blk_base[row] = x_off of its block
    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows_total; i += (long long)gridDim.x * blockDim.x) {
       const long long base = row_blk_base[i];

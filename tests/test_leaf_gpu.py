@@ -63,11 +63,11 @@ def test_leaf_multi_rhs_rows():
     s = pa.HipLdlSolver(blk["K"], n_primal=prob.n_i)
     s.matrixChanged()
     rng = np.random.default_rng(0)
-    R = rng.standard_normal((7, prob.n_leaf))
+    R = rng.standard_normal((40, prob.n_leaf))   # 40 right-hand sides: two chunks of the batched multi-RHS path
     X = R.copy()
     s.solve(X)
     lu = spl.splu(prob.K_full(0))
-    for k in range(7):
+    for k in range(40):
         xr = lu.solve(R[k])
         assert np.linalg.norm(X[k] - xr) / np.linalg.norm(xr) < 1e-9
 
