@@ -232,7 +232,7 @@ struct BlockInput {
    std::vector<double> btval;
 };
 
-struct LevelRange { int small_begin, small_cnt, large_begin, large_cnt; };
+struct LevelRange { int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt; };
 
 struct Engine {
    int device = 0;
@@ -378,7 +378,10 @@ struct Engine {
       for (int b = 0; b < nblk; ++b)
          for (int l = 0; l < (int)sym[b].sn.size(); ++l) {
             const HeadSupernode& s = sym[b].sn[l];
-            const int cls = (s.w <= 8 && s.r <= 64) ? 0 : 1;
+            // class 0: "simple leaf" (w = 1, r <= 16, level 0, every row in the tail/border) -> one thread each;
+            // class 1: small (one wave); class 2: large (256 threads)
+            int cls = (s.w <= 8 && s.r <= 64) ? 1 : 2;
+            if (s.w == 1 && s.r <= SIMPLE_RMAX && s.level == 0 && (s.r == 0 || sym[b].rowidx[s.rows] >= sym[b].n_head)) cls = 0;
             keys.push_back({s.level, cls, b, l});
             nlev = std::max(nlev, s.level + 1);
          }
@@ -388,14 +391,15 @@ struct Engine {
       std::vector<SnDesc> h_sns(nsn_total);
       std::vector<std::vector<int>> sorted_id(nblk);
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
-      levels.assign(nlev, LevelRange{0, 0, 0, 0});
+      levels.assign(nlev, LevelRange{0, 0, 0, 0, 0, 0});
       for (int i = 0; i < nsn_total; ++i) {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, s.w, s.r, s.c0, k.blk};
          sorted_id[k.blk][k.loc] = i;
          LevelRange& L = levels[k.level];
-         if (k.cls == 0) { if (L.small_cnt++ == 0) L.small_begin = i; }
+         if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
+         else if (k.cls == 1) { if (L.small_cnt++ == 0) L.small_begin = i; }
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
       }
       // ---- concatenated index arrays
@@ -515,6 +519,9 @@ struct Engine {
       const size_t total_rec = 0;
       for (const LevelRange& L : levels) {
          if (timer.on) timer.begin(stream, 1);
+         if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
+                               L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
          if (L.small_cnt > 0)
             hipLaunchKernelGGL((k_head_factor<64, 8, 512, 64>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
                                d_blks, d_rowidx, d_sncol, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
@@ -542,6 +549,9 @@ struct Engine {
       const dim3 pg(64, nblk, nrhs);
       hipLaunchKernelGGL(k_permute_in, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
       for (const LevelRange& L : levels) {
+         if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
+                               L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 0);
          // small and large supernodes of one level are contiguous in d_sns
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
@@ -562,6 +572,9 @@ struct Engine {
          const int cnt = L.small_cnt + L.large_cnt;
          if (cnt > 0)
             hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
+         if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
+                               L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 1);
       }
       hipLaunchKernelGGL(k_permute_out, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
       HIP_TRY(hipGetLastError());

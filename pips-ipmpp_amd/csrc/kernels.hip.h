@@ -345,6 +345,99 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// "simple leaf" head supernodes: width 1, at most 16 rows below, elimination-tree leaves whose rows all lie in the dense
+// tail or the border (every primal column of an LP block looks like this: ~10^4 per block).  One THREAD per supernode:
+// the launch is throughput-bound instead of paying a workgroup's dependent-load latency chain per 21-flop supernode.
+// ------------------------------------------------------------------------------------------------
+constexpr int SIMPLE_RMAX = 16;
+
+__global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
+                                                           const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                           const signed char* __restrict__ psign,
+                                                           const long long* __restrict__ psign_off, const int* __restrict__ bmap,
+                                                           double* __restrict__ arena, double* __restrict__ SC, int ldSC,
+                                                           int* __restrict__ inertia, const double* __restrict__ pref) {
+   __shared__ int cnt_s[3];
+   __shared__ int blk_s;
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (threadIdx.x == 0) blk_s = sns[sn_begin + min(blockIdx.x * blockDim.x, (unsigned)cnt - 1)].blk;
+   if (threadIdx.x < 3) cnt_s[threadIdx.x] = 0;
+   __syncthreads();
+   if (t < cnt) {
+      const SnDesc sn = sns[sn_begin + t];
+      const BlkDesc bd = blks[sn.blk];
+      const int r = sn.r;
+      double* P = arena + sn.panel;
+      const int* rows = rowidx + sn.rows;
+      bool pert;
+      const double d = fix_pivot(P[0], psign[psign_off[sn.blk] + sn.c0], pref[bd.xw_off + sn.c0], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
+      P[0] = d;
+      const int which = pert ? 2 : (d > 0 ? 0 : 1);
+      if (sn.blk == blk_s) atomicAdd(&cnt_s[which], 1); else atomicAdd(&inertia[3 * sn.blk + which], 1);
+      double l[SIMPLE_RMAX];
+      int ro[SIMPLE_RMAX];
+#pragma unroll
+      for (int a = 0; a < SIMPLE_RMAX; ++a)
+         if (a < r) { ro[a] = rows[a]; l[a] = P[1 + a] / d; P[1 + a] = l[a]; }
+      double* T = arena + bd.T;
+      const int* bm = bmap + bd.bmap_off;
+      const int n = bd.n, n_head = bd.n_head;
+#pragma unroll
+      for (int b = 0; b < SIMPLE_RMAX; ++b) {
+         if (b < r) {
+            const int cb = ro[b];
+            const double lbd = l[b] * d;
+#pragma unroll
+            for (int a = b; a < SIMPLE_RMAX; ++a) {
+               if (a < r) {
+                  const int ra = ro[a];
+                  const double u = l[a] * lbd;
+                  if (cb < n) {
+                     const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
+                     atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -u);
+                  } else if (SC) {
+                     atomic_add_f64(SC + bm[ra - n] + (long long)bm[cb - n] * ldSC, -u);
+                  }
+               }
+            }
+         }
+      }
+   }
+   __syncthreads();
+   if (threadIdx.x < 3 && cnt_s[threadIdx.x]) atomicAdd(&inertia[3 * blk_s + threadIdx.x], cnt_s[threadIdx.x]);
+}
+
+// forward / backward substitution for the simple leaves: y = b_c (unit pivot block); b[rows] -= l y   /   x_c = z_c - l^T x[rows]
+__global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
+                                                          const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                          const double* __restrict__ arena, double* __restrict__ xw,
+                                                          long long xw_stride, int backward) {
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= cnt) return;
+   const SnDesc sn = sns[sn_begin + t];
+   const BlkDesc bd = blks[sn.blk];
+   const double* P = arena + sn.panel;
+   const int* rows = rowidx + sn.rows;
+   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
+   if (!backward) {
+      const double y = xb[sn.c0];
+      for (int a = 0; a < sn.r; ++a) {
+         const int ra = rows[a];
+         if (ra >= bd.n) break;
+         atomic_add_f64(xb + ra, -P[1 + a] * y);
+      }
+   } else {
+      double s = 0.0;
+      for (int a = 0; a < sn.r; ++a) {
+         const int ra = rows[a];
+         if (ra >= bd.n) break;
+         s += P[1 + a] * xb[ra];
+      }
+      xb[sn.c0] -= s;
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tile GEMM on the FP64 matrix cores.
 //   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
 //   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
