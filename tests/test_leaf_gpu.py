@@ -232,3 +232,34 @@ def test_block_without_border_and_zero_schur_dim():
     for b in range(2):
         r = rhs.reshape(2, -1)[b]
         assert np.linalg.norm(prob.K_full(b) @ x.reshape(2, -1)[b] - r) / np.linalg.norm(r) < 1e-10
+
+
+@pytest.mark.parametrize("kind", ["spd_grid", "indefinite_banded"])
+def test_structured_matrices_without_inertia_hint(kind):
+    """No inertia hint (unconstrained ordering, sign-agnostic pivot rule) on structured matrices: a 2-D grid Laplacian
+    (deep elimination tree, wide supernodes) and a banded quasi-definite matrix."""
+    import scipy.sparse as sp
+    if kind == "spd_grid":
+        g = 40
+        I = sp.identity(g)
+        T = sp.diags([-1, 4.2, -1], [-1, 0, 1], shape=(g, g))
+        A = (sp.kron(I, T) + sp.kron(sp.diags([-1, -1], [-1, 1], shape=(g, g)), I)).tocsr()
+        want_inertia = (g * g, 0, 0)
+    else:
+        n, m = 900, 300
+        rng = np.random.default_rng(0)
+        W = sp.diags([rng.uniform(0.5, 1.5, m), rng.uniform(-1, 1, m), rng.uniform(-1, 1, m)], [0, 1, 2], shape=(m, n))
+        A = sp.bmat([[sp.diags(rng.uniform(0.5, 2.0, n)), W.T], [W, -1e-6 * sp.identity(m)]]).tocsr()
+        want_inertia = (n, m, 0)
+    low = sp.tril(A).tocsr()
+    low.sort_indices()
+    K = pa.Csr(low.shape[0], low.shape[1], low.indptr, low.indices, low.data)
+    s = pa.HipLdlSolver(K, n_primal=-1)
+    s.matrixChanged()
+    assert s.get_inertia() == want_inertia, (s.get_inertia(), s.info())
+    rhs = np.random.default_rng(1).standard_normal(A.shape[0])
+    x = rhs.copy()
+    s.solve(x)
+    assert np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs) < 1e-11
+    info = s.info()
+    assert info["n_levels"] >= 3 or info["m"] > 0
