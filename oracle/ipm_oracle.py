@@ -20,7 +20,7 @@ def stepbound(v, dv):
     return np.min(-v[neg] / dv[neg]) if neg.any() else np.inf
 
 
-def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None):
+def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0):
     A = sp.csr_matrix(A)
     ny, nx = A.shape
     dnorm = max(np.abs(A.data).max(), np.abs(b).max(), np.abs(c).max())
@@ -34,7 +34,7 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None):
     def solve(rQ, rA, rv, rg):
         dd = g / v
         rx = rQ + dd * rv + rg / v
-        K = sp.bmat([[sp.diags(dd), A.T], [A, None]], format="csc")
+        K = sp.bmat([[sp.diags(dd), A.T], [A, -dual_reg * sp.identity(ny) if dual_reg else None]], format="csc")
         sol = spl.splu(K).solve(np.concatenate([rx, rA]))
         dx, dyp = sol[:nx], sol[nx:]
         dy = -dyp

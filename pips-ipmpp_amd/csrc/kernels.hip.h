@@ -474,8 +474,12 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
 
    // XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
    // slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
+#if defined(PIPS_EXPERIMENT_NO_XCD)
+   const int tix = (int)blockIdx.x;
+#else
    const int per = (n_tasks + 7) >> 3;
    const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+#endif
    if (tix >= n_tasks) return;
    const TileTask task = tasks[tix];
    if (task.blk < 0) return;
@@ -588,7 +592,11 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
          const double v = acc[i][c];
          if (MODE == 0) {
             double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
+#if defined(PIPS_EXPERIMENT_NO_EPILOGUE)
+            if (v == 1.2345e300) *cp = v;
+#else
             *cp -= v;
+#endif
          } else if (MODE == 1) {
             double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
             *cp = v;
