@@ -53,6 +53,9 @@ struct HeadSupernode {
    int level;       // elimination-tree level among head supernodes (0 = leaves)
    int64_t panel;   // offset (doubles) of the (w+r) x w column-major panel inside the block arena
    int64_t rows;    // offset (ints) of the r row indices inside BlockSym::rowidx
+   int64_t upd;     // offset (ints) of this supernode's head-to-head update segments inside BlockSym::upd
+   int n_useg;      // number of such segments (distinct head supernodes among the below-rows)
+   int rb;          // index of the first border row among the below-rows (== r when there is none)
 };
 
 struct BlockSym {
@@ -73,6 +76,7 @@ struct BlockSym {
    std::vector<int> sn_of_col;          // [n_head]
    std::vector<int> rowidx;             // concatenated below-rows of head supernodes
                                         //   value < n : permuted row of K ; value >= n : n + compressed border index
+   std::vector<int> upd;                // head-to-head update segments, see symbolic.cpp "update segments"
    std::vector<int64_t> a_dst;          // [nnz(K lower)] arena offset of every CSR entry
    std::vector<int64_t> b_dst;          // [nnz(border)]  arena offset of every border entry, -1 if it lands in SC (never)
    std::vector<signed char> psign;      // [n] expected pivot sign in permuted order (+1/-1/0)
@@ -91,6 +95,7 @@ struct CsrPattern {
 struct AnalyzeOptions {
    int tile = 128;            // dense tile size
    int max_sn_width = 32;     // head supernode width cap
+   double relax_zeros = 0.4;  // supernode amalgamation: admissible share of explicit zeros in a panel (0 = fundamental)
    int min_tail = 256;        // do not open a dense tail smaller than this
    int force_n_head = -1;     // >=0: override the cost model (tests)
    double head_cost = 8.0e-11;  // seconds per scattered update entry (cost model; measured optimum on MI355X, config 2)

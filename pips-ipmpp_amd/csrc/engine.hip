@@ -234,6 +234,15 @@ struct BlockInput {
 
 struct LevelRange { int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt; };
 
+// Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
+static void apply_tuning(AnalyzeOptions& opt) {
+   opt.tile = TILE;
+   opt.max_sn_width = HEAD_WMAX;
+   if (const char* rz = getenv("PIPS_HIP_RELAX_ZEROS")) opt.relax_zeros = atof(rz);   // share of explicit zeros per panel
+   if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);       // seconds per scattered update
+   if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
+}
+
 struct Engine {
    int device = 0;
    hipStream_t stream = nullptr;
@@ -265,7 +274,7 @@ struct Engine {
              *d_perm_off = nullptr, *d_rowbase = nullptr, *d_bt_xoff = nullptr;
    SnDesc* d_sns = nullptr;
    BlkDesc* d_blks = nullptr;
-   int *d_rowidx = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr, *d_nprimal = nullptr;
+   int *d_rowidx = nullptr, *d_upd = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr, *d_nprimal = nullptr;
    int *d_krowptr = nullptr, *d_kcolidx = nullptr, *d_bt_rowptr = nullptr, *d_bt_colidx = nullptr, *d_bt_rowsc = nullptr;
    signed char* d_psign = nullptr;
    std::vector<int> h_inertia;
@@ -274,7 +283,7 @@ struct Engine {
    ~Engine() { release(); }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
-                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_sncol, d_bmap, d_perm,
+                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -286,7 +295,7 @@ struct Engine {
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
-      d_rowidx = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
+      d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
    }
@@ -322,10 +331,7 @@ struct Engine {
    int analyze(int n_threads) {
       for (int b = 0; b < nblk; ++b)
          if (in[b].n <= 0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_analyze: block %d was never set", b);
-      opt.tile = TILE;
-      opt.max_sn_width = HEAD_WMAX;
-      if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);   // cost-model tuning knob (seconds per scattered update)
-      if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
+      apply_tuning(opt);
       int rc = analyze_host(n_threads);
       if (rc) return rc;
       HIP_TRY(hipSetDevice(device));
@@ -337,7 +343,8 @@ struct Engine {
       h_blks.assign(nblk, BlkDesc());
       kptr.assign(nblk + 1, 0);
       x_off.assign(nblk + 1, 0);
-      std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0);
+      std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0),
+         upd_base(nblk + 1, 0);
       long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0;
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
@@ -364,6 +371,7 @@ struct Engine {
          bptr[b + 1] = bptr[b] + (long long)in[b].btcol.size();
          x_off[b + 1] = x_off[b] + s.n;
          rows_base[b + 1] = rows_base[b] + (long long)s.rowidx.size();
+         upd_base[b + 1] = upd_base[b] + (long long)s.upd.size();
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
          bmap_off[b + 1] = bmap_off[b] + s.nb;
       }
@@ -395,7 +403,8 @@ struct Engine {
       for (int i = 0; i < nsn_total; ++i) {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
-         h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, s.w, s.r, s.c0, k.blk};
+         h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
+                           s.n_useg, s.rb};
          sorted_id[k.blk][k.loc] = i;
          LevelRange& L = levels[k.level];
          if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
@@ -403,7 +412,8 @@ struct Engine {
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
       }
       // ---- concatenated index arrays
-      std::vector<int> h_rowidx, h_sncol, h_bmap, h_perm;
+      std::vector<int> h_rowidx, h_sncol, h_bmap, h_perm, h_upd;
+      h_upd.reserve(upd_base[nblk]);
       std::vector<signed char> h_psign;
       std::vector<long long> h_psign_off(nblk), h_perm_off(nblk), h_kdst(nnzK_total), h_bdst(nnzB_total), h_kdiag(n_total),
          h_rowbase(n_total);
@@ -413,6 +423,7 @@ struct Engine {
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
          h_rowidx.insert(h_rowidx.end(), s.rowidx.begin(), s.rowidx.end());
+         h_upd.insert(h_upd.end(), s.upd.begin(), s.upd.end());
          for (int c = 0; c < s.n_head; ++c) h_sncol.push_back(sorted_id[b][s.sn_of_col[c]]);
          h_bmap.insert(h_bmap.end(), s.bmap.begin(), s.bmap.end());
          h_psign_off[b] = (long long)h_psign.size();
@@ -477,6 +488,7 @@ struct Engine {
       if ((rc = dev_upload(&d_sns, h_sns, stream))) return rc;
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
       if ((rc = dev_upload(&d_rowidx, h_rowidx, stream))) return rc;
+      if ((rc = dev_upload(&d_upd, h_upd, stream))) return rc;
       if ((rc = dev_upload(&d_sncol, h_sncol, stream))) return rc;
       if ((rc = dev_upload(&d_bmap, h_bmap, stream))) return rc;
       if ((rc = dev_upload(&d_perm, h_perm, stream))) return rc;
@@ -523,11 +535,11 @@ struct Engine {
             hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
                                L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
          if (L.small_cnt > 0)
-            hipLaunchKernelGGL((k_head_factor<64, 8, 512, 64>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
-                               d_blks, d_rowidx, d_sncol, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
+            hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
+                               d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
          if (L.large_cnt > 0)
-            hipLaunchKernelGGL((k_head_factor<256, 32, 4096, 4096>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
-                               L.large_begin, d_blks, d_rowidx, d_sncol, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
+            hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
+                               L.large_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
                                d_inertia, d_pref);
          if (timer.on) timer.end(stream);
       }
@@ -1050,14 +1062,15 @@ int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero) {
 }
 
 static void sym_info(const std::vector<BlockSym>& sym, int64_t* what, int n_what) {
-   int64_t v[10] = {0};
+   int64_t v[11] = {0};
    for (const BlockSym& s : sym) {
+      v[10] += (int64_t)s.upd.size() * 4;
       v[0] += s.nnzL; v[1] += s.n; v[2] += s.n_head; v[3] += s.m; v[4] += (int64_t)s.sn.size();
       v[5] = std::max<int64_t>(v[5], s.n_levels);
       v[6] += (int64_t)s.flops_factor; v[7] += (int64_t)s.flops_border; v[8] += s.arena * 8;
       v[9] = std::max<int64_t>(v[9], s.m_pad / TILE);
    }
-   for (int i = 0; i < n_what && i < 10; ++i) what[i] = v[i];
+   for (int i = 0; i < n_what && i < 11; ++i) what[i] = v[i];
 }
 
 int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
@@ -1478,8 +1491,7 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
                         const int* Bt_colidx, int force_n_head, int64_t* what, int n_what, int* perm, int* colcount) {
    if (n <= 0 || !krow || !jcol) PIPS_FAIL(PIPS_ERR_ARG, "pips_symbolic_probe: bad arguments");
    AnalyzeOptions opt;
-   opt.tile = TILE;
-   opt.max_sn_width = HEAD_WMAX;
+   apply_tuning(opt);
    opt.force_n_head = force_n_head;
    CsrPattern K{n, n, krow, jcol};
    CsrPattern B{0, n, nullptr, nullptr};

@@ -22,7 +22,9 @@ constexpr int LDSW = TILE + LDS_PAD;
 struct SnDesc {
    long long panel;  // global arena offset of the (w+r) x w panel
    long long rows;   // global offset into rowidx
+   long long upd;    // global offset into upd (head-to-head update segments)
    int w, r, c0, blk;
+   int n_useg, rb;   // number of update segments; index of the first border row among the r below-rows
 };
 
 struct BlkDesc {
@@ -174,67 +176,69 @@ __global__ void k_block_absmax(const double* __restrict__ kval, const long long*
 // ------------------------------------------------------------------------------------------------
 constexpr int HEAD_WMAX = 32;   // widest head supernode (solve kernels)
 
-// BLOCK threads; WMAX widest supernode handled; LCAP doubles of L21 cached in LDS; PCAP ints of the position table
-template <int BLOCK, int WMAX, int LCAP, int PCAP>
+// Head-to-head update segments (symbolic.cpp "update segments"): 8-int header + positions, read-only on the device.
+constexpr int USEG_HDR = 8;
+
+// BLOCK threads; WMAX widest supernode handled; LCAP doubles of L21 cached in LDS.
+// Latency matters more than throughput here (a chain-like elimination tree runs one supernode per block per launch), so
+// everything on the dependent path is kept short: pivot references / signs are fetched once, the pivot block needs one
+// barrier per column (all threads derive the pivot, columns stay unscaled in LDS, 1/d is applied on the fly), and the
+// scatter positions come precomputed from the analysis instead of being searched.
+template <int BLOCK, int WMAX, int LCAP>
 __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict__ sns, int sn_begin,
                                                       const BlkDesc* __restrict__ blks,
-                                                      const int* __restrict__ rowidx, const int* __restrict__ sncol,
+                                                      const int* __restrict__ rowidx, const int* __restrict__ upd,
                                                       const signed char* __restrict__ psign,
                                                       const long long* __restrict__ psign_off,
                                                       const int* __restrict__ bmap, double* __restrict__ arena,
                                                       double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
                                                       const double* __restrict__ pref) {
-   __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w
+   __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w; column k keeps l_ik * d_k (unscaled)
    __shared__ double dk[WMAX];
+   __shared__ double prf[WMAX];
+   __shared__ int sgn[WMAX];
    __shared__ double Ls[LCAP];
-   __shared__ int pos[PCAP];
-   __shared__ int cnt[3];
 
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
    double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
-   const signed char* ps = psign + psign_off[sn.blk] + sn.c0;
 
-   if (tid < 3) cnt[tid] = 0;
    for (int i = tid; i < w * w; i += BLOCK) Ld[i] = P[(i % w) + (long long)(i / w) * ld];
+   if (tid < w) {
+      prf[tid] = pref[bd.xw_off + sn.c0 + tid];
+      sgn[tid] = psign[psign_off[sn.blk] + sn.c0 + tid];
+   }
    __syncthreads();
 
-   // ---- LDL^T of the w x w pivot block (right-looking, column by column)
+   // ---- LDL^T of the w x w pivot block (right-looking); L11 goes straight to the panel
+   int c_pos = 0, c_neg = 0, c_pert = 0;
    for (int k = 0; k < w; ++k) {
-      if (tid == 0) {
-         bool pert;
-         const double d = fix_pivot(Ld[k + k * w], ps[k], pref[bd.xw_off + sn.c0 + k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
-         dk[k] = d;
-         if (pert) ++cnt[2]; else if (d > 0) ++cnt[0]; else ++cnt[1];
+      bool pert;
+      const double d = fix_pivot(Ld[k + k * w], sgn[k], prf[k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
+      if (pert) ++c_pert; else if (d > 0) ++c_pos; else ++c_neg;
+      const double rd = 1.0 / d;
+      const int m = w - k - 1;
+      for (int idx = tid; idx < m * m; idx += BLOCK) {
+         const int i = k + 1 + idx % m, j = k + 1 + idx / m;
+         if (i >= j) Ld[i + j * w] -= Ld[i + k * w] * (Ld[j + k * w] * rd);
       }
+      if (tid < m) P[(k + 1 + tid) + (long long)k * ld] = Ld[(k + 1 + tid) + k * w] * rd;
+      if (tid == 0) { dk[k] = d; P[k + (long long)k * ld] = d; }
       __syncthreads();
-      const double d = dk[k];
-      // trailing update with the unscaled column k
-      for (int idx = tid; idx < (w - k - 1) * (w - k - 1); idx += BLOCK) {
-         const int i = k + 1 + idx % (w - k - 1), j = k + 1 + idx / (w - k - 1);
-         if (i >= j) Ld[i + j * w] -= Ld[i + k * w] * Ld[j + k * w] / d;
-      }
-      __syncthreads();
-      for (int i = k + 1 + tid; i < w; i += BLOCK) Ld[i + k * w] /= d;
-      __syncthreads();
-   }
-   // write back L11 (unit lower, D on the diagonal)
-   for (int i = tid; i < w * w; i += BLOCK) {
-      const int rr = i % w, cc = i / w;
-      if (rr > cc) P[rr + (long long)cc * ld] = Ld[i];
-      else if (rr == cc) P[rr + (long long)cc * ld] = dk[cc];
    }
    if (tid == 0) {
-      if (cnt[0]) atomicAdd(&inertia[3 * sn.blk + 0], cnt[0]);
-      if (cnt[1]) atomicAdd(&inertia[3 * sn.blk + 1], cnt[1]);
-      if (cnt[2]) atomicAdd(&inertia[3 * sn.blk + 2], cnt[2]);
+      if (c_pos) atomicAdd(&inertia[3 * sn.blk + 0], c_pos);
+      if (c_neg) atomicAdd(&inertia[3 * sn.blk + 1], c_neg);
+      if (c_pert) atomicAdd(&inertia[3 * sn.blk + 2], c_pert);
    }
    if (r == 0) return;
 
-   // ---- L21 := A21 L11^-T D^-1, one row per thread (coalesced along the rows of each column)
-   const bool cacheL = (long long)r * w <= LCAP;
+   // ---- L21 := A21 L11^-T D^-1, one row per thread (coalesced along the rows of each column).  With the unscaled
+   //      pivot block the recurrence reads  l_k = (a_k - sum_{l<k} l_l * Ld[k,l]) / d_k.
+   const int lw = w | 1;   // odd LDS row stride: conflict-free when lanes walk over rows
+   const bool cacheL = (long long)r * lw <= LCAP;
    for (int a = tid; a < r; a += BLOCK) {
       double y[WMAX];
       double* row = P + w + a;
@@ -244,103 +248,71 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
             double v = row[(long long)k * ld];
 #pragma unroll
             for (int l = 0; l < k; ++l) v -= y[l] * Ld[k + l * w];
-            y[k] = v;
+            y[k] = v / dk[k];
          }
       }
 #pragma unroll
       for (int k = 0; k < WMAX; ++k) {
          if (k < w) {
-            const double l = y[k] / dk[k];
-            row[(long long)k * ld] = l;
-            if (cacheL) Ls[a * w + k] = l;
+            row[(long long)k * ld] = y[k];
+            if (cacheL) Ls[a * lw + k] = y[k];
          }
       }
    }
    __syncthreads();
 
    // ---- Schur update, scattered with FP64 atomics.  Rows below are sorted: head columns < tail columns < border.
-   const int n = bd.n, n_head = bd.n_head;
-   double* T = arena + bd.T;
-   const int* bm = bmap + bd.bmap_off;
-   int b0 = 0;
-   while (b0 < r) {
-      const int cb0 = rows[b0];
-      int b1;          // end of the segment of columns sharing one target
-      int kind;        // 0 head supernode, 1 tail, 2 border
-      SnDesc tg;
-      if (cb0 < n_head) {
-         kind = 0;
-         const int tsn = sncol[bd.sncol_off + cb0];
-         tg = sns[tsn];
-         b1 = b0 + 1;
-         while (b1 < r && rows[b1] < tg.c0 + tg.w) ++b1;
-         // position table of rows[a], a in [b0,r), inside the target panel
-         const int* trows = rowidx + tg.rows;
-         const bool tbl = (r - b0) <= PCAP;
-         if (tbl) {
-            for (int a = b0 + tid; a < r; a += BLOCK) {
-               const int ra = rows[a];
-               int p;
-               if (ra < tg.c0 + tg.w) p = ra - tg.c0;
-               else {
-                  int lo = 0, hi = tg.r;
-                  while (lo < hi) { const int mid = (lo + hi) >> 1; if (trows[mid] < ra) lo = mid + 1; else hi = mid; }
-                  p = tg.w + lo;
-               }
-               pos[a - b0] = p;
-            }
-            __syncthreads();
-         }
-         const int tld = tg.w + tg.r;
-         double* TP = arena + tg.panel;
-         for (int b = b0; b < b1; ++b) {
-            const int lc = rows[b] - tg.c0;
-            for (int a = b + tid; a < r; a += BLOCK) {
-               double u = 0.0;
-               for (int k = 0; k < w; ++k) {
-                  const double la = cacheL ? Ls[a * w + k] : P[w + a + (long long)k * ld];
-                  const double lb = cacheL ? Ls[b * w + k] : P[w + b + (long long)k * ld];
-                  u += la * lb * dk[k];
-               }
-               int p;
-               if (tbl) p = pos[a - b0];
-               else {
-                  const int ra = rows[a];
-                  if (ra < tg.c0 + tg.w) p = ra - tg.c0;
-                  else {
-                     int lo = 0, hi = tg.r;
-                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (trows[mid] < ra) lo = mid + 1; else hi = mid; }
-                     p = tg.w + lo;
-                  }
-               }
-               atomic_add_f64(TP + p + (long long)lc * tld, -u);
-            }
-         }
-         __syncthreads();
+   auto entry = [&](int a, int b) -> double {   // (L21 D L21^T)[a, b]
+      double u = 0.0;
+      for (int k = 0; k < w; ++k) {
+         const double la = cacheL ? Ls[a * lw + k] : P[w + a + (long long)k * ld];
+         const double lb = cacheL ? Ls[b * lw + k] : P[w + b + (long long)k * ld];
+         u += la * lb * dk[k];
+      }
+      return u;
+   };
+   // all pairs b in [bs, be), a in [b, r): flattened over the bounding rectangle when a column alone cannot fill the
+   // workgroup (short supernodes on a chain), column by column otherwise
+   auto for_pairs = [&](int bs, int be, auto&& f) {
+      const int np = r - bs;
+      if (np >= 2 * BLOCK) {
+         for (int b = bs; b < be; ++b)
+            for (int a = b + tid; a < r; a += BLOCK) f(a, b);
       } else {
-         kind = cb0 < n ? 1 : 2;
-         b1 = b0 + 1;
-         if (kind == 1) { while (b1 < r && rows[b1] < n) ++b1; } else b1 = r;
-         for (int b = b0; b < b1; ++b) {
-            const int cb = rows[b];
-            for (int a = b + tid; a < r; a += BLOCK) {
-               double u = 0.0;
-               for (int k = 0; k < w; ++k) {
-                  const double la = cacheL ? Ls[a * w + k] : P[w + a + (long long)k * ld];
-                  const double lb = cacheL ? Ls[b * w + k] : P[w + b + (long long)k * ld];
-                  u += la * lb * dk[k];
-               }
-               const int ra = rows[a];
-               if (kind == 1) {
-                  const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
-                  atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -u);
-               } else if (SC) {  // SC == nullptr: factor-only call, the Schur contribution is not wanted
-                  atomic_add_f64(SC + bm[ra - n] + (long long)bm[cb - n] * ldSC, -u);
-               }
-            }
+         const int tot = (be - bs) * np;
+         for (int idx = tid; idx < tot; idx += BLOCK) {
+            const int bb = idx / np, aa = idx - bb * np;
+            if (aa >= bb) f(bs + aa, bs + bb);
          }
       }
-      b0 = b1;
+   };
+
+   int b0 = 0;
+   const int* U = upd + sn.upd;
+   for (int sg = 0; sg < sn.n_useg; ++sg) {   // targets inside the head: positions precomputed
+      const int sb0 = U[0], sb1 = U[1], tld = U[3];
+      const long long tpanel = (long long)(((unsigned long long)(unsigned)U[5] << 32) | (unsigned long long)(unsigned)U[4]);
+      const int* pp = U + USEG_HDR;
+      double* TP = arena + bd.arena_off + tpanel;
+      for_pairs(sb0, sb1, [&](int a, int b) { atomic_add_f64(TP + pp[a - sb0] + (long long)pp[b - sb0] * tld, -entry(a, b)); });
+      U += USEG_HDR + (r - sb0);
+      b0 = sb1;
+   }
+   const int n = bd.n, n_head = bd.n_head;
+   if (b0 < sn.rb) {   // target columns in the dense tail
+      double* T = arena + bd.T;
+      for_pairs(b0, sn.rb, [&](int a, int b) {
+         const int ra = rows[a], cb = rows[b];
+         const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
+         atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -entry(a, b));
+      });
+      b0 = sn.rb;
+   }
+   if (b0 < r && SC) {   // border x border: the Schur complement itself (SC == nullptr: factor-only call)
+      const int* bm = bmap + bd.bmap_off;
+      for_pairs(b0, r, [&](int a, int b) {
+         atomic_add_f64(SC + bm[rows[a] - n] + (long long)bm[rows[b] - n] * ldSC, -entry(a, b));
+      });
    }
 }
 

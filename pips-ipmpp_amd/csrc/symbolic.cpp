@@ -87,62 +87,113 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    out.nb_pad = round_up(nb, opt.tile);
    out.ldT = out.m_pad + out.nb_pad;
 
-   // ---- permuted strict-lower pattern by column (only columns < n_head are needed) + border rows per column
-   std::vector<int> cp(n_head + 1, 0);
-   auto for_each_head_entry = [&](auto&& f) {
-      for (int i = 0; i < n; ++i)
-         for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
-            const int j = K.colidx[p];
-            if (j == i) continue;
-            const int a = out.iperm[i], b = out.iperm[j];
-            const int c = std::min(a, b), r = std::max(a, b);
-            if (c < n_head) f(c, r);
+   // ---- column structures of the head (merge children) + elimination-tree parents, for the current permutation
+   std::vector<std::vector<int>> S;
+   std::vector<int> parent;
+   auto build_structures = [&]() {
+      // permuted strict-lower pattern by column (only columns < n_head are needed) + border rows per column
+      std::vector<int> cp(n_head + 1, 0);
+      auto for_each_head_entry = [&](auto&& f) {
+         for (int i = 0; i < n; ++i)
+            for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+               const int j = K.colidx[p];
+               if (j == i) continue;
+               const int a = out.iperm[i], b = out.iperm[j];
+               const int c = std::min(a, b), r = std::max(a, b);
+               if (c < n_head) f(c, r);
+            }
+         for (int s = 0; s < border.nrows; ++s)
+            for (int p = border.rowptr[s]; p < border.rowptr[s + 1]; ++p) {
+               const int c = out.iperm[border.colidx[p]];
+               if (c < n_head) f(c, n + bidx[s]);
+            }
+      };
+      for_each_head_entry([&](int c, int) { ++cp[c + 1]; });
+      for (int j = 0; j < n_head; ++j) cp[j + 1] += cp[j];
+      std::vector<int> ci(cp[n_head]);
+      {
+         std::vector<int> fill(cp.begin(), cp.end() - 1);
+         for_each_head_entry([&](int c, int r) { ci[fill[c]++] = r; });
+      }
+      S.assign(n_head, {});
+      parent.assign(n_head, -1);
+      std::vector<int> first_child(n_head, -1), next_sib(n_head, -1), mark(n + nb, -1);
+      for (int j = 0; j < n_head; ++j) {
+         auto& Sj = S[j];
+         for (int p = cp[j]; p < cp[j + 1]; ++p) {
+            const int r = ci[p];
+            if (mark[r] != j) { mark[r] = j; Sj.push_back(r); }
          }
-      for (int s = 0; s < border.nrows; ++s)
-         for (int p = border.rowptr[s]; p < border.rowptr[s + 1]; ++p) {
-            const int c = out.iperm[border.colidx[p]];
-            if (c < n_head) f(c, n + bidx[s]);
+         for (int c = first_child[j]; c >= 0; c = next_sib[c])
+            for (int r : S[c])
+               if (r != j && mark[r] != j) { mark[r] = j; Sj.push_back(r); }
+         std::sort(Sj.begin(), Sj.end());
+         if (!Sj.empty() && Sj[0] < n_head) {
+            parent[j] = Sj[0];
+            next_sib[j] = first_child[Sj[0]];
+            first_child[Sj[0]] = j;
          }
+      }
    };
-   for_each_head_entry([&](int c, int) { ++cp[c + 1]; });
-   for (int j = 0; j < n_head; ++j) cp[j + 1] += cp[j];
-   std::vector<int> ci(cp[n_head]);
-   {
-      std::vector<int> fill(cp.begin(), cp.end() - 1);
-      for_each_head_entry([&](int c, int r) { ci[fill[c]++] = r; });
+   build_structures();
+
+   // ---- postorder the head forest so that every parent/child chain is contiguous (AMD does not guarantee it); this
+   //      relabels columns inside the head only: the fill, the cut and the primal-before-dual constraint are unchanged
+   //      (a dual row is an ancestor of all its primal neighbours, and a postorder keeps descendants first)
+   if (n_head > 0) {
+      std::vector<int> first_child(n_head, -1), next_sib(n_head, -1), post;
+      post.reserve(n_head);
+      for (int j = n_head - 1; j >= 0; --j)   // reversed so that children lists are ascending
+         if (parent[j] >= 0) { next_sib[j] = first_child[parent[j]]; first_child[parent[j]] = j; }
+      std::vector<int> stack;
+      for (int root = 0; root < n_head; ++root) {
+         if (parent[root] >= 0) continue;
+         stack.push_back(root);
+         while (!stack.empty()) {
+            const int v = stack.back();
+            const int c = first_child[v];
+            if (c >= 0) { first_child[v] = next_sib[c]; stack.push_back(c); }
+            else { post.push_back(v); stack.pop_back(); }
+         }
+      }
+      bool identity = true;
+      for (int k = 0; k < n_head; ++k) if (post[k] != k) { identity = false; break; }
+      if (!identity) {
+         std::vector<int> np(out.perm.begin(), out.perm.begin() + n_head), nc(n_head);
+         for (int k = 0; k < n_head; ++k) { np[k] = out.perm[post[k]]; nc[k] = out.colcount[post[k]]; }
+         std::copy(np.begin(), np.end(), out.perm.begin());
+         std::copy(nc.begin(), nc.end(), out.colcount.begin());
+         for (int k = 0; k < n; ++k) out.iperm[out.perm[k]] = k;
+         if (n_primal >= 0)
+            for (int k = 0; k < n; ++k) out.psign[k] = out.perm[k] < n_primal ? 1 : -1;
+         build_structures();
+      }
    }
 
-   // ---- column structures of the head (merge children), elimination-tree parents
-   std::vector<std::vector<int>> S(n_head);
-   std::vector<int> parent(n_head, -1), first_child(n_head, -1), next_sib(n_head, -1), mark(n + nb, -1);
-   for (int j = 0; j < n_head; ++j) {
-      auto& Sj = S[j];
-      for (int p = cp[j]; p < cp[j + 1]; ++p) {
-         const int r = ci[p];
-         if (mark[r] != j) { mark[r] = j; Sj.push_back(r); }
-      }
-      for (int c = first_child[j]; c >= 0; c = next_sib[c])
-         for (int r : S[c])
-            if (r != j && mark[r] != j) { mark[r] = j; Sj.push_back(r); }
-      std::sort(Sj.begin(), Sj.end());
-      if (!Sj.empty() && Sj[0] < n_head) {
-         parent[j] = Sj[0];
-         next_sib[j] = first_child[Sj[0]];
-         first_child[Sj[0]] = j;
-      }
-   }
-
-   // ---- fundamental supernodes (width-capped)
+   // ---- supernodes: fundamental chains, relaxed by a bounded share of explicit zeros (width-capped).  Along a chain
+   //      (parent[e] == e+1) the below-rows of column e are contained in those of e+1, so the panel of a merged supernode
+   //      has the row set of its last column and a column that lacks some of these rows just stores zeros there.
    out.sn_of_col.assign(n_head, -1);
    for (int j = 0; j < n_head;) {
       int e = j;
-      while (e + 1 < n_head && e + 1 - j < opt.max_sn_width && parent[e] == e + 1 && S[e].size() == S[e + 1].size() + 1) ++e;
+      int64_t true_nnz = (int64_t)S[j].size() + 1;
+      while (e + 1 < n_head && e + 1 - j < opt.max_sn_width && parent[e] == e + 1) {
+         const int64_t w1 = e + 2 - j;
+         const int64_t stored = w1 * (w1 + 1) / 2 + w1 * (int64_t)S[e + 1].size();
+         const int64_t tn = true_nnz + (int64_t)S[e + 1].size() + 1;
+         if ((double)(stored - tn) > opt.relax_zeros * (double)stored) break;
+         true_nnz = tn;
+         ++e;
+      }
       HeadSupernode sn;
       sn.c0 = j;
       sn.w = e - j + 1;
       sn.r = (int)S[e].size();
       sn.level = 0;
       sn.panel = 0;
+      sn.upd = 0;
+      sn.n_useg = 0;
+      sn.rb = 0;
       sn.rows = (int64_t)out.rowidx.size();
       out.rowidx.insert(out.rowidx.end(), S[e].begin(), S[e].end());
       for (int c = j; c <= e; ++c) out.sn_of_col[c] = (int)out.sn.size();
@@ -185,6 +236,39 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    }
    out.flops_factor = fl;
    out.nnzL = nnzL;
+
+   // ---- update segments: where the Schur update of a head supernode lands inside later HEAD supernodes.  The below-rows
+   //      that are head columns split into runs belonging to one target supernode each; per run one record
+   //         { b0, b1, target c0, target ld, target panel offset (lo, hi), npos, 0 }  followed by npos = r - b0 ints,
+   //      the position inside a target panel column of every below-row a >= b0 (all of them occur there: the structure
+   //      of a column is contained in its parent's).  The device kernel then scatters without searching.
+   for (auto& sn : out.sn) {
+      sn.upd = (int64_t)out.upd.size();
+      sn.n_useg = 0;
+      const int* rows = out.rowidx.data() + sn.rows;
+      sn.rb = (int)(std::lower_bound(rows, rows + sn.r, n) - rows);
+      int b0 = 0;
+      while (b0 < sn.r && rows[b0] < n_head) {
+         const HeadSupernode& tg = out.sn[out.sn_of_col[rows[b0]]];
+         int b1 = b0 + 1;
+         while (b1 < sn.r && rows[b1] < tg.c0 + tg.w) ++b1;
+         const int npos = sn.r - b0;
+         const int hdr[8] = {b0, b1, tg.c0, tg.w + tg.r, (int)(uint32_t)(tg.panel & 0xffffffffLL), (int)(tg.panel >> 32), npos, 0};
+         out.upd.insert(out.upd.end(), hdr, hdr + 8);
+         const int* trows = out.rowidx.data() + tg.rows;
+         int q = 0;
+         for (int a = b0; a < sn.r; ++a) {
+            const int ra = rows[a];
+            if (ra < tg.c0 + tg.w) { out.upd.push_back(ra - tg.c0); continue; }
+            while (q < tg.r && trows[q] < ra) ++q;
+            if (q == tg.r || trows[q] != ra)
+               PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, row %d of supernode %d missing in its ancestor %d", ra, sn.c0, tg.c0);
+            out.upd.push_back(tg.w + q);
+         }
+         ++sn.n_useg;
+         b0 = b1;
+      }
+   }
 
    // ---- scatter maps
    auto head_dst = [&](int c, int r) -> int64_t {
