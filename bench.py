@@ -149,8 +149,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # PIPS_BENCH_FORCE_COMM=1 drives the whole multi-rank code path (process group, communicator bootstrap, packed Schur
+    # reduction, b0 reduction) with a single rank, so that it can be checked on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("PIPS_BENCH_FORCE_COMM"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if world == 1:
+            os.environ["PIPS_HIP_FORCE_REDUCE"] = "1"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import pips_ipmpp_amd as pa
 
@@ -162,12 +168,31 @@ def main():
     n_blocks_total = bpg * world
 
     comm = None
-    if world > 1:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(pa.Comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        comm = pa.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+    comm_kind = "none"
+    if use_dist:
+        # The library's own RCCL communicator (dlopen'd librccl, bootstrapped with a unique id broadcast over the process
+        # group).  PIPS_BENCH_COMM=torch selects the host-supplied all-reduce instead (torch.distributed, also RCCL); the
+        # same switch is taken on every rank if any rank fails to create its communicator.
+        want_own = os.environ.get("PIPS_BENCH_COMM", "rccl") != "torch"
+        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        if want_own:
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(pa.Comm.unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                comm = pa.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+            except Exception as e:
+                sys.stderr.write(f"[rank {rank}] own RCCL communicator unavailable ({e}); using torch.distributed\n")
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if want_own and int(ok.item()) == 1:
+            comm_kind = "rccl (library communicator)"
+        else:
+            if comm is not None:
+                comm.close()
+            comm = pa.ExternalComm.torch_distributed()
+            comm_kind = "rccl (torch.distributed callback)"
 
     bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank)
     F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
@@ -190,7 +215,7 @@ def main():
             kkt.solve_compressed(b0, b_leaf)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +227,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -235,7 +260,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""),
-                       "solves_per_unit": R_SOLVES, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(), "iter_per_s": round(a.steps / dt, 4),
+                       "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(), "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},
             "roofline": roofline,
@@ -246,8 +271,15 @@ def main():
             except Exception as e:  # the baseline must never break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "64-block work units/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+        # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a pipe: push it out
+        # first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -170,6 +170,12 @@ int pips_hip_comm_unique_id(void* id128);                 /* 128-byte ncclUnique
 int pips_hip_comm_create(void** comm, const void* id128, int n_ranks, int rank, int device);
 int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
 void pips_hip_comm_destroy(void* comm);
+/* Communicator backed by the host's own collective (what an MPI build of the reference would pass: a GPU-aware
+ * MPI_Allreduce(MPI_IN_PLACE, buf_dev, n, MPI_DOUBLE, MPI_SUM, comm) as in PIPS_MPIsumArrayInPlace, pipsdef.h).  The
+ * callback must return 0 after buf_dev (device memory, n doubles) holds the sum over all ranks and is safe to read
+ * from any stream; the library synchronises its own stream before calling it. */
+typedef int (*pips_hip_allreduce_cb)(void* user, double* buf_dev, size_t n);
+int pips_hip_comm_create_external(void** comm, pips_hip_allreduce_cb allreduce, void* user);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 4b. Flat-arena vector kernels: DistributedVector<T>/DenseVector<T> operations used around the path

@@ -43,7 +43,12 @@ struct Rccl {
    }
 };
 Rccl g_rccl;
-struct Comm { nccl_comm_t comm; int device; };
+struct Comm {
+   nccl_comm_t comm;
+   int device;
+   pips_hip_allreduce_cb external = nullptr;   // host-supplied reduction (GPU-aware MPI, torch.distributed, ...)
+   void* user = nullptr;
+};
 constexpr int kNcclDouble = 8;  // ncclFloat64
 constexpr int kNcclSum = 0;
 }  // namespace
@@ -76,9 +81,25 @@ int pips_hip_comm_create(void** comm, const void* id128, int n_ranks, int rank, 
    return 0;
 }
 
+int pips_hip_comm_create_external(void** comm, pips_hip_allreduce_cb allreduce, void* user) {
+   if (!comm || !allreduce) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_comm_create_external: bad arguments");
+   Comm* c = new Comm{nullptr, -1};
+   c->external = allreduce;
+   c->user = user;
+   *comm = c;
+   return 0;
+}
+
 int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream) {
    Comm* c = (Comm*)comm;
    if (!c || !buf_dev) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_allreduce_sum: bad arguments");
+   if (c->external) {
+      // the callback works on its own stream / on the host: hand over a quiescent buffer, take back a finished one
+      if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) PIPS_FAIL(pips::PIPS_ERR_HIP, "stream sync before the external all-reduce failed");
+      const int rc = c->external(c->user, buf_dev, n);
+      if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "external all-reduce callback returned %d", rc);
+      return 0;
+   }
    const int rc = g_rccl.allreduce(buf_dev, buf_dev, n, kNcclDouble, kNcclSum, c->comm, (hipStream_t)stream);
    if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclAllReduce failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
    return 0;

@@ -205,29 +205,48 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
    double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
 
-   for (int i = tid; i < w * w; i += BLOCK) Ld[i] = P[(i % w) + (long long)(i / w) * ld];
+   // Every thread owns NQ entries of the pivot block in registers: row ti, columns tj + CT*q.  Step k: the owners of
+   // column k publish it (unscaled) in LDS, one barrier, everybody derives the pivot and updates its own entries.
+   constexpr int CT = BLOCK / WMAX, NQ = WMAX / CT;
+   static_assert(CT * WMAX == BLOCK && NQ * CT == WMAX, "thread grid must tile the pivot block");
+   const int ti = tid % WMAX, tj = tid / WMAX;
+   double areg[NQ];
+#pragma unroll
+   for (int q = 0; q < NQ; ++q) {
+      const int j = tj + CT * q;
+      areg[q] = (ti < w && j <= ti) ? P[ti + (long long)j * ld] : 0.0;
+   }
    if (tid < w) {
       prf[tid] = pref[bd.xw_off + sn.c0 + tid];
       sgn[tid] = psign[psign_off[sn.blk] + sn.c0 + tid];
    }
-   __syncthreads();
 
    // ---- LDL^T of the w x w pivot block (right-looking); L11 goes straight to the panel
    int c_pos = 0, c_neg = 0, c_pert = 0;
    for (int k = 0; k < w; ++k) {
+      const bool own = (k % CT) == tj && ti >= k && ti < w;
+      double mine = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+         if (tj + CT * q == k) mine = areg[q];
+      if (own) Ld[ti + k * w] = mine;
+      __syncthreads();
       bool pert;
       const double d = fix_pivot(Ld[k + k * w], sgn[k], prf[k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
       if (pert) ++c_pert; else if (d > 0) ++c_pos; else ++c_neg;
       const double rd = 1.0 / d;
-      const int m = w - k - 1;
-      for (int idx = tid; idx < m * m; idx += BLOCK) {
-         const int i = k + 1 + idx % m, j = k + 1 + idx / m;
-         if (i >= j) Ld[i + j * w] -= Ld[i + k * w] * (Ld[j + k * w] * rd);
+      if (ti > k && ti < w) {
+         const double ci = Ld[ti + k * w];
+#pragma unroll
+         for (int q = 0; q < NQ; ++q) {
+            const int j = tj + CT * q;
+            if (j > k && j <= ti) areg[q] -= ci * (Ld[j + k * w] * rd);
+         }
       }
-      if (tid < m) P[(k + 1 + tid) + (long long)k * ld] = Ld[(k + 1 + tid) + k * w] * rd;
-      if (tid == 0) { dk[k] = d; P[k + (long long)k * ld] = d; }
-      __syncthreads();
+      if (own) P[ti + (long long)k * ld] = ti == k ? d : mine * rd;
+      if (tid == 0) dk[k] = d;
    }
+   __syncthreads();
    if (tid == 0) {
       if (c_pos) atomicAdd(&inertia[3 * sn.blk + 0], c_pos);
       if (c_neg) atomicAdd(&inertia[3 * sn.blk + 1], c_neg);

@@ -6,6 +6,7 @@ on top of the C entry points.  There is NO CPU fallback: if the shared library i
 compute call is made, the call raises.
 """
 import ctypes as C
+import sys
 import os
 
 import numpy as np
@@ -60,7 +61,7 @@ SYMBOLS = [
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
-    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
+    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_dot",
@@ -460,6 +461,46 @@ class Comm:
         if self._h:
             lib.pips_hip_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+
+_ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class _DeviceDoubles:
+    """Zero-copy view of n doubles of device memory for torch.as_tensor (CUDA array interface, also honoured on ROCm)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class ExternalComm(Comm):
+    """Communicator whose all-reduce is supplied by the host program (the reference would hand in its MPI communicator's
+    `PIPS_MPIsumArrayInPlace`); `torch_distributed()` builds one on an initialised torch.distributed process group."""
+
+    def __init__(self, allreduce):
+        def _cb(_user, ptr, n):
+            try:
+                allreduce(int(ptr), int(n))
+                return 0
+            except Exception as e:  # never unwind through the C frame
+                sys.stderr.write(f"external all-reduce failed: {e}\n")
+                return 1
+
+        self._cb = _ALLREDUCE_CB(_cb)   # keep the trampoline alive as long as the communicator
+        self._h = C.c_void_p()
+        _check(lib.pips_hip_comm_create_external(C.byref(self._h), self._cb, None), "pips_hip_comm_create_external")
+
+    @classmethod
+    def torch_distributed(cls, group=None):
+        import torch
+        import torch.distributed as dist
+
+        def allreduce(ptr, n):
+            t = torch.as_tensor(_DeviceDoubles(ptr, n), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.current_stream().synchronize()
+
+        return cls(allreduce)
 
 
 class KktSystem:

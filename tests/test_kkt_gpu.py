@@ -109,3 +109,50 @@ def test_reduction_path_with_one_rank_communicator(monkeypatch):
                          prob.n0, 0, 0, prob.myl, 0)
     assert np.linalg.norm(b0_d.cpu().numpy() - b0_o) / np.linalg.norm(b0_o) < 1e-8
     comm.close()
+
+
+def test_reduction_path_with_host_supplied_allreduce(monkeypatch):
+    """External communicator: the all-reduce is a host callback (here torch.distributed over a one-rank RCCL group, in the
+    reference it would be PIPS_MPIsumArrayInPlace on a GPU-aware MPI).  The callback must see every reduction of the path
+    (packed Schur triangle, b0) and the results must equal the oracle's."""
+    import torch
+    import torch.distributed as dist
+    monkeypatch.setenv("PIPS_HIP_FORCE_REDUCE", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29561")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        seen = []
+        inner = pa.ExternalComm.torch_distributed()
+
+        def counting(ptr, n):
+            seen.append(n)
+            t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+
+        comm = pa.ExternalComm(counting)
+        prob = Problem(79, 3, 200, 100, 24, 16, 0.04)
+        bt, kkt = build_system(prob, comm=comm, rank=0, n_ranks=1)
+        diag = torch.tensor(np.concatenate([b["diag"] for b in prob.blocks]), device="cuda")
+        kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+        got = hip_lower_as_rowmajor(kkt.schur_to_host(), prob.S)
+        want = np.tril(prob.oracle_finalize(prob.oracle_schur()))
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-9
+        rng = np.random.default_rng(6)
+        b0, bl = rng.standard_normal(prob.S), rng.standard_normal(prob.N * prob.n_leaf)
+        b0_d, bl_d = torch.tensor(b0, device="cuda"), torch.tensor(bl, device="cuda")
+        kkt.solve_compressed(b0_d, bl_d)
+        bt.sync()
+        assert seen == [prob.S * (prob.S + 1) // 2, prob.S]
+        root = orc.DenseRootSolver(prob.S)
+        root.matrixChanged(want)
+        bs_o = [bl.reshape(prob.N, -1)[b].copy() for b in range(prob.N)]
+        b0_o = b0.copy()
+        orc.solve_compressed(b0_o, bs_o, [prob.oracle_leaf(b) for b in range(prob.N)], [prob.Bt_scipy(b) for b in range(prob.N)], root,
+                             prob.n0, 0, 0, prob.myl, 0)
+        assert np.linalg.norm(b0_d.cpu().numpy() - b0_o) / np.linalg.norm(b0_o) < 1e-8
+        comm.close()
+        inner.close()
+    finally:
+        dist.destroy_process_group()
