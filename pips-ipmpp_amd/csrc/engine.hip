@@ -232,6 +232,8 @@ struct BlockInput {
    std::vector<double> btval;
 };
 
+constexpr long long CHAIN_LAUNCH_MAX = 1024;   // waves per launch below which the head solve kernels are latency-bound
+
 struct LevelRange { int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt; };
 
 // Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
@@ -567,7 +569,10 @@ struct Engine {
          // small and large supernodes of one level are contiguous in d_sns
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         if (cnt > 0)
+         // few supernodes in the launch: a chain-like tree, take the latency-lean kernel; many: the high-occupancy one
+         if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX)
+            hipLaunchKernelGGL(k_head_fwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
+         else if (cnt > 0)
             hipLaunchKernelGGL(k_head_fwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
       TailCtx c = ctx();
@@ -582,7 +587,9 @@ struct Engine {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         if (cnt > 0)
+         if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX)
+            hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
+         else if (cnt > 0)
             hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
          if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,

@@ -757,7 +757,8 @@ __global__ void k_permute_out(const BlkDesc* __restrict__ blks, const int* __res
       x[bd.x_off + p[k]] = xw[bd.xw_off + k];
 }
 
-// head forward: y_J = L11^-1 b_J ; b[rows] -= L21 y_J (atomics) ; one wave per supernode
+// head forward: y_J = L11^-1 b_J ; b[rows] -= L21 y_J (atomics) ; one wave per supernode.  Throughput variant (few
+// registers, high occupancy) for launches with many supernodes
 __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                 const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
@@ -785,19 +786,7 @@ __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns,
    }
 }
 
-// head diagonal scaling: z = D^-1 y for the head columns
-__global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
-                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
-   xw += xw_stride * blockIdx.y;
-   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsn; s += gridDim.x * blockDim.x) {
-      const SnDesc sn = sns[s];
-      const BlkDesc bd = blks[sn.blk];
-      const int ld = sn.w + sn.r;
-      for (int k = 0; k < sn.w; ++k) xw[bd.xw_off + sn.c0 + k] /= arena[sn.panel + k + (long long)k * ld];
-   }
-}
-
-// head backward: x_J = L11^-T (z_J - L21^T x_below)
+// head backward: x_J = L11^-T (z_J - L21^T x_below); throughput variant
 __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                 const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
@@ -824,6 +813,119 @@ __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns,
       __syncthreads();
    }
    if (tid < w) xb[sn.c0 + tid] = y[tid];
+}
+
+// head forward, latency-lean variant for launches with few supernodes (engine picks it per level).
+// On chain-like elimination trees a launch holds one supernode per block, so the kernel is a latency chain: all loads
+// are issued up front (row tid of L11 sits in registers), the substitution runs on wave shuffles without barriers.
+template <int WB>   // WB: compile-time bound of the supernode width (register arrays, unrolled substitution)
+__device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
+                                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
+                                              double* ys) {
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const double* P = arena + sn.panel;
+   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;   // blockIdx.y = right-hand side
+   const int* rows = rowidx + sn.rows;
+   const int a0 = tid;
+   const int ra0 = a0 < r ? rows[a0] : bd.n;               // first GEMV row of this lane, fetched early
+   double l[WB];
+#pragma unroll
+   for (int k = 0; k < WB; ++k) l[k] = (k < tid && tid < w) ? P[tid + (long long)k * ld] : 0.0;
+   double y = tid < w ? xb[sn.c0 + tid] : 0.0;
+#pragma unroll
+   for (int k = 0; k < WB; ++k)
+      if (k < w) y -= l[k] * __shfl(y, k);                 // l[k] == 0 for k >= tid
+   if (tid < w) { xb[sn.c0 + tid] = y; ys[tid] = y; }
+   __syncthreads();
+   for (int a = a0; a < r; a += 64) {
+      const int ra = a == a0 ? ra0 : rows[a];
+      if (ra >= bd.n) break;  // border rows do not take part in solves with K_i
+      double s = 0.0;
+      for (int k = 0; k < w; ++k) s += P[w + a + (long long)k * ld] * ys[k];
+      atomic_add_f64(xb + ra, -s);
+   }
+}
+
+__global__ __launch_bounds__(64) void k_head_fwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
+                                                const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+   __shared__ double ys[HEAD_WMAX];
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+   else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+   else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+}
+
+// head diagonal scaling: z = D^-1 y for the head columns
+__global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
+                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+   xw += xw_stride * blockIdx.y;
+   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsn; s += gridDim.x * blockDim.x) {
+      const SnDesc sn = sns[s];
+      const BlkDesc bd = blks[sn.blk];
+      const int ld = sn.w + sn.r;
+      for (int k = 0; k < sn.w; ++k) xw[bd.xw_off + sn.c0 + k] /= arena[sn.panel + k + (long long)k * ld];
+   }
+}
+
+// head backward, latency-lean variant (few supernodes per launch), same structure as k_head_fwd_chain:
+// lane a gathers x[rows[a]] once and forms its share of all w dot products, the w sums are finished through LDS, the
+// transposed substitution runs on shuffles with column tid of L11 in registers.
+template <int WB>
+__device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
+                                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
+                                              double (*red)[65]) {
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const double* P = arena + sn.panel;
+   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
+   const int* rows = rowidx + sn.rows;
+   double c[WB];   // column tid of L11 below the diagonal
+#pragma unroll
+   for (int k = 0; k < WB; ++k) c[k] = (k > tid && k < w) ? P[k + (long long)tid * ld] : 0.0;
+   double y = tid < w ? xb[sn.c0 + tid] : 0.0;
+   double part[WB];
+#pragma unroll
+   for (int k = 0; k < WB; ++k) part[k] = 0.0;
+   for (int a = tid; a < r; a += 64) {
+      const int ra = rows[a];
+      if (ra >= bd.n) break;
+      const double xa = xb[ra];
+#pragma unroll
+      for (int k = 0; k < WB; ++k)
+         if (k < w) part[k] += P[w + a + (long long)k * ld] * xa;
+   }
+   if (WB == 1) {   // a single sum: plain wave reduction
+      double s = part[0];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+      if (tid == 0) y -= s;
+   } else {         // w sums: transpose through LDS, lane (k, half) adds 32 of the 64 partial values of sum k
+#pragma unroll
+      for (int k = 0; k < WB; ++k)
+         if (k < w) red[k][tid] = part[k];
+      __syncthreads();
+      const int k = tid & 31, h = tid >> 5;
+      double s = 0.0;
+      if (k < w)
+         for (int j = 0; j < 32; ++j) s += red[k][h * 32 + j];
+      s += __shfl_down(s, 32);
+      if (tid < w) y -= s;
+   }
+#pragma unroll
+   for (int k = WB - 1; k >= 0; --k)
+      if (k < w) y -= c[k] * __shfl(y, k);                 // c[k] == 0 for k <= tid
+   if (tid < w) xb[sn.c0 + tid] = y;
+}
+
+__global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
+                                                const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+   __shared__ double red[HEAD_WMAX][65];
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, red);
+   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, red);
+   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, red);
 }
 
 // tail forward step j: tiles i >= j of block b:  b_i -= L(i,j-1) (d z)_{j-1}  (j >= 1) ; tile i == j: z_j = Winv_j b_j
