@@ -1,5 +1,5 @@
-"""BASELINE.json configs[1] at full size (64 blocks x 10 000 vars, Schur dim 2000) on one GPU, checked through
-size-independent properties: the full arrowhead residual of solveCompressed, linearity of the solve, exact inertia of every
+"""BASELINE.json configs[1] at full size (64 blocks x 10 000 vars, Schur dim 2000) and the per-GPU share of configs[2]
+(64 of the 512 blocks, Schur dim 4000) on one GPU, checked through size-independent properties: the full arrowhead residual of solveCompressed, linearity of the solve, exact inertia of every
 leaf and of the root."""
 import numpy as np
 import pytest
@@ -10,9 +10,11 @@ import pips_ipmpp_amd as pa
 pytestmark = pytest.mark.gpu
 
 
-def test_config2_full_size_properties():
+@pytest.mark.parametrize("schur_dim", [2000, 4000], ids=["config2", "config3_per_gpu_share"])
+def test_full_size_properties(schur_dim):
     import torch
-    N, n_i, my_i, n0, myl, rho, seed = 64, 10000, 5000, 1000, 1000, 1e-3, 20261002
+    N, n_i, my_i, rho, seed = 64, 10000, 5000, 1e-3, 20261002
+    n0 = myl = schur_dim // 2
     S, nleaf = n0 + myl, n_i + my_i
     bt = pa.LeafBatch(N, S)
     Ks, Bts, diags, vals = [], [], [], []

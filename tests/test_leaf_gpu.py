@@ -263,3 +263,68 @@ def test_structured_matrices_without_inertia_hint(kind):
     assert np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs) < 1e-11
     info = s.info()
     assert info["n_levels"] >= 3 or info["m"] > 0
+
+
+class _TimeCoupledProblem(Problem):
+    """Same as Problem but W_i is banded (time-coupled constraints): chain-like elimination trees, hundreds of levels,
+    wide amalgamated supernodes, head-to-head update segments."""
+
+    def __init__(self, seed, N, n_i, my_i, n0, myl, bw):
+        import scipy.sparse as sp
+        super().__init__(seed, N, n_i, my_i, n0, myl, 0.02)
+        rng = np.random.default_rng(seed)
+        for b, blk in enumerate(self.blocks):
+            rows, cols = [], []
+            for r in range(my_i):
+                center = int(r * n_i / my_i)
+                cs = np.union1d(np.clip(center + rng.integers(-bw, bw + 1, 5), 0, n_i - 1), [center])
+                rows += [r] * len(cs)
+                cols += list(cs)
+            W = sp.csr_matrix((rng.uniform(-1, 1, len(rows)), (rows, cols)), shape=(my_i, n_i))
+            W.sum_duplicates()
+            W.sort_indices()
+            Wp = pa.Csr(my_i, n_i, W.indptr, W.indices, W.data)
+            K, dpos = pa.kkt_leaf_assemble(n_i, Wp)
+            K.val[dpos] = blk["diag"]
+            blk.update(W=Wp, K=K, dpos=dpos)
+
+
+@pytest.mark.parametrize("cut", ["model", "all_head"])
+def test_time_coupled_blocks_match_oracle(cut):
+    import torch
+    prob = _TimeCoupledProblem(5, 3, 600, 300, 10, 8, 6)
+    S, N = prob.S, prob.N
+    bt = pa.LeafBatch(N, S)
+    for b in range(N):
+        bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    if cut == "all_head":
+        bt.set_options(force_n_head=prob.n_leaf)
+    bt.analyze(2)
+    info = bt.info()
+    if cut == "all_head":
+        assert info["n_levels"] >= 10, info          # really chain-like
+        assert info["n_sn"] < 0.9 * info["n_head"]    # amalgamation merged columns
+    for b in range(N):
+        bt.set_values(b, prob.blocks[b]["K"].val)
+    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
+    bt.factor(SC, S)
+    bt.sync()
+    got = hip_lower_as_rowmajor(SC.cpu().numpy(), S)
+    want = np.tril(prob.oracle_schur())
+    assert np.abs(got - want).max() / np.abs(want).max() < RTOL_SC, info
+    rhs = np.random.default_rng(3).standard_normal(N * prob.n_leaf)
+    x = rhs.copy()
+    bt.solve(x)
+    for b in range(N):
+        assert bt.inertia(b) == (prob.n_i, prob.my_i, 0)
+        xo = rhs.reshape(N, -1)[b].copy()
+        prob.oracle_leaf(b).solve(xo)
+        assert np.linalg.norm(x.reshape(N, -1)[b] - xo) / np.linalg.norm(xo) < RTOL_SOLVE
+    # multi-RHS through the same chain kernels (grid.y = right-hand side), drop-in handle of block 0
+    s0 = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
+    s0.matrixChanged()
+    X = np.random.default_rng(4).standard_normal((5, prob.n_leaf))
+    R = X.copy()
+    s0.solve(X)
+    for i in range(5):
+        assert np.linalg.norm(prob.K_full(0) @ X[i] - R[i]) / np.linalg.norm(R[i]) < 1e-10
