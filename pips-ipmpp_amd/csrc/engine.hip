@@ -53,11 +53,17 @@ struct TaskList { long long off = 0; int cnt = 0; };
 
 struct TailPlan {
    int ntc_max = 0;
-   std::vector<TaskList> upd, diag, trsm, fwd, bwd;
+   std::vector<TaskList> upd, diag, trsm, fwd, bwd, trail;
    TaskList schur;
    TileTask* d_tasks = nullptr;
 
-   int build(const std::vector<BlkDesc>& blks) {
+   // panel == 0: pure left-looking (tile column j is updated once, with everything to its left: minimal traffic on C,
+   //   one task per tile of the column - right when many blocks share every launch).
+   // panel == P > 0: blocked right-looking with panels of P tile columns (the dense root, a single block: a left-looking
+   //   column launch has at most ntr workgroups with a K as deep as the matrix; here the column update only reaches back
+   //   to the start of its panel and each finished panel is applied to the whole trailing matrix in one launch of
+   //   (ntr - p1)^2 / 2 tiles with K = P * TILE).  The K range rides in TileTask::pad = k0 | k1 << 16 (tile columns).
+   int build(const std::vector<BlkDesc>& blks, int panel = 0) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -66,15 +72,17 @@ struct TailPlan {
       trsm.assign(ntc_max, {});
       fwd.assign(ntc_max, {});
       bwd.assign(ntc_max, {});
+      trail.assign(ntc_max, {});
       const int nblk = (int)blks.size();
       auto begin = [&](TaskList& l) { l.off = (long long)all.size(); };
       auto end = [&](TaskList& l) { l.cnt = (int)((long long)all.size() - l.off); };
       for (int j = 0; j < ntc_max; ++j) {
+         const int p0 = panel > 0 ? j / panel * panel : 0;   // first tile column of j's panel
          begin(upd[j]);
-         if (j >= 1)
+         if (j > p0)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j)
-                  for (int ti = j; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j, 0});
+                  for (int ti = j; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j, p0 | (j << 16)});
          end(upd[j]);
          begin(diag[j]);
          for (int b = 0; b < nblk; ++b)
@@ -95,6 +103,12 @@ struct TailPlan {
             if (blks[b].ntc > j)
                for (int tj = 0; tj <= j; ++tj) all.push_back({b, tj, j, 0});
          end(bwd[j]);
+         begin(trail[j]);
+         if (panel > 0 && (j + 1) % panel == 0)   // panel [p0, j] complete: apply it to every tile right of it
+            for (int b = 0; b < nblk; ++b)
+               for (int tj = j + 1; tj < blks[b].ntc; ++tj)
+                  for (int ti = tj; ti < blks[b].ntr; ++ti) all.push_back({b, ti, tj, p0 | ((j + 1) << 16)});
+         end(trail[j]);
       }
       begin(schur);
       for (int b = 0; b < nblk; ++b)
@@ -181,6 +195,12 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       if (p.trsm[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 4);
          hipLaunchKernelGGL(k_tile_gemm<1>, dim3((p.trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trsm[j].off, p.trsm[j].cnt,
+                            c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+         if (c.timer) c.timer->end(c.stream);
+      }
+      if (p.trail[j].cnt > 0) {
+         if (c.timer) c.timer->begin(c.stream, 2);
+         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((p.trail[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trail[j].off, p.trail[j].cnt,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
          if (c.timer) c.timer->end(c.stream);
       }
@@ -731,7 +751,11 @@ struct DenseLdl {
       d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
       h_blks.assign(1, d);
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
-      if ((rc = plan.build(h_blks))) return rc;
+      // one block only: right-looking (measured on MI355X, tools/root_probe.py: S=2000 4.3 -> 2.3 ms, S=16000 183 -> 45 ms;
+      // panels of 1 tile column are best up to S = 8000, 2-3 beyond)
+      int panel = d.ntc <= 64 ? 1 : 2;
+      if (const char* pw = getenv("PIPS_HIP_ROOT_PANEL")) panel = atoi(pw);
+      if ((rc = plan.build(h_blks, panel))) return rc;
       std::vector<signed char> ps(npad, 1);
       for (int i = 0; i < n; ++i) ps[i] = n_primal < 0 ? 0 : (i < n_primal ? 1 : -1);
       if ((rc = dev_upload(&d_psign, ps, stream))) return rc;

@@ -486,11 +486,13 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    long long ldb;
    const double* dv = nullptr;
    if (MODE == 0) {
-      K = task.tj * TILE;
-      Ap = T + (long long)task.ti * TILE;
-      Bp = T + (long long)task.tj * TILE;
+      // K range in tile columns [k0, k1): pad = k0 | k1 << 16, k1 == 0 meaning "up to the tile's own column"
+      const int k0 = task.pad & 0xffff, k1 = (task.pad >> 16) ? (task.pad >> 16) : task.tj;
+      K = (k1 - k0) * TILE;
+      Ap = T + (long long)task.ti * TILE + (long long)k0 * TILE * ld;
+      Bp = T + (long long)task.tj * TILE + (long long)k0 * TILE * ld;
       ldb = ld;
-      dv = dtail + bd.dt_off;
+      dv = dtail + bd.dt_off + k0 * TILE;
    } else if (MODE == 1) {
       K = TILE;
       Ap = T + (long long)task.ti * TILE + (long long)task.tj * TILE * ld;
