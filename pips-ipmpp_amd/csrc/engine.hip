@@ -53,7 +53,7 @@ struct TaskList { long long off = 0; int cnt = 0; };
 
 struct TailPlan {
    int ntc_max = 0;
-   std::vector<TaskList> upd, diag, trsm, fwd, bwd, trail;
+   std::vector<TaskList> upd, diag, trsm, fwd, bwd, trail, trail_next;
    TaskList schur;
    TileTask* d_tasks = nullptr;
 
@@ -63,7 +63,7 @@ struct TailPlan {
    //   column launch has at most ntr workgroups with a K as deep as the matrix; here the column update only reaches back
    //   to the start of its panel and each finished panel is applied to the whole trailing matrix in one launch of
    //   (ntr - p1)^2 / 2 tiles with K = P * TILE).  The K range rides in TileTask::pad = k0 | k1 << 16 (tile columns).
-   int build(const std::vector<BlkDesc>& blks, int panel = 0) {
+   int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -73,6 +73,7 @@ struct TailPlan {
       fwd.assign(ntc_max, {});
       bwd.assign(ntc_max, {});
       trail.assign(ntc_max, {});
+      trail_next.assign(ntc_max, {});
       const int nblk = (int)blks.size();
       auto begin = [&](TaskList& l) { l.off = (long long)all.size(); };
       auto end = [&](TaskList& l) { l.cnt = (int)((long long)all.size() - l.off); };
@@ -103,12 +104,21 @@ struct TailPlan {
             if (blks[b].ntc > j)
                for (int tj = 0; tj <= j; ++tj) all.push_back({b, tj, j, 0});
          end(bwd[j]);
-         begin(trail[j]);
-         if (panel > 0 && (j + 1) % panel == 0)   // panel [p0, j] complete: apply it to every tile right of it
+         // panel [p0, j] complete: apply it to every tile right of it.  The next tile column is listed separately
+         // (trail_next) so that the driver can finish it first and overlap the next diagonal tile with the rest.
+         if (panel > 0 && (j + 1) % panel == 0) {
+            begin(trail_next[j]);
+            if (lookahead)
+               for (int b = 0; b < nblk; ++b)
+                  if (j + 1 < blks[b].ntc)
+                     for (int ti = j + 1; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j + 1, p0 | ((j + 1) << 16)});
+            end(trail_next[j]);
+            begin(trail[j]);
             for (int b = 0; b < nblk; ++b)
-               for (int tj = j + 1; tj < blks[b].ntc; ++tj)
+               for (int tj = j + (lookahead ? 2 : 1); tj < blks[b].ntc; ++tj)
                   for (int ti = tj; ti < blks[b].ntr; ++ti) all.push_back({b, ti, tj, p0 | ((j + 1) << 16)});
-         end(trail[j]);
+            end(trail[j]);
+         }
       }
       begin(schur);
       for (int b = 0; b < nblk; ++b)
@@ -176,16 +186,35 @@ struct TailCtx {
    hipStream_t stream;
    PhaseTimer* timer;
    const double* d_pref;
+   hipStream_t side = nullptr;          // second stream for the lookahead of the right-looking root factorisation
+   hipEvent_t ev_panel = nullptr;       // main -> side: panel j is final (trsm done)
+   hipEvent_t ev_rest = nullptr;        // side -> main: trailing update of panel j is done
 };
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
    const size_t diag_lds = 0;
+   auto gemm0 = [&](const TaskList& l, hipStream_t st) {
+      hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                         c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+   };
+   // Lookahead bookkeeping (right-looking modes with a side stream): while the side stream applies a finished panel to
+   // the tile columns >= side_from, the main stream may only write columns left of that.
+   bool side_busy = false;
+   int side_from = 0;
+   auto main_writes = [&](int col) -> int {
+      if (side_busy && col >= side_from) {
+         HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_rest, 0));
+         side_busy = false;
+      }
+      return PIPS_OK;
+   };
+   int rc;
    for (int j = 0; j < p.ntc_max; ++j) {
+      if ((rc = main_writes(j))) return rc;
       if (p.upd[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 2);
-         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((p.upd[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.upd[j].off, p.upd[j].cnt, c.d_blks,
-                            c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+         gemm0(p.upd[j], c.stream);
          if (c.timer) c.timer->end(c.stream);
       }
       if (c.timer) c.timer->begin(c.stream, 3);
@@ -198,13 +227,27 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
          if (c.timer) c.timer->end(c.stream);
       }
-      if (p.trail[j].cnt > 0) {
+      // right-looking modes: trailing update with the panel that ends at column j.  With a side stream the bulk of it
+      // (tile columns >= j+2) runs there, so that the main stream can finish column j+1 and go on with its diagonal tile
+      // and trsm meanwhile (lookahead of one column).
+      if (p.trail_next[j].cnt > 0 || p.trail[j].cnt > 0) {
+         if ((rc = main_writes(j + 1))) return rc;
+         const bool split = c.side && p.trail[j].cnt > 0;
+         if (split) {
+            HIP_TRY(hipEventRecord(c.ev_panel, c.stream));   // panel final: its trsm is queued before this point
+            HIP_TRY(hipStreamWaitEvent(c.side, c.ev_panel, 0));
+            gemm0(p.trail[j], c.side);                       // queued behind the bulk of the previous panel
+            HIP_TRY(hipEventRecord(c.ev_rest, c.side));
+            side_busy = true;
+            side_from = j + 2;
+         }
          if (c.timer) c.timer->begin(c.stream, 2);
-         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((p.trail[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trail[j].off, p.trail[j].cnt,
-                            c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+         if (p.trail_next[j].cnt > 0) gemm0(p.trail_next[j], c.stream);
+         if (!split && p.trail[j].cnt > 0) gemm0(p.trail[j], c.stream);
          if (c.timer) c.timer->end(c.stream);
       }
    }
+   if ((rc = main_writes(1 << 30))) return rc;   // join the side stream
    if (SC && p.schur.cnt > 0) {
       if (c.timer) c.timer->begin(c.stream, 5);
       hipLaunchKernelGGL(k_tile_gemm<2>, dim3((p.schur.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
@@ -733,8 +776,13 @@ struct DenseLdl {
    long long *d_psign_off = nullptr, *d_kptr = nullptr;
    int* d_inertia = nullptr;
    int h_inertia[3] = {0, 0, 0};
+   hipStream_t side = nullptr;
+   hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
 
    ~DenseLdl() {
+      if (side) (void)hipStreamDestroy(side);
+      if (ev_panel) (void)hipEventDestroy(ev_panel);
+      if (ev_rest) (void)hipEventDestroy(ev_rest);
       void* ptrs[] = {d_blks, d_R, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -755,7 +803,14 @@ struct DenseLdl {
       // panels of 1 tile column are best up to S = 8000, 2-3 beyond)
       int panel = d.ntc <= 64 ? 1 : 2;
       if (const char* pw = getenv("PIPS_HIP_ROOT_PANEL")) panel = atoi(pw);
-      if ((rc = plan.build(h_blks, panel))) return rc;
+      // lookahead (second stream) pays once the trailing update of a panel outlasts a diagonal tile: S >= 6000 measured
+      const bool lookahead = panel > 0 && d.ntc >= 48 && !getenv("PIPS_HIP_ROOT_NO_LOOKAHEAD");
+      if ((rc = plan.build(h_blks, panel, lookahead))) return rc;
+      if (lookahead) {
+         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+         HIP_TRY(hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&ev_rest, hipEventDisableTiming));
+      }
       std::vector<signed char> ps(npad, 1);
       for (int i = 0; i < n; ++i) ps[i] = n_primal < 0 ? 0 : (i < n_primal ? 1 : -1);
       if ((rc = dev_upload(&d_psign, ps, stream))) return rc;
@@ -771,7 +826,9 @@ struct DenseLdl {
       HIP_TRY(hipMalloc((void**)&d_inertia, 3 * sizeof(int)));
       return PIPS_OK;
    }
-   TailCtx ctx() { return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref}; }
+   TailCtx ctx() {
+      return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest};
+   }
 
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)
    // rowmajor = 1: A_dev is row-major (the reference's DenseStorage), 0: column-major; lower triangle authoritative

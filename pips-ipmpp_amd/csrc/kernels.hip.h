@@ -57,17 +57,13 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 // perturbed.  This is scale-invariant, unlike a threshold relative to max|K|: IPM diagonals span 1e-8..1e8.
 __device__ __forceinline__ double fix_pivot(double d, int sign, double pref, double thr_rel, double repl_rel,
                                             double repl_abs, bool& perturbed) {
+   // branch-free (selects only): the rule sits on the critical path of every pivot
    const double thr = thr_rel * pref;
    const double repl = pref > 0.0 ? repl_rel * pref : repl_abs;
-   perturbed = false;
-   if (sign > 0) {
-      if (!(d > thr)) { d = repl; perturbed = true; }
-   } else if (sign < 0) {
-      if (!(d < -thr)) { d = -repl; perturbed = true; }
-   } else {
-      if (!(fabs(d) > thr)) { d = (d < 0.0) ? -repl : repl; perturbed = true; }
-   }
-   return d;
+   const double s = sign > 0 ? 1.0 : (sign < 0 ? -1.0 : (d < 0.0 ? -1.0 : 1.0));   // no hint: keep the pivot's own sign
+   const bool ok = s * d > thr;                                                    // false for NaN
+   perturbed = !ok;
+   return ok ? d : s * repl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,13 +611,25 @@ struct DiagShared {
    double dk[TILE];
    double prs[TILE];
    int sgn[TILE];
-   int cnt[3];
 };
 
-// the 16 pivots k = 16 KB .. 16 KB + 15; KB is a template parameter so that every register-array index is a constant
+// 1/d on the pivot's critical path: hardware reciprocal + two Newton steps (full double precision for the normal-range
+// pivots the static rule lets through) instead of the IEEE division sequence
+__device__ __forceinline__ double pivot_rcp(double d) {
+   double r = __builtin_amdgcn_rcp(d);
+   r = fma(fma(-d, r, 1.0), r, r);
+   r = fma(fma(-d, r, 1.0), r, r);
+   return r;
+}
+
+// the 16 pivots k = 16 KB .. 16 KB + 15; KB is a template parameter so that every register-array index is a constant.
+// Each step is one barrier plus a dependent chain LDS -> pivot rule -> reciprocal -> FMAs, so the step is written
+// branch-free: every LDS operand is fetched unconditionally and up front, masks are applied with selects (the first
+// version let the compiler turn `i > k ? lds[i] : 0` into serialized conditional loads: 92 us per tile instead of 77;
+// what remains is the instruction stream of one wave per SIMD, ~150 VALU/LDS instructions per pivot).
 template <int KB>
 __device__ __forceinline__ void diag_block(double (&A)[8][8], double (&X)[8][8], DiagShared& sh, const BlkDesc& bd,
-                                           int tx, int ty, int tid, int gk0) {
+                                           int tx, int ty, int tid, int gk0, int3& cnt) {
    for (int kt = 0; kt < 16; ++kt) {
       const int k = KB * 16 + kt, buf = kt & 1;
       if (ty == kt) {
@@ -633,34 +641,47 @@ __device__ __forceinline__ void diag_block(double (&A)[8][8], double (&X)[8][8],
          for (int b = 0; b <= KB; ++b) sh.xrow[buf][ty + 16 * b] = X[KB][b];  // X(k, c), c < 16 (KB+1)
       }
       __syncthreads();
+      const double piv = sh.colk[buf][k], pr = sh.prs[k];
+      const int sg = sh.sgn[k];
+      double ci[8], cj[8], xr[8];
+#pragma unroll
+      for (int a = KB; a < 8; ++a) ci[a] = sh.colk[buf][tx + 16 * a];
+#pragma unroll
+      for (int b = KB; b < 8; ++b) cj[b] = sh.colk[buf][ty + 16 * b];
+#pragma unroll
+      for (int b = 0; b <= KB; ++b) xr[b] = sh.xrow[buf][ty + 16 * b];
       bool pert;
-      const double d = fix_pivot(sh.colk[buf][k], sh.sgn[k], sh.prs[k], bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
-      if (tid == 0) {
-         sh.dk[k] = d;
-         if (gk0 + k < bd.m) { if (pert) ++sh.cnt[2]; else if (d > 0) ++sh.cnt[0]; else ++sh.cnt[1]; }
-      }
-      const double dinv = 1.0 / d;
+      const double d = fix_pivot(piv, sg, pr, bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
+      if (gk0 + k < bd.m) { cnt.z += pert; cnt.x += (!pert && d > 0); cnt.y += (!pert && !(d > 0)); }   // alike in every thread
+      if (tid == 0) sh.dk[k] = d;
+      const double dinv = pivot_rcp(d);
+      // Row / column masks: i = tx + 16 a is below the pivot k = 16 KB + kt for every a > KB and, inside the pivot's own
+      // block (a == KB), iff tx > kt - so only the a == KB (b == KB) terms need a run-time select.
       double li[8];
+      li[KB] = tx > kt ? ci[KB] * dinv : 0.0;
 #pragma unroll
-      for (int a = KB; a < 8; ++a) {
-         const int i = tx + 16 * a;
-         li[a] = i > k ? sh.colk[buf][i] * dinv : 0.0;   // l_ik, zero for rows that are not below the pivot
+      for (int a = KB + 1; a < 8; ++a) li[a] = ci[a] * dinv;
+      // A(i,j) -= l_ik a_jk  for i >= j > k   (blocks above the diagonal are never touched)
+      {
+         const double ajk = ty > kt ? cj[KB] : 0.0;
+#pragma unroll
+         for (int a = KB; a < 8; ++a) A[a][KB] -= li[a] * ajk;
       }
-      // A(i,j) -= l_ik a_jk  for i >= j > k
 #pragma unroll
-      for (int b = KB; b < 8; ++b) {
-         const int j = ty + 16 * b;
-         const double ajk = j > k ? sh.colk[buf][j] : 0.0;
+      for (int b = KB + 1; b < 8; ++b) {
 #pragma unroll
-         for (int a = KB; a < 8; ++a) A[a][b] -= li[a] * ajk;
+         for (int a = b; a < 8; ++a) A[a][b] -= li[a] * cj[b];
       }
-      // X(i,c) -= l_ik X(k,c) for c < k ;  X(i,k) = -l_ik
+      // X(i,c) -= l_ik X(k,c) for c < k ;  X(i,k) = -l_ik     (c = ty + 16 b < k for every b < KB)
 #pragma unroll
-      for (int b = 0; b <= KB; ++b) {
-         const int c = ty + 16 * b;
-         const double xkc = c < k ? sh.xrow[buf][c] : (c == k ? 1.0 : 0.0);
+      for (int b = 0; b < KB; ++b) {
 #pragma unroll
-         for (int a = KB; a < 8; ++a) X[a][b] -= li[a] * xkc;
+         for (int a = KB; a < 8; ++a) X[a][b] -= li[a] * xr[b];
+      }
+      {
+         const double xkc = ty < kt ? xr[KB] : (ty == kt ? 1.0 : 0.0);
+#pragma unroll
+         for (int a = KB; a < 8; ++a) X[a][KB] -= li[a] * xkc;
       }
    }
 }
@@ -682,7 +703,6 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
    const int tid = threadIdx.x, tj = task.tj, ld = bd.ldT;
    const int tx = tid & 15, ty = tid >> 4;
    double* C = arena + bd.T + (long long)tj * TILE + (long long)tj * TILE * ld;
-   if (tid < 3) sh.cnt[tid] = 0;
    if (tid < TILE) {
       sh.prs[tid] = pref[bd.xw_off + bd.n_head + tj * TILE + tid];
       sh.sgn[tid] = tj * TILE + tid < bd.m ? (int)psign[psign_off[task.blk] + bd.n_head + tj * TILE + tid] : 1;
@@ -693,21 +713,21 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
          const int i = tx + 16 * a, j = ty + 16 * b;
-         A[a][b] = i >= j ? C[i + (long long)j * ld] : 0.0;
+         A[a][b] = (b <= a && i >= j) ? C[i + (long long)j * ld] : 0.0;   // blocks above the diagonal are never touched
          X[a][b] = 0.0;
       }
    __syncthreads();
    const int gk0 = tj * TILE;
-   diag_block<0>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<1>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<2>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<3>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<4>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<5>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<6>(A, X, sh, bd, tx, ty, tid, gk0);
-   diag_block<7>(A, X, sh, bd, tx, ty, tid, gk0);
+   int3 cnt = make_int3(0, 0, 0);   // accepted positive / negative / perturbed pivots (identical in every thread)
+   diag_block<0>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<1>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<2>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<3>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<4>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<5>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<6>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
+   diag_block<7>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
    double* dk = sh.dk;
-   int* cnt = sh.cnt;
    __syncthreads();
    // store L (unit lower, scaled), D, and Winv[n][k] = X[n][k] / d_n
    double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
@@ -716,6 +736,7 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
          const int i = tx + 16 * a, j = ty + 16 * b;
+         if (b > a) { W[i + (long long)j * TILE] = 0.0; continue; }
          if (i > j) C[i + (long long)j * ld] = A[a][b] / dk[j];
          else if (i == j) C[i + (long long)j * ld] = dk[j];
          const double x = i == j ? 1.0 : (i > j ? X[a][b] : 0.0);
@@ -723,9 +744,9 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
       }
    if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = dk[tid];
    if (tid == 0) {
-      if (cnt[0]) atomicAdd(&inertia[3 * task.blk + 0], cnt[0]);
-      if (cnt[1]) atomicAdd(&inertia[3 * task.blk + 1], cnt[1]);
-      if (cnt[2]) atomicAdd(&inertia[3 * task.blk + 2], cnt[2]);
+      if (cnt.x) atomicAdd(&inertia[3 * task.blk + 0], cnt.x);
+      if (cnt.y) atomicAdd(&inertia[3 * task.blk + 1], cnt.y);
+      if (cnt.z) atomicAdd(&inertia[3 * task.blk + 2], cnt.z);
    }
 }
 
