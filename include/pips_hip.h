@@ -224,6 +224,9 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
  * [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
 int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7);
 int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
+/* history of the last pips_ipm_solve, one row of 7 doubles per iterate: mu, ||r||inf, primal objective, dual objective, and the
+ * step taken from it: sigma, alpha_primal, alpha_dual (zeros in the final row).  rows7 may be NULL to query *n_rows. */
+int pips_ipm_get_trace(void* handle, double* rows7, int max_rows, int* n_rows);
 void pips_ipm_destroy(void* handle);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -69,4 +69,6 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
         ap, ad = min(1.0, tau * stepbound(v, dv)), min(1.0, tau * stepbound(g, dg))
         x += ap * dx; v += ap * dv
         y += ad * dy; g += ad * dg
+        if trace is not None:   # the step that leaves iterate `it`: (sigma, alpha_primal, alpha_dual) appended to its row
+            trace[-1] = trace[-1] + (sigma, ap, ad)
     return dict(objective=c @ x, iterations=it, mu=mu, rnorm=rnorm, status=status, dual_objective=b @ y, x=x, y=y, dnorm=dnorm)

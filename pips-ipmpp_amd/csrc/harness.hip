@@ -347,6 +347,7 @@ struct Ipm {
       return PIPS_OK;
    }
 
+   std::vector<double> trace;   // per iterate: mu, ||r||inf, primal obj, dual obj, then the step taken from it: sigma, alpha_p, alpha_d
    int run(int max_iter, double mutol, double artol, int verbose, double* result) {
       HIP_TRYH(hipSetDevice(device));
       // ---- start point: push_to_interior(sqrt(dnorm)), one affine solve, full step, shift (PIPSIPMppSolver.cpp:36-42, Solver.cpp:19-31)
@@ -374,9 +375,11 @@ struct Ipm {
       TRY(pips_hip_vec_add_const(nx, shift, g, stream));
 
       int it = 0, status = 1;  // 1 = max iterations
+      trace.clear();
       for (; it < max_iter; ++it) {
          TRY(residuals(&rnorm, &pobj, &dobj));
          TRY(mu(&m));
+         trace.insert(trace.end(), {m, rnorm, pobj, dobj, 0.0, 0.0, 0.0});   // step data filled in below
          if (verbose)
             printf("ipm it %3d  mu %.3e  ||r||inf %.3e  pobj %.10e  dobj %.10e  (last solve: %d outer its, rel.res %.1e)\n", it, m, rnorm, pobj,
                    dobj, last_outer_steps, last_outer_res);
@@ -406,6 +409,7 @@ struct Ipm {
          TRY(pips_hip_vec_axpy(nx, 1.0, cg, dg, stream));
          const double tau = std::max(0.99, 1.0 - m);
          TRY(step_lengths(dv, dg, tau, &ap, &ad));
+         { double* row = trace.data() + trace.size() - 7; row[4] = sigma; row[5] = ap; row[6] = ad; }
          TRY(pips_hip_vec_axpy(nx, ap, dx, x, stream));
          TRY(pips_hip_vec_axpy(nx, ap, dv, v, stream));
          TRY(pips_hip_vec_axpy(ny, ad, dy, y, stream));
@@ -549,6 +553,16 @@ int pips_ipm_get_solution(void* handle, double* x_host, double* y_host) {
    if (!p) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    if (x_host) HIP_TRYH(hipMemcpy(x_host, p->x, (size_t)p->nx * sizeof(double), hipMemcpyDeviceToHost));
    if (y_host) HIP_TRYH(hipMemcpy(y_host, p->y, (size_t)p->ny * sizeof(double), hipMemcpyDeviceToHost));
+   return PIPS_OK;
+}
+
+int pips_ipm_get_trace(void* handle, double* rows7, int max_rows, int* n_rows) {
+   Ipm* p = (Ipm*)handle;
+   if (!p || !n_rows) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_get_trace: bad arguments");
+   const int have = (int)(p->trace.size() / 7);
+   *n_rows = have;
+   if (rows7)
+      for (int i = 0; i < std::min(have, max_rows) * 7; ++i) rows7[i] = p->trace[i];
    return PIPS_OK;
 }
 

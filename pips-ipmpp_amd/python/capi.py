@@ -66,7 +66,7 @@ SYMBOLS = [
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_get_solution", "pips_ipm_destroy",
+    "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
 ]
@@ -698,6 +698,14 @@ class IpmSolver:
         y = np.zeros(self.ny)
         _check(lib.pips_ipm_get_solution(self._h, _ptr(x), _ptr(y)), "pips_ipm_get_solution")
         return x, y
+
+    def trace(self):
+        """(n_iterates, 7) history of the last solve: mu, ||r||inf, primal obj, dual obj, sigma, alpha_p, alpha_d."""
+        n = C.c_int()
+        _check(lib.pips_ipm_get_trace(self._h, None, C.c_int(0), C.byref(n)), "pips_ipm_get_trace")
+        out = np.zeros((n.value, 7))
+        _check(lib.pips_ipm_get_trace(self._h, _ptr(out), C.c_int(n.value), C.byref(n)), "pips_ipm_get_trace")
+        return out
 
     def close(self):
         if self._h:

@@ -52,6 +52,21 @@ def test_ipm_objective_matches_highs(shape):
     o = io.solve_lp(A, b, c, 100, 1e-9, 1e-8, trace)
     assert o["status"] == 0 and abs(o["iterations"] - res["iterations"]) <= 1, (o["iterations"], res["iterations"])
     assert abs(o["objective"] - res["objective"]) / abs(o["objective"]) < 1e-9
+    # iterate-by-iterate: mu, ||r||inf, primal / dual objective, centering parameter and both step lengths follow the CPU
+    # restatement (same start point, same predictor-corrector, InteriorPointMethod.cpp:68-234).  The two codes solve the
+    # KKT systems differently (Schur complement + LDL^T vs one SuperLU factorisation), so the paths agree to solver
+    # accuracy while the iterates are well conditioned and drift apart by a few digits close to the optimum.
+    tr = ipm.trace()
+    n_cmp = min(len(trace), tr.shape[0]) - 1
+    assert n_cmp >= 8
+    for k in range(n_cmp):
+        it, mu, rnorm, pobj, dobj, sigma, ap, ad = trace[k]
+        tol = 1e-6 if k < n_cmp - 4 else 1e-3
+        assert abs(tr[k, 0] - mu) <= tol * mu, (k, tr[k], trace[k])
+        assert abs(tr[k, 2] - pobj) <= tol * max(1.0, abs(pobj)), (k, tr[k], trace[k])
+        assert abs(tr[k, 3] - dobj) <= tol * max(1.0, abs(dobj)), (k, tr[k], trace[k])
+        assert abs(tr[k, 1] - rnorm) <= tol * max(rnorm, 1e-9 * o["dnorm"]) + 1e-12, (k, tr[k], trace[k])
+        assert abs(tr[k, 4] - sigma) <= 10 * tol and abs(tr[k, 5] - ap) <= 10 * tol and abs(tr[k, 6] - ad) <= 10 * tol, (k, tr[k], trace[k])
     x, y = ipm.solution()
     assert x.min() > -1e-9
     assert np.linalg.norm(A @ x - b, np.inf) <= 1e-8 * max(1.0, np.abs(b).max())
