@@ -189,14 +189,19 @@ struct TailCtx {
    hipStream_t side = nullptr;          // second stream for the lookahead of the right-looking root factorisation
    hipEvent_t ev_panel = nullptr;       // main -> side: panel j is final (trsm done)
    hipEvent_t ev_rest = nullptr;        // side -> main: trailing update of panel j is done
+   bool is_root = false;                // dense root: same update kernel under its own name (k_tile_gemm<3>)
 };
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
    const size_t diag_lds = 0;
    auto gemm0 = [&](const TaskList& l, hipStream_t st) {
-      hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                         c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+      if (c.is_root)
+         hipLaunchKernelGGL(k_tile_gemm<3>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+      else
+         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
    };
    // Lookahead bookkeeping (right-looking modes with a side stream): while the side stream applies a finished panel to
    // the tile columns >= side_from, the main stream may only write columns left of that.
@@ -582,7 +587,7 @@ struct Engine {
       if (timer.on) timer.begin(stream, 6);
       if (timer.on) timer.begin(stream, 0);
       hipLaunchKernelGGL(k_block_absmax, dim3(nblk), dim3(256), 0, stream, d_kval, d_kptr, d_blks, thr_rel, repl_rel);
-      HIP_TRY(hipMemsetAsync(d_arena, 0, arena_total * sizeof(double), stream));
+      hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
       if (nnzK_total > 0)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzK_total, 256)), dim3(256), 0, stream, d_kdst, d_kval, d_arena, nnzK_total);
@@ -827,7 +832,7 @@ struct DenseLdl {
       return PIPS_OK;
    }
    TailCtx ctx() {
-      return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest};
+      return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true};
    }
 
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)

@@ -75,6 +75,26 @@ __global__ void k_scatter(const long long* __restrict__ dst, const double* __res
       arena[dst[i]] = val[i];
 }
 
+// arena := 0 where a factorisation reads or accumulates: the head panels and, in the dense tail, every column from the
+// top of its diagonal tile down (the tiles above the diagonal are never touched: a third of the arena at config 2).
+// grid (x, block); 16-byte stores
+__global__ __launch_bounds__(256) void k_arena_clear(const BlkDesc* __restrict__ blks, double* __restrict__ arena) {
+   const BlkDesc bd = blks[blockIdx.y];
+   typedef double double2_t __attribute__((ext_vector_type(2)));
+   const double2_t z = {0.0, 0.0};
+   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
+   double2_t* head = (double2_t*)(arena + bd.arena_off);
+   const long long nh = (bd.T - bd.arena_off) / 2;   // panels are padded to 16 doubles
+   for (long long i = gtid; i < nh; i += gstride) head[i] = z;
+   // tail: a workgroup takes whole columns, its threads run down the rows
+   for (int c = blockIdx.x; c < bd.m_pad; c += gridDim.x) {
+      const int r0 = c / TILE * TILE;
+      double2_t* col = (double2_t*)(arena + bd.T + (long long)c * bd.ldT + r0);
+      const int n2 = (bd.ldT - r0) / 2;
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) col[i] = z;
+   }
+}
+
 // K values <- diagonal vector (a2: put_primal_diagonal / put_dual_inequalites_diagonal / regularisation)
 __global__ void k_put_diag(const long long* __restrict__ kdiag, const double* __restrict__ diag, double* __restrict__ kval,
                            long long n) {
@@ -429,6 +449,7 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
 //   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
 //   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
 //   MODE 2 (schur) : SC[bmap(ti), bmap(tj)] -= A(ti,0:K) diag(d) B(tj,0:K)^T   ti,tj border tile rows, K = m_pad
+//   MODE 3         : MODE 0 under its own name for the dense root (so that profiles keep the leaf update apart)
 // 512 threads = 8 waves in a 2 x 4 grid, each wave owns a 64 x 32 sub-tile (32 accumulators): ~110 VGPRs, so four
 // waves share a SIMD and hide each other's LDS / barrier / DMA-issue stalls (two 256-thread workgroups per CU).
 //
@@ -481,7 +502,7 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    const double* Bp;  // B panel: columns of C
    long long ldb;
    const double* dv = nullptr;
-   if (MODE == 0) {
+   if (MODE == 0 || MODE == 3) {
       // K range in tile columns [k0, k1): pad = k0 | k1 << 16, k1 == 0 meaning "up to the tile's own column"
       const int k0 = task.pad & 0xffff, k1 = (task.pad >> 16) ? (task.pad >> 16) : task.tj;
       K = (k1 - k0) * TILE;
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
       for (int c = 0; c < 8; ++c) {
          const int col = wc * 32 + c * 4 + (lane >> 4);
          const double v = acc[i][c];
-         if (MODE == 0) {
+         if (MODE == 0 || MODE == 3) {
             double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
 #if defined(PIPS_EXPERIMENT_NO_EPILOGUE)
             if (v == 1.2345e300) *cp = v;

@@ -65,7 +65,8 @@ def test_ipm_objective_matches_highs(shape):
         assert abs(tr[k, 0] - mu) <= tol * mu, (k, tr[k], trace[k])
         assert abs(tr[k, 2] - pobj) <= tol * max(1.0, abs(pobj)), (k, tr[k], trace[k])
         assert abs(tr[k, 3] - dobj) <= tol * max(1.0, abs(dobj)), (k, tr[k], trace[k])
-        assert abs(tr[k, 1] - rnorm) <= tol * max(rnorm, 1e-9 * o["dnorm"]) + 1e-12, (k, tr[k], trace[k])
+        # residual norms are compared down to the level the linear solves resolve (1e-10 relative to the data norm)
+        assert abs(tr[k, 1] - rnorm) <= tol * rnorm + 1e-10 * o["dnorm"], (k, tr[k], trace[k])
         assert abs(tr[k, 4] - sigma) <= 10 * tol and abs(tr[k, 5] - ap) <= 10 * tol and abs(tr[k, 6] - ad) <= 10 * tol, (k, tr[k], trace[k])
     x, y = ipm.solution()
     assert x.min() > -1e-9
