@@ -383,6 +383,7 @@ struct Ipm {
          if (verbose)
             printf("ipm it %3d  mu %.3e  ||r||inf %.3e  pobj %.10e  dobj %.10e  (last solve: %d outer its, rel.res %.1e)\n", it, m, rnorm, pobj,
                    dobj, last_outer_steps, last_outer_res);
+         if (verbose) fflush(stdout);
          if (!(m == m) || !(rnorm == rnorm)) { status = 2; break; }         // numerical breakdown (NaN)
          if (m <= mutol && rnorm <= artol * dnorm) { status = 0; break; }   // PIPSIPMppSolver.cpp:143-149
          // outer tolerance schedule (InteriorPointMethod.cpp:655-669): 1e-8 up to iteration 3, 1e-9 up to 7, then 1e-10
