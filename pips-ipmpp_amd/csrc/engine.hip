@@ -333,6 +333,8 @@ struct Engine {
    std::vector<long long> kptr;     // nblk+1 offsets into kval
    std::vector<long long> x_off;    // nblk+1 offsets into flat vectors
    std::vector<LevelRange> levels;
+   int spine_total = 0, n_levels_all = 0;   // supernodes handled by the per-block spine kernels; tree height before the cut
+   int *d_spine = nullptr, *d_spine_off = nullptr;
    long long n_total = 0, nnzK_total = 0, nnzB_total = 0, arena_total = 0, xw_total = 0, bt_rows_total = 0;
    int nsn_total = 0;
    TailPlan plan;
@@ -353,7 +355,7 @@ struct Engine {
    ~Engine() { release(); }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
-                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm,
+                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -365,6 +367,7 @@ struct Engine {
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
+      d_spine = d_spine_off = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
@@ -466,21 +469,46 @@ struct Engine {
       std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
          return a.level != b.level ? a.level < b.level : a.cls < b.cls;
       });
+      // ---- spine: the top levels that hold at most two supernodes of every block (chain-like trees of time-coupled
+      //      blocks).  One launch per level would be pure latency there; they go to the per-block spine kernels instead.
+      n_levels_all = nlev;
+      int lstar = nlev;
+      {
+         std::vector<int> width(nlev, 0);   // max over blocks of the supernode count per level
+         std::vector<int> cnt(nlev);
+         for (int b = 0; b < nblk; ++b) {
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (const HeadSupernode& s : sym[b].sn) ++cnt[s.level];
+            for (int l = 0; l < nlev; ++l) width[l] = std::max(width[l], cnt[l]);
+         }
+         while (lstar > 0 && width[lstar - 1] <= 2) --lstar;
+         const char* env = getenv("PIPS_HIP_SPINE");
+         if (nlev - lstar < 8 || (env && atoi(env) == 0)) lstar = nlev;
+      }
       std::vector<SnDesc> h_sns(nsn_total);
       std::vector<std::vector<int>> sorted_id(nblk);
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
-      levels.assign(nlev, LevelRange{0, 0, 0, 0, 0, 0});
+      levels.assign(lstar, LevelRange{0, 0, 0, 0, 0, 0});
       for (int i = 0; i < nsn_total; ++i) {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
                            s.n_useg, s.rb};
          sorted_id[k.blk][k.loc] = i;
+         if (k.level >= lstar) continue;   // spine member
          LevelRange& L = levels[k.level];
          if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
          else if (k.cls == 1) { if (L.small_cnt++ == 0) L.small_begin = i; }
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
       }
+      // spine lists: per block, ascending local index = postorder (children before parents)
+      std::vector<int> h_spine, h_spine_off(nblk + 1, 0);
+      for (int b = 0; b < nblk; ++b) {
+         for (int l = 0; l < (int)sym[b].sn.size(); ++l)
+            if (sym[b].sn[l].level >= lstar) h_spine.push_back(sorted_id[b][l]);
+         h_spine_off[b + 1] = (int)h_spine.size();
+      }
+      spine_total = (int)h_spine.size();
       // ---- concatenated index arrays
       std::vector<int> h_rowidx, h_sncol, h_bmap, h_perm, h_upd;
       h_upd.reserve(upd_base[nblk]);
@@ -559,6 +587,8 @@ struct Engine {
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
       if ((rc = dev_upload(&d_rowidx, h_rowidx, stream))) return rc;
       if ((rc = dev_upload(&d_upd, h_upd, stream))) return rc;
+      if ((rc = dev_upload(&d_spine, h_spine, stream))) return rc;
+      if ((rc = dev_upload(&d_spine_off, h_spine_off, stream))) return rc;
       if ((rc = dev_upload(&d_sncol, h_sncol, stream))) return rc;
       if ((rc = dev_upload(&d_bmap, h_bmap, stream))) return rc;
       if ((rc = dev_upload(&d_perm, h_perm, stream))) return rc;
@@ -613,6 +643,12 @@ struct Engine {
                                d_inertia, d_pref);
          if (timer.on) timer.end(stream);
       }
+      if (spine_total > 0) {
+         if (timer.on) timer.begin(stream, 1);
+         hipLaunchKernelGGL((k_head_factor_spine<256, 32, 6144>), dim3(nblk), dim3(256), 0, stream, d_spine, d_spine_off, d_sns, d_blks,
+                            d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
+         if (timer.on) timer.end(stream);
+      }
       hipLaunchKernelGGL(k_pref_tail, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_arena, d_pref, 0);
       HIP_TRY(hipGetLastError());
       TailCtx c = ctx();
@@ -643,6 +679,9 @@ struct Engine {
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_fwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
+      if (spine_total > 0)
+         hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
+                            d_arena, xw, xws, 0);
       TailCtx c = ctx();
       int rc = tail_fwd(c, xw, nrhs, xws);
       if (rc) return rc;
@@ -651,6 +690,9 @@ struct Engine {
                             d_arena, xw, xws);
       rc = tail_bwd(c, xw, nrhs, xws);
       if (rc) return rc;
+      if (spine_total > 0)
+         hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
+                            d_arena, xw, xws, 1);
       for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;

@@ -201,22 +201,17 @@ constexpr int USEG_HDR = 8;
 // barrier per column (all threads derive the pivot, columns stay unscaled in LDS, 1/d is applied on the fly), and the
 // scatter positions come precomputed from the analysis instead of being searched.
 template <int BLOCK, int WMAX, int LCAP>
-__global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict__ sns, int sn_begin,
-                                                      const BlkDesc* __restrict__ blks,
-                                                      const int* __restrict__ rowidx, const int* __restrict__ upd,
-                                                      const signed char* __restrict__ psign,
-                                                      const long long* __restrict__ psign_off,
-                                                      const int* __restrict__ bmap, double* __restrict__ arena,
-                                                      double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
-                                                      const double* __restrict__ pref) {
+__device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
+                                                 const int* __restrict__ upd, const signed char* __restrict__ psign,
+                                                 const long long* __restrict__ psign_off, const int* __restrict__ bmap,
+                                                 double* __restrict__ arena, double* __restrict__ SC, int ldSC,
+                                                 int* __restrict__ inertia, const double* __restrict__ pref) {
    __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w; column k keeps l_ik * d_k (unscaled)
    __shared__ double dk[WMAX];
    __shared__ double prf[WMAX];
    __shared__ int sgn[WMAX];
    __shared__ double Ls[LCAP];
 
-   const SnDesc sn = sns[sn_begin + blockIdx.x];
-   const BlkDesc bd = blks[sn.blk];
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
    double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
@@ -348,6 +343,45 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
       for_pairs(b0, r, [&](int a, int b) {
          atomic_add_f64(SC + bm[rows[a] - n] + (long long)bm[rows[b] - n] * ldSC, -entry(a, b));
       });
+   }
+}
+
+template <int BLOCK, int WMAX, int LCAP>
+__global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict__ sns, int sn_begin,
+                                                      const BlkDesc* __restrict__ blks,
+                                                      const int* __restrict__ rowidx, const int* __restrict__ upd,
+                                                      const signed char* __restrict__ psign,
+                                                      const long long* __restrict__ psign_off,
+                                                      const int* __restrict__ bmap, double* __restrict__ arena,
+                                                      double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
+                                                      const double* __restrict__ pref) {
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref);
+}
+
+// "Spine" of a chain-like elimination tree: the top levels that hold at most two supernodes per block.  Level scheduling
+// would spend one launch per level on them; here one workgroup per block walks its spine supernodes in postorder inside a
+// single launch.  A supernode's panel receives atomic updates (performed at L2) from earlier ones of the same workgroup:
+// the agent-scope fence drains this thread's atomics / stores and invalidates the L1 lines a neighbouring panel may have
+// left behind, the barrier orders the workgroup.
+template <int BLOCK, int WMAX, int LCAP>
+__global__ __launch_bounds__(BLOCK) void k_head_factor_spine(const int* __restrict__ spine, const int* __restrict__ spine_off,
+                                                            const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
+                                                            const int* __restrict__ rowidx, const int* __restrict__ upd,
+                                                            const signed char* __restrict__ psign,
+                                                            const long long* __restrict__ psign_off,
+                                                            const int* __restrict__ bmap, double* __restrict__ arena,
+                                                            double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
+                                                            const double* __restrict__ pref) {
+   const int p0 = spine_off[blockIdx.x], p1 = spine_off[blockIdx.x + 1];
+   if (p0 == p1) return;
+   const BlkDesc bd = blks[blockIdx.x];
+   for (int p = p0; p < p1; ++p) {
+      const SnDesc sn = sns[spine[p]];
+      head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref);
+      __threadfence();
+      __syncthreads();
    }
 }
 
@@ -970,6 +1004,33 @@ __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict_
    if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, red);
    else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, red);
    else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, red);
+}
+
+// spine sweeps of the solve: one wave per (block, right-hand side) walks the block's spine supernodes inside one launch
+// (ascending for the forward sweep, descending for the backward one); see k_head_factor_spine for the fence
+__global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__ spine, const int* __restrict__ spine_off,
+                                                        const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
+                                                        const int* __restrict__ rowidx, const double* __restrict__ arena,
+                                                        double* __restrict__ xw, long long xw_stride, int backward) {
+   __shared__ double ys[HEAD_WMAX];
+   __shared__ double red[HEAD_WMAX][65];
+   const int p0 = spine_off[blockIdx.x], p1 = spine_off[blockIdx.x + 1];
+   if (p0 == p1) return;
+   const BlkDesc bd = blks[blockIdx.x];
+   for (int q = 0; q < p1 - p0; ++q) {
+      const SnDesc sn = sns[spine[backward ? p1 - 1 - q : p0 + q]];
+      if (!backward) {
+         if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+         else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+         else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+      } else {
+         if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, red);
+         else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, red);
+         else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, red);
+      }
+      __threadfence();
+      __syncthreads();
+   }
 }
 
 // tail forward step j: tiles i >= j of block b:  b_i -= L(i,j-1) (d z)_{j-1}  (j >= 1) ; tile i == j: z_j = Winv_j b_j
