@@ -320,6 +320,15 @@ def test_time_coupled_blocks_match_oracle(cut):
         xo = rhs.reshape(N, -1)[b].copy()
         prob.oracle_leaf(b).solve(xo)
         assert np.linalg.norm(x.reshape(N, -1)[b] - xo) / np.linalg.norm(xo) < RTOL_SOLVE
+    if cut == "all_head":
+        # the narrow top levels are handled by the per-block spine kernels: far fewer launches than tree levels
+        bt.set_timing(True)
+        SC.zero_()
+        bt.factor(SC, S)
+        bt.sync()
+        assert bt.get_timing()["head"][1] < info["n_levels"] // 2, (bt.get_timing(), info)
+        bt.set_timing(False)
+        assert np.abs(hip_lower_as_rowmajor(SC.cpu().numpy(), S) - want).max() / np.abs(want).max() < RTOL_SC
     # multi-RHS through the same chain kernels (grid.y = right-hand side), drop-in handle of block 0
     s0 = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
     s0.matrixChanged()
