@@ -45,6 +45,12 @@ enum : int {
 void constrained_amd(int n, const std::vector<int>& ap, const std::vector<int>& ai, int n_primal,
                      std::vector<int>& perm, std::vector<int>& colcount);
 
+// Partial nested dissection (order.cpp): up to max_depth levels of dual-row separators, constrained minimum degree inside
+// the leaves, exact column counts.  Returns false (perm untouched or unusable) when the block has no small separators -
+// random sparsity - or is too small; the caller then uses constrained_amd on the whole block.
+bool dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& ai, int n_primal, int max_depth,
+                     std::vector<int>& perm, std::vector<int>& colcount);
+
 // ---- symbolic analysis of one leaf block (symbolic.cpp) --------------------------------------
 struct HeadSupernode {
    int c0;          // first column (permuted index)
@@ -95,6 +101,7 @@ struct CsrPattern {
 struct AnalyzeOptions {
    int tile = 128;            // dense tile size
    int max_sn_width = 32;     // head supernode width cap
+   int nd_depth = 4;          // levels of dual-row nested dissection tried before minimum degree (0 = off)
    double relax_zeros = 0.4;  // supernode amalgamation: admissible share of explicit zeros in a panel (0 = fundamental)
    int min_tail = 256;        // do not open a dense tail smaller than this
    int force_n_head = -1;     // >=0: override the cost model (tests)

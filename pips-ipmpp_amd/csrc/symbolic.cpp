@@ -48,7 +48,8 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             if (j != i) { ai[fill[i]++] = j; ai[fill[j]++] = i; }
          }
    }
-   constrained_amd(n, ap, ai, n_primal, out.perm, out.colcount);
+   if (!dissected_order(n, ap, ai, n_primal, opt.nd_depth, out.perm, out.colcount))
+      constrained_amd(n, ap, ai, n_primal, out.perm, out.colcount);
    out.iperm.assign(n, 0);
    for (int k = 0; k < n; ++k) out.iperm[out.perm[k]] = k;
    out.psign.assign(n, 0);

@@ -67,3 +67,64 @@ def test_rejects_upper_triangular_input():
     K = pa.Csr(2, 2, [0, 2, 3], [0, 1, 1], [1.0, 2.0, 3.0])
     with pytest.raises(pa.capi.PipsHipError):
         pa.symbolic_probe(K)
+
+
+def _banded_kkt(n_i, my_i, bw, seed=0):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for r in range(my_i):
+        center = int(r * n_i / my_i)
+        cs = np.union1d(np.clip(center + rng.integers(-bw, bw + 1, 9), 0, n_i - 1), [center])
+        rows += [r] * len(cs)
+        cols += list(cs)
+    W = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(my_i, n_i))
+    W.sum_duplicates()
+    W.sort_indices()
+    Wp = pa.Csr(my_i, n_i, W.indptr, W.indices, W.data)
+    K, _ = pa.kkt_leaf_assemble(n_i, Wp)
+    return K, W
+
+
+def test_partial_nested_dissection_on_time_coupled_block():
+    """Banded W: dual-row separators cut the chain into independent segments (far fewer tree levels, no more fill), the
+    static-pivot constraint (dual row after all its primal neighbours) still holds; random sparsity is left to minimum
+    degree (the first separator is rejected)."""
+    n_i, my_i = 6000, 3000
+    K, W = _banded_kkt(n_i, my_i, 20)
+    os.environ["PIPS_HIP_ND_DEPTH"] = "0"
+    try:
+        chain = pa.symbolic_probe(K, n_i, force_n_head=K.nrows)
+    finally:
+        del os.environ["PIPS_HIP_ND_DEPTH"]
+    nd = pa.symbolic_probe(K, n_i, force_n_head=K.nrows, want_perm=True)
+    assert nd["n_levels"] * 3 < chain["n_levels"], (nd["n_levels"], chain["n_levels"])
+    assert nd["nnzL"] < 1.5 * chain["nnzL"]
+    perm = nd["perm"]
+    assert sorted(perm.tolist()) == list(range(K.nrows))
+    pos = np.empty(K.nrows, dtype=np.int64)
+    pos[perm] = np.arange(K.nrows)
+    Wc = W.tocsr()
+    for r in range(my_i):
+        cols = Wc.indices[Wc.indptr[r]:Wc.indptr[r + 1]]
+        assert pos[n_i + r] > pos[cols].max()
+    # exact column counts: stored factor = symbolic count of the oracle for this order (fundamental supernodes)
+    os.environ["PIPS_HIP_RELAX_ZEROS"] = "0"
+    try:
+        fund = pa.symbolic_probe(K, n_i, force_n_head=K.nrows, want_perm=True)
+    finally:
+        del os.environ["PIPS_HIP_RELAX_ZEROS"]
+    import scipy.sparse as sp
+    Ks = sp.csr_matrix((np.ones(len(K.colidx)), K.colidx, K.rowptr), shape=(K.nrows, K.ncols))
+    assert fund["nnzL"] - K.nrows == orc.OracleLdl(Ks, perm=fund["perm"]).nnzL()
+    assert int(fund["colcount"].sum()) == fund["nnzL"] - K.nrows
+    # random sparsity: identical to the run without dissection
+    prob = Problem(9, 1, 2000, 1000, 4, 4, 0.005)
+    Kr = prob.blocks[0]["K"]
+    a = pa.symbolic_probe(Kr, 2000, want_perm=True)
+    os.environ["PIPS_HIP_ND_DEPTH"] = "0"
+    try:
+        b = pa.symbolic_probe(Kr, 2000, want_perm=True)
+    finally:
+        del os.environ["PIPS_HIP_ND_DEPTH"]
+    assert np.array_equal(a["perm"], b["perm"])

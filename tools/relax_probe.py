@@ -26,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({k: v for k, v in info.items() if k in ("nnzL", "n_head", "m", "n_sn", "n_levels", "flops_factor", "upd_bytes", "arena_bytes")}))
 else:
     for kind in ("banded", "random"):
-        for rz in ("0", "0.4"):
-            env = dict(os.environ, PIPS_HIP_RELAX_ZEROS=rz)
+        for nd in ("0", "2", "4", "6"):
+            env = dict(os.environ, PIPS_HIP_ND_DEPTH=nd)
             out = subprocess.run([sys.executable, __file__, "child", kind], env=env, capture_output=True, text=True)
-            print(kind, rz, out.stdout.strip() or out.stderr[-300:], flush=True)
+            print(kind, 'nd_depth', nd, out.stdout.strip() or out.stderr[-300:], flush=True)
