@@ -80,6 +80,14 @@ int pips_hip_batch_create(void** handle, int n_blocks, int S, int device, void* 
 int pips_hip_batch_set_block(void* handle, int b, int n, int n_primal, const int* K_rowptr, const int* K_colidx,
                              const int* Bt_rowptr, const int* Bt_colidx, const double* Bt_val);
 int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps, double thr_rel, double repl_rel);
+/* How the Schur contribution SC -= Br^T K^-1 Br is formed.  1: augmented partial factorisation (border columns ride as rows
+ * of every panel; dense MFMA work - the PardisoSchurSolver idea, PardisoSchurSolver.C:83-389).  2: blocked solves with the
+ * plain factor, 32 border columns at a time over all blocks (addTermToSchurComplBlocked, DistributedLeafLinearSystem.C:
+ * 214-252 + DistributedLinearSystem.C:766-1175: densify, multi-RHS solve, sparse border times dense columns).  0 (default):
+ * chosen at analyze time from the symbolic flop / byte counts - dense factors take 1, sparse structured ones 2.
+ * Call before analyze; get_schur_mode reports the choice. */
+int pips_hip_batch_set_schur_mode(void* handle, int mode);
+int pips_hip_batch_get_schur_mode(void* handle, int* mode);
 /* add_regularization_local_kkt (DistributedLeafLinearSystem.C:108-143): K diagonal += primal on the leading n_primal rows
  * of every block, -= dual on the remaining rows; used by the inertia-correcting loop (LinearSystem.C:296-325) */
 int pips_hip_batch_add_regularization(void* handle, double primal, double dual);

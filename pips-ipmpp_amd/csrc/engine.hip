@@ -334,6 +334,10 @@ struct Engine {
    std::vector<long long> kptr;     // nblk+1 offsets into kval
    std::vector<long long> x_off;    // nblk+1 offsets into flat vectors
    std::vector<LevelRange> levels;
+   int schur_mode = 0;        // requested: 0 auto, 1 augmented partial factorisation, 2 blocked solves (reference K4-K6)
+   int schur_mode_eff = 1;    // what analyze() settled on
+   std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
+   int *d_schur_cols = nullptr, *d_schur_slot = nullptr;
    int spine_total = 0, n_levels_all = 0;   // supernodes handled by the per-block spine kernels; tree height before the cut
    int *d_spine = nullptr, *d_spine_off = nullptr;
    long long n_total = 0, nnzK_total = 0, nnzB_total = 0, arena_total = 0, xw_total = 0, bt_rows_total = 0;
@@ -356,7 +360,7 @@ struct Engine {
    ~Engine() { release(); }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
-                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off,
+                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -368,7 +372,7 @@ struct Engine {
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
-      d_spine = d_spine_off = nullptr;
+      d_spine = d_spine_off = d_schur_cols = d_schur_slot = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
@@ -379,7 +383,7 @@ struct Engine {
                      timer.on ? &timer : nullptr, d_pref};
    }
 
-   int analyze_host(int n_threads) {
+   int analyze_host(int n_threads, bool with_border = true) {
       sym.assign(nblk, BlockSym());
       std::vector<int> rc(nblk, 0);
       std::vector<std::string> msgs(nblk);
@@ -388,7 +392,7 @@ struct Engine {
          for (int b = t; b < nblk; b += n_threads) {
             CsrPattern K{in[b].n, in[b].n, in[b].krow.data(), in[b].kcol.data()};
             CsrPattern B{0, in[b].n, nullptr, nullptr};
-            if (!in[b].btrow.empty()) B = CsrPattern{S, in[b].n, in[b].btrow.data(), in[b].btcol.data()};
+            if (with_border && !in[b].btrow.empty()) B = CsrPattern{S, in[b].n, in[b].btrow.data(), in[b].btcol.data()};
             rc[b] = analyze_block(K, B, in[b].n_primal, opt, sym[b]);
             if (rc[b]) msgs[b] = last_error();
          }
@@ -402,12 +406,51 @@ struct Engine {
       return PIPS_OK;
    }
 
+   // Schur contribution by the augmented partial factorisation (border rows ride in every panel: dense work, right when
+   // the factor is dense anyway) or by blocked solves with the plain factor (the reference's way: 4 nnz(L) flops per border
+   // column, right when L is sparse and L^-1 Br would fill in).  Estimated from the bordered symbolic analysis.
+   bool blocked_solves_cheaper() const {
+      double t_aug = 0.0, l_bytes = 0.0;
+      int max_levels = 0, max_ntc = 0;
+      std::vector<char> used(S, 0);
+      for (int b = 0; b < nblk; ++b) {
+         const BlockSym& s = sym[b];
+         double pairs = 0.0, border_entries = 0.0;
+         for (const HeadSupernode& sn : s.sn) {
+            const double rbd = sn.r - sn.rb;
+            // every scattered pair costs a w-long dot product besides its atomic (calibrated: 8e-11 s at w = 1, 1e-9 s at w = 25)
+            pairs += (rbd * (sn.r - rbd) + 0.5 * rbd * rbd) * std::max(1.0, 0.5 * sn.w);
+            border_entries += rbd * sn.w;
+         }
+         t_aug += opt.head_cost * pairs + s.flops_border / opt.mfma_rate;
+         l_bytes += 8.0 * ((double)s.nnzL - border_entries);
+         max_levels = std::max(max_levels, s.n_levels);
+         max_ntc = std::max(max_ntc, s.m_pad / TILE);
+         for (int c : s.bmap) used[c] = 1;
+      }
+      double ncols = 0;
+      for (char u : used) ncols += u;
+      const double launches = 2.0 * (max_levels + 2 * max_ntc) + 8;
+      // multi-RHS sweeps over a sparse factor run at ~0.8 TB/s effective (measured, tools/banded_schur_probe.py)
+      const double t_sol = ncols * 2.0 * l_bytes / 0.8e12 + std::ceil(ncols / 32.0) * launches * 12e-6;
+      if (getenv("PIPS_HIP_DEBUG_SCHUR")) fprintf(stderr, "[pips_hip] schur cost model: augmented %.1f ms, blocked solves %.1f ms\n", t_aug * 1e3, t_sol * 1e3);
+      return t_sol < t_aug;
+   }
+
    int analyze(int n_threads) {
       for (int b = 0; b < nblk; ++b)
          if (in[b].n <= 0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_analyze: block %d was never set", b);
       apply_tuning(opt);
-      int rc = analyze_host(n_threads);
+      if (const char* sm = getenv("PIPS_HIP_SCHUR_MODE")) schur_mode = atoi(sm);
+      bool any_border = false;
+      for (int b = 0; b < nblk; ++b) any_border = any_border || !in[b].btrow.empty();
+      int rc = analyze_host(n_threads, schur_mode != 2);
       if (rc) return rc;
+      schur_mode_eff = (schur_mode == 2 && any_border) ? 2 : 1;
+      if (schur_mode == 0 && any_border && blocked_solves_cheaper()) {
+         schur_mode_eff = 2;
+         if ((rc = analyze_host(n_threads, false))) return rc;
+      }
       HIP_TRY(hipSetDevice(device));
       rc = ensure_diag_lds();
       if (rc) return rc;
@@ -559,6 +602,19 @@ struct Engine {
          std::copy(in[b].btval.begin(), in[b].btval.end(), h_bval.begin() + bptr[b]);
       }
       bt_rows_total = (long long)h_bt_rowsc.size();
+      {  // non-empty Schur columns over all blocks (the reference skips empty border columns, :870-874)
+         std::vector<char> used(std::max(S, 1), 0);
+         for (int b = 0; b < nblk; ++b)
+            if (!in[b].btrow.empty())
+               for (int s2 = 0; s2 < S; ++s2)
+                  if (in[b].btrow[s2 + 1] > in[b].btrow[s2]) used[s2] = 1;
+         schur_cols.clear();
+         std::vector<int> slot(std::max(S, 1), -1);
+         for (int s2 = 0; s2 < S; ++s2)
+            if (used[s2]) { slot[s2] = (int)schur_cols.size(); schur_cols.push_back(s2); }
+         if ((rc = dev_upload(&d_schur_cols, schur_cols, stream))) return rc;
+         if ((rc = dev_upload(&d_schur_slot, slot, stream))) return rc;
+      }
 
       // ---- device allocation / upload
       HIP_TRY(hipMalloc((void**)&d_arena, std::max<long long>(arena_total, 1) * sizeof(double)));
@@ -622,7 +678,7 @@ struct Engine {
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
       if (nnzK_total > 0)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzK_total, 256)), dim3(256), 0, stream, d_kdst, d_kval, d_arena, nnzK_total);
-      if (nnzB_total > 0)
+      if (nnzB_total > 0 && schur_mode_eff == 1)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzB_total, 256)), dim3(256), 0, stream, d_bdst, d_bval, d_arena, nnzB_total);
       hipLaunchKernelGGL(k_tail_pad_diag, dim3(nblk), dim3(128), 0, stream, d_blks, d_arena, nblk);
       hipLaunchKernelGGL(k_pref_init, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, d_kval, d_kdiag, d_pref, d_nprimal,
@@ -655,9 +711,34 @@ struct Engine {
       TailCtx c = ctx();
       int rc = tail_factor(c, SC, ldSC);
       if (rc) return rc;
+      factored = true;
+      if (SC && schur_mode_eff == 2 && !schur_cols.empty()) {
+         if (timer.on) timer.begin(stream, 5);
+         rc = schur_by_solves(SC, ldSC);
+         if (timer.on) timer.end(stream);
+         if (rc) return rc;
+      }
       if (timer.on) (void)hipEventRecord(timer.recs[total_rec].b, stream);
       h_amax.clear();
-      factored = true;
+      return PIPS_OK;
+   }
+
+   // SC -= sum_b Br_b^T K_b^-1 Br_b, chunk by chunk of 32 border columns: densify, solve (all blocks at once), multiply back
+   int schur_by_solves(double* SC, int ldSC) {
+      int rc = ensure_multi_buffers();
+      if (rc) return rc;
+      const int bs = 32, ncols = (int)schur_cols.size();
+      for (int c0 = 0; c0 < ncols; c0 += bs) {
+         const int nr = std::min(bs, ncols - c0);
+         HIP_TRY(hipMemsetAsync(d_mx_rhs, 0, (size_t)nr * n_total * sizeof(double), stream));
+         hipLaunchKernelGGL(k_border_rows_to_dense, dim3(grid_for(bt_rows_total, 256)), dim3(256), 0, stream, d_bt_rowptr, d_bt_colidx,
+                            d_bval, d_bt_rowsc, d_bt_xoff, d_schur_slot, c0, nr, d_mx_rhs, n_total, bt_rows_total);
+         if ((rc = solve_once(d_mx_rhs, nr, n_total, d_mx_xw))) return rc;
+         hipLaunchKernelGGL(k_border_tmult_chunk, dim3(grid_for(bt_rows_total, 256, 1024), nr), dim3(256), 0, stream, d_bt_rowptr,
+                            d_bt_colidx, d_bval, d_bt_rowsc, d_bt_xoff, d_schur_cols + c0, nr, d_mx_rhs, n_total, SC, ldSC,
+                            bt_rows_total);
+      }
+      HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
 
@@ -716,16 +797,23 @@ struct Engine {
    // length n_total at distance x_stride.
    double *d_mx_xw = nullptr, *d_mx_rhs = nullptr, *d_mx_res = nullptr;
    int mx_cap = 0;
-   int solve_multi(double* X_dev, int nrhs, long long x_stride) {
-      if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
-      HIP_TRY(hipSetDevice(device));
+   int ensure_multi_buffers() {
       const int chunk_max = 32;
       if (mx_cap == 0) {
+         HIP_TRY(hipSetDevice(device));
          HIP_TRY(hipMalloc((void**)&d_mx_xw, (size_t)chunk_max * std::max<long long>(xw_total, 1) * sizeof(double)));
          HIP_TRY(hipMalloc((void**)&d_mx_rhs, (size_t)chunk_max * std::max<long long>(n_total, 1) * sizeof(double)));
          HIP_TRY(hipMalloc((void**)&d_mx_res, (size_t)chunk_max * std::max<long long>(n_total, 1) * sizeof(double)));
          mx_cap = chunk_max;
       }
+      return PIPS_OK;
+   }
+   int solve_multi(double* X_dev, int nrhs, long long x_stride) {
+      if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
+      HIP_TRY(hipSetDevice(device));
+      const int chunk_max = 32;
+      int rc0 = ensure_multi_buffers();
+      if (rc0) return rc0;
       for (int r0 = 0; r0 < nrhs; r0 += chunk_max) {
          const int nr = std::min(chunk_max, nrhs - r0);
          double* X = X_dev + (long long)r0 * x_stride;
@@ -1056,6 +1144,21 @@ int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps,
    if (refine_steps >= 0) e->refine_steps = refine_steps;
    if (thr_rel >= 0) e->thr_rel = thr_rel;
    if (repl_rel > 0) e->repl_rel = repl_rel;
+   return PIPS_OK;
+}
+
+int pips_hip_batch_set_schur_mode(void* handle, int mode) {
+   Engine* e = (Engine*)handle;
+   if (!e || mode < 0 || mode > 2) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_batch_set_schur_mode: mode must be 0 (auto), 1 or 2");
+   if (e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_set_schur_mode: call before analyze");
+   e->schur_mode = mode;
+   return PIPS_OK;
+}
+
+int pips_hip_batch_get_schur_mode(void* handle, int* mode) {
+   Engine* e = (Engine*)handle;
+   if (!e || !mode || !e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_get_schur_mode: analyze first");
+   *mode = e->schur_mode_eff;
    return PIPS_OK;
 }
 

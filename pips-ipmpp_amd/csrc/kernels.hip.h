@@ -1191,6 +1191,43 @@ __global__ void k_border_mult(const int* __restrict__ rowptr, const int* __restr
    }
 }
 
+// Blocked Schur path (the reference's K4-K6: addTermToSchurComplBlocked, DistributedLeafLinearSystem.C:214-252 +
+// DistributedLinearSystem.C:766-1047): a chunk of border columns is densified, solved with all blocks at once (one
+// right-hand side = the column's entries in every block), and multiplied back with the sparse border.
+//   slot[sc] = position of Schur column sc among the non-empty columns; the chunk holds positions [c0, c0 + nr)
+__global__ void k_border_rows_to_dense(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                       const double* __restrict__ val, const int* __restrict__ row_sc,
+                                       const long long* __restrict__ row_xoff, const int* __restrict__ slot, int c0, int nr,
+                                       double* __restrict__ R, long long r_stride, long long nrows) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      const int r = slot[row_sc[i]] - c0;
+      if (r < 0 || r >= nr) continue;
+      double* dst = R + r * r_stride + row_xoff[i];
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) dst[colidx[p]] = val[p];
+   }
+}
+
+// SC(s', col_r) -= Br_b^T(s', :) X_r  for every border row s' of every block and every right-hand side r of the chunk
+// (addLeftBorderTimesDenseColsToResTranspDense, DistributedLinearSystem.C:1115-1175); lower triangle only
+__global__ void k_border_tmult_chunk(const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                                     const double* __restrict__ val, const int* __restrict__ row_sc,
+                                     const long long* __restrict__ row_xoff, const int* __restrict__ chunk_cols, int nr,
+                                     const double* __restrict__ X, long long x_stride, double* __restrict__ SC, int ldSC,
+                                     long long nrows) {
+   const int r = blockIdx.y;
+   if (r >= nr) return;
+   const int col = chunk_cols[r];
+   const double* x = X + r * x_stride;
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      const int srow = row_sc[i];
+      if (srow < col || rowptr[i] == rowptr[i + 1]) continue;
+      const long long xo = row_xoff[i];
+      double s = 0.0;
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * x[xo + colidx[p]];
+      if (s != 0.0) atomic_add_f64(SC + srow + (long long)col * ldSC, -s);
+   }
+}
+
 // dense helpers for the root system
 __global__ void k_copy_lower_to_padded(const double* __restrict__ src, int lds, int n, double* __restrict__ dst, int ldd,
                                        int npad, int rowmajor) {

@@ -31,6 +31,7 @@ def test_full_size_properties(schur_dim):
         diags.append(d)
         vals.append(K.val)
     bt.analyze(16)
+    assert bt.schur_mode() == 1   # dense factor: augmented partial factorisation (MFMA) is the cheaper way
     for b in range(N):
         bt.set_values(b, vals[b])
     F0, c0, x0s = pa.gen_root(seed, n0, myl)

@@ -89,14 +89,18 @@ def test_refactor_after_diagonal_change():
         assert s.get_inertia() == (prob.n_i, prob.my_i, 0)
 
 
+@pytest.mark.parametrize("schur_mode", [1, 2], ids=["augmented", "blocked_solves"])
 @pytest.mark.parametrize("cut", ["model", "all_head", "all_tail"])
 @pytest.mark.parametrize("shape", [(3, 120, 16, 12, 0.05), (4, 1000, 100, 100, 0.01)])
-def test_schur_contribution_matches_oracle(shape, cut):
+def test_schur_contribution_matches_oracle(shape, cut, schur_mode):
+    """Both ways of forming SC -= Br^T K^-1 Br: the augmented partial factorisation and the reference's own blocked
+    multi-RHS solves (K4-K6) on the device."""
     import torch
     N, n_i, n0, myl, rho = shape
     prob = Problem(21, N, n_i, n_i // 2, n0, myl, rho)
     S = prob.S
     bt = pa.LeafBatch(N, S)
+    bt.set_schur_mode(schur_mode)
     for b in range(N):
         bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
     force = {"model": -1, "all_head": prob.n_leaf, "all_tail": 0}[cut]
@@ -104,6 +108,7 @@ def test_schur_contribution_matches_oracle(shape, cut):
     bt.analyze(4)
     for b in range(N):
         bt.set_values(b, prob.blocks[b]["K"].val)
+    assert bt.schur_mode() == schur_mode
     SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
     bt.factor(SC, S)
     bt.sync()
@@ -304,6 +309,7 @@ def test_time_coupled_blocks_match_oracle(cut, n_i):
         bt.set_options(force_n_head=prob.n_leaf)
     bt.analyze(2)
     info = bt.info()
+    assert bt.schur_mode() in (1, 2)
     if cut == "all_head" and n_i == 600:
         assert info["n_levels"] >= 10, info          # really chain-like
         assert info["n_sn"] < 0.9 * info["n_head"]    # amalgamation merged columns
