@@ -896,13 +896,19 @@ __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns,
 // head forward, latency-lean variant for launches with few supernodes (engine picks it per level).
 // On chain-like elimination trees a launch holds one supernode per block, so the kernel is a latency chain: all loads
 // are issued up front (row tid of L11 sits in registers), the substitution runs on wave shuffles without barriers.
+// LDS hand-over inside ONE wave (the bodies below are executed by single waves, each with LDS of its own): DS operations
+// of a wave execute in order, so a workgroup-scope fence (-> s_waitcnt lgkmcnt(0)) plus a scheduling barrier is enough.
+__device__ __forceinline__ void wave_lds_sync() {
+   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+   __builtin_amdgcn_wave_barrier();
+}
+
 template <int WB>   // WB: compile-time bound of the supernode width (register arrays, unrolled substitution)
 __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
-                                              double* ys) {
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+                                              const double* __restrict__ arena, double* __restrict__ xb, double* ys) {
+   // one wave; xb = the permuted work vector of this block and right-hand side; ys = HEAD_WMAX doubles of LDS of this wave
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
-   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;   // blockIdx.y = right-hand side
    const int* rows = rowidx + sn.rows;
    const int a0 = tid;
    const int ra0 = a0 < r ? rows[a0] : bd.n;               // first GEMV row of this lane, fetched early
@@ -914,7 +920,7 @@ __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& b
    for (int k = 0; k < WB; ++k)
       if (k < w) y -= l[k] * __shfl(y, k);                 // l[k] == 0 for k >= tid
    if (tid < w) { xb[sn.c0 + tid] = y; ys[tid] = y; }
-   __syncthreads();
+   wave_lds_sync();
    for (int a = a0; a < r; a += 64) {
       const int ra = a == a0 ? ra0 : rows[a];
       if (ra >= bd.n) break;  // border rows do not take part in solves with K_i
@@ -922,6 +928,15 @@ __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& b
       for (int k = 0; k < w; ++k) s += P[w + a + (long long)k * ld] * ys[k];
       atomic_add_f64(xb + ra, -s);
    }
+   wave_lds_sync();   // ys is reused by the caller's next supernode / right-hand side
+}
+
+template <int DUMMY = 0>
+__device__ __forceinline__ void head_fwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
+                                             const double* __restrict__ arena, double* __restrict__ xb, double* ys) {
+   if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xb, ys);
+   else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xb, ys);
+   else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, ys);
 }
 
 __global__ __launch_bounds__(64) void k_head_fwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
@@ -930,9 +945,7 @@ __global__ __launch_bounds__(64) void k_head_fwd_chain(const SnDesc* __restrict_
    __shared__ double ys[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, ys);
-   else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, ys);
-   else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, ys);
+   head_fwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, ys);   // blockIdx.y = right-hand side
 }
 
 // head diagonal scaling: z = D^-1 y for the head columns
@@ -950,13 +963,13 @@ __global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const Blk
 // head backward, latency-lean variant (few supernodes per launch), same structure as k_head_fwd_chain:
 // lane a gathers x[rows[a]] once and forms its share of all w dot products, the w sums are finished through LDS, the
 // transposed substitution runs on shuffles with column tid of L11 in registers.
+constexpr int RED_ROWS = 16;   // dot products finished per pass through the wave's LDS scratch (RED_ROWS x 65 doubles)
+
 template <int WB>
 __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
-                                              double (*red)[65]) {
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+                                              const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65]) {
+   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
-   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
    const int* rows = rowidx + sn.rows;
    double c[WB];   // column tid of L11 below the diagonal
 #pragma unroll
@@ -977,17 +990,24 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
       double s = part[0];
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
       if (tid == 0) y -= s;
-   } else {         // w sums: transpose through LDS, lane (k, half) adds 32 of the 64 partial values of sum k
+   } else {         // w sums, RED_ROWS at a time: transpose through LDS, lane (k, g) adds 16 of the 64 partial values of sum k
+      constexpr int RH = WB < RED_ROWS ? WB : RED_ROWS;
 #pragma unroll
-      for (int k = 0; k < WB; ++k)
-         if (k < w) red[k][tid] = part[k];
-      __syncthreads();
-      const int k = tid & 31, h = tid >> 5;
-      double s = 0.0;
-      if (k < w)
-         for (int j = 0; j < 32; ++j) s += red[k][h * 32 + j];
-      s += __shfl_down(s, 32);
-      if (tid < w) y -= s;
+      for (int k0 = 0; k0 < WB; k0 += RH) {
+         if (k0 < w) {
+#pragma unroll
+            for (int k = 0; k < RH; ++k) red[k][tid] = part[k0 + k];
+            wave_lds_sync();
+            const int k = tid % RH, g = tid / RH;          // 64 / RH groups of lanes per sum
+            constexpr int PER = 64 / (64 / RH);            // partial values per group = RH
+            double s = 0.0;
+            for (int j = 0; j < PER; ++j) s += red[k][g * PER + j];
+            for (int off = 32; off >= RH; off >>= 1) s += __shfl_down(s, off);   // lanes < RH hold the RH totals
+            const double mine = __shfl(s, (tid - k0) & 63);
+            if (tid >= k0 && tid < k0 + RH && tid < w) y -= mine;
+            wave_lds_sync();
+         }
+      }
    }
 #pragma unroll
    for (int k = WB - 1; k >= 0; --k)
@@ -995,15 +1015,21 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
    if (tid < w) xb[sn.c0 + tid] = y;
 }
 
+template <int DUMMY = 0>
+__device__ __forceinline__ void head_bwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
+                                             const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65]) {
+   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xb, red);
+   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xb, red);
+   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, red);
+}
+
 __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                 const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
-   __shared__ double red[HEAD_WMAX][65];
+   __shared__ double red[RED_ROWS][65];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, red);
-   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, red);
-   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, red);
+   head_bwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red);
 }
 
 // spine sweeps of the solve: one wave per (block, right-hand side) walks the block's spine supernodes inside one launch
@@ -1013,21 +1039,15 @@ __global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__
                                                         const int* __restrict__ rowidx, const double* __restrict__ arena,
                                                         double* __restrict__ xw, long long xw_stride, int backward) {
    __shared__ double ys[HEAD_WMAX];
-   __shared__ double red[HEAD_WMAX][65];
+   __shared__ double red[RED_ROWS][65];
    const int p0 = spine_off[blockIdx.x], p1 = spine_off[blockIdx.x + 1];
    if (p0 == p1) return;
    const BlkDesc bd = blks[blockIdx.x];
+   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
    for (int q = 0; q < p1 - p0; ++q) {
       const SnDesc sn = sns[spine[backward ? p1 - 1 - q : p0 + q]];
-      if (!backward) {
-         if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, ys);
-         else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, ys);
-         else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, ys);
-      } else {
-         if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xw, xw_stride, red);
-         else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xw, xw_stride, red);
-         else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xw, xw_stride, red);
-      }
+      if (!backward) head_fwd_any(sn, bd, rowidx, arena, xb, ys);
+      else head_bwd_any(sn, bd, rowidx, arena, xb, red);
       __threadfence();
       __syncthreads();
    }
