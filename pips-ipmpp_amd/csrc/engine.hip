@@ -334,6 +334,7 @@ struct Engine {
    std::vector<long long> kptr;     // nblk+1 offsets into kval
    std::vector<long long> x_off;    // nblk+1 offsets into flat vectors
    std::vector<LevelRange> levels;
+   std::vector<LevelRange> levels_top;   // the spine's levels, for the multi-vector sweeps (which are level-scheduled throughout)
    int schur_mode = 0;        // requested: 0 auto, 1 augmented partial factorisation, 2 blocked solves (reference K4-K6)
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
@@ -533,14 +534,14 @@ struct Engine {
       std::vector<std::vector<int>> sorted_id(nblk);
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
       levels.assign(lstar, LevelRange{0, 0, 0, 0, 0, 0});
+      levels_top.assign(nlev - lstar, LevelRange{0, 0, 0, 0, 0, 0});
       for (int i = 0; i < nsn_total; ++i) {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
                            s.n_useg, s.rb};
          sorted_id[k.blk][k.loc] = i;
-         if (k.level >= lstar) continue;   // spine member
-         LevelRange& L = levels[k.level];
+         LevelRange& L = k.level >= lstar ? levels_top[k.level - lstar] : levels[k.level];
          if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
          else if (k.cls == 1) { if (L.small_cnt++ == 0) L.small_begin = i; }
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
@@ -733,7 +734,7 @@ struct Engine {
          HIP_TRY(hipMemsetAsync(d_mx_rhs, 0, (size_t)nr * n_total * sizeof(double), stream));
          hipLaunchKernelGGL(k_border_rows_to_dense, dim3(grid_for(bt_rows_total, 256)), dim3(256), 0, stream, d_bt_rowptr, d_bt_colidx,
                             d_bval, d_bt_rowsc, d_bt_xoff, d_schur_slot, c0, nr, d_mx_rhs, n_total, bt_rows_total);
-         if ((rc = solve_once(d_mx_rhs, nr, n_total, d_mx_xw))) return rc;
+         if ((rc = use_multi(nr) ? solve_once_multi(d_mx_rhs, nr, n_total, d_mx_xw) : solve_once(d_mx_rhs, nr, n_total, d_mx_xw))) return rc;
          hipLaunchKernelGGL(k_border_tmult_chunk, dim3(grid_for(bt_rows_total, 256, 1024), nr), dim3(256), 0, stream, d_bt_rowptr,
                             d_bt_colidx, d_bval, d_bt_rowsc, d_bt_xoff, d_schur_cols + c0, nr, d_mx_rhs, n_total, SC, ldSC,
                             bt_rows_total);
@@ -792,6 +793,49 @@ struct Engine {
       return PIPS_OK;
    }
 
+   // The interleaved multi-vector sweep reads every entry of L once per chunk instead of once per right-hand side, but runs
+   // one workgroup per tile / supernode instead of one per (tile, right-hand side): it pays when the per-right-hand-side
+   // sweeps would be bandwidth-bound (many blocks with dense tails), not when a chunk is a latency chain anyway (a single
+   // block, sparse structured factors).  Measured: one config-2 block, 256 rhs: 11 ms separate / 43 ms interleaved.
+   bool use_multi(int nr) const {
+      if (const char* f = getenv("PIPS_HIP_MULTI")) return atoi(f) != 0 && nr >= 2;
+      double tail_bytes = 0.0;
+      for (const BlockSym& s : sym) tail_bytes += 4.0 * (double)s.m_pad * s.m_pad;
+      return nr >= 8 && tail_bytes * nr > 6.0e9;
+   }
+
+   // up to MQ right-hand sides at X + q * x_stride in one interleaved sweep (kernels.hip.h "multi-vector solves"); xm holds
+   // MQ * xw_total doubles
+   int solve_once_multi(double* X, int nr, long long x_stride, double* xm) {
+      const dim3 pg(64, nblk);
+      hipLaunchKernelGGL(k_mpermute, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, X, x_stride, nr, xm, 0);
+      auto head = [&](const LevelRange& L, int backward) {
+         const int cnt = L.simple_cnt + L.small_cnt + L.large_cnt;   // contiguous: sorted by (level, class)
+         if (cnt == 0) return;
+         const int begin = L.simple_cnt > 0 ? L.simple_begin : (L.small_cnt > 0 ? L.small_begin : L.large_begin);
+         hipLaunchKernelGGL(k_mhead, dim3((cnt + 3) / 4), dim3(256), 0, stream, d_sns, begin, cnt, d_blks, d_rowidx, d_arena, xm, backward);
+      };
+      for (const LevelRange& L : levels) head(L, 0);
+      for (const LevelRange& L : levels_top) head(L, 0);
+      const TailPlan& p = plan;
+      for (int j = 0; j < p.ntc_max; ++j)
+         if (p.fwd[j].cnt > 0)
+            hipLaunchKernelGGL(k_mtail_fwd, dim3(p.fwd[j].cnt), dim3(256), 0, stream, p.d_tasks + p.fwd[j].off, d_blks, d_arena, d_dtail,
+                               d_winv, xm, j);
+      if (nsn_total > 0)
+         hipLaunchKernelGGL(k_mhead_dscale, dim3(grid_for((long long)nsn_total * MQ, 256)), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
+                            d_arena, xm);
+      for (int i = p.ntc_max - 1; i >= 0; --i)
+         if (p.bwd[i].cnt > 0)
+            hipLaunchKernelGGL(k_mtail_bwd, dim3(p.bwd[i].cnt), dim3(256), 0, stream, p.d_tasks + p.bwd[i].off, d_blks, d_arena, d_dtail,
+                               d_winv, xm, i);
+      for (int l = (int)levels_top.size() - 1; l >= 0; --l) head(levels_top[l], 1);
+      for (int l = (int)levels.size() - 1; l >= 0; --l) head(levels[l], 1);
+      hipLaunchKernelGGL(k_mpermute, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, X, x_stride, nr, xm, 1);
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
+
    // multi-RHS solve (DoubleLinearSolver::solve(int nrhss, double* rhss, int*), PardisoSolver.C:276-352): all right-hand
    // sides share every launch (grid.y/z = rhs index); refine_steps unconditional refinement steps.  X_dev: nrhs vectors of
    // length n_total at distance x_stride.
@@ -820,7 +864,7 @@ struct Engine {
          if (refine_steps > 0)
             HIP_TRY(hipMemcpy2DAsync(d_mx_rhs, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
                                      (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
-         int rc = solve_once(X, nr, x_stride, d_mx_xw);
+         int rc = use_multi(nr) ? solve_once_multi(X, nr, x_stride, d_mx_xw) : solve_once(X, nr, x_stride, d_mx_xw);
          if (rc) return rc;
          for (int it = 0; it < refine_steps; ++it) {
             HIP_TRY(hipMemcpyAsync(d_mx_res, d_mx_rhs, (size_t)nr * n_total * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -830,7 +874,7 @@ struct Engine {
             // (d_mx_xw is free between solves; it is at least nr * n_total long because xw_total >= n_total)
             hipLaunchKernelGGL(k_sym_spmv_sub, dim3(grid_for(n_total, 256), nr), dim3(256), 0, stream, d_krowptr, d_kcolidx, d_kval,
                                d_mx_xw, d_mx_res, n_total, d_rowbase, n_total);
-            rc = solve_once(d_mx_res, nr, n_total, d_mx_xw);
+            rc = use_multi(nr) ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
             if (rc) return rc;
             for (int r = 0; r < nr; ++r)
                hipLaunchKernelGGL(k_axpy, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, X + (long long)r * x_stride,

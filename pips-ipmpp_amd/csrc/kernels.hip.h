@@ -1161,6 +1161,211 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ t
    if (tid < TILE) xt[tj * TILE + tid] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-vector solves: DoubleLinearSolver::solve(nrhs, ...) (PardisoSolver.C:276-352) and the blocked Schur path.
+// Up to MQ = 32 right-hand sides are interleaved, entry k of right-hand side q at xm[(xw_off + k) * MQ + q], and a lane
+// owns one right-hand side (lane & 31) for the whole sweep.  Factor entries are then wave-uniform operands and every entry
+// of L is fetched once for the 32 right-hand sides instead of once per right-hand side.
+// ------------------------------------------------------------------------------------------------
+constexpr int MQ = 32;
+
+// grid (x, block); transposing gather / scatter between nr vectors at distance x_stride and the interleaved work array
+__global__ void k_mpermute(const BlkDesc* __restrict__ blks, const int* __restrict__ perm, const long long* __restrict__ perm_off,
+                           double* __restrict__ x, long long x_stride, int nr, double* __restrict__ xm, int out) {
+   const BlkDesc bd = blks[blockIdx.y];
+   const int* p = perm + perm_off[blockIdx.y];
+   const long long len = (long long)(out ? bd.n : bd.n_head + bd.m_pad) * MQ;
+   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < len; idx += (long long)gridDim.x * blockDim.x) {
+      const int k = (int)(idx / MQ), q = (int)(idx % MQ);
+      double* w = xm + (bd.xw_off + k) * MQ + q;
+      if (out) { if (q < nr) x[q * x_stride + bd.x_off + p[k]] = *w; }
+      else *w = (k < bd.n && q < nr) ? x[q * x_stride + bd.x_off + p[k]] : 0.0;
+   }
+}
+
+// head forward / backward for one supernode and 32 right-hand sides: one wave, lane = (right-hand side, half); the two halves
+// split the below-rows.  sns are taken four per workgroup.
+template <int WB>
+__device__ __forceinline__ void mhead_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
+                                           const double* __restrict__ arena, double* __restrict__ xm, int backward) {
+   const int w = sn.w, r = sn.r, ld = w + r, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
+   const double* P = arena + sn.panel;
+   double* xb = xm + bd.xw_off * MQ;
+   const int* rows = rowidx + sn.rows;
+   double y[WB];
+#pragma unroll
+   for (int k = 0; k < WB; ++k) y[k] = k < w ? xb[(long long)(sn.c0 + k) * MQ + q] : 0.0;
+   if (!backward) {
+#pragma unroll
+      for (int k = 1; k < WB; ++k)
+         if (k < w) {
+            double v = y[k];
+#pragma unroll
+            for (int j = 0; j < k; ++j) v -= P[k + (long long)j * ld] * y[j];
+            y[k] = v;
+         }
+      if (h == 0) {
+#pragma unroll
+         for (int k = 0; k < WB; ++k)
+            if (k < w) xb[(long long)(sn.c0 + k) * MQ + q] = y[k];
+      }
+      for (int a = h; a < r; a += 2) {
+         const int ra = rows[a];
+         if (ra >= bd.n) break;   // border rows (sorted last) take no part in solves with K_i
+         double s = 0.0;
+#pragma unroll
+         for (int k = 0; k < WB; ++k)
+            if (k < w) s += P[w + a + (long long)k * ld] * y[k];
+         atomic_add_f64(xb + (long long)ra * MQ + q, -s);
+      }
+   } else {
+      double part[WB];
+#pragma unroll
+      for (int k = 0; k < WB; ++k) part[k] = 0.0;
+      for (int a = h; a < r; a += 2) {
+         const int ra = rows[a];
+         if (ra >= bd.n) break;
+         const double xa = xb[(long long)ra * MQ + q];
+#pragma unroll
+         for (int k = 0; k < WB; ++k)
+            if (k < w) part[k] += P[w + a + (long long)k * ld] * xa;
+      }
+#pragma unroll
+      for (int k = 0; k < WB; ++k)
+         if (k < w) y[k] -= part[k] + __shfl_xor(part[k], 32);
+#pragma unroll
+      for (int k = WB - 2; k >= 0; --k)
+         if (k < w - 1) {
+            double v = y[k];
+#pragma unroll
+            for (int j = k + 1; j < WB; ++j)
+               if (j < w) v -= P[j + (long long)k * ld] * y[j];
+            y[k] = v;
+         }
+      if (h == 0) {
+#pragma unroll
+         for (int k = 0; k < WB; ++k)
+            if (k < w) xb[(long long)(sn.c0 + k) * MQ + q] = y[k];
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void k_mhead(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
+                                              const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                              const double* __restrict__ arena, double* __restrict__ xm, int backward) {
+   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+   if (i >= cnt) return;
+   const SnDesc sn = sns[sn_begin + i];
+   const BlkDesc bd = blks[sn.blk];
+   if (sn.w == 1) mhead_body<1>(sn, bd, rowidx, arena, xm, backward);
+   else if (sn.w <= 8) mhead_body<8>(sn, bd, rowidx, arena, xm, backward);
+   else mhead_body<HEAD_WMAX>(sn, bd, rowidx, arena, xm, backward);
+}
+
+__global__ void k_mhead_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
+                               const double* __restrict__ arena, double* __restrict__ xm) {
+   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (long long)nsn * MQ; idx += (long long)gridDim.x * blockDim.x) {
+      const SnDesc sn = sns[idx / MQ];
+      const BlkDesc bd = blks[sn.blk];
+      const int q = (int)(idx % MQ), ld = sn.w + sn.r;
+      for (int k = 0; k < sn.w; ++k) xm[(bd.xw_off + sn.c0 + k) * MQ + q] /= arena[sn.panel + k + (long long)k * ld];
+   }
+}
+
+// acc[i] -= sum_c M(g*16 + i, c) V[c][q]   (TRANSPOSED = 0)   or   acc[i] -= sum_r M(r, g*16 + i) V[r][q]   (TRANSPOSED = 1)
+// for a 128 x 128 column-major tile M.  256 threads: q = tid & 31, g = tid >> 5.  The tile is staged through LDS sixteen
+// columns (rows) at a time with coalesced loads; inside a 32-lane group the staged entry is a broadcast read.
+template <int TRANSPOSED>
+__device__ __forceinline__ void mtile_apply(double (&acc)[16], const double* __restrict__ M, long long ldm,
+                                            const double (*V)[MQ], double (*Lt)[TILE + 1], int tid, double sign) {
+   const int q = tid & 31, g = tid >> 5;
+   for (int c0 = 0; c0 < TILE; c0 += 16) {
+      __syncthreads();
+      if (!TRANSPOSED) {
+#pragma unroll
+         for (int e = 0; e < 8; ++e) {          // 16 columns x 128 rows, rows contiguous
+            const int idx = e * 256 + tid, cc = idx >> 7, rr = idx & 127;
+            Lt[cc][rr] = M[rr + (long long)(c0 + cc) * ldm];
+         }
+      } else {
+#pragma unroll
+         for (int e = 0; e < 8; ++e) {          // 16 rows x 128 columns, the 16 rows of a column contiguous
+            const int idx = e * 256 + tid, col = idx >> 4, rl = idx & 15;
+            Lt[rl][col] = M[c0 + rl + (long long)col * ldm];
+         }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+         const double v = sign * V[c0 + cc][q];
+#pragma unroll
+         for (int i = 0; i < 16; ++i) acc[i] += Lt[cc][g * 16 + i] * v;
+      }
+   }
+}
+
+// tail forward step j for 32 right-hand sides: tiles i >= j:  b_i -= L(i,j-1) (d z)_{j-1} ; tile i == j: z_j = Winv_j b_j
+__global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
+                                                  const double* __restrict__ winv, double* __restrict__ xm, int j) {
+   __shared__ double V[TILE][MQ];
+   __shared__ double Lt[16][TILE + 1];
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, q = tid & 31, g = tid >> 5, ti = task.ti, ld = bd.ldT;
+   double* xt = xm + (bd.xw_off + bd.n_head) * MQ;
+   double acc[16];
+#pragma unroll
+   for (int i = 0; i < 16; ++i) acc[i] = xt[(long long)(ti * TILE + g * 16 + i) * MQ + q];
+   if (j >= 1) {
+      for (int idx = tid; idx < TILE * MQ; idx += 256) {
+         const int c = idx >> 5, qq = idx & 31;
+         V[c][qq] = xt[(long long)((j - 1) * TILE + c) * MQ + qq] * dtail[bd.dt_off + (j - 1) * TILE + c];
+      }
+      mtile_apply<0>(acc, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, V, Lt, tid, -1.0);
+   }
+   if (ti == j) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { V[g * 16 + i][q] = acc[i]; acc[i] = 0.0; }
+      mtile_apply<0>(acc, winv + bd.winv_off + (long long)j * TILE * TILE, TILE, V, Lt, tid, 1.0);
+   }
+#pragma unroll
+   for (int i = 0; i < 16; ++i) xt[(long long)(ti * TILE + g * 16 + i) * MQ + q] = acc[i];
+}
+
+// tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} ; tile j == i: x_i = Winv_i^T (d_i z_i)
+__global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
+                                                  const double* __restrict__ winv, double* __restrict__ xm, int i) {
+   __shared__ double V[TILE][MQ];
+   __shared__ double Lt[16][TILE + 1];
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, q = tid & 31, g = tid >> 5, tj = task.ti, ld = bd.ldT;
+   double* xt = xm + (bd.xw_off + bd.n_head) * MQ;
+   double acc[16];
+#pragma unroll
+   for (int e = 0; e < 16; ++e) acc[e] = xt[(long long)(tj * TILE + g * 16 + e) * MQ + q];
+   if (i + 1 < bd.ntc) {
+      for (int idx = tid; idx < TILE * MQ; idx += 256) V[idx >> 5][idx & 31] = xt[(long long)((i + 1) * TILE + (idx >> 5)) * MQ + (idx & 31)];
+      mtile_apply<1>(acc, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, V, Lt, tid, -1.0);
+   }
+   if (tj == i) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+         V[g * 16 + e][q] = acc[e] * dtail[bd.dt_off + i * TILE + g * 16 + e];
+         acc[e] = 0.0;
+      }
+      mtile_apply<1>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0);
+   }
+#pragma unroll
+   for (int e = 0; e < 16; ++e) xt[(long long)(tj * TILE + g * 16 + e) * MQ + q] = acc[e];
+}
+
 // y = alpha * K x + beta-free accumulate (y must be initialised): symmetric lower CSR, one thread per row, atomics for
 // the transposed part.  Used by iterative refinement:  r = b - K x.
 __global__ void k_sym_spmv_sub(const int* __restrict__ rowptr, const int* __restrict__ colidx,
