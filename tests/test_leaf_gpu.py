@@ -57,8 +57,13 @@ def test_leaf_solve_matches_oracle(n_i, rho, cut):
         _solve_check(prob, b, force)
 
 
-def test_leaf_multi_rhs_rows():
-    prob = Problem(5, 1, 200, 100, 4, 4, 0.03)
+@pytest.mark.parametrize("n_i", [200, 1500])
+@pytest.mark.parametrize("scheme", ["separate_sweeps", "interleaved"])
+def test_leaf_multi_rhs_rows(scheme, n_i, monkeypatch):
+    """solve(nrhs, ...) with one right-hand side per row: both device schemes (one sweep per right-hand side, interleaved
+    multi-vector layout) against SuperLU; n_i = 1500 has a dense tail of several tiles."""
+    monkeypatch.setenv("PIPS_HIP_MULTI", "1" if scheme == "interleaved" else "0")
+    prob = Problem(5, 1, n_i, n_i // 2, 4, 4, 6.0 / n_i)
     blk = prob.blocks[0]
     s = pa.HipLdlSolver(blk["K"], n_primal=prob.n_i)
     s.matrixChanged()
