@@ -53,7 +53,7 @@ struct TaskList { long long off = 0; int cnt = 0; };
 
 struct TailPlan {
    int ntc_max = 0;
-   std::vector<TaskList> upd, diag, trsm, fwd, bwd, trail, trail_next;
+   std::vector<TaskList> upd, upd_diag, diag, trsm, fwd, bwd, trail, trail_next;
    TaskList schur;
    TileTask* d_tasks = nullptr;
 
@@ -63,11 +63,14 @@ struct TailPlan {
    //   column launch has at most ntr workgroups with a K as deep as the matrix; here the column update only reaches back
    //   to the start of its panel and each finished panel is applied to the whole trailing matrix in one launch of
    //   (ntr - p1)^2 / 2 tiles with K = P * TILE).  The K range rides in TileTask::pad = k0 | k1 << 16 (tile columns).
-   int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false) {
+   // split_diag (left-looking batches): the update of the diagonal tile of column j gets a task list of its own (upd_diag),
+   // so that the driver can factorise that tile on a side stream while the rest of the column is still being updated.
+   int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false, bool split_diag = false) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
       upd.assign(ntc_max, {});
+      upd_diag.assign(ntc_max, {});
       diag.assign(ntc_max, {});
       trsm.assign(ntc_max, {});
       fwd.assign(ntc_max, {});
@@ -79,11 +82,16 @@ struct TailPlan {
       auto end = [&](TaskList& l) { l.cnt = (int)((long long)all.size() - l.off); };
       for (int j = 0; j < ntc_max; ++j) {
          const int p0 = panel > 0 ? j / panel * panel : 0;   // first tile column of j's panel
+         begin(upd_diag[j]);
+         if (j > p0 && split_diag)
+            for (int b = 0; b < nblk; ++b)
+               if (blks[b].ntc > j) all.push_back({b, j, j, p0 | (j << 16)});
+         end(upd_diag[j]);
          begin(upd[j]);
          if (j > p0)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j)
-                  for (int ti = j; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j, p0 | (j << 16)});
+                  for (int ti = split_diag ? j + 1 : j; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j, p0 | (j << 16)});
          end(upd[j]);
          begin(diag[j]);
          for (int b = 0; b < nblk; ++b)
@@ -195,6 +203,10 @@ struct TailCtx {
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
    const size_t diag_lds = 0;
+   auto gemm_diag_tiles = [&](const TaskList& l, hipStream_t st) {
+      hipLaunchKernelGGL(k_tile_gemm<4>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                         c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+   };
    auto gemm0 = [&](const TaskList& l, hipStream_t st) {
       if (c.is_root)
          hipLaunchKernelGGL(k_tile_gemm<3>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
@@ -217,15 +229,32 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    int rc;
    for (int j = 0; j < p.ntc_max; ++j) {
       if ((rc = main_writes(j))) return rc;
+      const bool ahead = c.side && p.upd_diag[j].cnt > 0;   // left-looking batch: diagonal tiles first, factorised on the side stream
+      if (ahead) {
+         // side stream: update the diagonal tiles of column j (deep K, one workgroup per block) and factorise them, while
+         // the main stream updates the rest of the column
+         HIP_TRY(hipEventRecord(c.ev_panel, c.stream));
+         HIP_TRY(hipStreamWaitEvent(c.side, c.ev_panel, 0));
+         gemm_diag_tiles(p.upd_diag[j], c.side);
+         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds, c.side, p.d_tasks + p.diag[j].off,
+                            c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
+         HIP_TRY(hipEventRecord(c.ev_rest, c.side));
+      } else if (p.upd_diag[j].cnt > 0) {
+         gemm_diag_tiles(p.upd_diag[j], c.stream);
+      }
       if (p.upd[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 2);
          gemm0(p.upd[j], c.stream);
          if (c.timer) c.timer->end(c.stream);
       }
-      if (c.timer) c.timer->begin(c.stream, 3);
-      hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds, c.stream, p.d_tasks + p.diag[j].off,
-                         c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
-      if (c.timer) c.timer->end(c.stream);
+      if (ahead) {
+         HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_rest, 0));   // trsm needs Winv_j and d_j
+      } else {
+         if (c.timer) c.timer->begin(c.stream, 3);
+         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds, c.stream, p.d_tasks + p.diag[j].off,
+                            c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
+         if (c.timer) c.timer->end(c.stream);
+      }
       if (p.trsm[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 4);
          hipLaunchKernelGGL(k_tile_gemm<1>, dim3((p.trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trsm[j].off, p.trsm[j].cnt,
@@ -358,7 +387,12 @@ struct Engine {
    std::vector<int> h_inertia;
    std::vector<double> h_amax;   // max|K_b| of the current factorisation (backward-error refinement criterion)
 
-   ~Engine() { release(); }
+   ~Engine() {
+      release();
+      if (side) (void)hipStreamDestroy(side);
+      if (ev_diag_in) (void)hipEventDestroy(ev_diag_in);
+      if (ev_diag_out) (void)hipEventDestroy(ev_diag_out);
+   }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot,
@@ -379,9 +413,11 @@ struct Engine {
       plan.release();
    }
 
+   hipStream_t side = nullptr;                       // diagonal tiles of the tail are factorised here, beside the column update
+   hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
    TailCtx ctx() {
       return TailCtx{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
-                     timer.on ? &timer : nullptr, d_pref};
+                     timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false};
    }
 
    int analyze_host(int n_threads, bool with_border = true) {
@@ -661,7 +697,13 @@ struct Engine {
          for (int b = 0; b < nblk; ++b) np[b] = in[b].n_primal;
          if ((rc = dev_upload(&d_nprimal, np, stream))) return rc;
       }
-      if ((rc = plan.build(h_blks))) return rc;
+      const bool diag_ahead = !getenv("PIPS_HIP_NO_DIAG_AHEAD");
+      if ((rc = plan.build(h_blks, 0, false, diag_ahead))) return rc;
+      if (diag_ahead && !side) {
+         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+         HIP_TRY(hipEventCreateWithFlags(&ev_diag_in, hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&ev_diag_out, hipEventDisableTiming));
+      }
       h_inertia.assign(3 * nblk, 0);
       analyzed = true;
       factored = false;

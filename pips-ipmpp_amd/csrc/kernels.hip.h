@@ -483,7 +483,8 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
 //   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
 //   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
 //   MODE 2 (schur) : SC[bmap(ti), bmap(tj)] -= A(ti,0:K) diag(d) B(tj,0:K)^T   ti,tj border tile rows, K = m_pad
-//   MODE 3         : MODE 0 under its own name for the dense root (so that profiles keep the leaf update apart)
+//   MODE 3 / 4     : MODE 0 under names of their own - 3 the dense root, 4 the diagonal tiles of a leaf column that are
+//                    updated ahead of the rest (so that profiles keep the leaf update kernel apart)
 // 512 threads = 8 waves in a 2 x 4 grid, each wave owns a 64 x 32 sub-tile (32 accumulators): ~110 VGPRs, so four
 // waves share a SIMD and hide each other's LDS / barrier / DMA-issue stalls (two 256-thread workgroups per CU).
 //
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    const double* Bp;  // B panel: columns of C
    long long ldb;
    const double* dv = nullptr;
-   if (MODE == 0 || MODE == 3) {
+   if (MODE == 0 || MODE >= 3) {
       // K range in tile columns [k0, k1): pad = k0 | k1 << 16, k1 == 0 meaning "up to the tile's own column"
       const int k0 = task.pad & 0xffff, k1 = (task.pad >> 16) ? (task.pad >> 16) : task.tj;
       K = (k1 - k0) * TILE;
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
       for (int c = 0; c < 8; ++c) {
          const int col = wc * 32 + c * 4 + (lane >> 4);
          const double v = acc[i][c];
-         if (MODE == 0 || MODE == 3) {
+         if (MODE == 0 || MODE >= 3) {
             double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
 #if defined(PIPS_EXPERIMENT_NO_EPILOGUE)
             if (v == 1.2345e300) *cp = v;
