@@ -700,7 +700,10 @@ struct Engine {
       const bool diag_ahead = !getenv("PIPS_HIP_NO_DIAG_AHEAD");
       if ((rc = plan.build(h_blks, 0, false, diag_ahead))) return rc;
       if (diag_ahead && !side) {
-         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+         // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
+         int prio_lo = 0, prio_hi = 0;
+         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+         HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_hi));
          HIP_TRY(hipEventCreateWithFlags(&ev_diag_in, hipEventDisableTiming));
          HIP_TRY(hipEventCreateWithFlags(&ev_diag_out, hipEventDisableTiming));
       }
@@ -1029,7 +1032,9 @@ struct DenseLdl {
       const bool lookahead = panel > 0 && d.ntc >= 48 && !getenv("PIPS_HIP_ROOT_NO_LOOKAHEAD");
       if ((rc = plan.build(h_blks, panel, lookahead))) return rc;
       if (lookahead) {
-         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+         int prio_lo = 0, prio_hi = 0;
+         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+         HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_lo));   // the bulk update: behind the diagonal chain
          HIP_TRY(hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming));
          HIP_TRY(hipEventCreateWithFlags(&ev_rest, hipEventDisableTiming));
       }
