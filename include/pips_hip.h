@@ -205,6 +205,9 @@ int pips_hip_vec_add_quotient(long long n, double a, const double* x_dev, const 
 int pips_hip_vec_divide_some(long long n, const double* x_dev, const double* mask_dev, double* y_dev, void* stream);
 int pips_hip_vec_select_nonzeros(long long n, const double* mask_dev, double* y_dev, void* stream);
 int pips_hip_vec_safe_invert(long long n, double* y_dev, void* stream);
+/* y_i = rmin - y_i if y_i < rmin, rmax - y_i if y_i > rmax, else 0; then y_i = max(y_i, -rmax)   (Vector::gondzioProjection,
+ * DenseVector.cpp:405-420, used by Residuals::project_r3, Residuals.cpp:262-290) */
+int pips_hip_vec_gondzio_projection(long long n, double rmin, double rmax, double* y_dev, void* stream);
 int pips_hip_vec_dot(long long n, long long skip_root, const double* x_dev, const double* y_dev, double* result, void* stream);
 int pips_hip_vec_one_norm(long long n, long long skip_root, const double* x_dev, double* result, void* stream);
 int pips_hip_vec_inf_norm(long long n, const double* x_dev, double* result, void* stream);
@@ -231,6 +234,9 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
 /* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown)
  * [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
 int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7);
+/* Gondzio multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358): 0 = plain Mehrotra predictor-
+ * corrector; default 2, i.e. 4 solves per iteration like the work unit of bench.py */
+int pips_ipm_set_gondzio(void* handle, int max_correctors);
 int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
 /* history of the last pips_ipm_solve, one row of 7 doubles per iterate: mu, ||r||inf, primal objective, dual objective, and the
  * step taken from it: sigma, alpha_primal, alpha_dual (zeros in the final row).  rows7 may be NULL to query *n_rows. */

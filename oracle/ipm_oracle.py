@@ -20,7 +20,7 @@ def stepbound(v, dv):
     return np.min(-v[neg] / dv[neg]) if neg.any() else np.inf
 
 
-def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0):
+def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0, gondzio=2):
     A = sp.csr_matrix(A)
     ny, nx = A.shape
     dnorm = max(np.abs(A.data).max(), np.abs(b).max(), np.abs(c).max())
@@ -67,6 +67,37 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
         dx += cx; dy += cy; dv += cv; dg += cg
         tau = max(0.99, 1 - mu)
         ap, ad = min(1.0, tau * stepbound(v, dv)), min(1.0, tau * stepbound(g, dg))
+        # Gondzio multiple centrality correctors (gondzio_correction_loop, InteriorPointMethod.cpp:236-358, primal-dual
+        # variant; projection: DenseVector.cpp:405-420; weight search: InteriorPointMethod.cpp:486-523)
+        rmin, rmax = sigma * mu * 0.1, sigma * mu * 10.0
+        ng = 0
+        while ng < gondzio and (ap < 1.0 or ad < 1.0):
+            apt, adt = min(1.0, 1.5 * ap + 0.3), min(1.0, 1.5 * ad + 0.3)
+            p = (v + apt * dv) * (g + adt * dg)
+            t = np.where(p < rmin, rmin - p, np.where(p > rmax, rmax - p, 0.0))
+            t = np.maximum(t, -rmax)
+            cx, cy, cv, cg = solve(z, np.zeros(ny), z, -t)
+            wmin = apt * adt
+            ape = ade = wp = wd = -1.0
+            for k in range(11):
+                w = min(1.0, wmin + (1.0 - wmin) / 10.0 * k)
+                a1 = min(1.0, tau * stepbound(v, dv + w * cv))
+                a2 = min(1.0, tau * stepbound(g, dg + w * cg))
+                if a1 > ape:
+                    ape, wp = a1, w
+                if a2 > ade:
+                    ade, wd = a2, w
+            both_one = ape >= 1.0 and ade >= 1.0
+            p_better, d_better = ape >= 1.01 * ap, ade >= 1.01 * ad
+            if not (both_one or p_better or d_better):
+                break
+            if both_one or p_better:
+                dx += wp * cx; dv += wp * cv; ap = ape
+            if both_one or d_better:
+                dy += wd * cy; dg += wd * cg; ad = ade
+            ng += 1
+            if both_one:
+                break
         x += ap * dx; v += ap * dv
         y += ad * dy; g += ad * dg
         if trace is not None:   # the step that leaves iterate `it`: (sigma, alpha_primal, alpha_dual) appended to its row

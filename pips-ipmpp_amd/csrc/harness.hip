@@ -110,6 +110,9 @@ struct Ipm {
    double *tx = nullptr, *ty = nullptr, *b0 = nullptr, *bl = nullptr, *leaf_diag = nullptr, *zx = nullptr, *zy = nullptr;
    double *bz = nullptr, *xz = nullptr, *w_r = nullptr, *w_r0 = nullptr, *w_best = nullptr, *w_v = nullptr, *w_t = nullptr, *w_p = nullptr,
           *w_dx = nullptr;
+   double *gv = nullptr, *gg = nullptr;   // Gondzio trial vectors
+   int max_gondzio = 2;   // multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358)
+   long long n_gondzio = 0;
    int outer_mode = 2;   // 1 = iterative refinement, 2 = BiCGStab (the reference's OUTER_SOLVE default)
    int outer_max = 10, last_outer_steps = 0;
    long long n_precond = 0;
@@ -347,6 +350,58 @@ struct Ipm {
       return PIPS_OK;
    }
 
+   // Gondzio's multiple centrality correctors (gondzio_correction_loop, InteriorPointMethod.cpp:236-358, primal-dual variant):
+   // aim at longer steps (1.5 alpha + 0.3), look at the complementarity products of that trial point, pull the outliers back
+   // into [beta_min, beta_max] * sigma * mu (Residuals::project_r3), solve for the corrector, blend it in with the weight in
+   // [alpha_p alpha_d, 1] that gives the longest steps (10-point search, :486-523), keep it if a step grows by >= 1 %.
+   int gondzio_loop(double sigma, double mu_now, double tau, double* ap, double* ad) {
+      const double beta_min = 0.1, beta_max = 10.0, step_factor0 = 0.3, step_factor1 = 1.5, accept = 0.01;
+      const double rmin = sigma * mu_now * beta_min, rmax = sigma * mu_now * beta_max;
+      int ng = 0;
+      while (ng < max_gondzio && (*ap < 1.0 || *ad < 1.0)) {
+         const double apt = std::min(1.0, step_factor1 * *ap + step_factor0), adt = std::min(1.0, step_factor1 * *ad + step_factor0);
+         // rg = -(projection step of the trial products)
+         TRY(pips_hip_vec_copy(nx, v, gv, stream));
+         TRY(pips_hip_vec_axpy(nx, apt, dv, gv, stream));
+         TRY(pips_hip_vec_copy(nx, g, rg, stream));
+         TRY(pips_hip_vec_axpy(nx, adt, dg, rg, stream));
+         TRY(pips_hip_vec_mul(nx, gv, rg, stream));
+         TRY(pips_hip_vec_gondzio_projection(nx, rmin, rmax, rg, stream));
+         TRY(pips_hip_vec_scale(nx, -1.0, rg, stream));
+         TRY(solve(zx, zy, zx, rg, cx, cy, cv, cg));
+         const double wmin = apt * adt;
+         double ape = -1.0, ade = -1.0, wp = -1.0, wd = -1.0;
+         for (int k = 0; k <= 10; ++k) {
+            const double w = std::min(1.0, wmin + (1.0 - wmin) / 10.0 * k);
+            TRY(pips_hip_vec_copy(nx, dv, gv, stream));
+            TRY(pips_hip_vec_axpy(nx, w, cv, gv, stream));
+            TRY(pips_hip_vec_copy(nx, dg, gg, stream));
+            TRY(pips_hip_vec_axpy(nx, w, cg, gg, stream));
+            double a1, a2;
+            TRY(step_lengths(gv, gg, tau, &a1, &a2));
+            if (a1 > ape) { ape = a1; wp = w; }
+            if (a2 > ade) { ade = a2; wd = w; }
+         }
+         const bool both_one = ape >= 1.0 && ade >= 1.0;
+         const bool p_better = ape >= (1.0 + accept) * *ap, d_better = ade >= (1.0 + accept) * *ad;
+         if (!both_one && !p_better && !d_better) break;
+         if (both_one || p_better) {
+            TRY(pips_hip_vec_axpy(nx, wp, cx, dx, stream));
+            TRY(pips_hip_vec_axpy(nx, wp, cv, dv, stream));
+            *ap = ape;
+         }
+         if (both_one || d_better) {
+            TRY(pips_hip_vec_axpy(ny, wd, cy, dy, stream));
+            TRY(pips_hip_vec_axpy(nx, wd, cg, dg, stream));
+            *ad = ade;
+         }
+         ++ng;
+         ++n_gondzio;
+         if (both_one) break;
+      }
+      return PIPS_OK;
+   }
+
    std::vector<double> trace;   // per iterate: mu, ||r||inf, primal obj, dual obj, then the step taken from it: sigma, alpha_p, alpha_d
    int run(int max_iter, double mutol, double artol, int verbose, double* result) {
       HIP_TRYH(hipSetDevice(device));
@@ -410,6 +465,7 @@ struct Ipm {
          TRY(pips_hip_vec_axpy(nx, 1.0, cg, dg, stream));
          const double tau = std::max(0.99, 1.0 - m);
          TRY(step_lengths(dv, dg, tau, &ap, &ad));
+         TRY(gondzio_loop(sigma, m, tau, &ap, &ad));
          { double* row = trace.data() + trace.size() - 7; row[4] = sigma; row[5] = ap; row[6] = ad; }
          TRY(pips_hip_vec_axpy(nx, ap, dx, x, stream));
          TRY(pips_hip_vec_axpy(nx, ap, dv, v, stream));
@@ -529,7 +585,7 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
       return rc;
    std::vector<double> hc(c, c + p->nx), hb(b, b + p->ny);
    if ((rc = p->up(&p->c, hc)) || (rc = p->up(&p->b, hb))) return rc;
-   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx};
+   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx, &p->gv, &p->gg};
    for (auto d : xs)
       if ((rc = p->alloc(d, p->nx))) return rc;
    double** ys[] = {&p->y, &p->rA, &p->dy, &p->cy, &p->ty, &p->zy};
@@ -554,6 +610,13 @@ int pips_ipm_get_solution(void* handle, double* x_host, double* y_host) {
    if (!p) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    if (x_host) HIP_TRYH(hipMemcpy(x_host, p->x, (size_t)p->nx * sizeof(double), hipMemcpyDeviceToHost));
    if (y_host) HIP_TRYH(hipMemcpy(y_host, p->y, (size_t)p->ny * sizeof(double), hipMemcpyDeviceToHost));
+   return PIPS_OK;
+}
+
+int pips_ipm_set_gondzio(void* handle, int max_correctors) {
+   Ipm* p = (Ipm*)handle;
+   if (!p || max_correctors < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_gondzio: bad arguments");
+   p->max_gondzio = max_correctors;
    return PIPS_OK;
 }
 

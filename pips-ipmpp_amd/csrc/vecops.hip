@@ -39,6 +39,7 @@ enum VecOp : int {
    OP_SAFE_INVERT,   // y = y != 0 ? 1/y : 0            (safe_invert)
    OP_ADD_CONST,     // y += a
    OP_AXPBY,         // y = a x + b y
+   OP_GONDZIO,       // y = projection step onto [a, b] (gondzioProjection, DenseVector.cpp:405-420)
 };
 
 __global__ void k_vec_op(int op, long long n, double a, double b, const double* __restrict__ x, const double* __restrict__ z,
@@ -60,6 +61,7 @@ __global__ void k_vec_op(int op, long long n, double a, double b, const double* 
          case OP_SAFE_INVERT: v = v != 0.0 ? 1.0 / v : 0.0; break;
          case OP_ADD_CONST: v += a; break;
          case OP_AXPBY: v = a * x[i] + b * v; break;
+         case OP_GONDZIO: v = v < a ? a - v : (v > b ? b - v : 0.0); v = v < -b ? -b : v; break;
       }
       y[i] = v;
    }
@@ -217,6 +219,10 @@ int pips_hip_vec_select_nonzeros(long long n, const double* mask_dev, double* y_
 }
 int pips_hip_vec_safe_invert(long long n, double* y_dev, void* stream) {
    return vec_apply(OP_SAFE_INVERT, n, 0, 0, nullptr, nullptr, nullptr, y_dev, (hipStream_t)stream);
+}
+
+int pips_hip_vec_gondzio_projection(long long n, double rmin, double rmax, double* y_dev, void* stream) {
+   return vec_apply(OP_GONDZIO, n, rmin, rmax, nullptr, nullptr, nullptr, y_dev, (hipStream_t)stream);
 }
 
 int pips_hip_vec_dot(long long n, long long skip_root, const double* x_dev, const double* y_dev, double* result, void* stream) {

@@ -64,9 +64,9 @@ SYMBOLS = [
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
-    "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_dot",
+    "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_destroy",
+    "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
 ]
@@ -629,6 +629,10 @@ class vec:
         _check(lib.pips_hip_vec_safe_invert(vec._n(y), _ptr(y), None), "vec_safe_invert")
 
     @staticmethod
+    def gondzio_projection(rmin, rmax, y):
+        _check(lib.pips_hip_vec_gondzio_projection(vec._n(y), C.c_double(rmin), C.c_double(rmax), _ptr(y), None), "vec_gondzio_projection")
+
+    @staticmethod
     def _red(fn, *args):
         out = C.c_double()
         _check(fn(*args, C.byref(out), None), fn.__name__)
@@ -694,6 +698,9 @@ class IpmSolver:
                                    _ptr(F0.rowptr) if F0 is not None else None, _ptr(F0.colidx) if F0 is not None else None,
                                    _ptr(F0.val) if F0 is not None else None, _ptr(self._keep[5]), _ptr(self._keep[6]),
                                    C.c_double(dual_reg), C.c_int(device)), "pips_ipm_create")
+
+    def set_gondzio(self, max_correctors):
+        _check(lib.pips_ipm_set_gondzio(self._h, C.c_int(max_correctors)), "pips_ipm_set_gondzio")
 
     def solve(self, max_iter=100, mutol=1e-6, artol=1e-4, verbose=False):
         res = np.zeros(7)
