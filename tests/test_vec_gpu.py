@@ -56,6 +56,14 @@ def test_elementwise_ops_match_numpy_exactly():
     assert np.array_equal(get(), y)
     V.axpby(2.0, xd, -0.5, yd)
     assert _ulp_close(get(), 2.0 * x + -0.5 * y, np.abs(2.0 * x) + np.abs(0.5 * y))
+    # gondzioProjection (DenseVector.cpp:405-420): step back into [rmin, rmax], never below -rmax
+    y = get()
+    rmin, rmax = 0.2, 0.9
+    V.gondzio_projection(rmin, rmax, yd)
+    want = np.where(y < rmin, rmin - y, np.where(y > rmax, rmax - y, 0.0))
+    want = np.maximum(want, -rmax)
+    assert np.array_equal(get(), want)
+    assert (want != 0).any() and (want == 0).any() and (want == -rmax).any()
 
 
 def test_reductions_match_numpy():
