@@ -202,7 +202,6 @@ struct TailCtx {
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
-   const size_t diag_lds = 0;
    auto gemm_diag_tiles = [&](const TaskList& l, hipStream_t st) {
       hipLaunchKernelGGL(k_tile_gemm<4>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
                          c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
@@ -236,7 +235,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipEventRecord(c.ev_panel, c.stream));
          HIP_TRY(hipStreamWaitEvent(c.side, c.ev_panel, 0));
          gemm_diag_tiles(p.upd_diag[j], c.side);
-         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds, c.side, p.d_tasks + p.diag[j].off,
+         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.side, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
          HIP_TRY(hipEventRecord(c.ev_rest, c.side));
       } else if (p.upd_diag[j].cnt > 0) {
@@ -251,7 +250,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_rest, 0));   // trsm needs Winv_j and d_j
       } else {
          if (c.timer) c.timer->begin(c.stream, 3);
-         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds, c.stream, p.d_tasks + p.diag[j].off,
+         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
          if (c.timer) c.timer->end(c.stream);
       }
@@ -312,12 +311,6 @@ static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_str
    return PIPS_OK;
 }
 
-static int ensure_diag_lds() {
-   static bool done = false;
-   if (done) return PIPS_OK;
-   done = true;
-   return PIPS_OK;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // batched leaf engine
@@ -489,8 +482,6 @@ struct Engine {
          if ((rc = analyze_host(n_threads, false))) return rc;
       }
       HIP_TRY(hipSetDevice(device));
-      rc = ensure_diag_lds();
-      if (rc) return rc;
       release();
 
       // ---- offsets
@@ -1015,8 +1006,7 @@ struct DenseLdl {
    }
    int init() {
       HIP_TRY(hipSetDevice(device));
-      int rc = ensure_diag_lds();
-      if (rc) return rc;
+      int rc = PIPS_OK;
       npad = (n + TILE - 1) / TILE * TILE;
       BlkDesc d{};
       d.n = n; d.n_head = 0; d.m = n; d.m_pad = npad; d.nb = 0; d.nb_pad = 0; d.ldT = npad;

@@ -657,9 +657,8 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// diagonal tile: LDL^T of the 128 x 128 tile in LDS, then Winv = D^-1 L^-1 (built in the free upper triangle)
+// diagonal tile: LDL^T of the 128 x 128 tile held in registers, together with Winv = D^-1 L^-1
 // ------------------------------------------------------------------------------------------------
-constexpr int DLD = TILE + 1;   // (kept for the launch-side LDS size query; the register kernel needs no tile image)
 
 struct DiagShared {
    double colk[2][TILE];
