@@ -384,3 +384,69 @@ def test_time_coupled_blocks_match_oracle(cut, n_i):
     s0.solve(X)
     for i in range(5):
         assert np.linalg.norm(prob.K_full(0) @ X[i] - R[i]) / np.linalg.norm(R[i]) < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 257])
+def test_dense_root_tile_boundaries(n):
+    """Sizes around the 128-wide tiles (identity padding, single-tile and two-tile paths) including the trivial ones."""
+    rng = np.random.default_rng(n)
+    n_primal = (n + 1) // 2
+    m = n - n_primal
+    H = rng.standard_normal((n_primal, n_primal))
+    H = H @ H.T + n_primal * np.eye(n_primal)
+    A = rng.standard_normal((m, n_primal))
+    M = np.block([[H, A.T], [A, -np.eye(m)]])
+    h = pa.HipDenseLdlSolver(n, n_primal)
+    h.matrixChanged(np.tril(M))
+    rhs = rng.standard_normal((3, n))
+    x = rhs.copy()
+    h.solve(x)
+    for k in range(3):
+        assert np.linalg.norm(M @ x[k] - rhs[k]) / np.linalg.norm(rhs[k]) < 1e-12
+    assert h.get_inertia() == (n_primal, m, 0)
+
+
+def test_degenerate_leaf_shapes():
+    """Blocks without dual rows (K_i is just the primal diagonal) next to an ordinary one, a single-variable block, and a
+    solve with zero right-hand sides."""
+    import scipy.sparse as sp
+    import torch
+    prob = Problem(3, 1, 300, 150, 6, 6, 0.03)
+    S = prob.S
+    # block 1: only primal variables, coupled to the root through F (linking rows) alone
+    n1 = 40
+    rng = np.random.default_rng(0)
+    K1 = pa.Csr(n1, n1, np.arange(n1 + 1, dtype=np.int32), np.arange(n1, dtype=np.int32), rng.uniform(0.5, 2.0, n1))
+    F1 = sp.random(prob.myl, n1, density=0.2, random_state=1, format="csr")
+    Bt1 = sp.vstack([sp.csr_matrix((prob.n0, n1)), F1]).tocsr()
+    Bt1.sort_indices()
+    Bt1p = pa.Csr(S, n1, Bt1.indptr, Bt1.indices, Bt1.data)
+    # block 2: one variable, no border entries at all
+    K2 = pa.Csr(1, 1, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([3.0]))
+    bt = pa.LeafBatch(3, S)
+    bt.set_block(0, prob.blocks[0]["K"], prob.n_i, prob.blocks[0]["Bt"])
+    bt.set_block(1, K1, n1, Bt1p)
+    bt.set_block(2, K2, 1)
+    bt.analyze(2)
+    bt.set_values(0, prob.blocks[0]["K"].val)
+    bt.set_values(1, K1.val)
+    bt.set_values(2, K2.val)
+    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
+    bt.factor(SC, S)
+    bt.sync()
+    want = prob.oracle_schur([0])
+    want -= (Bt1 @ sp.diags(1.0 / K1.val) @ Bt1.T).toarray()
+    got = hip_lower_as_rowmajor(SC.cpu().numpy(), S)
+    assert np.abs(got - np.tril(want)).max() / np.abs(want).max() < RTOL_SC
+    assert bt.inertia(0) == (prob.n_i, prob.my_i, 0) and bt.inertia(1) == (n1, 0, 0) and bt.inertia(2) == (1, 0, 0)
+    ntot = prob.n_leaf + n1 + 1
+    rhs = rng.standard_normal(ntot)
+    x = rhs.copy()
+    bt.solve(x)
+    assert np.allclose(x[prob.n_leaf:prob.n_leaf + n1], rhs[prob.n_leaf:prob.n_leaf + n1] / K1.val, rtol=1e-13)
+    assert np.isclose(x[-1], rhs[-1] / 3.0, rtol=1e-14)
+    s = pa.HipLdlSolver(K2, n_primal=1)
+    s.matrixChanged()
+    empty = np.zeros((0, 1))
+    s.solve(empty)          # zero right-hand sides: a no-op, not an error
+    assert s.get_inertia() == (1, 0, 0)
