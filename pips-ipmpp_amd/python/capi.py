@@ -17,7 +17,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpipship.so")
+LIB_PATH = os.environ.get("PIPS_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libpipship.so")   # override: experiment builds
 
 
 class PipsHipError(RuntimeError):
