@@ -2,6 +2,8 @@
 diagonal), C_i / G_i border parts, root equality rows A0 (my0 > 0), root inequality rows C0 (mz0 > 0, eliminated in
 Dsolve) and linking inequalities G0 with their diagonal — against the oracle restatement (finalizeKKTdense
 sLinsysRootAug.C:1769-1796, solveReducedLinkCons :384-466).  Also the inertia-correcting regularisation contract (a4)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -53,22 +55,44 @@ class GeneralProblem:
 
 
 def test_general_structure_factorize_and_solve_compressed():
+    _check_general(17, (3, 200, 80, 40, 20, 6, 7, 9, 5), 0.03, 0)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("PIPS_FUZZ_CASES", "30"))))
+def test_general_structure_sweep(case):
+    """Seeded sweep over the block dimensions, including the empty parts (no leaf inequalities, no root equality /
+    inequality rows, no linking rows of one kind) and the three Schur modes."""
+    rng = np.random.default_rng(7000 + case)
+    N = int(rng.integers(1, 4))
+    nx = int(rng.choice([40, 120, 260]))
+    my = int(nx * rng.choice([0.2, 0.4]))
+    mz = int(nx * rng.choice([0.0, 0.1, 0.3]))
+    n0 = int(rng.integers(2, 16))
+    my0, mz0 = int(rng.integers(0, min(5, n0 // 2 + 1))), int(rng.integers(0, 6))   # A0 needs full row rank: my0 <= n0 / 2
+    myl, mzl = int(rng.integers(0, 8)), int(rng.integers(0, 6))
+    rho = max(float(rng.choice([0.03, 0.08])), 4.0 / nx)   # >= 4 entries per row: one-entry rows make [W; D] rank deficient
+    _check_general(900 + case, (N, nx, my, mz, n0, my0, mz0, myl, mzl), rho, int(rng.integers(0, 3)))
+
+
+def _check_general(seed, dims, rho, schur_mode):
     import torch
-    N, nx, my, mz, n0, my0, mz0, myl, mzl = 3, 200, 80, 40, 20, 6, 7, 9, 5
-    gp = GeneralProblem(17, N, nx, my, mz, n0, my0, mz0, myl, mzl, 0.03)
+    N, nx, my, mz, n0, my0, mz0, myl, mzl = dims
+    gp = GeneralProblem(seed, N, nx, my, mz, n0, my0, mz0, myl, mzl, rho)
     S, nleaf = gp.S, nx + my + mz
     bt = pa.LeafBatch(N, S)
+    bt.set_schur_mode(schur_mode)
     for b in range(N):
         bt.set_block(b, gp.blocks[b]["K"], nx, gp.blocks[b]["Bt"])
     bt.analyze(4)
     for b in range(N):
         bt.set_values(b, gp.blocks[b]["K"].val)
-    kkt = pa.KktSystem(bt, n0, my0, myl, mzl, A0=gp.A0, F0=gp.F0, G0=gp.G0)
-    kkt.set_root_inequalities(gp.C0)
-    zd0 = torch.tensor(gp.z_diag0, device="cuda")
-    kkt.set_zdiag0(zd0)
+    kkt = pa.KktSystem(bt, n0, my0, myl, mzl, A0=gp.A0 if my0 else None, F0=gp.F0 if myl else None, G0=gp.G0 if mzl else None)
+    if mz0:
+        kkt.set_root_inequalities(gp.C0)
+        zd0 = torch.tensor(gp.z_diag0, device="cuda")
+        kkt.set_zdiag0(zd0)
     kkt.factorize(torch.tensor(np.concatenate([b["diag"] for b in gp.blocks]), device="cuda"),
-                  torch.tensor(gp.x_diag0, device="cuda"), torch.tensor(gp.z_diag_link, device="cuda"))
+                  torch.tensor(gp.x_diag0, device="cuda"), torch.tensor(gp.z_diag_link, device="cuda") if mzl else None)
     got = hip_lower_as_rowmajor(kkt.schur_to_host(), S)
     # ---- oracle
     leaf, Bts = [], []
@@ -84,7 +108,7 @@ def test_general_structure_factorize_and_solve_compressed():
     SCf = orc.finalize_kkt_dense(SC, n0, my0, myl, mzl, gp.x_diag0, A0=gp.A0.to_scipy(), F0=gp.F0.to_scipy(), G0=gp.G0.to_scipy(),
                                  C0=gp.C0.to_scipy(), z_diag=gp.z_diag0, z_diag_link=gp.z_diag_link)
     want = np.tril(SCf)
-    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9, (dims, schur_mode)
     root = orc.DenseRootSolver(S)
     root.matrixChanged(want)
     assert kkt.root_inertia() == (n0, my0 + myl + mzl, 0)
@@ -96,10 +120,10 @@ def test_general_structure_factorize_and_solve_compressed():
     bt.sync()
     b0_o, bs_o = b0.copy(), [bl.reshape(N, -1)[b].copy() for b in range(N)]
     orc.solve_compressed(b0_o, bs_o, leaf, Bts, root, n0, my0, mz0, myl, mzl, C0=gp.C0.to_scipy(), z_diag_reg=gp.z_diag0)
-    assert np.linalg.norm(b0_d.cpu().numpy() - b0_o) / np.linalg.norm(b0_o) < 1e-8
+    assert np.linalg.norm(b0_d.cpu().numpy() - b0_o) / np.linalg.norm(b0_o) < 1e-8, (dims, schur_mode)
     xl = bl_d.cpu().numpy().reshape(N, -1)
     for b in range(N):
-        assert np.linalg.norm(xl[b] - bs_o[b]) / np.linalg.norm(bs_o[b]) < 1e-8
+        assert np.linalg.norm(xl[b] - bs_o[b]) / np.linalg.norm(bs_o[b]) < 1e-8, (dims, schur_mode)
 
 
 def test_inertia_contract_drives_regularisation_loop():
