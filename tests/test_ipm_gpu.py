@@ -73,3 +73,22 @@ def test_ipm_objective_matches_highs(shape):
     assert np.linalg.norm(A @ x - b, np.inf) <= 1e-8 * max(1.0, np.abs(b).max())
     # duality: c^T x ~ b^T y at the optimum
     assert abs(res["objective"] - res["dual_objective"]) / max(1.0, abs(ref.fun)) < 1e-6
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_ipm_sweep_against_highs(case):
+    """Seeded family of small arrowhead LPs (1-4 blocks, 24-400 variables per block): the device harness must reach the
+    optimum of HiGHS (tools/ipm_sweep.py ran 400 of these without a failure)."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(31000 + case)
+    N = int(rng.integers(1, 5))
+    n_i = int(rng.choice([24, 60, 150, 400]))
+    my_i = int(n_i * rng.choice([0.3, 0.5]))
+    n0, myl = int(rng.integers(2, 12)), int(rng.integers(1, 10))
+    rho = max(4.0 / n_i, float(rng.choice([0.02, 0.1])))
+    blocks, F0, c, b, A = build_lp(4000 + case, N, n_i, my_i, n0, myl, rho)
+    ipm = pa.IpmSolver(n0, myl, blocks, F0, c, b)
+    res = ipm.solve(max_iter=150, mutol=1e-9, artol=1e-8)
+    ref = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
+    assert res["status"] == 0 and ref.status == 0, (res, ref.status)
+    assert abs(res["objective"] - ref.fun) / max(1.0, abs(ref.fun)) < 1e-7, (res, ref.fun)
