@@ -154,6 +154,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X backend has no CPU fallback")
+    # PIPS_BENCH_SHARE_GPU=1 (validation only, never a measurement): all ranks of a multi-process launch use device 0 and the
+    # reductions are staged through host memory over gloo - the N > 1 control flow of this script on a one-GPU box
+    share_gpu = world > 1 and bool(os.environ.get("PIPS_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # PIPS_BENCH_FORCE_COMM=1 drives the whole multi-rank code path (process group, communicator bootstrap, packed Schur
     # reduction, b0 reduction) with a single rank, so that it can be checked on a one-GPU box
@@ -163,7 +168,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         if world == 1:
             os.environ["PIPS_HIP_FORCE_REDUCE"] = "1"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import pips_ipmpp_amd as pa
 
     n_i, my_i = a.n, a.n // 2
@@ -179,8 +187,8 @@ def main():
         # The library's own RCCL communicator (dlopen'd librccl, bootstrapped with a unique id broadcast over the process
         # group).  PIPS_BENCH_COMM=torch selects the host-supplied all-reduce instead (torch.distributed, also RCCL); the
         # same switch is taken on every rank if any rank fails to create its communicator.
-        want_own = os.environ.get("PIPS_BENCH_COMM", "rccl") != "torch"
-        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        want_own = os.environ.get("PIPS_BENCH_COMM", "rccl") != "torch" and not share_gpu
+        ok = torch.ones(1, dtype=torch.int32, device="cpu" if share_gpu else "cuda")
         if want_own:
             try:
                 idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -197,8 +205,18 @@ def main():
         else:
             if comm is not None:
                 comm.close()
-            comm = pa.ExternalComm.torch_distributed()
-            comm_kind = "rccl (torch.distributed callback)"
+            if share_gpu:
+                def staged(ptr, n):
+                    t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                    torch.cuda.synchronize()
+                comm = pa.ExternalComm(staged)
+                comm_kind = "gloo, host-staged (ranks share one GPU: validation run, not a measurement)"
+            else:
+                comm = pa.ExternalComm.torch_distributed()
+                comm_kind = "rccl (torch.distributed callback)"
 
     bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank)
     F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
@@ -234,7 +252,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
