@@ -149,6 +149,21 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
                         int rank, int n_ranks);
 /* leaf_diag_dev: flat K diagonals of this rank's blocks (NULL: keep); xdiag0_dev: n0 primal diagonal of the root
  * (xDiag); zdiag_link_dev: mzl entries or NULL.  Asynchronous on the batch's stream. */
+/* Sparse-root variant of pips_hip_kkt_create (createSchurCompSymbSparseUpper DistributedProblem.cpp:2235+,
+ * finalizeKKTsparse sLinsysRootAug.C:1629-1739, PardisoIndefSolver as root solver): the Schur complement is kept as the value
+ * array of a lower-triangular CSR pattern - dense x0 block, per block the clique on its non-empty border columns, the root
+ * rows A0 / F0 / G0, full diagonal - and factorised / solved by the same sparse LDL^T machinery as the leaves.  Meant for
+ * 2-link structure (a linking row touches two blocks), where SC is sparse and S may be far beyond what S x S storage allows.
+ * blk_cols_ptr / blk_cols: border column sets (ascending Schur column ids) of ALL n_blocks_global blocks of the problem -
+ * required with n_ranks > 1 so that every rank reduces the same value array; NULL = the blocks of this batch.
+ * The batch must be analyzed and use Schur mode 1 (set it explicitly for structured blocks).  Not yet supported: mz0 > 0. */
+int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int myl, int mzl, const int* A0_rowptr,
+                               const int* A0_colidx, const double* A0_val, const int* F0_rowptr, const int* F0_colidx,
+                               const double* F0_val, const int* G0_rowptr, const int* G0_colidx, const double* G0_val,
+                               int n_blocks_global, const int* blk_cols_ptr, const int* blk_cols, void* comm, int rank,
+                               int n_ranks);
+/* pattern and values (host copies) of the sparse Schur complement; any output may be NULL; *nnz = number of entries */
+int pips_hip_kkt_get_schur_sparse(void* handle, int* nnz, int* rowptr, int* colidx, double* val_host);
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev);
 /* root inequality rows C0 (mz0 x n0, CSR): adds -C0^T diag(zdiag0)^-1 C0 to SC at every factorize (sLinsysRootAug.C:
  * 1276-1338) and the z0 elimination to solve_compressed (:384-466); zdiag0 (< 0, = nOmegaInv of the root, caller-owned

@@ -198,6 +198,7 @@ struct TailCtx {
    hipEvent_t ev_panel = nullptr;       // main -> side: panel j is final (trsm done)
    hipEvent_t ev_rest = nullptr;        // side -> main: trailing update of panel j is done
    bool is_root = false;                // dense root: same update kernel under its own name (k_tile_gemm<3>)
+   const int* d_sctab = nullptr;        // sparse Schur complement: per-block position tables (kernels.hip.h sc_entry)
 };
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
@@ -284,7 +285,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    if (SC && p.schur.cnt > 0) {
       if (c.timer) c.timer->begin(c.stream, 5);
       hipLaunchKernelGGL(k_tile_gemm<2>, dim3((p.schur.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
-                         c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC);
+                         c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab);
       if (c.timer) c.timer->end(c.stream);
    }
    HIP_TRY(hipGetLastError());
@@ -357,6 +358,7 @@ struct Engine {
    std::vector<long long> x_off;    // nblk+1 offsets into flat vectors
    std::vector<LevelRange> levels;
    std::vector<LevelRange> levels_top;   // the spine's levels, for the multi-vector sweeps (which are level-scheduled throughout)
+   int* d_sctab = nullptr;    // sparse Schur complement (set_sc_tables): position tables, BlkDesc::sctab_off
    int schur_mode = 0;        // requested: 0 auto, 1 augmented partial factorisation, 2 blocked solves (reference K4-K6)
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
@@ -388,7 +390,7 @@ struct Engine {
    }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
-                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot,
+                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -400,7 +402,7 @@ struct Engine {
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
-      d_spine = d_spine_off = d_schur_cols = d_schur_slot = nullptr;
+      d_spine = d_spine_off = d_schur_cols = d_schur_slot = d_sctab = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
@@ -410,7 +412,7 @@ struct Engine {
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
    TailCtx ctx() {
       return TailCtx{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
-                     timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false};
+                     timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab};
    }
 
    int analyze_host(int n_threads, bool with_border = true) {
@@ -704,6 +706,20 @@ struct Engine {
       return PIPS_OK;
    }
 
+   // Sparse Schur complement: tab holds, block after block, the nb x nb table "position of entry (la, lb), la >= lb, of this
+   // block's contribution inside the value array of SC's lower-triangular CSR"; factor(values, 0) then accumulates there.
+   int set_sc_tables(const std::vector<int>& tab, const std::vector<long long>& off) {
+      if (!analyzed) PIPS_FAIL(PIPS_ERR_STATE, "set_sc_tables: analyze first");
+      if (schur_mode_eff != 1) PIPS_FAIL(PIPS_ERR_STATE, "a sparse Schur complement needs Schur mode 1 (set it before analyze)");
+      HIP_TRY(hipSetDevice(device));
+      if (d_sctab) { (void)hipFree(d_sctab); d_sctab = nullptr; }
+      int rc = dev_upload(&d_sctab, tab, stream);
+      if (rc) return rc;
+      for (int b = 0; b < nblk; ++b) h_blks[b].sctab_off = off[b];
+      HIP_TRY(hipMemcpy(d_blks, h_blks.data(), (size_t)nblk * sizeof(BlkDesc), hipMemcpyHostToDevice));
+      return PIPS_OK;
+   }
+
    int factor(double* SC, int ldSC) {
       if (!analyzed) PIPS_FAIL(PIPS_ERR_STATE, "factor called before analyze");
       HIP_TRY(hipSetDevice(device));
@@ -727,20 +743,20 @@ struct Engine {
          if (timer.on) timer.begin(stream, 1);
          if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
-                               L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
+                               L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab);
          if (L.small_cnt > 0)
             hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
-                               d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
+                               d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab);
          if (L.large_cnt > 0)
             hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
                                L.large_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
-                               d_inertia, d_pref);
+                               d_inertia, d_pref, d_sctab);
          if (timer.on) timer.end(stream);
       }
       if (spine_total > 0) {
          if (timer.on) timer.begin(stream, 1);
          hipLaunchKernelGGL((k_head_factor_spine<256, 32, 6144>), dim3(nblk), dim3(256), 0, stream, d_spine, d_spine_off, d_sns, d_blks,
-                            d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref);
+                            d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab);
          if (timer.on) timer.end(stream);
       }
       hipLaunchKernelGGL(k_pref_tail, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_arena, d_pref, 0);
@@ -1094,12 +1110,23 @@ struct KktSystem {
    int mz0 = 0;
    int *d_c0_rp = nullptr, *d_c0_ci = nullptr;
    const double* d_zdiag0 = nullptr;   // caller-owned, set per iteration
+   // sparse root: SC lives as the value array of a lower-triangular CSR pattern inside a one-block sparse
+   // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
+   bool sparse = false;
+   std::unique_ptr<Engine> root_sp;
+   std::vector<int> sc_rowptr, sc_colidx;
+   long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
    ~KktSystem() {
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
 };
+
+// vals[pos[i]] += d[i]
+__global__ void k_add_at(double* __restrict__ vals, const long long* __restrict__ pos, const double* __restrict__ d, int n) {
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) vals[pos[i]] += d[i];
+}
 
 // SC[0:n0,0:n0] -= C0^T diag(zdiag)^-1 C0 (lower triangle; zdiag < 0): schur_complement_add_CTDC_block
 // (sLinsysRootAug.C:1276-1338, SparseStorage::matTransDinvMultMat SparseStorage.C:1257).  One thread per row of C0.
@@ -1688,11 +1715,137 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    return PIPS_OK;
 }
 
+// Sparse-root variant (createSchurCompSymbSparseUpper, DistributedProblem.cpp:2235+; finalizeKKTsparse, sLinsysRootAug.C:
+// 1629-1739).  Pattern of SC (lower): the dense x0 block, for every block the clique on its non-empty border columns, the
+// root rows A0 / F0 / G0 and a full diagonal.  With 2-link structure (a linking row touches two blocks) it stays sparse.
+// blk_cols_ptr / blk_cols (optional): the border column sets of ALL blocks of the problem (needed with n_ranks > 1, where a
+// rank only knows its own blocks but every rank must reduce the same value array); NULL: the blocks of this batch.
+int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int myl, int mzl, const int* A0_rowptr,
+                               const int* A0_colidx, const double* A0_val, const int* F0_rowptr, const int* F0_colidx,
+                               const double* F0_val, const int* G0_rowptr, const int* G0_colidx, const double* G0_val,
+                               int n_blocks_global, const int* blk_cols_ptr, const int* blk_cols, void* comm, int rank,
+                               int n_ranks) {
+   Engine* e = (Engine*)batch;
+   if (!handle || !e || !e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_create_sparse: the batch must be analyzed");
+   const int S = n0 + my0 + myl + mzl;
+   if (S != e->S) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_create_sparse: n0+my0+myl+mzl = %d but the batch was created with S = %d", S, e->S);
+   if (n_ranks > 1 && !blk_cols_ptr) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_create_sparse: n_ranks > 1 needs the border column sets of all blocks");
+   auto k = std::make_unique<KktSystem>();
+   k->leaves = e;
+   k->n0 = n0; k->my0 = my0; k->myl = myl; k->mzl = mzl; k->S = S;
+   k->comm = comm; k->rank = rank; k->n_ranks = n_ranks;
+   k->sparse = true;
+   HIP_TRY(hipSetDevice(e->device));
+   // ---- pattern, row by row (lower triangle, sorted, explicit diagonal)
+   std::vector<std::vector<int>> rows(S);
+   for (int r = 0; r < S; ++r) rows[r].push_back(r);
+   for (int r = 0; r < n0; ++r)
+      for (int c = 0; c < r; ++c) rows[r].push_back(c);
+   auto add_rows = [&](const int* rp, const int* ci, int nrows, int r0) {
+      if (!rp) return;
+      for (int r = 0; r < nrows; ++r)
+         for (int p = rp[r]; p < rp[r + 1]; ++p) rows[r0 + r].push_back(ci[p]);
+   };
+   add_rows(A0_rowptr, A0_colidx, my0, n0);
+   add_rows(F0_rowptr, F0_colidx, myl, n0 + my0);
+   add_rows(G0_rowptr, G0_colidx, mzl, n0 + my0 + myl);
+   auto add_clique = [&](const int* cols, int nc) {
+      for (int a = 0; a < nc; ++a)
+         for (int b = 0; b <= a; ++b) rows[cols[a]].push_back(cols[b]);   // cols ascending: cols[a] >= cols[b]
+   };
+   if (blk_cols_ptr) {
+      for (int b = 0; b < n_blocks_global; ++b) add_clique(blk_cols + blk_cols_ptr[b], blk_cols_ptr[b + 1] - blk_cols_ptr[b]);
+   }
+   for (int b = 0; b < e->nblk; ++b) add_clique(e->sym[b].bmap.data(), (int)e->sym[b].bmap.size());
+   k->sc_rowptr.assign(S + 1, 0);
+   for (int r = 0; r < S; ++r) {
+      std::sort(rows[r].begin(), rows[r].end());
+      rows[r].erase(std::unique(rows[r].begin(), rows[r].end()), rows[r].end());
+      k->sc_rowptr[r + 1] = k->sc_rowptr[r] + (int)rows[r].size();
+   }
+   k->sc_colidx.reserve(k->sc_rowptr[S]);
+   for (int r = 0; r < S; ++r) k->sc_colidx.insert(k->sc_colidx.end(), rows[r].begin(), rows[r].end());
+   auto pos_of = [&](int r, int c) -> long long {
+      const int* b0 = k->sc_colidx.data() + k->sc_rowptr[r];
+      const int* b1 = k->sc_colidx.data() + k->sc_rowptr[r + 1];
+      const int* it = std::lower_bound(b0, b1, c);
+      return (it != b1 && *it == c) ? (long long)(it - k->sc_colidx.data()) : -1;
+   };
+   // ---- per-block position tables for the leaf kernels
+   std::vector<int> tab;
+   std::vector<long long> off(e->nblk, 0);
+   for (int b = 0; b < e->nblk; ++b) {
+      const std::vector<int>& bm = e->sym[b].bmap;
+      const int nb = (int)bm.size();
+      off[b] = (long long)tab.size();
+      tab.resize(tab.size() + (size_t)nb * nb, 0);
+      for (int la = 0; la < nb; ++la)
+         for (int lb = 0; lb <= la; ++lb) tab[off[b] + (long long)la * nb + lb] = (int)pos_of(bm[la], bm[lb]);
+   }
+   int rc = e->set_sc_tables(tab, off);
+   if (rc) return rc;
+   // ---- the root as a one-block sparse engine; its value array is the Schur complement
+   k->root_sp = std::make_unique<Engine>();
+   Engine* r = k->root_sp.get();
+   r->nblk = 1; r->S = 0; r->device = e->device; r->stream = e->stream;
+   r->thr_rel = e->thr_rel; r->repl_rel = e->repl_rel;
+   r->in.assign(1, BlockInput());
+   r->in[0].n = S; r->in[0].n_primal = n0;
+   r->in[0].krow = k->sc_rowptr; r->in[0].kcol = k->sc_colidx;
+   if ((rc = r->analyze(4))) return rc;
+   // ---- constant root entries and the diagonals added by finalizeKKT
+   std::vector<long long> idx, xpos(n0), zpos(mzl);
+   std::vector<double> val;
+   auto add = [&](const int* rp, const int* ci, const double* v, int nrows, int r0) {
+      if (!rp) return;
+      for (int rr = 0; rr < nrows; ++rr)
+         for (int p = rp[rr]; p < rp[rr + 1]; ++p) { idx.push_back(pos_of(r0 + rr, ci[p])); val.push_back(v[p]); }
+   };
+   add(A0_rowptr, A0_colidx, A0_val, my0, n0);
+   add(F0_rowptr, F0_colidx, F0_val, myl, n0 + my0);
+   add(G0_rowptr, G0_colidx, G0_val, mzl, n0 + my0 + myl);
+   for (int i = 0; i < n0; ++i) xpos[i] = pos_of(i, i);
+   for (int i = 0; i < mzl; ++i) zpos[i] = pos_of(n0 + my0 + myl + i, n0 + my0 + myl + i);
+   k->n_fin = (long long)idx.size();
+   if ((rc = dev_upload(&k->d_fin_idx, idx, nullptr))) return rc;
+   if ((rc = dev_upload(&k->d_fin_val, val, nullptr))) return rc;
+   if ((rc = dev_upload(&k->d_xdiag_pos, xpos, nullptr))) return rc;
+   if ((rc = dev_upload(&k->d_zlink_pos, zpos, nullptr))) return rc;
+   HIP_TRY(hipMalloc((void**)&k->d_t, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
+   *handle = k.release();
+   return PIPS_OK;
+}
+
+static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev) {
+   Engine* e = k->leaves;
+   Engine* r = k->root_sp.get();
+   int rc;
+   if (leaf_diag_dev && (rc = pips_hip_batch_set_diagonals_dev(e, leaf_diag_dev))) return rc;
+   const size_t nnz = (size_t)k->sc_rowptr[k->S];
+   HIP_TRY(hipMemsetAsync(r->d_kval, 0, nnz * sizeof(double), e->stream));
+   if ((rc = e->factor(r->d_kval, 0))) return rc;
+   const bool reduce = k->n_ranks > 1 || (k->comm && getenv("PIPS_HIP_FORCE_REDUCE"));
+   if (reduce) {
+      if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
+      if ((rc = pips_hip_allreduce_sum(k->comm, r->d_kval, nnz, e->stream))) return rc;
+   }
+   if (xdiag0_dev && k->n0 > 0)
+      hipLaunchKernelGGL(k_add_at, dim3(grid_for(k->n0, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_xdiag_pos, xdiag0_dev, k->n0);
+   if (k->n_fin > 0)
+      hipLaunchKernelGGL(k_add_entries, dim3(grid_for(k->n_fin, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_fin_idx, k->d_fin_val,
+                         k->n_fin);
+   if (zdiag_link_dev && k->mzl > 0)
+      hipLaunchKernelGGL(k_add_at, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_zlink_pos, zdiag_link_dev, k->mzl);
+   HIP_TRY(hipGetLastError());
+   return r->factor(nullptr, 0);
+}
+
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev) {
    KktSystem* k = (KktSystem*)handle;
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    Engine* e = k->leaves;
    HIP_TRY(hipSetDevice(e->device));
+   if (k->sparse) return kkt_factorize_sparse(k, leaf_diag_dev, xdiag0_dev, zdiag_link_dev);
    int rc;
    if (leaf_diag_dev && (rc = pips_hip_batch_set_diagonals_dev(e, leaf_diag_dev))) return rc;
    const size_t n = (size_t)k->S * k->S;
@@ -1753,7 +1906,10 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    if (k->mz0 > 0)
       hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
-   if ((rc = k->root->solve_dev(red))) return rc;
+   if (k->sparse) {
+      if (k->mz0 > 0) PIPS_FAIL(PIPS_ERR_STATE, "root inequality rows are not supported with the sparse root yet");
+      if ((rc = k->root_sp->solve(red))) return rc;
+   } else if ((rc = k->root->solve_dev(red))) return rc;
    if (k->mz0 > 0) {
       hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 1, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
@@ -1773,6 +1929,7 @@ int pips_hip_kkt_set_root_inequalities(void* handle, int mz0, const int* C0_rowp
    KktSystem* k = (KktSystem*)handle;
    if (!k || mz0 < 0 || (mz0 > 0 && (!C0_rowptr || !C0_colidx || !C0_val))) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_root_inequalities: bad arguments");
    HIP_TRY(hipSetDevice(k->leaves->device));
+   if (k->sparse && mz0 > 0) PIPS_FAIL(PIPS_ERR_STATE, "root inequality rows are not supported with the sparse root yet");
    k->mz0 = mz0;
    if (mz0 == 0) return PIPS_OK;
    std::vector<int> rp(C0_rowptr, C0_rowptr + mz0 + 1), ci(C0_colidx, C0_colidx + C0_rowptr[mz0]);
@@ -1793,6 +1950,7 @@ int pips_hip_kkt_set_zdiag0_dev(void* handle, const double* zdiag0_dev) {
 int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld) {
    KktSystem* k = (KktSystem*)handle;
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (k->sparse) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_get_schur: sparse-root system, use pips_hip_kkt_get_schur_sparse");
    if (SC_dev) *SC_dev = k->d_SC;
    if (ld) *ld = k->S;
    return PIPS_OK;
@@ -1801,7 +1959,23 @@ int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld) {
 int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero) {
    KktSystem* k = (KktSystem*)handle;
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (k->sparse) return pips_hip_batch_inertia(k->root_sp.get(), 0, pos, neg, zero);
    return pips_hip_dense_ldl_inertia(k->root.get(), pos, neg, zero);
+}
+
+int pips_hip_kkt_get_schur_sparse(void* handle, int* nnz, int* rowptr, int* colidx, double* val_host) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || !k->sparse) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_get_schur_sparse: not a sparse-root system");
+   const int n = k->sc_rowptr[k->S];
+   if (nnz) *nnz = n;
+   if (rowptr) std::copy(k->sc_rowptr.begin(), k->sc_rowptr.end(), rowptr);
+   if (colidx) std::copy(k->sc_colidx.begin(), k->sc_colidx.end(), colidx);
+   if (val_host) {
+      HIP_TRY(hipSetDevice(k->leaves->device));
+      HIP_TRY(hipStreamSynchronize(k->leaves->stream));
+      HIP_TRY(hipMemcpy(val_host, k->root_sp->d_kval, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+   }
+   return PIPS_OK;
 }
 
 void pips_hip_kkt_destroy(void* handle) { delete (KktSystem*)handle; }

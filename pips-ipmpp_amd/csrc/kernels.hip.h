@@ -36,6 +36,7 @@ struct BlkDesc {
    long long bmap_off;   // offset into bmap
    long long winv_off;   // offset into winv (ntc tiles of TILE*TILE)
    long long dt_off;     // offset into dtail (m_pad)
+   long long sctab_off;  // offset of this block's nb x nb position table inside sctab (sparse Schur complement), else 0
    int n, n_head, m, m_pad, nb, nb_pad, ldT, ntc, ntr;
    int pad0;
    double thr_rel, repl_rel;  // pivot threshold / replacement relative to the pivot's reference magnitude pref[k]
@@ -48,6 +49,14 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Where the (la, lb) entry of a block's Schur contribution lives (la >= lb: compressed border ids, ascending like the Schur
+// column ids they map to).  Dense root: column-major S x S array, bm = the block's bmap.  Sparse root (sctab != nullptr): the
+// value array of the lower-triangular CSR pattern of SC, looked up in the block's nb x nb position table.
+__device__ __forceinline__ double* sc_entry(double* SC, int ldSC, const int* __restrict__ bm, const int* __restrict__ sctab,
+                                            long long tab_off, int nb, int la, int lb) {
+   return sctab ? SC + sctab[tab_off + (long long)la * nb + lb] : SC + bm[la] + (long long)bm[lb] * ldSC;
 }
 
 // Static pivoting rule.  Every pivot has a reference magnitude pref (|original diagonal entry|, refreshed for the dense
@@ -205,7 +214,8 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
                                                  const int* __restrict__ upd, const signed char* __restrict__ psign,
                                                  const long long* __restrict__ psign_off, const int* __restrict__ bmap,
                                                  double* __restrict__ arena, double* __restrict__ SC, int ldSC,
-                                                 int* __restrict__ inertia, const double* __restrict__ pref) {
+                                                 int* __restrict__ inertia, const double* __restrict__ pref,
+                                                 const int* __restrict__ sctab) {
    __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w; column k keeps l_ik * d_k (unscaled)
    __shared__ double dk[WMAX];
    __shared__ double prf[WMAX];
@@ -341,7 +351,7 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
    if (b0 < r && SC) {   // border x border: the Schur complement itself (SC == nullptr: factor-only call)
       const int* bm = bmap + bd.bmap_off;
       for_pairs(b0, r, [&](int a, int b) {
-         atomic_add_f64(SC + bm[rows[a] - n] + (long long)bm[rows[b] - n] * ldSC, -entry(a, b));
+         atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, rows[a] - n, rows[b] - n), -entry(a, b));
       });
    }
 }
@@ -354,10 +364,10 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
                                                       const long long* __restrict__ psign_off,
                                                       const int* __restrict__ bmap, double* __restrict__ arena,
                                                       double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
-                                                      const double* __restrict__ pref) {
+                                                      const double* __restrict__ pref, const int* __restrict__ sctab) {
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref);
+   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab);
 }
 
 // "Spine" of a chain-like elimination tree: the top levels that hold at most two supernodes per block.  Level scheduling
@@ -373,13 +383,13 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor_spine(const int* __restri
                                                             const long long* __restrict__ psign_off,
                                                             const int* __restrict__ bmap, double* __restrict__ arena,
                                                             double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
-                                                            const double* __restrict__ pref) {
+                                                            const double* __restrict__ pref, const int* __restrict__ sctab) {
    const int p0 = spine_off[blockIdx.x], p1 = spine_off[blockIdx.x + 1];
    if (p0 == p1) return;
    const BlkDesc bd = blks[blockIdx.x];
    for (int p = p0; p < p1; ++p) {
       const SnDesc sn = sns[spine[p]];
-      head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref);
+      head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab);
       __threadfence();
       __syncthreads();
    }
@@ -397,7 +407,8 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                                                            const signed char* __restrict__ psign,
                                                            const long long* __restrict__ psign_off, const int* __restrict__ bmap,
                                                            double* __restrict__ arena, double* __restrict__ SC, int ldSC,
-                                                           int* __restrict__ inertia, const double* __restrict__ pref) {
+                                                           int* __restrict__ inertia, const double* __restrict__ pref,
+                                                           const int* __restrict__ sctab) {
    __shared__ int cnt_s[3];
    __shared__ int blk_s;
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                      const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
                      atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -u);
                   } else if (SC) {
-                     atomic_add_f64(SC + bm[ra - n] + (long long)bm[cb - n] * ldSC, -u);
+                     atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n), -u);
                   }
                }
             }
@@ -510,7 +521,8 @@ template <int MODE>
 __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
                                                      const BlkDesc* __restrict__ blks, double* __restrict__ arena,
                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
-                                                     const int* __restrict__ bmap, double* __restrict__ SC, int ldSC) {
+                                                     const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
+                                                     const int* __restrict__ sctab = nullptr) {
    __shared__ __attribute__((aligned(16))) double As[2][KB * LDSW];
    __shared__ __attribute__((aligned(16))) double Bs[2][KB * LDSW];
    __shared__ double Ds[2][KB];   // diagonal scaling d_k of the stage
@@ -649,7 +661,7 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
             const int gi = task.ti * TILE + row, gj = task.tj * TILE + col;
             if (gi < bd.nb && gj < bd.nb && gi >= gj) {
                const int* bm = bmap + bd.bmap_off;
-               atomic_add_f64(SC + bm[gi] + (long long)bm[gj] * ldSC, -v);
+               atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, gi, gj), -v);
             }
          }
       }

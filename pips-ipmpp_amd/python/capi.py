@@ -57,7 +57,7 @@ SYMBOLS = [
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
-    "pips_hip_kkt_create", "pips_hip_kkt_factorize", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
+    "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
@@ -515,7 +515,8 @@ class ExternalComm(Comm):
 class KktSystem:
     """Mirror of the root linear system's factor2()/solveCompressed() for the blocks one rank owns."""
 
-    def __init__(self, batch, n0, my0, myl, mzl, A0=None, F0=None, G0=None, comm=None, rank=0, n_ranks=1):
+    def __init__(self, batch, n0, my0, myl, mzl, A0=None, F0=None, G0=None, comm=None, rank=0, n_ranks=1, sparse_root=False,
+                 all_block_cols=None):
         self.batch = batch
         self.S = n0 + my0 + myl + mzl
         self._h = C.c_void_p()
@@ -523,9 +524,24 @@ class KktSystem:
         def trip(M):
             return (None, None, None) if M is None else (_ptr(M.rowptr), _ptr(M.colidx), _ptr(M.val))
 
-        _check(lib.pips_hip_kkt_create(C.byref(self._h), batch._h, C.c_int(n0), C.c_int(my0), C.c_int(myl), C.c_int(mzl),
-                                       *trip(A0), *trip(F0), *trip(G0), comm._h if comm is not None else None,
-                                       C.c_int(rank), C.c_int(n_ranks)), "pips_hip_kkt_create")
+        self.sparse_root = bool(sparse_root)
+        if sparse_root:
+            cp = cc = None
+            nglob = 0
+            if all_block_cols is not None:     # border column sets of all blocks of the problem (needed with n_ranks > 1)
+                nglob = len(all_block_cols)
+                cp = np.zeros(nglob + 1, np.int32)
+                cp[1:] = np.cumsum([len(x) for x in all_block_cols])
+                cc = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int32) for x in all_block_cols]) if nglob else np.zeros(0, np.int32))
+            self._keep_cols = (cp, cc)
+            _check(lib.pips_hip_kkt_create_sparse(C.byref(self._h), batch._h, C.c_int(n0), C.c_int(my0), C.c_int(myl), C.c_int(mzl),
+                                                  *trip(A0), *trip(F0), *trip(G0), C.c_int(nglob), _ptr(cp), _ptr(cc),
+                                                  comm._h if comm is not None else None, C.c_int(rank), C.c_int(n_ranks)),
+                   "pips_hip_kkt_create_sparse")
+        else:
+            _check(lib.pips_hip_kkt_create(C.byref(self._h), batch._h, C.c_int(n0), C.c_int(my0), C.c_int(myl), C.c_int(mzl),
+                                           *trip(A0), *trip(F0), *trip(G0), comm._h if comm is not None else None,
+                                           C.c_int(rank), C.c_int(n_ranks)), "pips_hip_kkt_create")
 
     def set_root_inequalities(self, C0):
         self.mz0 = C0.nrows
@@ -542,6 +558,15 @@ class KktSystem:
 
     def solve_compressed(self, b0_dev, b_leaf_dev):
         _check(lib.pips_hip_kkt_solve_compressed(self._h, _ptr(b0_dev), _ptr(b_leaf_dev)), "pips_hip_kkt_solve_compressed")
+
+    def schur_sparse_to_host(self):
+        """Sparse-root systems: the Schur complement as a scipy CSR matrix (lower triangle)."""
+        import scipy.sparse as sp
+        nnz = C.c_int()
+        _check(lib.pips_hip_kkt_get_schur_sparse(self._h, C.byref(nnz), None, None, None), "pips_hip_kkt_get_schur_sparse")
+        rp, ci, v = np.zeros(self.S + 1, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nnz.value)
+        _check(lib.pips_hip_kkt_get_schur_sparse(self._h, C.byref(nnz), _ptr(rp), _ptr(ci), _ptr(v)), "pips_hip_kkt_get_schur_sparse")
+        return sp.csr_matrix((v, ci, rp), shape=(self.S, self.S))
 
     def schur_ptr(self):
         p = C.c_void_p()
