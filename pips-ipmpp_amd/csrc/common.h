@@ -90,6 +90,8 @@ struct BlockSym {
    double flops_factor = 0;             // head + tail factor flops
    double flops_border = 0;             // border TRSM + Schur SYRK flops
    std::vector<int> colcount;           // AMD column counts (diagnostics)
+   std::vector<int> tile_first;         // per tile row of the tail panel (m_pad + nb_pad rows): first tile column inside the
+                                        // row envelope of the tail's Schur complement (0 = dense row); fill stays inside it
 };
 
 struct CsrPattern {
@@ -102,6 +104,9 @@ struct AnalyzeOptions {
    int tile = 128;            // dense tile size
    int max_sn_width = 32;     // head supernode width cap
    int nd_depth = 4;          // levels of dual-row nested dissection tried before minimum degree (0 = off)
+   const int* user_perm = nullptr;   // given elimination order (perm[new] = old) instead of minimum degree / dissection
+   bool constrain_order = true;   // dual rows only after their primal neighbours (leaf KKT blocks); false: plain minimum degree,
+                                  // the inertia hint still supplies the expected pivot signs (sparse Schur complement)
    double relax_zeros = 0.4;  // supernode amalgamation: admissible share of explicit zeros in a panel (0 = fundamental)
    int min_tail = 256;        // do not open a dense tail smaller than this
    int force_n_head = -1;     // >=0: override the cost model (tests)

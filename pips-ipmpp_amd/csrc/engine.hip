@@ -65,7 +65,10 @@ struct TailPlan {
    //   (ntr - p1)^2 / 2 tiles with K = P * TILE).  The K range rides in TileTask::pad = k0 | k1 << 16 (tile columns).
    // split_diag (left-looking batches): the update of the diagonal tile of column j gets a task list of its own (upd_diag),
    // so that the driver can factorise that tile on a side stream while the rest of the column is still being updated.
-   int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false, bool split_diag = false) {
+   // first: per block the tile-row envelope of its tail (BlockSym::tile_first); tiles left of it hold structural zeros and
+   // get no task, update depths start at the envelope (a banded tail costs band^2 per column instead of column^2)
+   int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false, bool split_diag = false,
+             const std::vector<const std::vector<int>*>* first = nullptr) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -82,16 +85,24 @@ struct TailPlan {
       auto end = [&](TaskList& l) { l.cnt = (int)((long long)all.size() - l.off); };
       for (int j = 0; j < ntc_max; ++j) {
          const int p0 = panel > 0 ? j / panel * panel : 0;   // first tile column of j's panel
+         auto fst = [&](int b, int t) { return first ? (*(*first)[b])[t] : 0; };
          begin(upd_diag[j]);
          if (j > p0 && split_diag)
             for (int b = 0; b < nblk; ++b)
-               if (blks[b].ntc > j) all.push_back({b, j, j, p0 | (j << 16)});
+               if (blks[b].ntc > j) {
+                  const int k0 = std::max(p0, fst(b, j));
+                  if (k0 < j) all.push_back({b, j, j, k0 | (j << 16)});
+               }
          end(upd_diag[j]);
          begin(upd[j]);
          if (j > p0)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j)
-                  for (int ti = split_diag ? j + 1 : j; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j, p0 | (j << 16)});
+                  for (int ti = split_diag ? j + 1 : j; ti < blks[b].ntr; ++ti) {
+                     if (j < fst(b, ti)) continue;                                  // outside the envelope: stays zero
+                     const int k0 = std::max({p0, fst(b, ti), fst(b, j)});
+                     if (k0 < j) all.push_back({b, ti, j, k0 | (j << 16)});
+                  }
          end(upd[j]);
          begin(diag[j]);
          for (int b = 0; b < nblk; ++b)
@@ -100,17 +111,20 @@ struct TailPlan {
          begin(trsm[j]);
          for (int b = 0; b < nblk; ++b)
             if (blks[b].ntc > j)
-               for (int ti = j + 1; ti < blks[b].ntr; ++ti) all.push_back({b, ti, j, 0});
+               for (int ti = j + 1; ti < blks[b].ntr; ++ti)
+                  if (j >= fst(b, ti)) all.push_back({b, ti, j, 0});
          end(trsm[j]);
          begin(fwd[j]);
          for (int b = 0; b < nblk; ++b)
             if (blks[b].ntc > j)
-               for (int ti = j; ti < blks[b].ntc; ++ti) all.push_back({b, ti, j, 0});
+               for (int ti = j; ti < blks[b].ntc; ++ti)
+                  if (ti == j || (j >= 1 && j - 1 >= fst(b, ti))) all.push_back({b, ti, j, 0});   // L(ti, j-1) inside the envelope
          end(fwd[j]);
          begin(bwd[j]);
          for (int b = 0; b < nblk; ++b)
             if (blks[b].ntc > j)
-               for (int tj = 0; tj <= j; ++tj) all.push_back({b, tj, j, 0});
+               for (int tj = 0; tj <= j; ++tj)
+                  if (tj == j || (j + 1 < blks[b].ntc && tj >= fst(b, j + 1))) all.push_back({b, tj, j, 0});   // L(j+1, tj)
          end(bwd[j]);
          // panel [p0, j] complete: apply it to every tile right of it.  The next tile column is listed separately
          // (trail_next) so that the driver can finish it first and overlap the next diagonal tile with the rest.
@@ -691,7 +705,9 @@ struct Engine {
          if ((rc = dev_upload(&d_nprimal, np, stream))) return rc;
       }
       const bool diag_ahead = !getenv("PIPS_HIP_NO_DIAG_AHEAD");
-      if ((rc = plan.build(h_blks, 0, false, diag_ahead))) return rc;
+      std::vector<const std::vector<int>*> firsts(nblk);
+      for (int b = 0; b < nblk; ++b) firsts[b] = &sym[b].tile_first;
+      if ((rc = plan.build(h_blks, 0, false, diag_ahead, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts))) return rc;
       if (diag_ahead && !side) {
          // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
          int prio_lo = 0, prio_hi = 0;
@@ -1114,7 +1130,7 @@ struct KktSystem {
    // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
    bool sparse = false;
    std::unique_ptr<Engine> root_sp;
-   std::vector<int> sc_rowptr, sc_colidx;
+   std::vector<int> sc_rowptr, sc_colidx, root_perm;
    long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
    ~KktSystem() {
       void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos};
@@ -1792,6 +1808,36 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
    r->in.assign(1, BlockInput());
    r->in[0].n = S; r->in[0].n_primal = n0;
    r->in[0].krow = k->sc_rowptr; r->in[0].kcol = k->sc_colidx;
+   // Elimination order.  The link-link block of SC is negative definite on its own (-sum F_i (K_i^-1)_xx F_i^T), so the linking
+   // rows can go first with their expected signs, then x0, then the root equality rows y0 (zero diagonal block: they need x0
+   // before them).  In that order a 2-link Schur complement is banded: if its tile envelope is thin the root is factorised as
+   // an all-dense-tile band (TailPlan envelope: band^2 work per column on the MFMA kernels) - otherwise minimum degree with
+   // the usual head / tail split decides (linking rows still before x0 unless y0 rows exist).
+   k->root_perm.clear();
+   for (int i = n0 + my0; i < S; ++i) k->root_perm.push_back(i);
+   for (int i = 0; i < n0 + my0; ++i) k->root_perm.push_back(i);
+   {
+      std::vector<int> ipos(S);
+      for (int t = 0; t < S; ++t) ipos[k->root_perm[t]] = t;
+      const int nt = (S + TILE - 1) / TILE;
+      std::vector<int> first(nt);
+      for (int t = 0; t < nt; ++t) first[t] = t;
+      for (int rr = 0; rr < S; ++rr)
+         for (int p = k->sc_rowptr[rr]; p < k->sc_rowptr[rr + 1]; ++p) {
+            const int a = ipos[rr], b = ipos[k->sc_colidx[p]];
+            const int tr = std::max(a, b) / TILE, tc = std::min(a, b) / TILE;
+            first[tr] = std::min(first[tr], tc);
+         }
+      double env = 0;
+      for (int t = 0; t < nt; ++t) env += t - first[t] + 1;
+      const bool banded = env <= 0.25 * 0.5 * nt * (nt + 1.0) && !getenv("PIPS_HIP_SPARSE_ROOT_AMD");
+      if (banded) {
+         r->opt.user_perm = k->root_perm.data();
+         r->opt.force_n_head = 0;
+      } else {
+         r->opt.constrain_order = my0 > 0;
+      }
+   }
    if ((rc = r->analyze(4))) return rc;
    // ---- constant root entries and the diagonals added by finalizeKKT
    std::vector<long long> idx, xpos(n0), zpos(mzl);

@@ -48,7 +48,12 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             if (j != i) { ai[fill[i]++] = j; ai[fill[j]++] = i; }
          }
    }
-   if (!dissected_order(n, ap, ai, n_primal, opt.nd_depth, out.perm, out.colcount))
+   if (opt.user_perm) {
+      out.perm.assign(opt.user_perm, opt.user_perm + n);
+      out.colcount.assign(n, 0);
+   } else if (!opt.constrain_order)
+      constrained_amd(n, ap, ai, -1, out.perm, out.colcount);
+   else if (!dissected_order(n, ap, ai, n_primal, opt.nd_depth, out.perm, out.colcount))
       constrained_amd(n, ap, ai, n_primal, out.perm, out.colcount);
    out.iperm.assign(n, 0);
    for (int k = 0; k < n; ++k) out.iperm[out.perm[k]] = k;
@@ -213,6 +218,35 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    }
    out.n_levels = n_levels;
    { std::vector<std::vector<int>>().swap(S); }
+
+   // ---- row envelope of the tail at tile granularity: the first tile column that carries an entry of the tail's Schur
+   //      complement in each tile row - original entries of K inside the tail, and the cliques the head supernodes leave on
+   //      their tail rows.  Factorisation without pivoting fills only inside the row envelope, so tile tasks left of it are
+   //      never generated (TailPlan); a dense tail simply has first = 0 everywhere.  Border rows are kept dense.
+   {
+      const int ntr = out.ldT / opt.tile, ntc = out.m_pad / opt.tile;
+      out.tile_first.assign(ntr, 0);
+      for (int t = 0; t < ntc; ++t) out.tile_first[t] = t;   // at least the diagonal tile
+      auto touch = [&](int r_perm, int c_perm) {             // both >= n_head, r >= c
+         const int tr = (r_perm - n_head) / opt.tile, tc = (c_perm - n_head) / opt.tile;
+         if (tc < out.tile_first[tr]) out.tile_first[tr] = tc;
+      };
+      for (int i = 0; i < n; ++i)
+         for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+            const int a = out.iperm[i], b = out.iperm[K.colidx[p]];
+            if (a >= n_head && b >= n_head) touch(std::max(a, b), std::min(a, b));
+         }
+      for (const HeadSupernode& sn : out.sn) {
+         const int* rows = out.rowidx.data() + sn.rows;
+         int first_tail = -1;
+         for (int a = 0; a < sn.r; ++a) {
+            const int ra = rows[a];
+            if (ra < n_head || ra >= n) continue;
+            if (first_tail < 0) first_tail = ra;
+            touch(ra, first_tail);
+         }
+      }
+   }
 
    // ---- arena layout
    int64_t off = 0;
