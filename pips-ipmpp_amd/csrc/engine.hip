@@ -1830,7 +1830,8 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
          }
       double env = 0;
       for (int t = 0; t < nt; ++t) env += t - first[t] + 1;
-      const bool banded = env <= 0.25 * 0.5 * nt * (nt + 1.0) && !getenv("PIPS_HIP_SPARSE_ROOT_AMD");
+      bool banded = env <= 0.25 * 0.5 * nt * (nt + 1.0);
+      if (const char* f = getenv("PIPS_HIP_SPARSE_ROOT_BAND")) banded = atoi(f) != 0;   // tests: force either path
       if (banded) {
          r->opt.user_perm = k->root_perm.data();
          r->opt.force_n_head = 0;
