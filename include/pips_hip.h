@@ -156,7 +156,7 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
  * 2-link structure (a linking row touches two blocks), where SC is sparse and S may be far beyond what S x S storage allows.
  * blk_cols_ptr / blk_cols: border column sets (ascending Schur column ids) of ALL n_blocks_global blocks of the problem -
  * required with n_ranks > 1 so that every rank reduces the same value array; NULL = the blocks of this batch.
- * The batch must be analyzed and use Schur mode 1 (set it explicitly for structured blocks).  Not yet supported: mz0 > 0. */
+ * The batch must be analyzed and use Schur mode 1 (set it explicitly for structured blocks). */
 int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int myl, int mzl, const int* A0_rowptr,
                                const int* A0_colidx, const double* A0_val, const int* F0_rowptr, const int* F0_colidx,
                                const double* F0_val, const int* G0_rowptr, const int* G0_colidx, const double* G0_val,

@@ -1132,8 +1132,9 @@ struct KktSystem {
    std::unique_ptr<Engine> root_sp;
    std::vector<int> sc_rowptr, sc_colidx, root_perm;
    long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
+   int* d_sc_rowptr = nullptr;
    ~KktSystem() {
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
@@ -1146,14 +1147,16 @@ __global__ void k_add_at(double* __restrict__ vals, const long long* __restrict_
 
 // SC[0:n0,0:n0] -= C0^T diag(zdiag)^-1 C0 (lower triangle; zdiag < 0): schur_complement_add_CTDC_block
 // (sLinsysRootAug.C:1276-1338, SparseStorage::matTransDinvMultMat SparseStorage.C:1257).  One thread per row of C0.
+// sc_rowptr != nullptr: SC is the value array of the sparse root's CSR pattern, whose x0 block is dense: (i, j), j <= i < n0,
+// sits at sc_rowptr[i] + j
 __global__ void k_ctdc(int mz0, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
-                       const double* __restrict__ zdiag, double* __restrict__ SC, int ld) {
+                       const double* __restrict__ zdiag, double* __restrict__ SC, int ld, const int* __restrict__ sc_rowptr) {
    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < mz0; k += gridDim.x * blockDim.x) {
       const double dinv = 1.0 / zdiag[k];
       for (int p = rp[k]; p < rp[k + 1]; ++p)
          for (int q = rp[k]; q < rp[k + 1]; ++q) {
             const int i = ci[p], j = ci[q];
-            if (i >= j) atomic_add_f64(SC + i + (long long)j * ld, -v[p] * v[q] * dinv);
+            if (i >= j) atomic_add_f64(sc_rowptr ? SC + sc_rowptr[i] + j : SC + i + (long long)j * ld, -v[p] * v[q] * dinv);
          }
    }
 }
@@ -1858,6 +1861,7 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
    if ((rc = dev_upload(&k->d_fin_val, val, nullptr))) return rc;
    if ((rc = dev_upload(&k->d_xdiag_pos, xpos, nullptr))) return rc;
    if ((rc = dev_upload(&k->d_zlink_pos, zpos, nullptr))) return rc;
+   if ((rc = dev_upload(&k->d_sc_rowptr, k->sc_rowptr, nullptr))) return rc;
    HIP_TRY(hipMalloc((void**)&k->d_t, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
    *handle = k.release();
    return PIPS_OK;
@@ -1881,6 +1885,11 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    if (k->n_fin > 0)
       hipLaunchKernelGGL(k_add_entries, dim3(grid_for(k->n_fin, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_fin_idx, k->d_fin_val,
                          k->n_fin);
+   if (k->mz0 > 0) {
+      if (!k->d_zdiag0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: mz0 > 0 needs pips_hip_kkt_set_root_inequalities + a zdiag0 vector");
+      hipLaunchKernelGGL(k_ctdc, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val, k->d_zdiag0,
+                         r->d_kval, 0, k->d_sc_rowptr);
+   }
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_at, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_zlink_pos, zdiag_link_dev, k->mzl);
    HIP_TRY(hipGetLastError());
@@ -1919,7 +1928,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    if (k->mz0 > 0) {
       if (!k->d_zdiag0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: mz0 > 0 needs pips_hip_kkt_set_root_inequalities + a zdiag0 vector");
       hipLaunchKernelGGL(k_ctdc, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val, k->d_zdiag0,
-                         k->d_SC, k->S);
+                         k->d_SC, k->S, (const int*)nullptr);
    }
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, k->d_SC, k->S,
@@ -1954,7 +1963,6 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
       hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
    if (k->sparse) {
-      if (k->mz0 > 0) PIPS_FAIL(PIPS_ERR_STATE, "root inequality rows are not supported with the sparse root yet");
       if ((rc = k->root_sp->solve(red))) return rc;
    } else if ((rc = k->root->solve_dev(red))) return rc;
    if (k->mz0 > 0) {
@@ -1976,7 +1984,6 @@ int pips_hip_kkt_set_root_inequalities(void* handle, int mz0, const int* C0_rowp
    KktSystem* k = (KktSystem*)handle;
    if (!k || mz0 < 0 || (mz0 > 0 && (!C0_rowptr || !C0_colidx || !C0_val))) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_root_inequalities: bad arguments");
    HIP_TRY(hipSetDevice(k->leaves->device));
-   if (k->sparse && mz0 > 0) PIPS_FAIL(PIPS_ERR_STATE, "root inequality rows are not supported with the sparse root yet");
    k->mz0 = mz0;
    if (mz0 == 0) return PIPS_OK;
    std::vector<int> rp(C0_rowptr, C0_rowptr + mz0 + 1), ci(C0_colidx, C0_colidx + C0_rowptr[mz0]);

@@ -59,7 +59,7 @@ def test_general_structure_factorize_and_solve_compressed():
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("PIPS_FUZZ_CASES", "30"))))
-def test_general_structure_sweep(case):
+def test_general_structure_sweep(case, monkeypatch):
     """Seeded sweep over the block dimensions, including the empty parts (no leaf inequalities, no root equality /
     inequality rows, no linking rows of one kind) and the three Schur modes."""
     rng = np.random.default_rng(7000 + case)
@@ -71,10 +71,12 @@ def test_general_structure_sweep(case):
     my0, mz0 = int(rng.integers(0, min(5, n0 // 2 + 1))), int(rng.integers(0, 6))   # A0 needs full row rank: my0 <= n0 / 2
     myl, mzl = int(rng.integers(0, 8)), int(rng.integers(0, 6))
     rho = max(float(rng.choice([0.03, 0.08])), 4.0 / nx)   # >= 4 entries per row: one-entry rows make [W; D] rank deficient
-    _check_general(900 + case, (N, nx, my, mz, n0, my0, mz0, myl, mzl), rho, int(rng.integers(0, 3)))
+    sparse_root = bool(rng.integers(0, 2))      # the CSR Schur complement + one-block sparse engine as root
+    monkeypatch.setenv("PIPS_HIP_SPARSE_ROOT_BAND", str(int(rng.integers(0, 2))))   # ... with either elimination path
+    _check_general(900 + case, (N, nx, my, mz, n0, my0, mz0, myl, mzl), rho, 1 if sparse_root else int(rng.integers(0, 3)), sparse_root)
 
 
-def _check_general(seed, dims, rho, schur_mode):
+def _check_general(seed, dims, rho, schur_mode, sparse_root=False):
     import torch
     N, nx, my, mz, n0, my0, mz0, myl, mzl = dims
     gp = GeneralProblem(seed, N, nx, my, mz, n0, my0, mz0, myl, mzl, rho)
@@ -86,14 +88,15 @@ def _check_general(seed, dims, rho, schur_mode):
     bt.analyze(4)
     for b in range(N):
         bt.set_values(b, gp.blocks[b]["K"].val)
-    kkt = pa.KktSystem(bt, n0, my0, myl, mzl, A0=gp.A0 if my0 else None, F0=gp.F0 if myl else None, G0=gp.G0 if mzl else None)
+    kkt = pa.KktSystem(bt, n0, my0, myl, mzl, A0=gp.A0 if my0 else None, F0=gp.F0 if myl else None, G0=gp.G0 if mzl else None,
+                       sparse_root=sparse_root)
     if mz0:
         kkt.set_root_inequalities(gp.C0)
         zd0 = torch.tensor(gp.z_diag0, device="cuda")
         kkt.set_zdiag0(zd0)
     kkt.factorize(torch.tensor(np.concatenate([b["diag"] for b in gp.blocks]), device="cuda"),
                   torch.tensor(gp.x_diag0, device="cuda"), torch.tensor(gp.z_diag_link, device="cuda") if mzl else None)
-    got = hip_lower_as_rowmajor(kkt.schur_to_host(), S)
+    got = kkt.schur_sparse_to_host().toarray() if sparse_root else hip_lower_as_rowmajor(kkt.schur_to_host(), S)
     # ---- oracle
     leaf, Bts = [], []
     SC = np.zeros((S, S))
@@ -108,7 +111,7 @@ def _check_general(seed, dims, rho, schur_mode):
     SCf = orc.finalize_kkt_dense(SC, n0, my0, myl, mzl, gp.x_diag0, A0=gp.A0.to_scipy(), F0=gp.F0.to_scipy(), G0=gp.G0.to_scipy(),
                                  C0=gp.C0.to_scipy(), z_diag=gp.z_diag0, z_diag_link=gp.z_diag_link)
     want = np.tril(SCf)
-    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9, (dims, schur_mode)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9, (dims, schur_mode, sparse_root)
     root = orc.DenseRootSolver(S)
     root.matrixChanged(want)
     assert kkt.root_inertia() == (n0, my0 + myl + mzl, 0)
