@@ -571,12 +571,20 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
          }
       }
    }
+   // PIPS_IPM_SPARSE_ROOT=1: keep the Schur complement sparse and factorise it with the sparse engine (2-link problems)
+   const bool sparse_root = getenv("PIPS_IPM_SPARSE_ROOT") && atoi(getenv("PIPS_IPM_SPARSE_ROOT")) != 0;
+   if (sparse_root && (rc = pips_hip_batch_set_schur_mode(p->batch, 1))) return rc;
    rc = pips_hip_batch_analyze(p->batch, 16);
    if (rc) return rc;
    for (int i = 0; i < N; ++i)
       if ((rc = pips_hip_batch_set_values(p->batch, i, kvals[i].data()))) return rc;
    if ((rc = pips_hip_batch_set_refinement_backward_error(p->batch, 2, 1e-15))) return rc;   // PARDISO iparm[7]=2 semantics
-   rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr, nullptr, nullptr, 0, 1);
+   if (sparse_root)
+      rc = pips_hip_kkt_create_sparse(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr,
+                                      nullptr, 0, nullptr, nullptr, nullptr, 0, 1);
+   else
+      rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr, nullptr,
+                               nullptr, 0, 1);
    if (rc) return rc;
    HIP_TRYH(hipGetDevice(&p->device));
    if ((rc = p->up(&p->A_rp, Arp)) || (rc = p->up(&p->A_ci, Aci)) || (rc = p->up(&p->A_v, Av)) || (rc = p->up(&p->At_rp, Atrp)) ||
