@@ -57,13 +57,37 @@ namespace pips {
    } while (0)
 
 // y = alpha * A x + beta * y, CSR, one thread per row (SparseStorage::mult, SparseStorage.C:818-845; the rows have ~10 entries)
+// Rows longer than CSR_LONG_ROW are left to k_csr_mult_long: with few first-stage variables a row of A^T that belongs to
+// x_0 collects the T_i entries of every block (80 000 entries at n0 = 8, 64 blocks x 5000 rows) and would keep one thread busy
+// for milliseconds.
+constexpr int CSR_LONG_ROW = 512;
+
 __global__ void k_csr_mult(int nrows, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
                            const double* __restrict__ x, double alpha, double beta, double* __restrict__ y) {
    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+      if (rp[r + 1] - rp[r] > CSR_LONG_ROW) continue;
       double s = 0.0;
       for (int p = rp[r]; p < rp[r + 1]; ++p) s += v[p] * x[ci[p]];
       y[r] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[r]);
    }
+}
+
+// one workgroup per long row (rows listed in long_rows)
+__global__ __launch_bounds__(256) void k_csr_mult_long(const int* __restrict__ long_rows, const int* __restrict__ rp,
+                                                      const int* __restrict__ ci, const double* __restrict__ v,
+                                                      const double* __restrict__ x, double alpha, double beta,
+                                                      double* __restrict__ y) {
+   __shared__ double red[256];
+   const int r = long_rows[blockIdx.x];
+   double s = 0.0;
+   for (int p = rp[r] + threadIdx.x; p < rp[r + 1]; p += 256) s += v[p] * x[ci[p]];
+   red[threadIdx.x] = s;
+   __syncthreads();
+   for (int k = 128; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) y[r] = alpha * red[0] + (beta == 0.0 ? 0.0 : beta * y[r]);
 }
 
 // pack (rx, ry) into the KKT right-hand sides: b0 = [rx_0 | ry_link], leaf block i = [rx_i | ry_i]; unpack is the inverse
@@ -139,12 +163,17 @@ struct Ipm {
       owned.push_back(*d);
       return PIPS_OK;
    }
-   void mult(const int* rp, const int* ci, const double* vals, int nrows, const double* xin, double alpha, double beta, double* yout) {
+   int *A_long = nullptr, *At_long = nullptr;   // rows of A / A^T with more than CSR_LONG_ROW entries
+   int nA_long = 0, nAt_long = 0;
+   void mult(const int* rp, const int* ci, const double* vals, int nrows, const int* long_rows, int n_long, const double* xin, double alpha,
+             double beta, double* yout) {
       const int g = std::min(2048, (nrows + 255) / 256 > 0 ? (nrows + 255) / 256 : 1);
       hipLaunchKernelGGL(k_csr_mult, dim3(g), dim3(256), 0, stream, nrows, rp, ci, vals, xin, alpha, beta, yout);
+      if (n_long > 0)
+         hipLaunchKernelGGL(k_csr_mult_long, dim3(n_long), dim3(256), 0, stream, long_rows, rp, ci, vals, xin, alpha, beta, yout);
    }
-   void Amult(const double* xin, double alpha, double beta, double* yout) { mult(A_rp, A_ci, A_v, ny, xin, alpha, beta, yout); }
-   void ATmult(const double* yin, double alpha, double beta, double* xout) { mult(At_rp, At_ci, At_v, nx, yin, alpha, beta, xout); }
+   void Amult(const double* xin, double alpha, double beta, double* yout) { mult(A_rp, A_ci, A_v, ny, A_long, nA_long, xin, alpha, beta, yout); }
+   void ATmult(const double* yin, double alpha, double beta, double* xout) { mult(At_rp, At_ci, At_v, nx, At_long, nAt_long, yin, alpha, beta, xout); }
 
    // Residuals::evaluate for this problem class: rQ = c - A^T y - gamma, rA = A x - b, rv = x - v; returns the inf-norm
    int residuals(double* rnorm, double* pobj, double* dobj) {
@@ -587,6 +616,14 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
                                nullptr, 0, 1);
    if (rc) return rc;
    HIP_TRYH(hipGetDevice(&p->device));
+   {
+      std::vector<int> la, lat;
+      for (int r = 0; r < p->ny; ++r) if (Arp[r + 1] - Arp[r] > CSR_LONG_ROW) la.push_back(r);
+      for (int r = 0; r < p->nx; ++r) if (Atrp[r + 1] - Atrp[r] > CSR_LONG_ROW) lat.push_back(r);
+      p->nA_long = (int)la.size(); p->nAt_long = (int)lat.size();
+      la.push_back(0); lat.push_back(0);   // never upload an empty array
+      if ((rc = p->up(&p->A_long, la)) || (rc = p->up(&p->At_long, lat))) return rc;
+   }
    if ((rc = p->up(&p->A_rp, Arp)) || (rc = p->up(&p->A_ci, Aci)) || (rc = p->up(&p->A_v, Av)) || (rc = p->up(&p->At_rp, Atrp)) ||
        (rc = p->up(&p->At_ci, Atci)) || (rc = p->up(&p->At_v, Atv)) || (rc = p->up(&p->d_xoff, xoff)) || (rc = p->up(&p->d_yoff, yoff)) ||
        (rc = p->up(&p->d_koff, koff)))
