@@ -372,6 +372,7 @@ struct Engine {
    std::vector<long long> x_off;    // nblk+1 offsets into flat vectors
    std::vector<LevelRange> levels;
    std::vector<LevelRange> levels_top;   // the spine's levels, for the multi-vector sweeps (which are level-scheduled throughout)
+   int *d_frowptr = nullptr, *d_fcol = nullptr, *d_fsrc = nullptr;   // full row structure of K for the refinement residual
    int* d_sctab = nullptr;    // sparse Schur complement (set_sc_tables): position tables, BlkDesc::sctab_off
    int schur_mode = 0;        // requested: 0 auto, 1 augmented partial factorisation, 2 blocked solves (reference K4-K6)
    int schur_mode_eff = 1;    // what analyze() settled on
@@ -404,7 +405,7 @@ struct Engine {
    }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
-                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab,
+                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -417,6 +418,7 @@ struct Engine {
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
       d_spine = d_spine_off = d_schur_cols = d_schur_slot = d_sctab = nullptr;
+      d_frowptr = d_fcol = d_fsrc = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
@@ -630,6 +632,27 @@ struct Engine {
          std::copy(in[b].kcol.begin(), in[b].kcol.end(), h_kcolidx.begin() + kptr[b]);
       }
       h_krowptr[n_total] = (int)nnzK_total;
+      {  // both triangles, row by row: entry (i, j) of the lower CSR also appears in row j as (j, i)
+         std::vector<int> frp(n_total + 1, 0);
+         for (int b = 0; b < nblk; ++b)
+            for (int i = 0; i < sym[b].n; ++i)
+               for (int p = in[b].krow[i]; p < in[b].krow[i + 1]; ++p) {
+                  const int j = in[b].kcol[p];
+                  ++frp[x_off[b] + i + 1];
+                  if (j != i) ++frp[x_off[b] + j + 1];
+               }
+         for (long long r = 0; r < n_total; ++r) frp[r + 1] += frp[r];
+         std::vector<int> fcol(frp[n_total]), fsrc(frp[n_total]), fill(frp.begin(), frp.end() - 1);
+         for (int b = 0; b < nblk; ++b)
+            for (int i = 0; i < sym[b].n; ++i)
+               for (int p = in[b].krow[i]; p < in[b].krow[i + 1]; ++p) {
+                  const int j = in[b].kcol[p], src = (int)(kptr[b] + p);
+                  int q = fill[x_off[b] + i]++;
+                  fcol[q] = j; fsrc[q] = src;
+                  if (j != i) { q = fill[x_off[b] + j]++; fcol[q] = i; fsrc[q] = src; }
+               }
+         if ((rc = dev_upload(&d_frowptr, frp, stream)) || (rc = dev_upload(&d_fcol, fcol, stream)) || (rc = dev_upload(&d_fsrc, fsrc, stream))) return rc;
+      }
       // border CSR, global
       std::vector<int> h_bt_rowptr, h_bt_colidx(nnzB_total), h_bt_rowsc;
       std::vector<long long> h_bt_xoff;
@@ -940,7 +963,7 @@ struct Engine {
             HIP_TRY(hipMemcpy2DAsync(d_mx_xw, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
                                      (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
             // (d_mx_xw is free between solves; it is at least nr * n_total long because xw_total >= n_total)
-            hipLaunchKernelGGL(k_sym_spmv_sub, dim3(grid_for(n_total, 256), nr), dim3(256), 0, stream, d_krowptr, d_kcolidx, d_kval,
+            hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256), nr), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                                d_mx_xw, d_mx_res, n_total, d_rowbase, n_total);
             rc = use_multi(nr) ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
             if (rc) return rc;
@@ -969,7 +992,7 @@ struct Engine {
       if (rc) return rc;
       for (int it = 0; it < refine_steps; ++it) {
          HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
-         hipLaunchKernelGGL(k_sym_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_krowptr, d_kcolidx, d_kval,
+         hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                             x_dev, d_res, n_total, d_rowbase, 0LL);
          if (refine_tol > 0.0) {
             hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);

@@ -1378,25 +1378,19 @@ __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ 
    for (int e = 0; e < 16; ++e) xt[(long long)(tj * TILE + g * 16 + e) * MQ + q] = acc[e];
 }
 
-// y = alpha * K x + beta-free accumulate (y must be initialised): symmetric lower CSR, one thread per row, atomics for
-// the transposed part.  Used by iterative refinement:  r = b - K x.
-__global__ void k_sym_spmv_sub(const int* __restrict__ rowptr, const int* __restrict__ colidx,
-                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
-                               long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride) {
-   x += vec_stride * blockIdx.y;   // blockIdx.y = right-hand side
+// refinement residual r = b - K x (r holds b on entry): the full (both triangles) row structure is built at analyze time -
+// frowptr / fcol (block-local column) / fsrc (index of the value inside kval) - so the product is gather-only, no atomics:
+//   y_i -= sum_j K_ij x_j
+__global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __restrict__ fcol, const int* __restrict__ fsrc,
+                                const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+                                long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride) {
+   x += vec_stride * blockIdx.y;
    y += vec_stride * blockIdx.y;
-   // rowptr is global over all blocks (entries index kval), colidx is block-local; row_blk_base[row] = x_off of its block
    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows_total; i += (long long)gridDim.x * blockDim.x) {
       const long long base = row_blk_base[i];
-      const double xi = x[i];
       double s = 0.0;
-      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-         const long long j = base + colidx[p];
-         const double a = val[p];
-         s += a * x[j];
-         if (j != i) atomic_add_f64(y + j, -a * xi);
-      }
-      atomic_add_f64(y + i, -s);
+      for (int p = frowptr[i]; p < frowptr[i + 1]; ++p) s += val[fsrc[p]] * x[base + fcol[p]];
+      y[i] -= s;
    }
 }
 
