@@ -373,6 +373,8 @@ struct Engine {
    std::vector<LevelRange> levels;
    std::vector<LevelRange> levels_top;   // the spine's levels, for the multi-vector sweeps (which are level-scheduled throughout)
    int *d_frowptr = nullptr, *d_fcol = nullptr, *d_fsrc = nullptr;   // full row structure of K for the refinement residual
+   long long* d_flong = nullptr;   // its rows longer than FULL_LONG_ROW
+   int n_flong = 0;
    int* d_sctab = nullptr;    // sparse Schur complement (set_sc_tables): position tables, BlkDesc::sctab_off
    int schur_mode = 0;        // requested: 0 auto, 1 augmented partial factorisation, 2 blocked solves (reference K4-K6)
    int schur_mode_eff = 1;    // what analyze() settled on
@@ -405,7 +407,7 @@ struct Engine {
    }
    void release() {
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
-                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc,
+                      d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc, d_flong,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -418,7 +420,7 @@ struct Engine {
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
       d_spine = d_spine_off = d_schur_cols = d_schur_slot = d_sctab = nullptr;
-      d_frowptr = d_fcol = d_fsrc = nullptr;
+      d_frowptr = d_fcol = d_fsrc = nullptr; d_flong = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
@@ -651,7 +653,13 @@ struct Engine {
                   fcol[q] = j; fsrc[q] = src;
                   if (j != i) { q = fill[x_off[b] + j]++; fcol[q] = i; fsrc[q] = src; }
                }
-         if ((rc = dev_upload(&d_frowptr, frp, stream)) || (rc = dev_upload(&d_fcol, fcol, stream)) || (rc = dev_upload(&d_fsrc, fsrc, stream))) return rc;
+         std::vector<long long> flong;
+         for (long long r = 0; r < n_total; ++r)
+            if (frp[r + 1] - frp[r] > FULL_LONG_ROW) flong.push_back(r);
+         n_flong = (int)flong.size();
+         if ((rc = dev_upload(&d_frowptr, frp, stream)) || (rc = dev_upload(&d_fcol, fcol, stream)) || (rc = dev_upload(&d_fsrc, fsrc, stream)) ||
+             (rc = dev_upload(&d_flong, flong, stream)))
+            return rc;
       }
       // border CSR, global
       std::vector<int> h_bt_rowptr, h_bt_colidx(nnzB_total), h_bt_rowsc;
@@ -765,7 +773,10 @@ struct Engine {
       timer.reset();
       if (timer.on) timer.begin(stream, 6);
       if (timer.on) timer.begin(stream, 0);
-      hipLaunchKernelGGL(k_block_absmax, dim3(nblk), dim3(256), 0, stream, d_kval, d_kptr, d_blks, thr_rel, repl_rel);
+      hipLaunchKernelGGL(k_block_absmax_init, dim3((nblk + 255) / 256), dim3(256), 0, stream, d_blks, nblk);
+      hipLaunchKernelGGL(k_block_absmax, dim3(std::max(1, std::min(64, (int)(nnzK_total / nblk / 4096))), nblk), dim3(256), 0, stream, d_kval,
+                         d_kptr, d_blks);
+      hipLaunchKernelGGL(k_block_absmax_finish, dim3((nblk + 255) / 256), dim3(256), 0, stream, d_blks, nblk, thr_rel, repl_rel);
       hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
       if (nnzK_total > 0)
@@ -965,6 +976,9 @@ struct Engine {
             // (d_mx_xw is free between solves; it is at least nr * n_total long because xw_total >= n_total)
             hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256), nr), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                                d_mx_xw, d_mx_res, n_total, d_rowbase, n_total);
+            if (n_flong > 0)
+               hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong, nr), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval,
+                                  d_mx_xw, d_mx_res, d_rowbase, n_total);
             rc = use_multi(nr) ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
             if (rc) return rc;
             for (int r = 0; r < nr; ++r)
@@ -994,6 +1008,9 @@ struct Engine {
          HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
          hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                             x_dev, d_res, n_total, d_rowbase, 0LL);
+         if (n_flong > 0)
+            hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev,
+                               d_res, d_rowbase, 0LL);
          if (refine_tol > 0.0) {
             hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
             if (refine_mode == 1)
@@ -1109,7 +1126,9 @@ struct DenseLdl {
       hipLaunchKernelGGL(k_copy_lower_to_padded, dim3(grid_for((long long)npad * npad, 256)), dim3(256), 0, stream, A_dev,
                          lda, n, d_R, npad, npad, rowmajor);
       hipLaunchKernelGGL(k_pref_tail, dim3(8, 1), dim3(256), 0, stream, d_blks, d_R, d_pref, 1);
-      hipLaunchKernelGGL(k_block_absmax, dim3(1), dim3(256), 0, stream, d_pref, d_kptr, d_blks, thr_rel, repl_rel);
+      hipLaunchKernelGGL(k_block_absmax_init, dim3(1), dim3(256), 0, stream, d_blks, 1);
+      hipLaunchKernelGGL(k_block_absmax, dim3(8, 1), dim3(256), 0, stream, d_pref, d_kptr, d_blks);
+      hipLaunchKernelGGL(k_block_absmax_finish, dim3(1), dim3(256), 0, stream, d_blks, 1, thr_rel, repl_rel);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, 3 * sizeof(int), stream));
       int rc = tail_factor(ctx(), nullptr, 0);
       if (rc) return rc;

@@ -31,7 +31,7 @@ for i in range(N):
 c = np.concatenate(cs); b = np.concatenate([blink] + bs)
 F0p = pa.Csr(myl, n0, F0.indptr, F0.indices, F0.data)
 print(f"{N} blocks x {n_i} vars ({my_i} time-coupled rows, band {bw}), {L} linking rows per neighbouring pair: S = {n0 + myl}, {c.size:,} variables", flush=True)
-for sparse in (1, 0):
+for sparse in ((1,) if os.environ.get("PIPS_DEMO_ONLY_SPARSE") else (1, 0)):
     os.environ["PIPS_IPM_SPARSE_ROOT"] = str(sparse)
     t0 = time.time(); ipm = pa.IpmSolver(n0, myl, blocks, F0p, c, b); ts = time.time() - t0
     t0 = time.time(); res = ipm.solve(max_iter=150, mutol=1e-8, artol=1e-8); dt = time.time() - t0
