@@ -20,11 +20,18 @@ pytestmark = pytest.mark.gpu
 SHAPE = dict(seed=92, N=5, n_i=300, my_i=150, n0=12, myl=10, rho=0.03)
 
 
-def _worker(rank, world, port, out):
+def _make_problem(sparse_root):
+    if sparse_root:
+        from tests.test_sparse_root_gpu import TwoLinkProblem
+        return TwoLinkProblem(93, 6, 240, 120, 5, 4, 5.0 / 240)
+    return Problem(**SHAPE)
+
+
+def _worker(rank, world, port, out, sparse_root):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    prob = Problem(**SHAPE)
+    prob = _make_problem(sparse_root)
     mine = np.nonzero(pa.map_children_to_ranks(prob.N, world) == rank)[0]
     S = prob.S
     calls = []
@@ -39,15 +46,20 @@ def _worker(rank, world, port, out):
 
     comm = pa.ExternalComm(allreduce)
     bt = pa.LeafBatch(len(mine), S, device=0)
+    if sparse_root:
+        bt.set_schur_mode(1)
     for i, b in enumerate(mine):
         bt.set_block(i, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
     bt.analyze(2)
     for i, b in enumerate(mine):
         bt.set_values(i, prob.blocks[b]["K"].val)
-    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=world)
+    # sparse root: every rank needs the border column sets of ALL blocks (one common pattern to reduce)
+    cols = [np.nonzero(np.diff(prob.blocks[b]["Bt"].rowptr) > 0)[0] for b in range(prob.N)] if sparse_root else None
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=world, sparse_root=sparse_root,
+                       all_block_cols=cols)
     diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in mine]), device="cuda")
     kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
-    SC = hip_lower_as_rowmajor(kkt.schur_to_host(), S)
+    SC = kkt.schur_sparse_to_host().toarray() if sparse_root else hip_lower_as_rowmajor(kkt.schur_to_host(), S)
     rng = np.random.default_rng(4)
     b0_full = rng.standard_normal(S)
     bs_full = [rng.standard_normal(prob.n_leaf) for _ in range(prob.N)]
@@ -62,11 +74,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_processes_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("sparse_root", [False, True], ids=["dense_root", "sparse_root"])
+def test_two_processes_share_one_gpu(tmp_path, sparse_root):
     world = 2
-    port = 29500 + (os.getpid() % 2000)
-    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
-    prob = Problem(**SHAPE)
+    port = 29500 + (os.getpid() % 2000) + (7 if sparse_root else 0)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), sparse_root), nprocs=world, join=True, start_method="spawn")
+    prob = _make_problem(sparse_root)
     S = prob.S
     SC1 = np.tril(prob.oracle_finalize(prob.oracle_schur()))
     root = orc.DenseRootSolver(S)
@@ -79,7 +92,9 @@ def test_two_processes_share_one_gpu(tmp_path):
     seen = []
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
-        assert list(g["calls"]) == [S * (S + 1) // 2, S]          # packed Schur triangle, then b0
+        assert len(g["calls"]) == 2 and g["calls"][1] == S          # Schur complement (packed triangle / CSR values), then b0
+        if not sparse_root:
+            assert g["calls"][0] == S * (S + 1) // 2
         assert np.abs(g["SC"] - SC1).max() / np.abs(SC1).max() < 1e-9
         assert np.linalg.norm(g["xroot"] - b0) / np.linalg.norm(b0) < 1e-8
         for b in g["blocks"]:
