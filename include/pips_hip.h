@@ -246,7 +246,8 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
                     const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
                     const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
                     const double* F0_val, const double* c, const double* b, double dual_reg, int device);
-/* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown)
+/* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown before any
+ * usable iterate, 3 numerical troubles: the best iterate so far is returned - its mu / residual are in [2] / [3])
  * [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
 int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7);
 /* Gondzio multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358): 0 = plain Mehrotra predictor-

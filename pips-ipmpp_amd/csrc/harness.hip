@@ -135,6 +135,7 @@ struct Ipm {
    double *bz = nullptr, *xz = nullptr, *w_r = nullptr, *w_r0 = nullptr, *w_best = nullptr, *w_v = nullptr, *w_t = nullptr, *w_p = nullptr,
           *w_dx = nullptr;
    double *gv = nullptr, *gg = nullptr;   // Gondzio trial vectors
+   double *bx = nullptr, *bv = nullptr, *bg = nullptr, *by = nullptr;   // best iterate so far (numerical-trouble fallback)
    int max_gondzio = 2;   // multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358)
    long long n_gondzio = 0;
    int outer_mode = 2;   // 1 = iterative refinement, 2 = BiCGStab (the reference's OUTER_SOLVE default)
@@ -279,12 +280,15 @@ struct Ipm {
       double rho = 1.0, omega = 1.0, alpha = 1.0;
       int ndiv = 0, nstag = 0;
       auto is_zero = [](double v) { return std::fabs(v) < 1e-40; };   // PIPSisZero with pips_eps0 (pipsdef.h:35,108)
+      // breakdown guard: near the optimum rho / (r0, v) can lose all digits and alpha, omega overflow; a non-finite quantity
+      // ends the iteration and the best iterate so far is returned (NaN compares false, so the roll-backs below would miss it)
+      auto bad = [](double v) { return !(v == v) || std::fabs(v) > 1e300; };
       auto stagn = [&](double step, double step_norm, double xn) { if (std::fabs(step) * step_norm <= eps * xn) ++nstag; else nstag = 0; };
       int it = 0;
       for (; it < 75; ++it) {
          const double rho_last = rho;
          TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_r, &rho, stream));
-         if (is_zero(rho)) break;
+         if (is_zero(rho) || bad(rho)) break;
          if (it == 0) TRY(pips_hip_vec_copy(nz(), w_r, w_p, stream));
          else {
             const double beta = (rho / rho_last) * (alpha / omega);
@@ -297,14 +301,16 @@ struct Ipm {
          TRY(kmult(w_dx, w_v));
          double rtv, dxn, xn;
          TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_v, &rtv, stream));
-         if (is_zero(rtv)) break;
+         if (is_zero(rtv) || bad(rtv)) break;
          alpha = rho / rtv;
+         if (bad(alpha)) break;
          TRY(two_norm(w_dx, &dxn));
          TRY(two_norm(x_, &xn));
          stagn(alpha, dxn, xn);
          TRY(pips_hip_vec_axpy(nz(), alpha, w_dx, x_, stream));   // half-way iterate
          TRY(pips_hip_vec_axpy(nz(), -alpha, w_v, w_r, stream));
          TRY(two_norm(w_r, &rn));
+         if (bad(rn)) break;
          if (rn <= target) {
             TRY(residual(b_, x_, w_r, &rn));
             if (rn <= target) break;
@@ -315,15 +321,17 @@ struct Ipm {
          TRY(kmult(w_dx, w_t));
          double tt, tr;
          TRY(pips_hip_vec_dot(nz(), 0, w_t, w_t, &tt, stream));
-         if (is_zero(tt)) break;
+         if (is_zero(tt) || bad(tt)) break;
          TRY(pips_hip_vec_dot(nz(), 0, w_t, w_r, &tr, stream));
          omega = tr / tt;
+         if (bad(omega)) break;
          TRY(two_norm(w_dx, &dxn));
          TRY(two_norm(x_, &xn));
          stagn(omega, dxn, xn);
          TRY(pips_hip_vec_axpy(nz(), omega, w_dx, x_, stream));
          TRY(pips_hip_vec_axpy(nz(), -omega, w_t, w_r, stream));
          TRY(two_norm(w_r, &rn));
+         if (bad(rn)) break;
          if (rn <= target || nstag >= 4) {
             TRY(residual(b_, x_, w_r, &rn));
             if (rn <= target) break;
@@ -335,7 +343,7 @@ struct Ipm {
          if (nstag >= 4) { if (min_rn < rn) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; } break; }
          if (is_zero(omega)) break;
       }
-      if (min_rn < rn) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; }
+      if (min_rn < rn || bad(rn)) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; }
       last_outer_steps = it + 1;
       last_outer_res = bn > 0 ? rn / bn : rn;
       return PIPS_OK;
@@ -460,15 +468,44 @@ struct Ipm {
 
       int it = 0, status = 1;  // 1 = max iterations
       trace.clear();
+      // Numerical-trouble fallback.  Far below the reference's default accuracy (mu 1e-6) the leaf diagonals span sixteen
+      // decades and a step can come out useless (step lengths of 1e-16) or harmful (a full step that throws the residual
+      // from 1e-11 to 1); the reference answers with its "numerical troubles" logic (InteriorPointMethod.cpp:264-274,
+      // PIPSIPMppSolver.cpp:163-185).  Here the iterate with the best merit max(mu / mutol, ||r|| / (artol dnorm)) is kept
+      // and returned with status 3 when the iteration breaks down (NaN, residual blow-up, two stalled steps).
+      double best_merit = INFINITY, best_rnorm = INFINITY;
+      int n_stall = 0;
+      auto merit = [&](double mm, double rr) { return std::max(mm / mutol, rr / (artol * dnorm)); };
+      auto save_best = [&]() -> int {
+         TRY(pips_hip_vec_copy(nx, x, bx, stream)); TRY(pips_hip_vec_copy(nx, v, bv, stream));
+         TRY(pips_hip_vec_copy(nx, g, bg, stream)); TRY(pips_hip_vec_copy(ny, y, by, stream));
+         return PIPS_OK;
+      };
+      auto restore_best = [&]() -> int {
+         TRY(pips_hip_vec_copy(nx, bx, x, stream)); TRY(pips_hip_vec_copy(nx, bv, v, stream));
+         TRY(pips_hip_vec_copy(nx, bg, g, stream)); TRY(pips_hip_vec_copy(ny, by, y, stream));
+         TRY(residuals(&rnorm, &pobj, &dobj));
+         TRY(mu(&m));
+         return PIPS_OK;
+      };
       for (; it < max_iter; ++it) {
          TRY(residuals(&rnorm, &pobj, &dobj));
          TRY(mu(&m));
+         const bool is_nan = !(m == m) || !(rnorm == rnorm) || !(pobj == pobj);
+         const bool blown = !is_nan && best_merit < INFINITY && rnorm > 1e4 * std::max(best_rnorm, artol * dnorm);
+         if ((is_nan || blown || n_stall >= 2) && best_merit < INFINITY) {
+            TRY(restore_best());
+            trace.insert(trace.end(), {m, rnorm, pobj, dobj, 0.0, 0.0, 0.0});
+            status = (m <= mutol && rnorm <= artol * dnorm) ? 0 : 3;
+            break;
+         }
+         if (!is_nan && merit(m, rnorm) < best_merit) { best_merit = merit(m, rnorm); best_rnorm = rnorm; TRY(save_best()); }
          trace.insert(trace.end(), {m, rnorm, pobj, dobj, 0.0, 0.0, 0.0});   // step data filled in below
          if (verbose)
             printf("ipm it %3d  mu %.3e  ||r||inf %.3e  pobj %.10e  dobj %.10e  (last solve: %d outer its, rel.res %.1e)\n", it, m, rnorm, pobj,
                    dobj, last_outer_steps, last_outer_res);
          if (verbose) fflush(stdout);
-         if (!(m == m) || !(rnorm == rnorm)) { status = 2; break; }         // numerical breakdown (NaN)
+         if (is_nan) { status = 2; break; }                                 // numerical breakdown before any usable iterate
          if (m <= mutol && rnorm <= artol * dnorm) { status = 0; break; }   // PIPSIPMppSolver.cpp:143-149
          // outer tolerance schedule (InteriorPointMethod.cpp:655-669): 1e-8 up to iteration 3, 1e-9 up to 7, then 1e-10
          outer_tol = it <= 3 ? 1e-8 : (it <= 7 ? 1e-9 : 1e-10);
@@ -495,6 +532,7 @@ struct Ipm {
          const double tau = std::max(0.99, 1.0 - m);
          TRY(step_lengths(dv, dg, tau, &ap, &ad));
          TRY(gondzio_loop(sigma, m, tau, &ap, &ad));
+         n_stall = (ap < 1e-10 && ad < 1e-10) ? n_stall + 1 : 0;
          { double* row = trace.data() + trace.size() - 7; row[4] = sigma; row[5] = ap; row[6] = ad; }
          TRY(pips_hip_vec_axpy(nx, ap, dx, x, stream));
          TRY(pips_hip_vec_axpy(nx, ap, dv, v, stream));
@@ -630,10 +668,10 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
       return rc;
    std::vector<double> hc(c, c + p->nx), hb(b, b + p->ny);
    if ((rc = p->up(&p->c, hc)) || (rc = p->up(&p->b, hb))) return rc;
-   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx, &p->gv, &p->gg};
+   double** xs[] = {&p->x, &p->v, &p->g, &p->rQ, &p->rv, &p->rg, &p->dd, &p->dx, &p->dv, &p->dg, &p->cx, &p->cv, &p->cg, &p->tx, &p->zx, &p->gv, &p->gg, &p->bx, &p->bv, &p->bg};
    for (auto d : xs)
       if ((rc = p->alloc(d, p->nx))) return rc;
-   double** ys[] = {&p->y, &p->rA, &p->dy, &p->cy, &p->ty, &p->zy};
+   double** ys[] = {&p->y, &p->rA, &p->dy, &p->cy, &p->ty, &p->zy, &p->by};
    for (auto d : ys)
       if ((rc = p->alloc(d, p->ny))) return rc;
    double** zs[] = {&p->bz, &p->xz, &p->w_r, &p->w_r0, &p->w_best, &p->w_v, &p->w_t, &p->w_p, &p->w_dx};
