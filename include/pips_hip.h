@@ -231,6 +231,10 @@ int pips_hip_vec_min(long long n, const double* x_dev, double* result, void* str
 int pips_hip_vec_sumsq_scaled(long long n, long long skip_root, double scale_inv, const double* x_dev, double* result, void* stream);
 /* min over {dx_i < 0, mask_i != 0} of -x_i/dx_i (fraction_to_boundary / stepbound, Variables.C:191-225) */
 int pips_hip_vec_stepbound(long long n, const double* x_dev, const double* dx_dev, const double* mask_dev, double* result, void* stream);
+/* Variables::find_blocking (Variables.C:227-308) for one pair of complementary vectors: out5 = [min ratio -x_i/dx_i over
+ * dx_i < 0 (inf if no entry blocks), then x, dx, y, dy at the blocking index (smallest index on ties)] */
+int pips_hip_vec_find_blocking(long long n, const double* x_dev, const double* dx_dev, const double* y_dev, const double* dy_dev,
+                               double* out5, void* stream);
 /* sum (x + a dx)(y + b dy)  (mustep_pd, Variables.C:109) */
 int pips_hip_vec_dot_shifted(long long n, long long skip_root, const double* x_dev, double a, const double* dx_dev,
                              const double* y_dev, double b, const double* dy_dev, double* result, void* stream);
@@ -257,6 +261,9 @@ int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
 /* history of the last pips_ipm_solve, one row of 7 doubles per iterate: mu, ||r||inf, primal objective, dual objective, and the
  * step taken from it: sigma, alpha_primal, alpha_dual (zeros in the final row).  rows7 may be NULL to query *n_rows. */
 int pips_ipm_get_trace(void* handle, double* rows7, int max_rows, int* n_rows);
+/* counters of the last pips_ipm_solve: [0] KKT factorisations, [1] of which repeats with added dual regularisation (the inertia
+ * loop, LinearSystem.C:295-325), [2] solveCompressed calls (preconditioner applications), [3] Gondzio correctors accepted */
+int pips_ipm_get_stats(void* handle, long long* stats4);
 void pips_ipm_destroy(void* handle);
 
 /* ---------------------------------------------------------------------------------------------------------------

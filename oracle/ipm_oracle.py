@@ -5,10 +5,12 @@ generator's problem class  min c^T x, A x = b, x >= 0  (ixlow = 1 everywhere, no
   start point        PIPSIPMppSolver::solve (PIPSIPMppSolver.cpp:36-42), Solver::solve_linear_system (Solver.cpp:19-31)
   residuals          Residuals::evaluate (Residuals.cpp:58-171): rQ = c - A^T y - gamma, rA = A x - b, rv = x - v
   linear system      LinearSystem::computeDiagonals/solve/solveXYZS (LinearSystem.C:262-294,327-447,449-548)
-  predictor/corrector InteriorPointMethod.cpp:68-90,178-234: sigma = (mu_aff/mu)^3, tau = max(0.99, 1-mu)
+  predictor/corrector InteriorPointMethod.cpp:68-90,178-234: sigma = (mu_aff/mu)^3, corrector blended in with the weight
+                     of the 10-point search (:486-523), Gondzio correctors (:236-358)
+  step length        PrimalDualInteriorPointMethod::mehrotra_step_length (InteriorPointMethod.cpp:745-812)
   termination        PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm
 The KKT system [dd A^T; A 0] is solved with SuperLU here (the arithmetic under test lives in the HIP path).
-Not reproduced (neither here nor in the harness): Gondzio correctors, Mehrotra's step heuristic, filter line search.
+Not reproduced (neither here nor in the harness): the filter line search and the small-corrector heuristics.
 """
 import numpy as np
 import scipy.sparse as sp
@@ -18,6 +20,49 @@ import scipy.sparse.linalg as spl
 def stepbound(v, dv):
     neg = dv < 0
     return np.min(-v[neg] / dv[neg]) if neg.any() else np.inf
+
+
+def find_blocking(v, dv, g, dg):
+    """(ratio, v_b, dv_b, g_b, dg_b) of the first entry attaining the step bound (DenseVector::find_blocking)."""
+    neg = dv < 0
+    if not neg.any():
+        return np.inf, 0.0, 0.0, 0.0, 0.0
+    r = np.where(neg, -v / np.where(neg, dv, -1.0), np.inf)
+    i = int(np.argmin(r))
+    return r[i], v[i], dv[i], g[i], dg[i]
+
+
+def weight_search(v, dv, cv, g, dg, cg, apt, adt):
+    wmin = apt * adt
+    ape = ade = wp = wd = -1.0
+    for k in range(11):
+        w = min(1.0, wmin + (1.0 - wmin) / 10.0 * k)
+        a1 = min(1.0, stepbound(v, dv + w * cv))
+        a2 = min(1.0, stepbound(g, dg + w * cg))
+        if a1 > ape:
+            ape, wp = a1, w
+        if a2 > ade:
+            ade, wd = a2, w
+    return ape, ade, wp, wd
+
+
+def mehrotra_step_length(v, dv, g, dg):
+    gamma_f, factor = 0.99, 0.99999999
+    gamma_a = 1.0 / (1.0 - gamma_f)
+    nx = len(v)
+    pb, db = find_blocking(v, dv, g, dg), find_blocking(g, dg, v, dv)
+    amax_p, amax_d = min(1.0, pb[0]), min(1.0, db[0])
+    mufull = (v + amax_p * dv) @ (g + amax_d * dg) / nx / gamma_a
+    a_p = a_d = 1.0
+    if pb[0] < 1.0:
+        est = pb[3] + amax_d * pb[4]
+        a_p = 0.0 if est == 0.0 else (-pb[1] + mufull / est) / pb[2]
+    if db[0] < 1.0:
+        est = db[3] + amax_p * db[4]
+        a_d = 0.0 if est == 0.0 else (-db[1] + mufull / est) / db[2]
+    a_p = max(min(a_p, amax_p), gamma_f * amax_p) * factor
+    a_d = max(min(a_d, amax_d), gamma_f * amax_d) * factor
+    return a_p, a_d
 
 
 def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0, gondzio=2):
@@ -64,9 +109,9 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
         sigma = (mu_aff / mu) ** 3
         z = np.zeros(nx)
         cx, cy, cv, cg = solve(z, np.zeros(ny), z, dv * dg - sigma * mu)
-        dx += cx; dy += cy; dv += cv; dg += cg
-        tau = max(0.99, 1 - mu)
-        ap, ad = min(1.0, tau * stepbound(v, dv)), min(1.0, tau * stepbound(g, dg))
+        ap, ad, wp, wd = weight_search(v, dv, cv, g, dg, cg, ap, ad)
+        dx += wp * cx; dv += wp * cv
+        dy += wd * cy; dg += wd * cg
         # Gondzio multiple centrality correctors (gondzio_correction_loop, InteriorPointMethod.cpp:236-358, primal-dual
         # variant; projection: DenseVector.cpp:405-420; weight search: InteriorPointMethod.cpp:486-523)
         rmin, rmax = sigma * mu * 0.1, sigma * mu * 10.0
@@ -77,16 +122,7 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
             t = np.where(p < rmin, rmin - p, np.where(p > rmax, rmax - p, 0.0))
             t = np.maximum(t, -rmax)
             cx, cy, cv, cg = solve(z, np.zeros(ny), z, -t)
-            wmin = apt * adt
-            ape = ade = wp = wd = -1.0
-            for k in range(11):
-                w = min(1.0, wmin + (1.0 - wmin) / 10.0 * k)
-                a1 = min(1.0, tau * stepbound(v, dv + w * cv))
-                a2 = min(1.0, tau * stepbound(g, dg + w * cg))
-                if a1 > ape:
-                    ape, wp = a1, w
-                if a2 > ade:
-                    ade, wd = a2, w
+            ape, ade, wp, wd = weight_search(v, dv, cv, g, dg, cg, apt, adt)
             both_one = ape >= 1.0 and ade >= 1.0
             p_better, d_better = ape >= 1.01 * ap, ade >= 1.01 * ad
             if not (both_one or p_better or d_better):
@@ -98,6 +134,7 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
             ng += 1
             if both_one:
                 break
+        ap, ad = mehrotra_step_length(v, dv, g, dg)
         x += ap * dx; v += ap * dv
         y += ad * dy; g += ad * dg
         if trace is not None:   # the step that leaves iterate `it`: (sigma, alpha_primal, alpha_dual) appended to its row

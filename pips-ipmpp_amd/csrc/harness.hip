@@ -201,11 +201,37 @@ struct Ipm {
       return PIPS_OK;
    }
    // LinearSystem::factorize: dd = gamma / v, K diagonals, factor2 of the two-level system
+   // KKT factorisation with the inertia contract of LinearSystem::factorize_with_correct_inertia (LinearSystem.C:295-325):
+   // factor once as is; while a leaf or the root reports perturbed pivots (close to a vertex the dual pivots of a leaf are
+   // differences of 1e10-sized terms and can come out with the wrong sign), add dual regularisation to the leaves, 1e-8
+   // times 100 per try, and factor again.  The regularised factors only precondition: the outer solve works on the
+   // unregularised system.
+   int n_regularised = 0, n_factorize = 0, verbose_run = 0;
+   double last_reg = 0.0;
+   int perturbed_pivots(int* total) {
+      int p_, n_, z_;
+      TRY(pips_hip_kkt_root_inertia(kkt, &p_, &n_, &z_));
+      *total = z_;
+      for (int b = 0; b < N; ++b) { TRY(pips_hip_batch_inertia(batch, b, &p_, &n_, &z_)); *total += z_; }
+      return PIPS_OK;
+   }
    int factorize() {
       TRY(pips_hip_vec_copy(nx, g, dd, stream));
       TRY(pips_hip_vec_div(nx, v, dd, stream));
-      hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, dual_reg, leaf_diag);
-      return pips_hip_kkt_factorize(kkt, leaf_diag, dd, nullptr);
+      double reg = 0.0;
+      for (int attempt = 0;; ++attempt) {
+         hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, dual_reg + reg, leaf_diag);
+         TRY(pips_hip_kkt_factorize(kkt, leaf_diag, dd, nullptr));
+         ++n_factorize;
+         int pert;
+         TRY(perturbed_pivots(&pert));
+         if (verbose_run && (pert || reg > 0.0)) printf("   factorize: dual regularisation %.1e, %d perturbed pivots\n", dual_reg + reg, pert);
+         if (pert == 0 || attempt == 4) break;
+         reg = reg == 0.0 ? 1e-8 : reg * 100.0;
+         ++n_regularised;
+      }
+      last_reg = reg;
+      return PIPS_OK;
    }
    // ---- outer solve machinery on concatenated vectors z = [x | y] of length nz = nx + ny ------------------------------
    // z := M^-1 z with M^-1 = solveCompressed (the Schur-complement decomposition as preconditioner)
@@ -387,6 +413,52 @@ struct Ipm {
       return PIPS_OK;
    }
 
+   // 10-point search for the corrector weight in [alpha_p alpha_d, 1] that allows the longest steps
+   // (calculate_alpha_pd_weight_candidate, InteriorPointMethod.cpp:486-523); step bounds are plain ratios capped at 1
+   int weight_search(double apt, double adt, double* ape, double* ade, double* wp, double* wd) {
+      const double wmin = apt * adt;
+      *ape = *ade = *wp = *wd = -1.0;
+      for (int k = 0; k <= 10; ++k) {
+         const double w = std::min(1.0, wmin + (1.0 - wmin) / 10.0 * k);
+         TRY(pips_hip_vec_copy(nx, dv, gv, stream));
+         TRY(pips_hip_vec_axpy(nx, w, cv, gv, stream));
+         TRY(pips_hip_vec_copy(nx, dg, gg, stream));
+         TRY(pips_hip_vec_axpy(nx, w, cg, gg, stream));
+         double a1, a2;
+         TRY(step_lengths(gv, gg, 1.0, &a1, &a2));
+         if (a1 > *ape) { *ape = a1; *wp = w; }
+         if (a2 > *ade) { *ade = a2; *wd = w; }
+      }
+      return PIPS_OK;
+   }
+
+   // Mehrotra's step length heuristic (PrimalDualInteriorPointMethod::mehrotra_step_length, InteriorPointMethod.cpp:745-812):
+   // let the blocking pair land on the complementarity value mu_full / gamma_a instead of on the boundary, stay within
+   // [gamma_f, 1] of the maximal step, back off by 1e-8.
+   int mehrotra_step_length(double* ap, double* ad) {
+      const double gamma_f = 0.99, gamma_a = 1.0 / (1.0 - gamma_f), steplength_factor = 0.99999999;
+      double pb[5], db[5];
+      TRY(pips_hip_vec_find_blocking(nx, v, dv, g, dg, pb, stream));   // primal blocking: [ratio, v_b, dv_b, g_b, dg_b]
+      TRY(pips_hip_vec_find_blocking(nx, g, dg, v, dv, db, stream));   // dual blocking:   [ratio, g_b, dg_b, v_b, dv_b]
+      const double amax_p = std::min(1.0, pb[0]), amax_d = std::min(1.0, db[0]);
+      double mufull;
+      TRY(pips_hip_vec_dot_shifted(nx, 0, v, amax_p, dv, g, amax_d, dg, &mufull, stream));
+      mufull = mufull / nx / gamma_a;
+      double a_p = 1.0, a_d = 1.0;
+      if (pb[0] < 1.0) {
+         const double est = pb[3] + amax_d * pb[4];
+         a_p = est == 0.0 ? 0.0 : (-pb[1] + mufull / est) / pb[2];
+      }
+      if (db[0] < 1.0) {
+         const double est = db[3] + amax_p * db[4];
+         a_d = est == 0.0 ? 0.0 : (-db[1] + mufull / est) / db[2];
+      }
+      a_p = std::max(std::min(a_p, amax_p), gamma_f * amax_p) * steplength_factor;
+      a_d = std::max(std::min(a_d, amax_d), gamma_f * amax_d) * steplength_factor;
+      *ap = a_p; *ad = a_d;
+      return PIPS_OK;
+   }
+
    // Gondzio's multiple centrality correctors (gondzio_correction_loop, InteriorPointMethod.cpp:236-358, primal-dual variant):
    // aim at longer steps (1.5 alpha + 0.3), look at the complementarity products of that trial point, pull the outliers back
    // into [beta_min, beta_max] * sigma * mu (Residuals::project_r3), solve for the corrector, blend it in with the weight in
@@ -406,19 +478,8 @@ struct Ipm {
          TRY(pips_hip_vec_gondzio_projection(nx, rmin, rmax, rg, stream));
          TRY(pips_hip_vec_scale(nx, -1.0, rg, stream));
          TRY(solve(zx, zy, zx, rg, cx, cy, cv, cg));
-         const double wmin = apt * adt;
-         double ape = -1.0, ade = -1.0, wp = -1.0, wd = -1.0;
-         for (int k = 0; k <= 10; ++k) {
-            const double w = std::min(1.0, wmin + (1.0 - wmin) / 10.0 * k);
-            TRY(pips_hip_vec_copy(nx, dv, gv, stream));
-            TRY(pips_hip_vec_axpy(nx, w, cv, gv, stream));
-            TRY(pips_hip_vec_copy(nx, dg, gg, stream));
-            TRY(pips_hip_vec_axpy(nx, w, cg, gg, stream));
-            double a1, a2;
-            TRY(step_lengths(gv, gg, tau, &a1, &a2));
-            if (a1 > ape) { ape = a1; wp = w; }
-            if (a2 > ade) { ade = a2; wd = w; }
-         }
+         double ape, ade, wp, wd;
+         TRY(weight_search(apt, adt, &ape, &ade, &wp, &wd));
          const bool both_one = ape >= 1.0 && ade >= 1.0;
          const bool p_better = ape >= (1.0 + accept) * *ap, d_better = ade >= (1.0 + accept) * *ad;
          if (!both_one && !p_better && !d_better) break;
@@ -442,6 +503,9 @@ struct Ipm {
    std::vector<double> trace;   // per iterate: mu, ||r||inf, primal obj, dual obj, then the step taken from it: sigma, alpha_p, alpha_d
    int run(int max_iter, double mutol, double artol, int verbose, double* result) {
       HIP_TRYH(hipSetDevice(device));
+      verbose_run = verbose;
+      n_gondzio = n_precond = 0;
+      n_regularised = n_factorize = 0;
       // ---- start point: push_to_interior(sqrt(dnorm)), one affine solve, full step, shift (PIPSIPMppSolver.cpp:36-42, Solver.cpp:19-31)
       const double s0 = std::sqrt(dnorm);
       TRY(pips_hip_vec_set(nx, 0.0, x, stream));
@@ -494,6 +558,9 @@ struct Ipm {
          const bool is_nan = !(m == m) || !(rnorm == rnorm) || !(pobj == pobj);
          const bool blown = !is_nan && best_merit < INFINITY && rnorm > 1e4 * std::max(best_rnorm, artol * dnorm);
          if ((is_nan || blown || n_stall >= 2) && best_merit < INFINITY) {
+            if (verbose)
+               printf("ipm it %3d  numerical troubles (%s: mu %.3e ||r||inf %.3e), falling back to the best iterate\n", it,
+                      is_nan ? "nan" : (blown ? "residual blow-up" : "stalled"), m, rnorm);
             TRY(restore_best());
             trace.insert(trace.end(), {m, rnorm, pobj, dobj, 0.0, 0.0, 0.0});
             status = (m <= mutol && rnorm <= artol * dnorm) ? 0 : 3;
@@ -525,13 +592,16 @@ struct Ipm {
          TRY(pips_hip_vec_mul(nx, dg, rg, stream));
          TRY(pips_hip_vec_add_const(nx, -sigma * m, rg, stream));
          TRY(solve(zx, zy, zx, rg, cx, cy, cv, cg));   // zx / zy: constant zero vectors (clear_linear_residuals)
-         TRY(pips_hip_vec_axpy(nx, 1.0, cx, dx, stream));
-         TRY(pips_hip_vec_axpy(ny, 1.0, cy, dy, stream));
-         TRY(pips_hip_vec_axpy(nx, 1.0, cv, dv, stream));
-         TRY(pips_hip_vec_axpy(nx, 1.0, cg, dg, stream));
-         const double tau = std::max(0.99, 1.0 - m);
-         TRY(step_lengths(dv, dg, tau, &ap, &ad));
-         TRY(gondzio_loop(sigma, m, tau, &ap, &ad));
+         // weighted predictor-corrector step (compute_corrector_step, InteriorPointMethod.cpp:178-206), Gondzio loop, then
+         // the step length by Mehrotra's heuristic
+         double wp, wd;
+         TRY(weight_search(ap, ad, &ap, &ad, &wp, &wd));
+         TRY(pips_hip_vec_axpy(nx, wp, cx, dx, stream));
+         TRY(pips_hip_vec_axpy(nx, wp, cv, dv, stream));
+         TRY(pips_hip_vec_axpy(ny, wd, cy, dy, stream));
+         TRY(pips_hip_vec_axpy(nx, wd, cg, dg, stream));
+         TRY(gondzio_loop(sigma, m, 1.0, &ap, &ad));
+         TRY(mehrotra_step_length(&ap, &ad));
          n_stall = (ap < 1e-10 && ad < 1e-10) ? n_stall + 1 : 0;
          { double* row = trace.data() + trace.size() - 7; row[4] = sigma; row[5] = ap; row[6] = ad; }
          TRY(pips_hip_vec_axpy(nx, ap, dx, x, stream));
@@ -710,6 +780,13 @@ int pips_ipm_get_trace(void* handle, double* rows7, int max_rows, int* n_rows) {
    *n_rows = have;
    if (rows7)
       for (int i = 0; i < std::min(have, max_rows) * 7; ++i) rows7[i] = p->trace[i];
+   return PIPS_OK;
+}
+
+int pips_ipm_get_stats(void* handle, long long* stats4) {
+   Ipm* p = (Ipm*)handle;
+   if (!p || !stats4) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_get_stats: bad arguments");
+   stats4[0] = p->n_factorize; stats4[1] = p->n_regularised; stats4[2] = p->n_precond; stats4[3] = p->n_gondzio;
    return PIPS_OK;
 }
 

@@ -135,6 +135,22 @@ __global__ void k_vec_reduce_final(int op, int n, const double* __restrict__ par
    if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// find_blocking (Variables::find_blocking, Variables.C:227-308): index of the entry that attains the minimum ratio -x_i / dx_i
+// over dx_i < 0 (smallest index on ties), then the values of x, dx and of the paired vectors y, dy there
+__global__ void k_find_index(long long n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ target,
+                             unsigned long long* __restrict__ idx) {
+   const double t = target[0];
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      if (dx[i] < 0.0 && -x[i] / dx[i] == t) atomicMin(idx, (unsigned long long)i);
+}
+
+__global__ void k_gather_blocking(const unsigned long long* __restrict__ idx, const double* __restrict__ x, const double* __restrict__ dx,
+                                  const double* __restrict__ y, const double* __restrict__ dy, double* __restrict__ out) {
+   const unsigned long long i = idx[0];
+   if (i == ~0ULL) { out[1] = out[2] = out[3] = out[4] = 0.0; return; }
+   out[1] = x[i]; out[2] = dx[i]; out[3] = y[i]; out[4] = dy[i];
+}
+
 static double red_identity_host(int op) { return (op == RED_MIN || op == RED_STEPBOUND) ? INFINITY : 0.0; }
 
 struct VecWorkspace {
@@ -245,6 +261,27 @@ int pips_hip_vec_sumsq_scaled(long long n, long long skip_root, double scale_inv
 /* largest alpha in (0, +inf] with x + alpha dx >= 0 on the masked entries (min ratio test) */
 int pips_hip_vec_stepbound(long long n, const double* x_dev, const double* dx_dev, const double* mask_dev, double* result, void* stream) {
    return vec_reduce(RED_STEPBOUND, n, 0, 0, 0, x_dev, nullptr, dx_dev, nullptr, mask_dev, result, (hipStream_t)stream);
+}
+/* out5 = [min ratio -x_i/dx_i over dx_i < 0 (inf if none), x_b, dx_b, y_b, dy_b at the blocking index b]
+ * (Variables::find_blocking, Variables.C:227-308, for one pair of complementary vectors) */
+int pips_hip_vec_find_blocking(long long n, const double* x_dev, const double* dx_dev, const double* y_dev, const double* dy_dev,
+                               double* out5, void* stream) {
+   hipStream_t s = (hipStream_t)stream;
+   double ratio;
+   int rc = vec_reduce(RED_STEPBOUND, n, 0, 0, 0, x_dev, nullptr, dx_dev, nullptr, nullptr, &ratio, s);
+   if (rc) return rc;
+   out5[0] = ratio;
+   out5[1] = out5[2] = out5[3] = out5[4] = 0.0;
+   if (n <= 0 || !(ratio < INFINITY)) return PIPS_OK;
+   // slot layout of the workspace: [2048] the minimum (still there from vec_reduce), [2049] the index, [2050..2054] the result
+   unsigned long long* d_idx = (unsigned long long*)(g_ws.d_partial + 2049);
+   HIP_TRYV(hipMemsetAsync(d_idx, 0xff, sizeof(unsigned long long), s));
+   hipLaunchKernelGGL(k_find_index, dim3(vgrid(n)), dim3(256), 0, s, n, x_dev, dx_dev, g_ws.d_partial + 2048, d_idx);
+   hipLaunchKernelGGL(k_gather_blocking, dim3(1), dim3(1), 0, s, d_idx, x_dev, dx_dev, y_dev, dy_dev, g_ws.d_partial + 2050);
+   HIP_TRYV(hipMemcpyAsync(g_ws.h_out, g_ws.d_partial + 2050, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+   HIP_TRYV(hipStreamSynchronize(s));
+   for (int i = 1; i < 5; ++i) out5[i] = g_ws.h_out[i];
+   return PIPS_OK;
 }
 /* sum (x + a dx)(y + b dy)  (complementarity after a trial step) */
 int pips_hip_vec_dot_shifted(long long n, long long skip_root, const double* x_dev, double a, const double* dx_dev,

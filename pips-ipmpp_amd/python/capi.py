@@ -66,7 +66,7 @@ SYMBOLS = [
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_destroy",
+    "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
 ]
@@ -654,6 +654,12 @@ class vec:
         _check(lib.pips_hip_vec_safe_invert(vec._n(y), _ptr(y), None), "vec_safe_invert")
 
     @staticmethod
+    def find_blocking(x, dx, y, dy):
+        out = np.zeros(5)
+        _check(lib.pips_hip_vec_find_blocking(vec._n(x), _ptr(x), _ptr(dx), _ptr(y), _ptr(dy), _ptr(out), None), "vec_find_blocking")
+        return out
+
+    @staticmethod
     def gondzio_projection(rmin, rmax, y):
         _check(lib.pips_hip_vec_gondzio_projection(vec._n(y), C.c_double(rmin), C.c_double(rmax), _ptr(y), None), "vec_gondzio_projection")
 
@@ -747,6 +753,13 @@ class IpmSolver:
         out = np.zeros((n.value, 7))
         _check(lib.pips_ipm_get_trace(self._h, _ptr(out), C.c_int(n.value), C.byref(n)), "pips_ipm_get_trace")
         return out
+
+    def stats(self):
+        """Counters of the last solve: KKT factorisations, repeats with added dual regularisation (inertia loop), solveCompressed
+        calls, accepted Gondzio correctors."""
+        out = (C.c_longlong * 4)()
+        _check(lib.pips_ipm_get_stats(self._h, out), "pips_ipm_get_stats")
+        return dict(factorizations=out[0], regularised_repeats=out[1], solve_compressed=out[2], gondzio_correctors=out[3])
 
     def close(self):
         if self._h:

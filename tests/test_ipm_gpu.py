@@ -68,6 +68,9 @@ def test_ipm_objective_matches_highs(shape):
         # residual norms are compared down to the level the linear solves resolve (1e-10 relative to the data norm)
         assert abs(tr[k, 1] - rnorm) <= tol * rnorm + 1e-10 * o["dnorm"], (k, tr[k], trace[k])
         assert abs(tr[k, 4] - sigma) <= 10 * tol and abs(tr[k, 5] - ap) <= 10 * tol and abs(tr[k, 6] - ad) <= 10 * tol, (k, tr[k], trace[k])
+    st = ipm.stats()
+    assert st["factorizations"] >= res["iterations"] + 1 and st["factorizations"] - st["regularised_repeats"] == res["iterations"] + 1
+    assert st["solve_compressed"] >= 2 * res["iterations"]
     x, y = ipm.solution()
     assert x.min() > -1e-9
     assert np.linalg.norm(A @ x - b, np.inf) <= 1e-8 * max(1.0, np.abs(b).max())

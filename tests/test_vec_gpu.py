@@ -96,3 +96,26 @@ def test_empty_and_tiny_vectors():
     assert V.dot(e, e) == 0.0 and V.inf_norm(e) == 0.0 and V.min(e) == float("inf")
     one = torch.tensor([-3.0], dtype=torch.float64, device="cuda")
     assert V.inf_norm(one) == 3.0 and V.two_norm(one) == 3.0
+
+
+def test_find_blocking_matches_numpy():
+    """DenseVector::find_blocking (DenseVector.cpp:1002-1050 region): the entry that attains the step bound, with the
+    complementary pair's values at that index; ties resolve to the lowest index; no blocking entry -> inf and zeros."""
+    import torch
+    V = pa.capi.vec
+    for seed, n in ((1, 7), (2, 1000), (3, 300001)):
+        rng = np.random.default_rng(seed)
+        v, g = rng.random(n) + 0.05, rng.random(n) + 0.05
+        dv, dg = rng.standard_normal(n), rng.standard_normal(n)
+        if n > 100:   # a tie: two entries with exactly the same (minimal) ratio
+            v[[17, 90]], dv[[17, 90]] = 0.001, -8.0
+        t = [torch.tensor(a, device="cuda") for a in (v, dv, g, dg)]
+        out = V.find_blocking(*t)
+        r = np.where(dv < 0, -v / np.where(dv < 0, dv, -1.0), np.inf)
+        i = int(np.argmin(r))
+        assert np.array_equal(out, [r[i], v[i], dv[i], g[i], dg[i]])
+        if n > 100:
+            assert i == 17
+    z = torch.tensor(np.abs(dv), device="cuda")
+    out = V.find_blocking(t[0], z, t[2], t[3])
+    assert out[0] == np.inf and not out[1:].any()
