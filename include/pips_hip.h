@@ -165,6 +165,9 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
 /* pattern and values (host copies) of the sparse Schur complement; any output may be NULL; *nnz = number of entries */
 int pips_hip_kkt_get_schur_sparse(void* handle, int* nnz, int* rowptr, int* colidx, double* val_host);
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev);
+/* sLinsysRootAug::add_regularization_local_kkt (sLinsysRootAug.C:1545-1600) as a setting of the following factorizations: the
+ * x0 diagonal of the Schur complement gets + primal, the diagonal of its dual rows (y0, y_link, z_link) - dual; (0, 0) = off */
+int pips_hip_kkt_set_root_regularization(void* handle, double primal, double dual);
 /* root inequality rows C0 (mz0 x n0, CSR): adds -C0^T diag(zdiag0)^-1 C0 to SC at every factorize (sLinsysRootAug.C:
  * 1276-1338) and the z0 elimination to solve_compressed (:384-466); zdiag0 (< 0, = nOmegaInv of the root, caller-owned
  * device vector of mz0 entries) must be set before pips_hip_kkt_factorize */

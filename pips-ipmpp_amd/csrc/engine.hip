@@ -1168,6 +1168,7 @@ struct KktSystem {
    int mz0 = 0;
    int *d_c0_rp = nullptr, *d_c0_ci = nullptr;
    const double* d_zdiag0 = nullptr;   // caller-owned, set per iteration
+   double root_reg_primal = 0.0, root_reg_dual = 0.0;   // pips_hip_kkt_set_root_regularization
    // sparse root: SC lives as the value array of a lower-triangular CSR pattern inside a one-block sparse
    // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
    bool sparse = false;
@@ -1238,6 +1239,16 @@ __global__ void k_pack_lower(const double* __restrict__ M, int ld, int S, double
    for (int r = c + blockIdx.x * blockDim.x + threadIdx.x; r < S; r += gridDim.x * blockDim.x) {
       if (unpack) col[r] = packed[base + (r - c)];
       else packed[base + (r - c)] = col[r];
+   }
+}
+
+// diagonal_add_constant_from: dense column-major SC (rowptr == nullptr) or the CSR lower pattern of the sparse SC, whose rows end
+// with their diagonal entry
+__global__ void k_add_const_diag(double* __restrict__ M, int ld, const int* __restrict__ rowptr, int first, int n, double value) {
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int r = first + i;
+      if (rowptr) M[rowptr[r + 1] - 1] += value;
+      else M[(long long)r * ld + r] += value;
    }
 }
 
@@ -1934,6 +1945,11 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    }
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_at, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_zlink_pos, zdiag_link_dev, k->mzl);
+   if (k->root_reg_primal != 0.0 && k->n0 > 0)
+      hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->n0, 256)), dim3(256), 0, e->stream, r->d_kval, 0, k->d_sc_rowptr, 0, k->n0, k->root_reg_primal);
+   if (k->root_reg_dual != 0.0 && k->S > k->n0)
+      hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->S - k->n0, 256)), dim3(256), 0, e->stream, r->d_kval, 0, k->d_sc_rowptr, k->n0,
+                         k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
    return r->factor(nullptr, 0);
 }
@@ -1975,8 +1991,22 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, k->d_SC, k->S,
                          k->n0 + k->my0 + k->myl, zdiag_link_dev, k->mzl);
+   if (k->root_reg_primal != 0.0 && k->n0 > 0)
+      hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->n0, 256)), dim3(256), 0, e->stream, k->d_SC, k->S, (const int*)nullptr, 0, k->n0,
+                         k->root_reg_primal);
+   if (k->root_reg_dual != 0.0 && k->S > k->n0)
+      hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->S - k->n0, 256)), dim3(256), 0, e->stream, k->d_SC, k->S, (const int*)nullptr, k->n0,
+                         k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
    return k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)
+}
+
+int pips_hip_kkt_set_root_regularization(void* handle, double primal, double dual) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || primal < 0.0 || dual < 0.0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_root_regularization: bad arguments");
+   k->root_reg_primal = primal;
+   k->root_reg_dual = dual;
+   return PIPS_OK;
 }
 
 int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev) {

@@ -108,11 +108,11 @@ __global__ void k_kkt_pack(int N, int n0, int myl, const int* __restrict__ xoff,
 
 // K diagonals from the primal diagonal dd = gamma/v (computeDiagonals) and the dual regularisation (clear_dual_equality_diagonal)
 __global__ void k_leaf_diag(int N, const int* __restrict__ xoff, const int* __restrict__ yoff, const long long* __restrict__ koff,
-                            const double* __restrict__ dd, double dual_reg, double* __restrict__ leaf_diag) {
+                            const double* __restrict__ dd, double primal_reg, double dual_reg, double* __restrict__ leaf_diag) {
    const int b = blockIdx.y + 1;
    const int nx = xoff[b + 1] - xoff[b], ny = yoff[b + 1] - yoff[b];
    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx + ny; i += gridDim.x * blockDim.x)
-      leaf_diag[koff[b] + i] = i < nx ? dd[xoff[b] + i] : -dual_reg;
+      leaf_diag[koff[b] + i] = i < nx ? dd[xoff[b] + i] + primal_reg : -dual_reg;
 }
 
 struct Ipm {
@@ -202,17 +202,25 @@ struct Ipm {
    }
    // LinearSystem::factorize: dd = gamma / v, K diagonals, factor2 of the two-level system
    // KKT factorisation with the inertia contract of LinearSystem::factorize_with_correct_inertia (LinearSystem.C:295-325):
-   // factor once as is; while a leaf or the root reports perturbed pivots (close to a vertex the dual pivots of a leaf are
-   // differences of 1e10-sized terms and can come out with the wrong sign), add dual regularisation to the leaves, 1e-8
-   // times 100 per try, and factor again.  The regularised factors only precondition: the outer solve works on the
-   // unregularised system.
+   // factor once as is; while a leaf or the root reports perturbed pivots, add primal and dual regularisation (1e-8, times
+   // 100 per try; leaves: add_regularization_local_kkt DistributedLeafLinearSystem.C:108-143, root: sLinsysRootAug.C:
+   // 1545-1600) and factor again.  Two sources were seen: close to a vertex the dual pivots are differences of 1e10-sized
+   // terms and come out with the wrong sign, and split free variables (x = x+ - x-, both drifting) leave primal pivots of
+   // 1e-10 - the reference's GAMSsmall instances are full of them.  The regularised factors only precondition: the outer
+   // solve works on the unregularised system.
    int n_regularised = 0, n_factorize = 0, verbose_run = 0;
    double last_reg = 0.0;
    int perturbed_pivots(int* total) {
       int p_, n_, z_;
       TRY(pips_hip_kkt_root_inertia(kkt, &p_, &n_, &z_));
       *total = z_;
-      for (int b = 0; b < N; ++b) { TRY(pips_hip_batch_inertia(batch, b, &p_, &n_, &z_)); *total += z_; }
+      if (verbose_run > 1) printf("   inertia: root (%d %d %d) leaves", p_, n_, z_);
+      for (int b = 0; b < N; ++b) {
+         TRY(pips_hip_batch_inertia(batch, b, &p_, &n_, &z_));
+         *total += z_;
+         if (verbose_run > 1) printf(" (%d %d %d)", p_, n_, z_);
+      }
+      if (verbose_run > 1) printf("\n");
       return PIPS_OK;
    }
    int factorize() {
@@ -220,7 +228,8 @@ struct Ipm {
       TRY(pips_hip_vec_div(nx, v, dd, stream));
       double reg = 0.0;
       for (int attempt = 0;; ++attempt) {
-         hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, dual_reg + reg, leaf_diag);
+         hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, reg, dual_reg + reg, leaf_diag);
+         TRY(pips_hip_kkt_set_root_regularization(kkt, reg, dual_reg + reg));
          TRY(pips_hip_kkt_factorize(kkt, leaf_diag, dd, nullptr));
          ++n_factorize;
          int pert;

@@ -57,7 +57,7 @@ SYMBOLS = [
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
-    "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
+    "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
@@ -556,6 +556,10 @@ class KktSystem:
         _check(lib.pips_hip_kkt_factorize(self._h, _ptr(leaf_diag_dev), _ptr(xdiag0_dev), _ptr(zdiag_link_dev)),
                "pips_hip_kkt_factorize")
 
+    def set_root_regularization(self, primal, dual):
+        """+primal on the x0 diagonal, -dual on the dual rows of the Schur complement in the factorizations that follow."""
+        _check(lib.pips_hip_kkt_set_root_regularization(self._h, C.c_double(primal), C.c_double(dual)), "pips_hip_kkt_set_root_regularization")
+
     def solve_compressed(self, b0_dev, b_leaf_dev):
         _check(lib.pips_hip_kkt_solve_compressed(self._h, _ptr(b0_dev), _ptr(b_leaf_dev)), "pips_hip_kkt_solve_compressed")
 
@@ -735,7 +739,7 @@ class IpmSolver:
 
     def solve(self, max_iter=100, mutol=1e-6, artol=1e-4, verbose=False):
         res = np.zeros(7)
-        _check(lib.pips_ipm_solve(self._h, C.c_int(max_iter), C.c_double(mutol), C.c_double(artol), C.c_int(1 if verbose else 0),
+        _check(lib.pips_ipm_solve(self._h, C.c_int(max_iter), C.c_double(mutol), C.c_double(artol), C.c_int(int(verbose)),
                                   _ptr(res)), "pips_ipm_solve")
         return dict(objective=res[0], iterations=int(res[1]), mu=res[2], rnorm=res[3], status=int(res[4]), dual_objective=res[5],
                     dnorm=res[6])

@@ -1,0 +1,118 @@
+"""The reference's own known-answer instances (Test/IntegrationTests/gamssmall_instance_data.txt: 26 active GAMSsmall LPs with
+expected objective and iteration count; t_pips.cpp:115-119 checks EXPECT_NEAR(objective, expected, 1e-4) and
+iterations <= 1.1 * expected) through the GDX reader, the CPU restatement of the IPM and the device harness.
+
+tests/golden/gamssmall.json holds the block data extracted from the per-block GDX files (tests/golden/make_gamssmall.py)."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.lp_general_form import block_standard_form, general_lp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = json.load(open(os.path.join(HERE, "golden", "gamssmall.json")))["instances"]
+IDS = [d["name"] for d in DATA]
+REF = "/root/reference"
+OBJ_TOL = 1e-4   # t_pips.cpp:27,116
+
+
+def test_fixture_has_the_reference_instance_list():
+    assert len(DATA) == 26
+    assert {d["name"] for d in DATA} >= {"exampleAC_boundStrength", "hier_approach_8blocks_2by3", "example_breakSingletonRows"}
+    assert all(len(d["blocks"]) == d["num_blocks"] for d in DATA)
+
+
+def test_gdx_container_round_trip(tmp_path):
+    """Writer and reader of the GDX container agree on every record kind the jacobian files use: scalars, sets, equation /
+    variable records with special values, a 2-dimensional parameter with byte, word and integer sized keys."""
+    from pips_ipmpp_amd import gdx
+    rng = np.random.default_rng(5)
+    for top in (200, 40000, 3000000):
+        rows = np.sort(rng.choice(np.arange(1, top), size=40, replace=False))
+        cols = np.sort(rng.choice(np.arange(top, 2 * top), size=60, replace=False))
+        keys = sorted({(int(rng.choice(rows)), int(rng.choice(cols))) for _ in range(300)})
+        avals = rng.choice([0.5, 1.0, -1.0, 2.0, 0.0, 3.25, -7e5, 1e-9], size=len(keys))
+        evals = np.column_stack([rng.standard_normal(len(rows)), np.zeros(len(rows)),
+                                 rng.choice([gdx.SV_MINF, 0.0, 4.0], size=len(rows)), rng.choice([gdx.SV_PINF, 9.0], size=len(rows)),
+                                 rng.integers(1, 6, size=len(rows)).astype(float)])
+        xvals = np.column_stack([np.zeros(len(cols)), np.zeros(len(cols)), rng.choice([gdx.SV_MINF, 0.0, 0.8], size=len(cols)),
+                                 rng.choice([gdx.SV_PINF, 5.0], size=len(cols)), rng.integers(1, 5, size=len(cols)).astype(float)])
+        path = str(tmp_path / f"t{top}.gdx")
+        syms = [("numUel", gdx.PARAMETER, "Number of UELS", np.zeros((1, 0)), [[2.0 * top]]),
+                ("i", gdx.SET, "Equation names", rows[:, None], rows[:, None].astype(float)),
+                ("j", gdx.SET, "Variable names", cols[:, None], cols[:, None].astype(float)),
+                ("e", gdx.EQUATION, "Equations", rows[:, None], evals),
+                ("x", gdx.VARIABLE, "Variables", cols[:, None], xvals),
+                ("A", gdx.PARAMETER, "Jacobian", np.array(keys), avals[:, None])]
+        gdx.write_gdx(path, syms)
+        g = gdx.GdxFile(path)
+        assert g.names() == [s[0] for s in syms] and g.uels == []
+        for name, typ, text, k, v in syms:
+            s = g.symbol(name)
+            assert s.type == typ and s.text == text and s.dim == np.asarray(k).shape[1]
+            assert np.array_equal(s.keys, np.asarray(k).reshape(len(v), -1))
+            assert np.array_equal(s.values, np.asarray(v, dtype=float).reshape(len(v), -1))
+    with pytest.raises(gdx.GdxError):
+        open(tmp_path / "bad.gdx", "wb").write(b"not a gdx file at all, just bytes" * 4)
+        gdx.GdxFile(str(tmp_path / "bad.gdx"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box): the committed fixture stands in")
+def test_fixture_is_what_the_reader_extracts_from_the_reference_files():
+    from pips_ipmpp_amd import gdx
+    for d in DATA:
+        blocks = gdx.read_problem(REF + d["source"], d["num_blocks"])
+        for got, want in zip(blocks, d["blocks"]):
+            for key, w in want.items():
+                gv = got[key]
+                if isinstance(w, dict):
+                    assert gv is not None and all(list(np.asarray(gv[f]).ravel()) == list(np.asarray(w[f]).ravel()) for f in w), (d["name"], key)
+                elif w is None:
+                    assert gv is None
+                else:
+                    assert np.array_equal(np.asarray(gv), np.asarray(w)), (d["name"], key)
+    # the whole-model file of an instance (label table present, byte-sized keys) reads as well
+    g = gdx.GdxFile(REF + DATA[0]["source"] + ".gdx")
+    assert len(g.uels) == 23 and g.symbol("A").keys.shape[1] == 2 and g.symbol("x").values.shape[1] == 5
+
+
+@pytest.mark.parametrize("inst", DATA, ids=IDS)
+def test_highs_reproduces_the_reference_objective(inst):
+    """Pins the extracted data (bounded two-sided form) and the conversion to the harness' standard form."""
+    from scipy.optimize import linprog
+    c, A_eq, b_eq, A_ub, b_ub, bounds = general_lp(inst["blocks"])
+    r = linprog(c, A_eq=A_eq, b_eq=b_eq, A_ub=A_ub, b_ub=b_ub, bounds=bounds, method="highs")
+    assert r.status == 0 and abs(r.fun - inst["expected_objective"]) < OBJ_TOL
+    sf = block_standard_form(inst["blocks"])
+    r2 = linprog(sf["c"], A_eq=sf["A"], b_eq=sf["b"], bounds=(0, None), method="highs")
+    assert r2.status == 0 and abs(r2.fun + sf["offset"] - inst["expected_objective"]) < OBJ_TOL
+
+
+@pytest.mark.parametrize("inst", DATA, ids=IDS)
+def test_ipm_oracle_reproduces_the_reference_objective(inst):
+    from oracle import ipm_oracle as io
+    sf = block_standard_form(inst["blocks"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # several instances carry parallel / redundant rows on purpose (the reference removes them in its presolve): dual regularisation
+        o = io.solve_lp(sf["A"], sf["b"], sf["c"], 200, 1e-8, 1e-8, dual_reg=1e-9)
+    assert o["status"] == 0
+    assert abs(o["objective"] + sf["offset"] - inst["expected_objective"]) < OBJ_TOL
+    assert o["iterations"] <= 1.1 * inst["expected_iterations"]   # t_pips.cpp:119
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inst", DATA, ids=IDS)
+def test_device_harness_reproduces_the_reference_objective(inst):
+    import pips_ipmpp_amd as pa
+    sf = block_standard_form(inst["blocks"])
+    ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=1e-9)
+    res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8)
+    assert res["status"] == 0, res
+    assert abs(res["objective"] + sf["offset"] - inst["expected_objective"]) < OBJ_TOL, res
+    assert res["iterations"] <= 1.1 * inst["expected_iterations"] + 1
+    x, _ = ipm.solution()
+    assert x.min() > -1e-8 and np.linalg.norm(sf["A"] @ x - sf["b"], np.inf) < 1e-6 * max(1.0, np.abs(sf["b"]).max())
