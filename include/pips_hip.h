@@ -294,6 +294,22 @@ int pips_map_children_to_ranks(int n_children, int n_ranks, int* map);
 int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, int S, const int* Bt_rowptr,
                         const int* Bt_colidx, int force_n_head, int64_t* what, int n_what, int* perm, int* colcount);
 
+/* ---- 7. input files ---------------------------------------------------------------------------------------------------
+ * One block of a block-structured LP from a "jacobian" GDX file, the format gmspips_reader opens per block
+ * (Drivers/gams/gmspips/gmspips_reader.cpp:30-60; extraction rules of readBlock, gmspipsio.c:1357-2033; fields of
+ * GMSPIPSBlockData_t, gmspipsio.h:5-58).  Uncompressed GDX version 7 files.  offset = stage number of block 0 (the
+ * reference passes 1).  Host only. */
+int pips_gdx_read_block(void** block, const char* path, int num_blocks, int act_block, int offset);
+/* counts14 = {n0, ni, mA, mC, mBL, mDL, nnzA, nnzB, nnzC, nnzD, nnzBL, nnzDL, numBlocks, blockID} */
+int pips_gdx_block_counts(void* block, long long* counts14);
+/* which: 0 c, 1 xlow, 2 xupp, 3 ixlow, 4 ixupp, 5 b, 6 clow, 7 cupp, 8 iclow, 9 icupp, 10 bL, 11 dlow, 12 dupp, 13 idlow,
+ * 14 idupp (indicators as 0.0 / 1.0); out may be NULL to query *length */
+int pips_gdx_block_vector(void* block, int which, double* out, int capacity, int* length);
+/* which: 0 A, 1 B, 2 C, 3 D, 4 BL, 5 DL; *present = 0 where the reference leaves the matrix pointers NULL; the arrays (any may
+ * be NULL) must hold rows + 1 / nnz / nnz entries (sizes from pips_gdx_block_counts) */
+int pips_gdx_block_matrix(void* block, int which, int* present, int* rows, int* cols, int* rowptr, int* colidx, double* val);
+void pips_gdx_block_destroy(void* block);
+
 #ifdef __cplusplus
 }
 #endif

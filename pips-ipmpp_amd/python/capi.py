@@ -67,6 +67,7 @@ SYMBOLS = [
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
     "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
+    "pips_gdx_read_block", "pips_gdx_block_counts", "pips_gdx_block_vector", "pips_gdx_block_matrix", "pips_gdx_block_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
 ]
@@ -775,3 +776,35 @@ class IpmSolver:
             self.close()
         except Exception:
             pass
+
+
+def gdx_read_block(path, num_blocks, act_block, offset=1):
+    """One block of a jacobian GDX file through the library's reader (pips_gdx_read_block): the same dict as
+    pips_ipmpp_amd.gdx.read_block (fields of GMSPIPSBlockData_t, gmspipsio.h:5-58)."""
+    h = C.c_void_p()
+    _check(lib.pips_gdx_read_block(C.byref(h), str(path).encode(), C.c_int(num_blocks), C.c_int(act_block), C.c_int(offset)), "pips_gdx_read_block")
+    try:
+        cnt = (C.c_longlong * 14)()
+        _check(lib.pips_gdx_block_counts(h, cnt), "pips_gdx_block_counts")
+        out = dict(numBlocks=int(cnt[12]), blockID=int(cnt[13]), n0=int(cnt[0]), ni=int(cnt[1]), mA=int(cnt[2]), mC=int(cnt[3]), mBL=int(cnt[4]),
+                   mDL=int(cnt[5]))
+        names = ["c", "xlow", "xupp", "ixlow", "ixupp", "b", "clow", "cupp", "iclow", "icupp", "bL", "dlow", "dupp", "idlow", "idupp"]
+        for which, name in enumerate(names):
+            n = C.c_int()
+            _check(lib.pips_gdx_block_vector(h, C.c_int(which), None, C.c_int(0), C.byref(n)), "pips_gdx_block_vector")
+            v = np.zeros(n.value)
+            _check(lib.pips_gdx_block_vector(h, C.c_int(which), _ptr(v), C.c_int(n.value), C.byref(n)), "pips_gdx_block_vector")
+            out[name] = v.astype(np.int16) if name.startswith("i") else v
+        for which, name in enumerate(["A", "B", "C", "D", "BL", "DL"]):
+            present, rows, cols = C.c_int(), C.c_int(), C.c_int()
+            _check(lib.pips_gdx_block_matrix(h, C.c_int(which), C.byref(present), C.byref(rows), C.byref(cols), None, None, None), "pips_gdx_block_matrix")
+            if not present.value:
+                out[name] = None
+                continue
+            nnz = int(cnt[6 + which])
+            rp, ci, va = np.zeros(rows.value + 1, dtype=np.int32), np.zeros(nnz, dtype=np.int32), np.zeros(nnz)
+            _check(lib.pips_gdx_block_matrix(h, C.c_int(which), None, None, None, _ptr(rp), _ptr(ci), _ptr(va)), "pips_gdx_block_matrix")
+            out[name] = dict(rows=rows.value, cols=cols.value, rowptr=rp.tolist(), colidx=ci.tolist(), val=va.tolist())
+        return out
+    finally:
+        lib.pips_gdx_block_destroy(h)

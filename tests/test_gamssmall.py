@@ -116,3 +116,85 @@ def test_device_harness_reproduces_the_reference_objective(inst):
     assert res["iterations"] <= 1.1 * inst["expected_iterations"] + 1
     x, _ = ipm.solution()
     assert x.min() > -1e-8 and np.linalg.norm(sf["A"] @ x - sf["b"], np.inf) < 1e-6 * max(1.0, np.abs(sf["b"]).max())
+
+
+def _same_block(got, want, tag):
+    for key, w in want.items():
+        g = got[key]
+        if isinstance(w, dict):
+            assert g is not None, (tag, key)
+            for f in w:
+                assert list(np.asarray(g[f]).ravel()) == list(np.asarray(w[f]).ravel()), (tag, key, f)
+        elif w is None:
+            assert g is None, (tag, key)
+        else:
+            assert np.array_equal(np.asarray(g, dtype=float), np.asarray(w, dtype=float)), (tag, key)
+
+
+def _synthetic_jacobian(path, rng, num_blocks):
+    """A jacobian GDX file of a random block-structured LP (all blocks in one file, stages as in the reference's files):
+    labels 1..m are rows, m+1..m+n columns, the last column is the objective variable, the last row the objective row."""
+    from pips_ipmpp_amd import gdx
+    nvar = [int(rng.integers(1, 4)) for _ in range(num_blocks)]
+    nrow = [int(rng.integers(1, 4)) for _ in range(num_blocks)]
+    nlink = int(rng.integers(1, 3))
+    m, n = sum(nrow) + nlink + 1, sum(nvar) + 1
+    row_stage = sum(([k + 1] * nrow[k] for k in range(num_blocks)), []) + [num_blocks + 1] * nlink + [num_blocks + 1]
+    col_stage = sum(([k + 1] * nvar[k] for k in range(num_blocks)), []) + [1]
+    rows, cols = np.arange(1, m + 1), np.arange(m + 1, m + n + 1)
+    evals, xvals, keys, avals = [], [], [], []
+    for i in range(m - 1):
+        kind = rng.integers(0, 4)
+        lo = gdx.SV_MINF if kind == 1 else float(rng.integers(-3, 4))
+        up = gdx.SV_PINF if kind == 2 else (lo if kind == 0 else float(rng.integers(4, 9)))
+        evals.append([0.0, 0.0, lo, up, float(row_stage[i])])
+    evals.append([0.0, 0.0, 0.0, 0.0, float(row_stage[-1])])
+    for j in range(n - 1):
+        kind = rng.integers(0, 4)
+        lo = gdx.SV_MINF if kind == 1 else float(rng.integers(0, 2))
+        up = gdx.SV_PINF if kind != 3 else lo + float(rng.integers(0, 5))
+        xvals.append([0.0, 0.0, lo, up, float(col_stage[j])])
+    xvals.append([0.0, 0.0, gdx.SV_MINF, gdx.SV_PINF, 1.0])
+    for i in range(m - 1):
+        blk = row_stage[i] - 1
+        for j in range(n - 1):
+            cb = col_stage[j] - 1
+            if (blk == num_blocks or cb == 0 or cb == blk) and rng.random() < 0.6:
+                keys.append((rows[i], cols[j])); avals.append(float(rng.choice([1.0, -1.0, 2.0, 0.5, 3.75, -7.0])))
+    for j in range(n - 1):
+        if rng.random() < 0.8:
+            keys.append((rows[-1], cols[j])); avals.append(-float(rng.integers(1, 5)))
+    keys.append((rows[-1], cols[-1])); avals.append(1.0)
+    syms = [("numUel", gdx.PARAMETER, "Number of UELS", np.zeros((1, 0)), [[float(m + n)]]),
+            ("i", gdx.SET, "Equation names", rows[:, None], rows[:, None].astype(float)),
+            ("j", gdx.SET, "Variable names", cols[:, None], cols[:, None].astype(float)),
+            ("jobj", gdx.SET, "Objective name", np.array([[cols[-1]]]), [[0.0]]),
+            ("iobj", gdx.SET, "Objective row", np.array([[rows[-1]]]), [[0.0]]),
+            ("objcoef", gdx.PARAMETER, "Objective coefficient", np.zeros((1, 0)), [[float(rng.choice([1.0, -1.0]))]]),
+            ("e", gdx.EQUATION, "Equations", rows[:, None], np.array(evals)),
+            ("x", gdx.VARIABLE, "Variables", cols[:, None], np.array(xvals)),
+            ("A", gdx.PARAMETER, "Jacobian", np.array(keys), np.array(avals)[:, None])]
+    gdx.write_gdx(path, syms)
+
+
+def test_library_gdx_reader_matches_the_python_restatement(tmp_path):
+    """pips_gdx_read_block (C ABI, csrc/gdx.cpp) against pips_ipmpp_amd.gdx.read_block on synthetic jacobian files and, when the
+    reference tree is here, on every block file of the 26 instances."""
+    import pips_ipmpp_amd as pa
+    from pips_ipmpp_amd import gdx
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        nb = int(rng.integers(2, 5))
+        path = str(tmp_path / f"syn{case}.gdx")
+        _synthetic_jacobian(path, rng, nb)
+        for k in range(nb):
+            _same_block(pa.capi.gdx_read_block(path, nb, k), gdx.read_block(path, nb, k), (case, k))
+    with pytest.raises(RuntimeError):
+        pa.capi.gdx_read_block(str(tmp_path / "does_not_exist.gdx"), 2, 0)
+    open(tmp_path / "junk.gdx", "wb").write(bytes(range(256)) * 3)
+    with pytest.raises(RuntimeError):
+        pa.capi.gdx_read_block(str(tmp_path / "junk.gdx"), 2, 0)
+    if os.path.isdir(REF):
+        for d in DATA:
+            for k in range(d["num_blocks"]):
+                _same_block(pa.capi.gdx_read_block(f"{REF}{d['source']}{k}.gdx", d["num_blocks"], k), d["blocks"][k], (d["name"], k))
