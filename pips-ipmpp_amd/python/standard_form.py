@@ -1,5 +1,5 @@
 """Block data in the reference's reader layout (GMSPIPSBlockData_t, gmspipsio.h:5-58; one dict per block as returned by
-pips_ipmpp_amd.gdx.read_block or stored in tests/golden/gamssmall.json) -> the harness' problem class
+capi.gdx_read_block / pips_ipmpp_amd.gdx.read_block or stored in tests/golden/gamssmall.json) -> the harness' problem class
     min c^T y + offset,  A y = b,  y >= 0,   A block-angular with linking variables and linking rows.
 
 Per variable:   fixed -> constant;  lower bound only -> x = l + x';  upper bound only -> x = u - x';  both -> x = l + x' and a
@@ -11,7 +11,7 @@ separate root equality block in this problem class.
 import numpy as np
 import scipy.sparse as sp
 
-import pips_ipmpp_amd as pa
+from . import capi as pa
 
 
 def _csr(d, rows, cols):
@@ -161,7 +161,18 @@ def block_standard_form(blocks):
         r[1 + i] = W.to_scipy()
         rows.append(r)
     Afull = sp.bmat(rows, format="csr")
-    return dict(n0=n0s, myl=n_link, blocks=out_blocks, F0=_to_pa(F0), c=c, b=b, A=Afull, offset=offset, recover=recover)
+    return dict(n0=n0s, myl=n_link, blocks=out_blocks, F0=_to_pa(F0), c=c, b=b, A=Afull, offset=offset, recover=recover,
+                sizes=[n0s] + [f.to_scipy().shape[1] for (_, _, f) in out_blocks])
+
+
+def recover_solution(sf, y):
+    """Solution of the standard form (flat vector y, blocks in order) -> the original variables of every block:
+    x_k = xc_k + M_k y_k[:n'_k]  (slack columns dropped)."""
+    out, at = [], 0
+    for (xc, M), size in zip(sf["recover"], sf["sizes"]):
+        out.append(xc + M @ y[at:at + M.shape[1]])
+        at += size
+    return out
 
 
 def general_lp(blocks):

@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 import pytest
 
-from tests.lp_general_form import block_standard_form, general_lp
+from pips_ipmpp_amd.standard_form import block_standard_form, general_lp, recover_solution
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = json.load(open(os.path.join(HERE, "golden", "gamssmall.json")))["instances"]
@@ -89,6 +89,11 @@ def test_highs_reproduces_the_reference_objective(inst):
     sf = block_standard_form(inst["blocks"])
     r2 = linprog(sf["c"], A_eq=sf["A"], b_eq=sf["b"], bounds=(0, None), method="highs")
     assert r2.status == 0 and abs(r2.fun + sf["offset"] - inst["expected_objective"]) < OBJ_TOL
+    # back to the original variables: feasible for the bounded form, same objective
+    x = np.concatenate(recover_solution(sf, r2.x))
+    assert abs(c @ x - inst["expected_objective"]) < OBJ_TOL
+    assert np.abs(A_eq @ x - b_eq).max() < 1e-7 and (A_ub is None or (A_ub @ x - b_ub).max() < 1e-7)
+    assert all((lo is None or xi >= lo - 1e-7) and (up is None or xi <= up + 1e-7) for xi, (lo, up) in zip(x, bounds))
 
 
 @pytest.mark.parametrize("inst", DATA, ids=IDS)

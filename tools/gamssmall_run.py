@@ -3,7 +3,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pips_ipmpp_amd as pa
-from tests.lp_general_form import block_standard_form
+from pips_ipmpp_amd.standard_form import block_standard_form
 data = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "gamssmall.json")))["instances"]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 reg = float(os.environ.get("REG", "1e-9"))
