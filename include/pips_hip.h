@@ -40,7 +40,8 @@ int pips_hip_ldl_analyze(void* handle);
 /* = DoubleLinearSolver::matrixChanged(): numeric LDL^T of the current values (host array of length nnz, CSR order) */
 int pips_hip_ldl_factor(void* handle, const double* vals_host);
 /* = DoubleLinearSolver::solve(int nrhss, double* rhss, int* colSparsity) (PardisoSolver.C:276-352): nrhs contiguous
- * right-hand sides of length ld >= n, overwritten by the solutions.  nrhs = 1 is DoubleLinearSolver::solve(Vector&). */
+ * right-hand sides of length ld >= n, overwritten by the solutions; all-zero right-hand sides are left out of the transfer and
+ * of the solve, as the reference's packing does.  nrhs = 1 is DoubleLinearSolver::solve(Vector&). */
 int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs_inout_host, int ld);
 /* = DoubleLinearSolver::get_inertia(): (positive, negative, zero/perturbed) pivots of the last factorisation */
 int pips_hip_ldl_inertia(void* handle, int* pos, int* neg, int* zero);

@@ -1610,12 +1610,35 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
       HIP_TRY(hipStreamSynchronize(e.stream));
       return PIPS_OK;
    }
-   // all right-hand sides in one pass (one RHS per row of length ld, PardisoSolver.C:276-352)
+   // all right-hand sides in one pass (one RHS per row of length ld).  Like PardisoSolver::solve (PardisoSolver.C:276-352)
+   // only the non-zero right-hand sides travel and are solved: the blocked Schur loop hands over chunks in which many
+   // border columns are empty (DistributedLinearSystem.C:870-874)
+   std::vector<int> nz;
+   nz.reserve(nrhs);
+   for (int r = 0; r < nrhs; ++r) {
+      const double* v = rhs + (size_t)r * ld;
+      bool any = false;
+      for (int i = 0; i < e.n_total && !any; ++i) any = v[i] != 0.0;
+      if (any) nz.push_back(r);
+   }
+   const int nnz_rhs = (int)nz.size();
+   if (nnz_rhs == 0) return PIPS_OK;
    double* d_X = nullptr;
-   HIP_TRY(hipMalloc((void**)&d_X, (size_t)nrhs * row));
-   hipError_t err = hipMemcpy2DAsync(d_X, row, rhs, (size_t)ld * sizeof(double), row, nrhs, hipMemcpyHostToDevice, e.stream);
-   int rc = err == hipSuccess ? e.solve_multi(d_X, nrhs, e.n_total) : PIPS_ERR_HIP;
-   if (!rc) err = hipMemcpy2DAsync(rhs, (size_t)ld * sizeof(double), d_X, row, row, nrhs, hipMemcpyDeviceToHost, e.stream);
+   HIP_TRY(hipMalloc((void**)&d_X, (size_t)nnz_rhs * row));
+   hipError_t err = hipSuccess;
+   if (nnz_rhs == nrhs)
+      err = hipMemcpy2DAsync(d_X, row, rhs, (size_t)ld * sizeof(double), row, nrhs, hipMemcpyHostToDevice, e.stream);
+   else
+      for (int q = 0; q < nnz_rhs && err == hipSuccess; ++q)
+         err = hipMemcpyAsync(d_X + (size_t)q * e.n_total, rhs + (size_t)nz[q] * ld, row, hipMemcpyHostToDevice, e.stream);
+   int rc = err == hipSuccess ? (nnz_rhs == 1 ? e.solve(d_X) : e.solve_multi(d_X, nnz_rhs, e.n_total)) : PIPS_ERR_HIP;
+   if (!rc) {
+      if (nnz_rhs == nrhs)
+         err = hipMemcpy2DAsync(rhs, (size_t)ld * sizeof(double), d_X, row, row, nrhs, hipMemcpyDeviceToHost, e.stream);
+      else
+         for (int q = 0; q < nnz_rhs && err == hipSuccess; ++q)
+            err = hipMemcpyAsync(rhs + (size_t)nz[q] * ld, d_X + (size_t)q * e.n_total, row, hipMemcpyDeviceToHost, e.stream);
+   }
    if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
    (void)hipFree(d_X);
    if (rc) return rc;

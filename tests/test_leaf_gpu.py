@@ -75,6 +75,18 @@ def test_leaf_multi_rhs_rows(scheme, n_i, monkeypatch):
     for k in range(40):
         xr = lu.solve(R[k])
         assert np.linalg.norm(X[k] - xr) / np.linalg.norm(xr) < 1e-9
+    # empty right-hand sides stay out of the solve, as in PardisoSolver::solve (PardisoSolver.C:276-352): zero rows come back
+    # as zeros and the non-zero ones are unaffected by the packing (chunks with one, several and no non-zero row)
+    for keep in ([3], [0, 7, 8, 30], []):
+        Rz = np.zeros((40, prob.n_leaf))
+        Rz[keep] = R[keep]
+        Xz = Rz.copy()
+        s.solve(Xz)
+        for k in range(40):
+            if k in keep:
+                assert np.linalg.norm(Xz[k] - X[k]) / np.linalg.norm(X[k]) < 1e-12
+            else:
+                assert not Xz[k].any()
 
 
 def test_refactor_after_diagonal_change():
