@@ -261,6 +261,10 @@ int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int v
 /* Gondzio multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358): 0 = plain Mehrotra predictor-
  * corrector; default 2, i.e. 4 solves per iteration like the work unit of bench.py */
 int pips_ipm_set_gondzio(void* handle, int max_correctors);
+/* harness settings under the reference's option identifiers (Options.C:18-73, PIPSIPMppOptions.C:170-264): GONDZIO_MAX_CORRECTORS,
+ * OUTER_SOLVE (1 iterative refinement, 2 BiCGStab), OUTER_BICG_MAX_ITER, REGULARIZATION (0/1: the inertia-correcting loop);
+ * anything else returns an error */
+int pips_ipm_set_option(void* handle, const char* name, double value);
 int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
 /* history of the last pips_ipm_solve, one row of 7 doubles per iterate: mu, ||r||inf, primal objective, dual objective, and the
  * step taken from it: sigma, alpha_primal, alpha_dual (zeros in the final row).  rows7 may be NULL to query *n_rows. */

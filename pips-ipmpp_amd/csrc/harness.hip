@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -140,6 +141,8 @@ struct Ipm {
    long long n_gondzio = 0;
    int outer_mode = 2;   // 1 = iterative refinement, 2 = BiCGStab (the reference's OUTER_SOLVE default)
    int outer_max = 10, last_outer_steps = 0;
+   int bicg_max_iter = 75;      // OUTER_BICG_MAX_ITER
+   bool regularize = true;      // REGULARIZATION: the inertia-correcting loop of factorize()
    long long n_precond = 0;
    double outer_tol = 1e-10, last_outer_res = 0.0;
    std::vector<void*> owned;
@@ -235,7 +238,7 @@ struct Ipm {
          int pert;
          TRY(perturbed_pivots(&pert));
          if (verbose_run && (pert || reg > 0.0)) printf("   factorize: dual regularisation %.1e, %d perturbed pivots\n", dual_reg + reg, pert);
-         if (pert == 0 || attempt == 4) break;
+         if (pert == 0 || attempt == 4 || !regularize) break;
          reg = reg == 0.0 ? 1e-8 : reg * 100.0;
          ++n_regularised;
       }
@@ -320,7 +323,7 @@ struct Ipm {
       auto bad = [](double v) { return !(v == v) || std::fabs(v) > 1e300; };
       auto stagn = [&](double step, double step_norm, double xn) { if (std::fabs(step) * step_norm <= eps * xn) ++nstag; else nstag = 0; };
       int it = 0;
-      for (; it < 75; ++it) {
+      for (; it < bicg_max_iter; ++it) {
          const double rho_last = rho;
          TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_r, &rho, stream));
          if (is_zero(rho) || bad(rho)) break;
@@ -779,6 +782,28 @@ int pips_ipm_set_gondzio(void* handle, int max_correctors) {
    Ipm* p = (Ipm*)handle;
    if (!p || max_correctors < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_gondzio: bad arguments");
    p->max_gondzio = max_correctors;
+   return PIPS_OK;
+}
+
+int pips_ipm_set_option(void* handle, const char* name, double value) {
+   Ipm* p = (Ipm*)handle;
+   if (!p || !name) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_option: bad arguments");
+   const std::string key(name);
+   // identifiers of the reference's option tables (Options.C:18-73, PIPSIPMppOptions.C:170-264)
+   if (key == "GONDZIO_MAX_CORRECTORS") {
+      if (value < 0) PIPS_FAIL(PIPS_ERR_ARG, "GONDZIO_MAX_CORRECTORS must be >= 0");
+      p->max_gondzio = (int)value;
+   }
+   else if (key == "OUTER_SOLVE") {
+      if (value != 1 && value != 2) PIPS_FAIL(PIPS_ERR_ARG, "OUTER_SOLVE: 1 (iterative refinement) or 2 (BiCGStab) - the harness always runs an outer solve");
+      p->outer_mode = (int)value;
+   }
+   else if (key == "OUTER_BICG_MAX_ITER") {
+      if (value < 1) PIPS_FAIL(PIPS_ERR_ARG, "OUTER_BICG_MAX_ITER must be >= 1");
+      p->bicg_max_iter = (int)value;
+   }
+   else if (key == "REGULARIZATION") p->regularize = value != 0.0;
+   else PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_option: unknown or unsupported identifier %s", name);
    return PIPS_OK;
 }
 
