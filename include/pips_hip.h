@@ -257,6 +257,15 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
 /* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown before any
  * usable iterate, 3 numerical troubles: the best iterate so far is returned - its mu / residual are in [2] / [3])
  * [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
+/* the same on several ranks: this rank's N blocks; c = [c0 | blocks], b = [b_link | blocks] with the root parts
+ * and F0 identical on every rank; comm as for pips_hip_kkt_create.  Scalars are reduced over the ranks (replicated parts
+ * counted on rank 0 only, DistributedVector.C:1293-1303), the link rows of A x and the x0 rows of A^T y are summed
+ * (DistributedMatrix.C:224-326); every rank returns the same result and holds x0 / y_link and its blocks' part of the solution */
+int pips_ipm_create_rank(void** handle, int N, int n0, int myl, const int* n_i, const int* my_i, const int* W_rowptr,
+                         const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
+                         const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
+                         const double* F0_val, const double* c, const double* b, double dual_reg, int device, void* comm, int rank,
+                         int n_ranks);
 int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7);
 /* Gondzio multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358): 0 = plain Mehrotra predictor-
  * corrector; default 2, i.e. 4 solves per iteration like the work unit of bench.py */

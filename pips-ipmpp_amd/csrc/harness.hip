@@ -167,6 +167,79 @@ struct Ipm {
       owned.push_back(*d);
       return PIPS_OK;
    }
+   // ---- several ranks: the blocks are sharded over the ranks, the root parts of every vector (x0 at the head of
+   // the x-type vectors, y_link at the head of the y-type ones) are replicated.  Sums count a replicated part on rank 0 only
+   // (iAmSpecial, DistributedVector.C:1293-1303), maxima / minima travel in one slot per rank of a summed vector, the link
+   // rows of A x and the x0 rows of A^T y are summed over the ranks.  All scalars that steer the iteration are therefore
+   // identical on every rank.
+   void* comm = nullptr;
+   int rank = 0, n_ranks = 1;
+   long long nx_global = 0;
+   double* d_red = nullptr;
+   enum Kind { KX, KY, KZ };
+   int reduce_host(double* vals, int n) {
+      HIP_TRYH(hipMemcpyAsync(d_red, vals, n * sizeof(double), hipMemcpyHostToDevice, stream));
+      TRY(pips_hip_allreduce_sum(comm, d_red, (size_t)n, stream));
+      HIP_TRYH(hipMemcpyAsync(vals, d_red, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_TRYH(hipStreamSynchronize(stream));
+      return PIPS_OK;
+   }
+   int gsum(double* val) { return n_ranks > 1 ? reduce_host(val, 1) : PIPS_OK; }
+   int gext(double* val, bool want_max) {
+      if (n_ranks == 1) return PIPS_OK;
+      std::vector<double> slots(n_ranks, 0.0);
+      slots[rank] = *val;
+      TRY(reduce_host(slots.data(), n_ranks));
+      for (int r = 0; r < n_ranks; ++r) *val = r == 0 ? slots[0] : (want_max ? std::max(*val, slots[r]) : std::min(*val, slots[r]));
+      return PIPS_OK;
+   }
+   long long skx() const { return rank ? n0 : 0; }
+   long long sky() const { return rank ? myl : 0; }
+   int gdot(Kind k, const double* a, const double* b2, double* out) {
+      if (k == KX) TRY(pips_hip_vec_dot(nx, skx(), a, b2, out, stream));
+      else if (k == KY) TRY(pips_hip_vec_dot(ny, sky(), a, b2, out, stream));
+      else if (rank == 0) TRY(pips_hip_vec_dot(nz(), 0, a, b2, out, stream));
+      else {
+         double p1, p2;
+         TRY(pips_hip_vec_dot(nx, skx(), a, b2, &p1, stream));
+         TRY(pips_hip_vec_dot(ny, sky(), a + nx, b2 + nx, &p2, stream));
+         *out = p1 + p2;
+      }
+      return gsum(out);
+   }
+   int ginf(long long len, const double* z, double* out) {
+      TRY(pips_hip_vec_inf_norm(len, z, out, stream));
+      return gext(out, true);
+   }
+   int gvmin(const double* z, double* out) {
+      TRY(pips_hip_vec_min(nx, z, out, stream));
+      return gext(out, false);
+   }
+   int gstepbound(const double* z, const double* dz, double* out) {
+      TRY(pips_hip_vec_stepbound(nx, z, dz, nullptr, out, stream));
+      return gext(out, false);
+   }
+   int gdot_shifted(const double* a, double sa, const double* da, const double* b2, double sb, const double* db, double* out) {
+      TRY(pips_hip_vec_dot_shifted(nx, skx(), a, sa, da, b2, sb, db, out, stream));
+      return gsum(out);
+   }
+   // blocking entry over all ranks: the smallest ratio wins, the lowest rank on ties
+   int gfind_blocking(const double* a, const double* da, const double* b2, const double* db, double* out5) {
+      TRY(pips_hip_vec_find_blocking(nx, a, da, b2, db, out5, stream));
+      if (n_ranks == 1) return PIPS_OK;
+      std::vector<double> slots(5 * (size_t)n_ranks, 0.0);
+      const bool none = !(out5[0] < INFINITY);
+      for (int q = 0; q < 5; ++q) slots[5 * rank + q] = (q == 0 && none) ? -1.0 : out5[q];   // infinities do not travel through a sum
+      TRY(reduce_host(slots.data(), 5 * n_ranks));
+      int best = -1;
+      for (int r = 0; r < n_ranks; ++r)
+         if (slots[5 * r] >= 0.0 && (best < 0 || slots[5 * r] < slots[5 * best])) best = r;
+      if (best < 0) { out5[0] = INFINITY; out5[1] = out5[2] = out5[3] = out5[4] = 0.0; }
+      else for (int q = 0; q < 5; ++q) out5[q] = slots[5 * best + q];
+      return PIPS_OK;
+   }
+   int root_sum(double* part, int n) { return (n_ranks > 1 && n > 0) ? pips_hip_allreduce_sum(comm, part, (size_t)n, stream) : PIPS_OK; }
+
    int *A_long = nullptr, *At_long = nullptr;   // rows of A / A^T with more than CSR_LONG_ROW entries
    int nA_long = 0, nAt_long = 0;
    void mult(const int* rp, const int* ci, const double* vals, int nrows, const int* long_rows, int n_long, const double* xin, double alpha,
@@ -176,31 +249,42 @@ struct Ipm {
       if (n_long > 0)
          hipLaunchKernelGGL(k_csr_mult_long, dim3(n_long), dim3(256), 0, stream, long_rows, rp, ci, vals, xin, alpha, beta, yout);
    }
-   void Amult(const double* xin, double alpha, double beta, double* yout) { mult(A_rp, A_ci, A_v, ny, A_long, nA_long, xin, alpha, beta, yout); }
-   void ATmult(const double* yin, double alpha, double beta, double* xout) { mult(At_rp, At_ci, At_v, nx, At_long, nAt_long, yin, alpha, beta, xout); }
+   // y = alpha A x + beta y and x = alpha A^T y + beta x; with several ranks the local A holds F0 on rank 0 only, the other ranks
+   // start their replicated output part from zero and the part is summed (DistributedMatrix::mult / transpose_mult,
+   // DistributedMatrix.C:224-326)
+   int Amult(const double* xin, double alpha, double beta, double* yout) {
+      if (rank && beta != 0.0 && myl > 0) HIP_TRYH(hipMemsetAsync(yout, 0, (size_t)myl * sizeof(double), stream));
+      mult(A_rp, A_ci, A_v, ny, A_long, nA_long, xin, alpha, beta, yout);
+      return root_sum(yout, myl);
+   }
+   int ATmult(const double* yin, double alpha, double beta, double* xout) {
+      if (rank && beta != 0.0 && n0 > 0) HIP_TRYH(hipMemsetAsync(xout, 0, (size_t)n0 * sizeof(double), stream));
+      mult(At_rp, At_ci, At_v, nx, At_long, nAt_long, yin, alpha, beta, xout);
+      return root_sum(xout, n0);
+   }
 
    // Residuals::evaluate for this problem class: rQ = c - A^T y - gamma, rA = A x - b, rv = x - v; returns the inf-norm
    int residuals(double* rnorm, double* pobj, double* dobj) {
       TRY(pips_hip_vec_copy(nx, c, rQ, stream));
-      ATmult(y, -1.0, 1.0, rQ);
+      TRY(ATmult(y, -1.0, 1.0, rQ));
       TRY(pips_hip_vec_axpy(nx, -1.0, g, rQ, stream));
       TRY(pips_hip_vec_copy(ny, b, rA, stream));
-      Amult(x, 1.0, -1.0, rA);
+      TRY(Amult(x, 1.0, -1.0, rA));
       TRY(pips_hip_vec_copy(nx, x, rv, stream));
       TRY(pips_hip_vec_axpy(nx, -1.0, v, rv, stream));
       double a1, a2, a3;
-      TRY(pips_hip_vec_inf_norm(nx, rQ, &a1, stream));
-      TRY(pips_hip_vec_inf_norm(ny, rA, &a2, stream));
-      TRY(pips_hip_vec_inf_norm(nx, rv, &a3, stream));
+      TRY(ginf(nx, rQ, &a1));
+      TRY(ginf(ny, rA, &a2));
+      TRY(ginf(nx, rv, &a3));
       *rnorm = std::max(a1, std::max(a2, a3));
-      TRY(pips_hip_vec_dot(nx, 0, c, x, pobj, stream));
-      TRY(pips_hip_vec_dot(ny, 0, b, y, dobj, stream));
+      TRY(gdot(KX, c, x, pobj));
+      TRY(gdot(KY, b, y, dobj));
       return PIPS_OK;
    }
    int mu(double* out) {
       double s;
-      TRY(pips_hip_vec_dot(nx, 0, v, g, &s, stream));
-      *out = s / nx;
+      TRY(gdot(KX, v, g, &s));
+      *out = s / nx_global;
       return PIPS_OK;
    }
    // LinearSystem::factorize: dd = gamma / v, K diagonals, factor2 of the two-level system
@@ -218,12 +302,15 @@ struct Ipm {
       TRY(pips_hip_kkt_root_inertia(kkt, &p_, &n_, &z_));
       *total = z_;
       if (verbose_run > 1) printf("   inertia: root (%d %d %d) leaves", p_, n_, z_);
+      double leaves = 0.0;
       for (int b = 0; b < N; ++b) {
          TRY(pips_hip_batch_inertia(batch, b, &p_, &n_, &z_));
-         *total += z_;
+         leaves += z_;
          if (verbose_run > 1) printf(" (%d %d %d)", p_, n_, z_);
       }
       if (verbose_run > 1) printf("\n");
+      TRY(gsum(&leaves));
+      *total += (int)leaves;
       return PIPS_OK;
    }
    int factorize() {
@@ -258,8 +345,8 @@ struct Ipm {
    int kmult(const double* z, double* out) {
       TRY(pips_hip_vec_set(nx, 0.0, out, stream));
       TRY(pips_hip_vec_add_product(nx, 1.0, dd, z, out, stream));
-      ATmult(z + nx, 1.0, 1.0, out);
-      Amult(z, 1.0, 0.0, out + nx);
+      TRY(ATmult(z + nx, 1.0, 1.0, out));
+      TRY(Amult(z, 1.0, 0.0, out + nx));
       return PIPS_OK;
    }
    int residual(const double* rhs, const double* z, double* r, double* nrm) {   // r = rhs - K z, two-norm
@@ -270,9 +357,16 @@ struct Ipm {
    long long nz() const { return (long long)nx + ny; }
    int two_norm(const double* z, double* out) {   // DistributedVector::two_norm: s * sqrt(sum (z/s)^2), s = inf_norm
       double s, q;
-      TRY(pips_hip_vec_inf_norm(nz(), z, &s, stream));
+      TRY(ginf(nz(), z, &s));
       if (s == 0.0) { *out = 0.0; return PIPS_OK; }
-      TRY(pips_hip_vec_sumsq_scaled(nz(), 0, 1.0 / s, z, &q, stream));
+      if (rank == 0) TRY(pips_hip_vec_sumsq_scaled(nz(), 0, 1.0 / s, z, &q, stream));
+      else {
+         double q1, q2;
+         TRY(pips_hip_vec_sumsq_scaled(nx, skx(), 1.0 / s, z, &q1, stream));
+         TRY(pips_hip_vec_sumsq_scaled(ny, sky(), 1.0 / s, z + nx, &q2, stream));
+         q = q1 + q2;
+      }
+      TRY(gsum(&q));
       *out = s * std::sqrt(q);
       return PIPS_OK;
    }
@@ -325,7 +419,7 @@ struct Ipm {
       int it = 0;
       for (; it < bicg_max_iter; ++it) {
          const double rho_last = rho;
-         TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_r, &rho, stream));
+         TRY(gdot(KZ, w_r0, w_r, &rho));
          if (is_zero(rho) || bad(rho)) break;
          if (it == 0) TRY(pips_hip_vec_copy(nz(), w_r, w_p, stream));
          else {
@@ -338,7 +432,7 @@ struct Ipm {
          TRY(precond(w_dx));
          TRY(kmult(w_dx, w_v));
          double rtv, dxn, xn;
-         TRY(pips_hip_vec_dot(nz(), 0, w_r0, w_v, &rtv, stream));
+         TRY(gdot(KZ, w_r0, w_v, &rtv));
          if (is_zero(rtv) || bad(rtv)) break;
          alpha = rho / rtv;
          if (bad(alpha)) break;
@@ -358,9 +452,9 @@ struct Ipm {
          TRY(precond(w_dx));
          TRY(kmult(w_dx, w_t));
          double tt, tr;
-         TRY(pips_hip_vec_dot(nz(), 0, w_t, w_t, &tt, stream));
+         TRY(gdot(KZ, w_t, w_t, &tt));
          if (is_zero(tt) || bad(tt)) break;
-         TRY(pips_hip_vec_dot(nz(), 0, w_t, w_r, &tr, stream));
+         TRY(gdot(KZ, w_t, w_r, &tr));
          omega = tr / tt;
          if (bad(omega)) break;
          TRY(two_norm(w_dx, &dxn));
@@ -418,8 +512,8 @@ struct Ipm {
    }
    int step_lengths(const double* sv, const double* sg, double tau, double* ap, double* ad) {
       double bp, bd;
-      TRY(pips_hip_vec_stepbound(nx, v, sv, nullptr, &bp, stream));
-      TRY(pips_hip_vec_stepbound(nx, g, sg, nullptr, &bd, stream));
+      TRY(gstepbound(v, sv, &bp));
+      TRY(gstepbound(g, sg, &bd));
       *ap = std::min(1.0, tau * bp);
       *ad = std::min(1.0, tau * bd);
       return PIPS_OK;
@@ -450,12 +544,12 @@ struct Ipm {
    int mehrotra_step_length(double* ap, double* ad) {
       const double gamma_f = 0.99, gamma_a = 1.0 / (1.0 - gamma_f), steplength_factor = 0.99999999;
       double pb[5], db[5];
-      TRY(pips_hip_vec_find_blocking(nx, v, dv, g, dg, pb, stream));   // primal blocking: [ratio, v_b, dv_b, g_b, dg_b]
-      TRY(pips_hip_vec_find_blocking(nx, g, dg, v, dv, db, stream));   // dual blocking:   [ratio, g_b, dg_b, v_b, dv_b]
+      TRY(gfind_blocking(v, dv, g, dg, pb));   // primal blocking: [ratio, v_b, dv_b, g_b, dg_b]
+      TRY(gfind_blocking(g, dg, v, dv, db));   // dual blocking:   [ratio, g_b, dg_b, v_b, dv_b]
       const double amax_p = std::min(1.0, pb[0]), amax_d = std::min(1.0, db[0]);
       double mufull;
-      TRY(pips_hip_vec_dot_shifted(nx, 0, v, amax_p, dv, g, amax_d, dg, &mufull, stream));
-      mufull = mufull / nx / gamma_a;
+      TRY(gdot_shifted(v, amax_p, dv, g, amax_d, dg, &mufull));
+      mufull = mufull / nx_global / gamma_a;
       double a_p = 1.0, a_d = 1.0;
       if (pb[0] < 1.0) {
          const double est = pb[3] + amax_d * pb[4];
@@ -515,7 +609,7 @@ struct Ipm {
    std::vector<double> trace;   // per iterate: mu, ||r||inf, primal obj, dual obj, then the step taken from it: sigma, alpha_p, alpha_d
    int run(int max_iter, double mutol, double artol, int verbose, double* result) {
       HIP_TRYH(hipSetDevice(device));
-      verbose_run = verbose;
+      verbose_run = verbose = rank == 0 ? verbose : 0;
       n_gondzio = n_precond = 0;
       n_regularised = n_factorize = 0;
       // ---- start point: push_to_interior(sqrt(dnorm)), one affine solve, full step, shift (PIPSIPMppSolver.cpp:36-42, Solver.cpp:19-31)
@@ -535,8 +629,8 @@ struct Ipm {
       TRY(pips_hip_vec_axpy(nx, 1.0, dv, v, stream));
       TRY(pips_hip_vec_axpy(nx, 1.0, dg, g, stream));
       double vmin, gmin;
-      TRY(pips_hip_vec_min(nx, v, &vmin, stream));
-      TRY(pips_hip_vec_min(nx, g, &gmin, stream));
+      TRY(gvmin(v, &vmin));
+      TRY(gvmin(g, &gmin));
       const double viol = std::max(0.0, std::max(-vmin, -gmin));
       const double shift = 1e3 + 2.0 * viol;
       TRY(pips_hip_vec_add_const(nx, shift, v, stream));
@@ -596,8 +690,8 @@ struct Ipm {
          double ap, ad;
          TRY(step_lengths(dv, dg, 1.0, &ap, &ad));
          double maff;
-         TRY(pips_hip_vec_dot_shifted(nx, 0, v, ap, dv, g, ad, dg, &maff, stream));
-         maff /= nx;
+         TRY(gdot_shifted(v, ap, dv, g, ad, dg, &maff));
+         maff /= nx_global;
          const double sigma = std::pow(maff / m, 3.0);
          // ---- corrector: linear residuals cleared, rgamma = dV_aff dGamma_aff - sigma mu  (set_complementarity_residual(step, -sigma mu))
          TRY(pips_hip_vec_copy(nx, dv, rg, stream));
@@ -638,9 +732,20 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
                     const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
                     const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
                     const double* F0_val, const double* c, const double* b, double dual_reg, int device) {
-   if (!handle || N <= 0 || n0 < 0 || myl < 0 || !n_i || !my_i) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_create: bad arguments");
+   return pips_ipm_create_rank(handle, N, n0, myl, n_i, my_i, W_rowptr, W_colidx, W_val, T_rowptr, T_colidx, T_val, F_rowptr, F_colidx, F_val,
+                               F0_rowptr, F0_colidx, F0_val, c, b, dual_reg, device, nullptr, 0, 1);
+}
+
+int pips_ipm_create_rank(void** handle, int N, int n0, int myl, const int* n_i, const int* my_i, const int* W_rowptr,
+                         const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
+                         const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
+                         const double* F0_val, const double* c, const double* b, double dual_reg, int device, void* comm, int rank,
+                         int n_ranks) {
+   if (!handle || N <= 0 || n0 < 0 || myl < 0 || !n_i || !my_i || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !comm))
+      PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_create: bad arguments");
    auto p = std::make_unique<Ipm>();
    p->N = N; p->n0 = n0; p->myl = myl; p->dual_reg = dual_reg;
+   p->comm = comm; p->rank = rank; p->n_ranks = n_ranks;
    std::vector<int> xoff(N + 2, 0), yoff(N + 2, 0);
    std::vector<long long> koff(N + 2, 0);
    xoff[1] = n0; yoff[1] = myl;
@@ -695,7 +800,10 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
    }
    if (F0_rowptr)
       for (int l = 0; l < myl; ++l)
-         for (int q = F0_rowptr[l]; q < F0_rowptr[l + 1]; ++q) { Arows[l].push_back({F0_colidx[q], F0_val[q]}); dn = std::max(dn, std::fabs(F0_val[q])); }
+         for (int q = F0_rowptr[l]; q < F0_rowptr[l + 1]; ++q) {
+            if (rank == 0) Arows[l].push_back({F0_colidx[q], F0_val[q]});   // the replicated root block enters the summed products once
+            dn = std::max(dn, std::fabs(F0_val[q]));
+         }
    for (int j = 0; j < p->nx; ++j) dn = std::max(dn, std::fabs(c[j]));
    for (int r = 0; r < p->ny; ++r) dn = std::max(dn, std::fabs(b[r]));
    p->dnorm = dn > 0 ? dn : 1.0;
@@ -730,12 +838,20 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
    if ((rc = pips_hip_batch_set_refinement_backward_error(p->batch, 2, 1e-15))) return rc;   // PARDISO iparm[7]=2 semantics
    if (sparse_root)
       rc = pips_hip_kkt_create_sparse(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr,
-                                      nullptr, 0, nullptr, nullptr, nullptr, 0, 1);
+                                      nullptr, 0, nullptr, nullptr, comm, rank, n_ranks);
    else
       rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, 0, myl, 0, nullptr, nullptr, nullptr, F0_rowptr, F0_colidx, F0_val, nullptr, nullptr, nullptr,
-                               nullptr, 0, 1);
+                               comm, rank, n_ranks);
    if (rc) return rc;
    HIP_TRYH(hipGetDevice(&p->device));
+   if ((rc = p->alloc(&p->d_red, 8 * (long long)n_ranks))) return rc;
+   // data norm and number of complementarity pairs over all ranks
+   if ((rc = p->gext(&p->dnorm, true))) return rc;
+   {
+      double pairs = (double)(p->nx - n0);
+      if ((rc = p->gsum(&pairs))) return rc;
+      p->nx_global = (long long)pairs + n0;
+   }
    {
       std::vector<int> la, lat;
       for (int r = 0; r < p->ny; ++r) if (Arp[r + 1] - Arp[r] > CSR_LONG_ROW) la.push_back(r);

@@ -66,7 +66,7 @@ SYMBOLS = [
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
+    "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
     "pips_gdx_read_block", "pips_gdx_block_counts", "pips_gdx_block_vector", "pips_gdx_block_matrix", "pips_gdx_block_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
@@ -712,8 +712,9 @@ class vec:
 class IpmSolver:
     """The host harness: Mehrotra predictor-corrector on the device for the generator's LP class."""
 
-    def __init__(self, n0, myl, blocks, F0, c, b, dual_reg=0.0, device=-1):
-        """blocks: list of (W, T, F) Csr triples; c: [x0 | x1..xN]; b: [link | block rows]."""
+    def __init__(self, n0, myl, blocks, F0, c, b, dual_reg=0.0, device=-1, comm=None, rank=0, n_ranks=1):
+        """blocks: list of (W, T, F) Csr triples; c: [x0 | x1..xN]; b: [link | block rows].
+        Several ranks: blocks / c / b hold this rank's blocks behind the replicated root parts; comm: Comm or ExternalComm."""
         N = len(blocks)
         n_i = _i32([w.ncols for (w, t, f) in blocks])
         my_i = _i32([w.nrows for (w, t, f) in blocks])
@@ -729,11 +730,13 @@ class IpmSolver:
         self.nx = n0 + int(n_i.sum())
         self.ny = myl + int(my_i.sum())
         self._h = C.c_void_p()
-        _check(lib.pips_ipm_create(C.byref(self._h), C.c_int(N), C.c_int(n0), C.c_int(myl), _ptr(n_i), _ptr(my_i),
-                                   *[_ptr(a) for a in W], *[_ptr(a) for a in T], *[_ptr(a) for a in F],
-                                   _ptr(F0.rowptr) if F0 is not None else None, _ptr(F0.colidx) if F0 is not None else None,
-                                   _ptr(F0.val) if F0 is not None else None, _ptr(self._keep[5]), _ptr(self._keep[6]),
-                                   C.c_double(dual_reg), C.c_int(device)), "pips_ipm_create")
+        self._comm = comm
+        _check(lib.pips_ipm_create_rank(C.byref(self._h), C.c_int(N), C.c_int(n0), C.c_int(myl), _ptr(n_i), _ptr(my_i),
+                                        *[_ptr(a) for a in W], *[_ptr(a) for a in T], *[_ptr(a) for a in F],
+                                        _ptr(F0.rowptr) if F0 is not None else None, _ptr(F0.colidx) if F0 is not None else None,
+                                        _ptr(F0.val) if F0 is not None else None, _ptr(self._keep[5]), _ptr(self._keep[6]),
+                                        C.c_double(dual_reg), C.c_int(device), comm._h if comm is not None else None, C.c_int(rank),
+                                        C.c_int(n_ranks)), "pips_ipm_create_rank")
 
     def set_gondzio(self, max_correctors):
         _check(lib.pips_ipm_set_gondzio(self._h, C.c_int(max_correctors)), "pips_ipm_set_gondzio")

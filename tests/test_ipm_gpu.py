@@ -1,5 +1,7 @@
 """End-to-end harness IPM (a18) on the GPU vs an independent LP solver (HiGHS through scipy): the final objective must
 agree to the tolerance implied by the termination rule of the reference (mu <= mutol, ||r|| <= artol * dnorm)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -95,3 +97,34 @@ def test_ipm_sweep_against_highs(case):
     ref = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
     assert res["status"] == 0 and ref.status == 0, (res, ref.status)
     assert abs(res["objective"] - ref.fun) / max(1.0, abs(ref.fun)) < 1e-7, (res, ref.fun)
+
+
+GOLDEN_CFG1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ipm_config1_trace.npz")
+
+
+@pytest.mark.gpu
+def test_config1_trace_follows_the_oracle_capture():
+    """BASELINE configs[0] (4 blocks x 1000 variables, Schur dimension 200): the device harness against the committed
+    per-iteration capture of the CPU restatement - iteration count (+10 % allowed, t_pips.cpp:119), final objective to
+    1e-9, and mu, both objectives, sigma and both step lengths of every iterate (1e-6 relative while the iterates are well
+    conditioned, 1e-3 over the last four)."""
+    g = np.load(GOLDEN_CFG1)
+    N, n_i, my_i, n0, myl = (int(v) for v in g["shape"][:5])
+    blocks, F0, c, b, A = build_lp(int(g["seed"]), N, n_i, my_i, n0, myl, float(g["shape"][5]))
+    ipm = pa.IpmSolver(n0, myl, blocks, F0, c, b)
+    res = ipm.solve(max_iter=100, mutol=float(g["mutol"]), artol=float(g["artol"]))
+    assert res["status"] == 0, res
+    want_it = int(g["iterations"])
+    assert res["iterations"] <= int(np.ceil(1.1 * want_it)) and res["iterations"] >= want_it - 2
+    assert abs(res["objective"] - float(g["objective"])) / abs(float(g["objective"])) < 1e-9
+    tr, gt = ipm.trace(), g["trace"]
+    n_cmp = min(tr.shape[0], gt.shape[0]) - 1
+    assert n_cmp >= 15
+    for k in range(n_cmp):
+        tol = 1e-6 if k < n_cmp - 4 else 1e-3
+        mu, rnorm, pobj, dobj, sigma, ap, ad = gt[k]
+        assert abs(tr[k, 0] - mu) <= tol * mu, (k, tr[k], gt[k])
+        assert abs(tr[k, 2] - pobj) <= tol * max(1.0, abs(pobj)) and abs(tr[k, 3] - dobj) <= tol * max(1.0, abs(dobj)), (k, tr[k], gt[k])
+        assert abs(tr[k, 4] - sigma) <= 10 * tol and abs(tr[k, 5] - ap) <= 10 * tol and abs(tr[k, 6] - ad) <= 10 * tol, (k, tr[k], gt[k])
+    x, _ = ipm.solution()
+    assert np.abs(x[:n0] - g["x0"]).max() <= 1e-6 * max(1.0, np.abs(g["x0"]).max())

@@ -1,0 +1,84 @@
+"""The IPM harness on two ranks (vector reductions with the replicated root part counted once, link rows of A x
+and x0 rows of A^T y summed, the Schur complement and b0 reduced inside factorize / solveCompressed): two processes share
+device 0 and reduce through an ExternalComm (gloo, staged through host memory), each owns half of the blocks.  Every rank must
+return what the one-process run returns: status, iteration count, objective, the per-iterate history, x0 and its blocks' x."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pips_ipmpp_amd as pa
+from tests.test_ipm_gpu import build_lp
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (2027, 4, 120, 60, 8, 6, 0.08)   # seed, N, n_i, my_i, n0, myl, rho
+
+
+def _local(blocks, c, b, mine, n_i, my_i, n0, myl):
+    cl = np.concatenate([c[:n0]] + [c[n0 + k * n_i:n0 + (k + 1) * n_i] for k in mine])
+    bl = np.concatenate([b[:myl]] + [b[myl + k * my_i:myl + (k + 1) * my_i] for k in mine])
+    return [blocks[k] for k in mine], cl, bl
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seed, N, n_i, my_i, n0, myl, rho = SHAPE
+    blocks, F0, c, b, A = build_lp(seed, N, n_i, my_i, n0, myl, rho)
+    mine = np.nonzero(pa.map_children_to_ranks(N, world) == rank)[0]
+    calls = []
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        torch.cuda.synchronize()
+        calls.append(n)
+
+    comm = pa.ExternalComm(allreduce)
+    lb, lc, lbv = _local(blocks, c, b, mine, n_i, my_i, n0, myl)
+    ipm = pa.IpmSolver(n0, myl, lb, F0, lc, lbv, comm=comm, rank=rank, n_ranks=world)
+    res = ipm.solve(max_iter=100, mutol=1e-9, artol=1e-8)
+    x, y = ipm.solution()
+    np.savez(os.path.join(out, f"rank{rank}.npz"), res=np.array([res[k] for k in ("status", "iterations", "objective", "dual_objective", "mu", "rnorm", "dnorm")]),
+             trace=ipm.trace(), x=x, y=y, mine=mine, ncalls=len(calls), stats=np.array(list(ipm.stats().values())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ipm_matches_one_rank(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + 13
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    seed, N, n_i, my_i, n0, myl, rho = SHAPE
+    blocks, F0, c, b, A = build_lp(seed, N, n_i, my_i, n0, myl, rho)
+    one = pa.IpmSolver(n0, myl, blocks, F0, c, b)
+    r1 = one.solve(max_iter=100, mutol=1e-9, artol=1e-8)
+    x1, y1 = one.solution()
+    t1 = one.trace()
+    assert r1["status"] == 0
+    got = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    # every rank reports the same scalars (they steer the iteration: any difference would desynchronise the collectives)
+    assert np.array_equal(got[0]["res"], got[1]["res"]) and np.array_equal(got[0]["trace"], got[1]["trace"])
+    assert np.array_equal(got[0]["x"][:n0], got[1]["x"][:n0]) and np.array_equal(got[0]["y"][:myl], got[1]["y"][:myl])
+    seen = []
+    for g in got:
+        status, its, obj = int(g["res"][0]), int(g["res"][1]), g["res"][2]
+        assert status == 0 and abs(its - r1["iterations"]) <= 1
+        assert abs(obj - r1["objective"]) <= 1e-9 * abs(r1["objective"])
+        assert g["res"][6] == r1["dnorm"]
+        n_cmp = min(g["trace"].shape[0], t1.shape[0]) - 4
+        assert n_cmp >= 8 and np.allclose(g["trace"][:n_cmp, [0, 2, 3]], t1[:n_cmp, [0, 2, 3]], rtol=1e-6, atol=0)
+        assert np.abs(g["x"][:n0] - x1[:n0]).max() <= 1e-6 * max(1.0, np.abs(x1[:n0]).max())
+        for i, k in enumerate(g["mine"]):
+            xs = g["x"][n0 + i * n_i:n0 + (i + 1) * n_i]
+            assert np.abs(xs - x1[n0 + k * n_i:n0 + (k + 1) * n_i]).max() <= 1e-6 * max(1.0, np.abs(x1).max())
+            seen.append(int(k))
+        assert g["ncalls"] > 50
+    assert sorted(seen) == list(range(N))
