@@ -76,6 +76,29 @@ def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
     return bt, np.concatenate(diags)
 
 
+def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho):
+    """Full interior-point solve (Mehrotra + Gondzio harness, termination mu <= 1e-8 and ||r||inf <= 1e-8 dnorm) of the LP the
+    generator defines for this shape: b = A x*, x* ~ U(0.5, 1.5)."""
+    F0, c0, x0s = pa.gen_root(seed, n0, myl)
+    blocks, cs, bs = [], [c0], []
+    blink = F0.to_scipy() @ x0s
+    for b in range(1, N + 1):
+        W, T, F, c, xs = pa.gen_block(seed, b, n_i, my_i, n0, myl, rho)
+        blocks.append((W, T, F))
+        cs.append(c)
+        bs.append(T.to_scipy() @ x0s + W.to_scipy() @ xs)
+        blink = blink + F.to_scipy() @ xs
+    ipm = pa.IpmSolver(n0, myl, blocks, F0, np.concatenate(cs), np.concatenate([blink] + bs))
+    t0 = time.perf_counter()
+    res = ipm.solve(max_iter=150, mutol=1e-8, artol=1e-8)
+    dt = time.perf_counter() - t0
+    st = ipm.stats()
+    ipm.close()
+    return {"status": res["status"], "iterations": res["iterations"], "seconds": round(dt, 3), "iterations_per_s": round(res["iterations"] / dt, 3),
+            "objective": res["objective"], "mu": res["mu"], "rel_residual": res["rnorm"] / res["dnorm"], "factorizations": st["factorizations"],
+            "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i)}
+
+
 def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
     """Reference-style CPU path timed on a bounded sample and extrapolated linearly (all blocks are statistically
     identical and independent): per block PARDISO phase 12 (or the oracle LDL^T) + multi-RHS solves for the border
@@ -147,6 +170,7 @@ def main():
     ap.add_argument("--rho", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ipm", action="store_true", help="skip the end-to-end IPM run reported next to the metric (N = 1 only)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -302,6 +326,13 @@ def main():
             except Exception as e:  # the baseline must never break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "64-block work units/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+        if not a.no_ipm and world == 1:
+            # "report units/s, and separately end-to-end IPM iterations/s of a full solve with the host driver" - the
+            # device-resident harness on the LP of the same generator and shape, outside the timed region of the metric
+            try:
+                out["ipm_end_to_end"] = ipm_end_to_end(pa, a.seed, n_blocks_total, n_i, my_i, n0, myl, a.rho)
+            except Exception as e:
+                out["ipm_end_to_end"] = {"error": str(e)}
         # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a pipe: push it out
         # first so that the JSON line is the last line of stdout
         try:

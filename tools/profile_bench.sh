@@ -6,9 +6,9 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ipm > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-ipm > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-ipm > $OUT/write.log 2>&1
 # counter files are large: keep only the per-kernel sums
 python3 $R/tools/profile_summarise.py $OUT > $OUT/summary.json 2> $OUT/summary.err
 find $OUT -name "*counter_collection.csv" -delete
