@@ -66,7 +66,8 @@ def test_two_rank_ipm_matches_one_rank(tmp_path):
     got = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
     # every rank reports the same scalars (they steer the iteration: any difference would desynchronise the collectives)
     assert np.array_equal(got[0]["res"], got[1]["res"]) and np.array_equal(got[0]["trace"], got[1]["trace"])
-    assert np.array_equal(got[0]["x"][:n0], got[1]["x"][:n0]) and np.array_equal(got[0]["y"][:myl], got[1]["y"][:myl])
+    # the replicated root parts agree (to rounding: each rank factorises the reduced Schur complement on its own)
+    assert np.allclose(got[0]["x"][:n0], got[1]["x"][:n0], rtol=1e-10, atol=1e-12) and np.allclose(got[0]["y"][:myl], got[1]["y"][:myl], rtol=1e-10, atol=1e-12)
     seen = []
     for g in got:
         status, its, obj = int(g["res"][0]), int(g["res"][1]), g["res"][2]
