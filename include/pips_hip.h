@@ -274,6 +274,11 @@ int pips_ipm_set_gondzio(void* handle, int max_correctors);
  * OUTER_SOLVE (1 iterative refinement, 2 BiCGStab), OUTER_BICG_MAX_ITER, REGULARIZATION (0/1: the inertia-correcting loop);
  * anything else returns an error */
 int pips_ipm_set_option(void* handle, const char* name, double value);
+/* free variables: bounded_mask (nx host doubles, this rank's layout) is 1 for x_j >= 0 and 0 for a free x_j (the reference's
+ * ixlow = ixupp = 0, whose computeDiagonals leaves dd_j = 0: LinearSystem.C:262-294).  Free entries carry no complementarity pair;
+ * the preconditioner gets a proximal term on their diagonal (1e-6, option FREE_VARIABLE_PROXIMAL_TERM), the outer solve none.
+ * Call before pips_ipm_solve; with several ranks on every rank. */
+int pips_ipm_set_free_variables(void* handle, const double* bounded_mask_host);
 int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
 /* history of the last pips_ipm_solve, one row of 7 doubles per iterate: mu, ||r||inf, primal objective, dual objective, and the
  * step taken from it: sigma, alpha_primal, alpha_dual (zeros in the final row).  rows7 may be NULL to query *n_rows. */

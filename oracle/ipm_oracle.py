@@ -46,10 +46,10 @@ def weight_search(v, dv, cv, g, dg, cg, apt, adt):
     return ape, ade, wp, wd
 
 
-def mehrotra_step_length(v, dv, g, dg):
+def mehrotra_step_length(v, dv, g, dg, n_pairs=None):
     gamma_f, factor = 0.99, 0.99999999
     gamma_a = 1.0 / (1.0 - gamma_f)
-    nx = len(v)
+    nx = len(v) if n_pairs is None else n_pairs
     pb, db = find_blocking(v, dv, g, dg), find_blocking(g, dg, v, dv)
     amax_p, amax_d = min(1.0, pb[0]), min(1.0, db[0])
     mufull = (v + amax_p * dv) @ (g + amax_d * dg) / nx / gamma_a
@@ -65,26 +65,35 @@ def mehrotra_step_length(v, dv, g, dg):
     return a_p, a_d
 
 
-def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0, gondzio=2):
+def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0, gondzio=2, bounded=None, free_diag=0.0):
+    """bounded: optional 0/1 mask, 0 = free variable (the reference's ixlow = ixupp = 0: no complementarity pair, dd_j = 0,
+    LinearSystem.C:262-294); free entries carry the constant pair v = 1, gamma = 0 and masked rv, rgamma, dv, dgamma.
+    free_diag: primal regularisation on the free entries of the KKT matrix (a free column without any coefficient makes the
+    unregularised matrix exactly singular for SuperLU)."""
     A = sp.csr_matrix(A)
     ny, nx = A.shape
+    fm = np.ones(nx) if bounded is None else np.asarray(bounded, dtype=float)
+    free = fm == 0.0
+    n_pairs = int(fm.sum())
     dnorm = max(np.abs(A.data).max(), np.abs(b).max(), np.abs(c).max())
     s0 = np.sqrt(dnorm)
     x, y = np.zeros(nx), np.zeros(ny)
     v, g = np.full(nx, s0), np.full(nx, s0)
+    v[free], g[free] = 1.0, 0.0
 
     def residuals():
-        return c - A.T @ y - g, A @ x - b, x - v
+        return c - A.T @ y - g, A @ x - b, (x - v) * fm
 
     def solve(rQ, rA, rv, rg):
         dd = g / v
+        rg = rg * fm
         rx = rQ + dd * rv + rg / v
-        K = sp.bmat([[sp.diags(dd), A.T], [A, -dual_reg * sp.identity(ny) if dual_reg else None]], format="csc")
+        K = sp.bmat([[sp.diags(dd + free_diag * (1.0 - fm)), A.T], [A, -dual_reg * sp.identity(ny) if dual_reg else None]], format="csc")
         sol = spl.splu(K).solve(np.concatenate([rx, rA]))
         dx, dyp = sol[:nx], sol[nx:]
         dy = -dyp
-        dv = dx - rv
-        dg = (rg - g * dv) / v
+        dv = (dx - rv) * fm
+        dg = (rg - g * dv) / v * fm
         return -dx, -dy, -dv, -dg
 
     rQ, rA, rv = residuals()
@@ -93,11 +102,12 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
     viol = max(0.0, -v.min(), -g.min())
     v += 1e3 + 2 * viol
     g += 1e3 + 2 * viol
+    v[free], g[free] = 1.0, 0.0
     status, it = 1, 0
     for it in range(max_iter):
         rQ, rA, rv = residuals()
         rnorm = max(np.abs(rQ).max(), np.abs(rA).max(), np.abs(rv).max())
-        mu = v @ g / nx
+        mu = v @ g / n_pairs
         if trace is not None:
             trace.append((it, mu, rnorm, c @ x, b @ y))
         if mu <= mutol and rnorm <= artol * dnorm:
@@ -105,7 +115,7 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
             break
         dx, dy, dv, dg = solve(rQ, rA, rv, v * g)
         ap, ad = min(1.0, stepbound(v, dv)), min(1.0, stepbound(g, dg))
-        mu_aff = (v + ap * dv) @ (g + ad * dg) / nx
+        mu_aff = (v + ap * dv) @ (g + ad * dg) / n_pairs
         sigma = (mu_aff / mu) ** 3
         z = np.zeros(nx)
         cx, cy, cv, cg = solve(z, np.zeros(ny), z, dv * dg - sigma * mu)
@@ -134,7 +144,7 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
             ng += 1
             if both_one:
                 break
-        ap, ad = mehrotra_step_length(v, dv, g, dg)
+        ap, ad = mehrotra_step_length(v, dv, g, dg, n_pairs)
         x += ap * dx; v += ap * dv
         y += ad * dy; g += ad * dg
         if trace is not None:   # the step that leaves iterate `it`: (sigma, alpha_primal, alpha_dual) appended to its row

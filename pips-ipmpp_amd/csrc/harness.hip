@@ -116,6 +116,18 @@ __global__ void k_leaf_diag(int N, const int* __restrict__ xoff, const int* __re
       leaf_diag[koff[b] + i] = i < nx ? dd[xoff[b] + i] + primal_reg : -dual_reg;
 }
 
+// free entries: v = 1, gamma = 0
+__global__ void k_fix_free(long long n, const double* __restrict__ fmask, double* __restrict__ v, double* __restrict__ g) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      if (fmask[i] == 0.0) { v[i] = 1.0; g[i] = 0.0; }
+}
+// preconditioner diagonal: ddp = dd + free_reg on free entries
+__global__ void k_precond_diag(long long n, const double* __restrict__ fmask, const double* __restrict__ dd, double free_reg,
+                               double* __restrict__ ddp) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      ddp[i] = dd[i] + (fmask[i] == 0.0 ? free_reg : 0.0);
+}
+
 struct Ipm {
    int device = 0;
    hipStream_t stream = nullptr;
@@ -137,6 +149,13 @@ struct Ipm {
           *w_dx = nullptr;
    double *gv = nullptr, *gg = nullptr;   // Gondzio trial vectors
    double *bx = nullptr, *bv = nullptr, *bg = nullptr, *by = nullptr;   // best iterate so far (numerical-trouble fallback)
+   // Free variables (no bound: ixlow = ixupp = 0 in the reference, whose computeDiagonals gives them dd = 0, LinearSystem.C:
+   // 262-294): fmask is 1 on x >= 0 entries and 0 on free ones.  A free entry carries the constant pair v = 1, gamma = 0, takes
+   // no part in the complementarity terms (its rv, rgamma, dv, dgamma are masked to zero) and gets the proximal term free_reg
+   // on the diagonal of the *preconditioner* only (ddp); the outer solve works with dd = 0 there.
+   double *fmask = nullptr, *ddp = nullptr;
+   bool has_free = false;
+   double free_reg = 1e-6;
    int max_gondzio = 2;   // multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358)
    long long n_gondzio = 0;
    int outer_mode = 2;   // 1 = iterative refinement, 2 = BiCGStab (the reference's OUTER_SOLVE default)
@@ -272,6 +291,7 @@ struct Ipm {
       TRY(Amult(x, 1.0, -1.0, rA));
       TRY(pips_hip_vec_copy(nx, x, rv, stream));
       TRY(pips_hip_vec_axpy(nx, -1.0, v, rv, stream));
+      if (has_free) TRY(pips_hip_vec_mul(nx, fmask, rv, stream));
       double a1, a2, a3;
       TRY(ginf(nx, rQ, &a1));
       TRY(ginf(ny, rA, &a2));
@@ -316,11 +336,16 @@ struct Ipm {
    int factorize() {
       TRY(pips_hip_vec_copy(nx, g, dd, stream));
       TRY(pips_hip_vec_div(nx, v, dd, stream));
+      const double* dfac = dd;
+      if (has_free) {
+         hipLaunchKernelGGL(k_precond_diag, dim3(std::min<long long>(2048, (nx + 255) / 256)), dim3(256), 0, stream, (long long)nx, fmask, dd, free_reg, ddp);
+         dfac = ddp;
+      }
       double reg = 0.0;
       for (int attempt = 0;; ++attempt) {
-         hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dd, reg, dual_reg + reg, leaf_diag);
+         hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dfac, reg, dual_reg + reg, leaf_diag);
          TRY(pips_hip_kkt_set_root_regularization(kkt, reg, dual_reg + reg));
-         TRY(pips_hip_kkt_factorize(kkt, leaf_diag, dd, nullptr));
+         TRY(pips_hip_kkt_factorize(kkt, leaf_diag, dfac, nullptr));
          ++n_factorize;
          int pert;
          TRY(perturbed_pivots(&pert));
@@ -486,7 +511,7 @@ struct Ipm {
       // rx = rQ + Gamma/V rv + rgamma/V ; ry = rA
       TRY(pips_hip_vec_copy(nx, rQ_, tx, stream));
       TRY(pips_hip_vec_add_product(nx, 1.0, dd, rv_, tx, stream));
-      TRY(pips_hip_vec_add_quotient(nx, 1.0, rg_, v, nullptr, tx, stream));
+      TRY(pips_hip_vec_add_quotient(nx, 1.0, rg_, v, has_free ? fmask : nullptr, tx, stream));
       TRY(pips_hip_vec_copy(ny, rA_, ty, stream));
       // joinRHS: z = [rx | ry]; outer solve on the ORIGINAL system [dd A^T; A 0] preconditioned by solveCompressed
       TRY(pips_hip_vec_copy(nx, tx, bz, stream));
@@ -503,6 +528,10 @@ struct Ipm {
       TRY(pips_hip_vec_copy(nx, rg_, sg, stream));
       TRY(pips_hip_vec_add_product(nx, -1.0, g, sv, sg, stream));
       TRY(pips_hip_vec_div(nx, v, sg, stream));
+      if (has_free) {
+         TRY(pips_hip_vec_mul(nx, fmask, sv, stream));
+         TRY(pips_hip_vec_mul(nx, fmask, sg, stream));
+      }
       // step.negate()
       TRY(pips_hip_vec_scale(nx, -1.0, sx, stream));
       TRY(pips_hip_vec_scale(ny, -1.0, sy, stream));
@@ -618,6 +647,10 @@ struct Ipm {
       TRY(pips_hip_vec_set(ny, 0.0, y, stream));
       TRY(pips_hip_vec_set(nx, s0, v, stream));
       TRY(pips_hip_vec_set(nx, s0, g, stream));
+      auto fix_free = [&]() {
+         if (has_free) hipLaunchKernelGGL(k_fix_free, dim3(std::min<long long>(2048, (nx + 255) / 256)), dim3(256), 0, stream, (long long)nx, fmask, v, g);
+      };
+      fix_free();
       double rnorm, pobj, dobj, m;
       TRY(residuals(&rnorm, &pobj, &dobj));
       TRY(pips_hip_vec_copy(nx, v, rg, stream));
@@ -635,6 +668,7 @@ struct Ipm {
       const double shift = 1e3 + 2.0 * viol;
       TRY(pips_hip_vec_add_const(nx, shift, v, stream));
       TRY(pips_hip_vec_add_const(nx, shift, g, stream));
+      fix_free();
 
       int it = 0, status = 1;  // 1 = max iterations
       trace.clear();
@@ -901,6 +935,29 @@ int pips_ipm_set_gondzio(void* handle, int max_correctors) {
    return PIPS_OK;
 }
 
+int pips_ipm_set_free_variables(void* handle, const double* bounded_mask_host) {
+   Ipm* p = (Ipm*)handle;
+   if (!p || !bounded_mask_host) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_free_variables: bad arguments");
+   HIP_TRYH(hipSetDevice(p->device));
+   double local_bounded = 0.0;
+   bool any_free = false;
+   for (int j = 0; j < p->nx; ++j) {
+      if (bounded_mask_host[j] != 0.0 && bounded_mask_host[j] != 1.0) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_free_variables: mask entries must be 0 or 1");
+      any_free |= bounded_mask_host[j] == 0.0;
+      if (j >= p->n0 || p->rank == 0) local_bounded += bounded_mask_host[j];
+   }
+   int rc;
+   if (!p->fmask && ((rc = p->alloc(&p->fmask, p->nx)) || (rc = p->alloc(&p->ddp, p->nx)))) return rc;
+   HIP_TRYH(hipMemcpy(p->fmask, bounded_mask_host, (size_t)p->nx * sizeof(double), hipMemcpyHostToDevice));
+   // the number of complementarity pairs (divisor of mu) and whether any rank has free entries: over all ranks
+   double flags[2] = {local_bounded, any_free ? 1.0 : 0.0};
+   if (p->n_ranks > 1 && (rc = p->reduce_host(flags, 2))) return rc;
+   p->nx_global = (long long)flags[0];
+   p->has_free = flags[1] > 0.0;
+   if (p->nx_global <= 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_free_variables: no bounded variable left");
+   return PIPS_OK;
+}
+
 int pips_ipm_set_option(void* handle, const char* name, double value) {
    Ipm* p = (Ipm*)handle;
    if (!p || !name) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_option: bad arguments");
@@ -919,6 +976,10 @@ int pips_ipm_set_option(void* handle, const char* name, double value) {
       p->bicg_max_iter = (int)value;
    }
    else if (key == "REGULARIZATION") p->regularize = value != 0.0;
+   else if (key == "FREE_VARIABLE_PROXIMAL_TERM") {   // not a reference identifier: diagonal of the free variables in the preconditioner
+      if (!(value > 0.0)) PIPS_FAIL(PIPS_ERR_ARG, "FREE_VARIABLE_PROXIMAL_TERM must be > 0");
+      p->free_reg = value;
+   }
    else PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_set_option: unknown or unsupported identifier %s", name);
    return PIPS_OK;
 }

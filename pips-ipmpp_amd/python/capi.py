@@ -66,7 +66,7 @@ SYMBOLS = [
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
+    "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_set_free_variables", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
     "pips_gdx_read_block", "pips_gdx_block_counts", "pips_gdx_block_vector", "pips_gdx_block_matrix", "pips_gdx_block_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
@@ -761,6 +761,13 @@ class IpmSolver:
         out = np.zeros((n.value, 7))
         _check(lib.pips_ipm_get_trace(self._h, _ptr(out), C.c_int(n.value), C.byref(n)), "pips_ipm_get_trace")
         return out
+
+    def set_free_variables(self, bounded_mask):
+        """bounded_mask: 1 where x_j >= 0, 0 where x_j is free (no complementarity pair, dd_j = 0 like the reference's computeDiagonals)."""
+        m = _f64(bounded_mask)
+        if m.shape[0] != self.nx:
+            raise ValueError("bounded_mask must have nx entries")
+        _check(lib.pips_ipm_set_free_variables(self._h, _ptr(m)), "pips_ipm_set_free_variables")
 
     def set_option(self, name, value):
         """Harness setting under the reference's option identifier (GONDZIO_MAX_CORRECTORS, OUTER_SOLVE, OUTER_BICG_MAX_ITER, REGULARIZATION)."""

@@ -27,12 +27,13 @@ def _to_pa(M):
     return pa.Csr(M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
 
 
-def _var_transform(blk, n):
-    """x = xc + M x'  and the list of (column of x', width) that need a bound row x'_j + s = width."""
+def _var_transform(blk, n, split_free=True):
+    """x = xc + M x', the list of (column of x', width) that need a bound row x'_j + s = width, and the 0/1 mask of the columns
+    of x' that are sign-constrained (0 = a free variable kept as one column, split_free=False)."""
     xlow, xupp = np.asarray(blk["xlow"], dtype=float), np.asarray(blk["xupp"], dtype=float)
     il, iu = np.asarray(blk["ixlow"]), np.asarray(blk["ixupp"])
     xc = np.zeros(n)
-    ri, ci, vv, ranges = [], [], [], []
+    ri, ci, vv, ranges, free_cols = [], [], [], [], []
     ncol = 0
     for j in range(n):
         if il[j] and iu[j] and xlow[j] == xupp[j]:
@@ -47,10 +48,16 @@ def _var_transform(blk, n):
             xc[j] = xupp[j]
             ri.append(j); ci.append(ncol); vv.append(-1.0)
             ncol += 1
-        else:
+        elif split_free:
             ri += [j, j]; ci += [ncol, ncol + 1]; vv += [1.0, -1.0]
             ncol += 2
-    return xc, sp.csr_matrix((vv, (ri, ci)), shape=(n, ncol)), ranges
+        else:
+            ri.append(j); ci.append(ncol); vv.append(1.0)
+            free_cols.append(ncol)
+            ncol += 1
+    mask = np.ones(ncol)
+    mask[free_cols] = 0.0
+    return xc, sp.csr_matrix((vv, (ri, ci)), shape=(n, ncol)), ranges, mask
 
 
 def _ineq_rows(low, ilow, upp, iupp):
@@ -78,11 +85,13 @@ def _select(cols_widths, ncols):
     return E, np.array([w for _, w in cols_widths], dtype=float)
 
 
-def block_standard_form(blocks):
+def block_standard_form(blocks, split_free=True):
+    """split_free=False keeps a free variable as one column and reports it in `bounded_mask` (0 there) for
+    IpmSolver.set_free_variables; the default splits it into x+ - x-."""
     root, kids = blocks[0], blocks[1:]
     n0 = root["n0"]
     mBL, mDL = root["mBL"], root["mDL"]
-    xc0, M0, vr0 = _var_transform(root, n0)
+    xc0, M0, vr0, mask0 = _var_transform(root, n0, split_free)
     n0p = M0.shape[1]
     # ---- root rows: [link eq | link ineq | A0 | C0 | range rows of link ineq and C0 | bound rows of x0]
     sgnL, rhsL, rngL = _ineq_rows(root["dlow"], root["idlow"], root["dupp"], root["idupp"])
@@ -123,9 +132,10 @@ def block_standard_form(blocks):
     c0 = np.concatenate([M0.T @ np.asarray(root["c"], dtype=float), np.zeros(n0s - n0p)])
     offset = float(np.asarray(root["c"], dtype=float) @ xc0)
     out_blocks, cs, bs, recover = [], [], [], [(xc0, M0)]
+    masks = [np.concatenate([mask0, np.ones(n0s - n0p)])]
     for k in kids:
         ni, mA, mC = k["ni"], k["mA"], k["mC"]
-        xc, M, vr = _var_transform(k, ni)
+        xc, M, vr, maskk = _var_transform(k, ni, split_free)
         n1 = M.shape[1]
         sgn, rhs, rng = _ineq_rows(k["clow"], k["iclow"], k["cupp"], k["icupp"])
         n2, nb = len(rng), len(vr)
@@ -153,6 +163,7 @@ def block_standard_form(blocks):
                                   np.array([ww for _, ww in rng], dtype=float), w]))
         offset += float(np.asarray(k["c"], dtype=float) @ xc)
         recover.append((xc, M))
+        masks.append(np.concatenate([maskk, np.ones(nloc - n1)]))
     c = np.concatenate([c0] + cs)
     b = np.concatenate([b_link] + bs)
     rows = [[F0] + [f.to_scipy() for (_, _, f) in out_blocks]]
@@ -162,6 +173,7 @@ def block_standard_form(blocks):
         rows.append(r)
     Afull = sp.bmat(rows, format="csr")
     return dict(n0=n0s, myl=n_link, blocks=out_blocks, F0=_to_pa(F0), c=c, b=b, A=Afull, offset=offset, recover=recover,
+                bounded_mask=np.concatenate(masks),
                 sizes=[n0s] + [f.to_scipy().shape[1] for (_, _, f) in out_blocks])
 
 

@@ -96,31 +96,37 @@ def test_highs_reproduces_the_reference_objective(inst):
     assert all((lo is None or xi >= lo - 1e-7) and (up is None or xi <= up + 1e-7) for xi, (lo, up) in zip(x, bounds))
 
 
+@pytest.mark.parametrize("free", ["split", "native"])
 @pytest.mark.parametrize("inst", DATA, ids=IDS)
-def test_ipm_oracle_reproduces_the_reference_objective(inst):
+def test_ipm_oracle_reproduces_the_reference_objective(inst, free):
+    """free variables either split into x+ - x- or kept as one column without a complementarity pair (the reference's way)"""
     from oracle import ipm_oracle as io
-    sf = block_standard_form(inst["blocks"])
+    sf = block_standard_form(inst["blocks"], split_free=free == "split")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         # several instances carry parallel / redundant rows on purpose (the reference removes them in its presolve): dual regularisation
-        o = io.solve_lp(sf["A"], sf["b"], sf["c"], 200, 1e-8, 1e-8, dual_reg=1e-9)
+        o = io.solve_lp(sf["A"], sf["b"], sf["c"], 200, 1e-8, 1e-8, dual_reg=1e-9, bounded=sf["bounded_mask"], free_diag=1e-10)
     assert o["status"] == 0
     assert abs(o["objective"] + sf["offset"] - inst["expected_objective"]) < OBJ_TOL
     assert o["iterations"] <= 1.1 * inst["expected_iterations"]   # t_pips.cpp:119
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("free", ["split", "native"])
 @pytest.mark.parametrize("inst", DATA, ids=IDS)
-def test_device_harness_reproduces_the_reference_objective(inst):
+def test_device_harness_reproduces_the_reference_objective(inst, free):
     import pips_ipmpp_amd as pa
-    sf = block_standard_form(inst["blocks"])
+    sf = block_standard_form(inst["blocks"], split_free=free == "split")
     ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=1e-9)
+    if free == "native":
+        assert (sf["bounded_mask"] == 0).any() or inst["name"].startswith("exampleAC_")   # three instances have no free variable
+        ipm.set_free_variables(sf["bounded_mask"])
     res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8)
     assert res["status"] == 0, res
     assert abs(res["objective"] + sf["offset"] - inst["expected_objective"]) < OBJ_TOL, res
     assert res["iterations"] <= 1.1 * inst["expected_iterations"] + 1
     x, _ = ipm.solution()
-    assert x.min() > -1e-8 and np.linalg.norm(sf["A"] @ x - sf["b"], np.inf) < 1e-6 * max(1.0, np.abs(sf["b"]).max())
+    assert x[sf["bounded_mask"] == 1].min() > -1e-8 and np.linalg.norm(sf["A"] @ x - sf["b"], np.inf) < 1e-6 * max(1.0, np.abs(sf["b"]).max())
 
 
 def _same_block(got, want, tag):

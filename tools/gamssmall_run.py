@@ -10,8 +10,11 @@ reg = float(os.environ.get("REG", "1e-9"))
 for inst in data:
     if only and only not in inst["name"]:
         continue
-    sf = block_standard_form(inst["blocks"])
+    native_free = bool(os.environ.get("NATIVE_FREE"))
+    sf = block_standard_form(inst["blocks"], split_free=not native_free)
     ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=reg)
+    if native_free:
+        ipm.set_free_variables(sf["bounded_mask"])
     res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8, verbose=int(os.environ.get("VERB", "2")) if only else 0)
     st = ipm.stats()
     print(f"{inst['name'][:50]:50s} exp {inst['expected_objective']:8.2f} ({inst['expected_iterations']:2d})  status {res['status']} it {res['iterations']:3d} "
