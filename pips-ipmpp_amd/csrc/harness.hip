@@ -864,6 +864,9 @@ int pips_ipm_create_rank(void** handle, int N, int n0, int myl, const int* n_i, 
    }
    // PIPS_IPM_SPARSE_ROOT=1: keep the Schur complement sparse and factorise it with the sparse engine (2-link problems)
    const bool sparse_root = getenv("PIPS_IPM_SPARSE_ROOT") && atoi(getenv("PIPS_IPM_SPARSE_ROOT")) != 0;
+   if (sparse_root && n_ranks > 1)
+      PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_create_rank: the sparse root needs the border column sets of all blocks on every rank (pips_hip_kkt_create_sparse); "
+                              "the harness passes only its own - use the dense root with several ranks");
    if (sparse_root && (rc = pips_hip_batch_set_schur_mode(p->batch, 1))) return rc;
    rc = pips_hip_batch_analyze(p->batch, 16);
    if (rc) return rc;

@@ -21,6 +21,8 @@ c = np.concatenate(cs); bvec = np.concatenate([blink] + bs)
 print(f"generated {N} blocks x {n_i} vars, S={S} in {time.time()-t0:.1f}s", flush=True)
 t0 = time.time()
 ipm = pa.IpmSolver(n0, myl, blocks, F0, c, bvec)
+if os.environ.get("GONDZIO"):
+    ipm.set_gondzio(int(os.environ["GONDZIO"]))
 print(f"setup (symbolic analysis, device upload) {time.time()-t0:.1f}s", flush=True)
 t0 = time.time()
 res = ipm.solve(max_iter=100, mutol=1e-8, artol=1e-8, verbose=True)
