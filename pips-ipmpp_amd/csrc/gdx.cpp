@@ -109,7 +109,7 @@ struct GdxFile {
          if (s.take<uint8_t>() != 0)
             for (int d = 0; d < y.dim; ++d) s.take<int32_t>();
          const int ncomment = s.take<int32_t>();
-         for (int k = 0; k < ncomment; ++k) s.str();
+         for (int k = 0; k < ncomment && s.ok; ++k) s.str();
          y.nvals = (y.type == GDX_VARIABLE || y.type == GDX_EQUATION) ? 5 : 1;
          syms.push_back(std::move(y));
       }
@@ -144,10 +144,18 @@ struct GdxFile {
          const int b = c.take<uint8_t>();
          if (b == 255) break;
          if (y.dim > 0) {
-            if (b > y.dim) key[y.dim - 1] += b - y.dim;
+            constexpr int64_t KEY_MAX = 2000000000;   // label numbers are positive 32-bit integers
+            if (b > y.dim) {
+               const int64_t kv = (int64_t)key[y.dim - 1] + (b - y.dim);
+               if (kv > KEY_MAX) return fail("symbol " + y.name + ": key out of range");
+               key[y.dim - 1] = (int)kv;
+            }
             else if (b >= 1)
-               for (int d = b - 1; d < y.dim; ++d)
-                  key[d] = lo[d] + (width[d] == 1 ? (int)c.take<uint8_t>() : (width[d] == 2 ? (int)c.take<uint16_t>() : (int)c.take<int32_t>()));
+               for (int d = b - 1; d < y.dim; ++d) {
+                  const int64_t kv = (int64_t)lo[d] + (width[d] == 1 ? (int64_t)c.take<uint8_t>() : (width[d] == 2 ? (int64_t)c.take<uint16_t>() : (int64_t)c.take<int32_t>()));
+                  if (kv < -KEY_MAX || kv > KEY_MAX) return fail("symbol " + y.name + ": key out of range");
+                  key[d] = (int)kv;
+               }
             else return fail("symbol " + y.name + ": bad record header");
          }
          for (int v = 0; v < y.nvals; ++v) {
@@ -165,6 +173,9 @@ struct GdxFile {
       return true;
    }
 };
+
+// stage / direction fields are doubles in the file: anything that is not a small integer maps to a value that matches no block
+inline int to_int(double v) { return (v > -1.0e9 && v < 1.0e9) ? (int)v : -1000000000; }
 
 struct CsrRows {
    int rows = 0, cols = 0;
@@ -190,7 +201,7 @@ static int read_block(const char* path, int num_blocks, int act_block, int offse
       err = "not a jacobian GDX file (symbol shapes)";
       return PIPS_ERR_ARG;
    }
-   const int direction = (int)objcoef->vals[V_LEVEL];
+   const int direction = to_int(objcoef->vals[V_LEVEL]);
    if (direction != 1 && direction != -1) { err = "objcoef must be 1 (min) or -1 (max)"; return PIPS_ERR_ARG; }
    const int obj_var = jobj->keys[0];
    std::map<int, int> col_of, row_of;
@@ -207,7 +218,7 @@ static int read_block(const char* path, int num_blocks, int act_block, int offse
       if (k == obj_var) continue;
       int cj;
       if (!col(k, &cj)) { err = "variable record without a label in set j"; return PIPS_ERR_ARG; }
-      const int blk = (int)x->vals[5 * r + V_SCALE] - offset;
+      const int blk = to_int(x->vals[5 * r + V_SCALE]) - offset;
       if (blk == 0) { var_perm[cj] = 1; ++n0; }
       else if (blk == act_block) { var_perm[cj] = 2; ++ni; }
    }
@@ -219,7 +230,7 @@ static int read_block(const char* path, int num_blocks, int act_block, int offse
    std::vector<double>&c = out.vec[0], &xlow = out.vec[1], &xupp = out.vec[2], &ixlow = out.vec[3], &ixupp = out.vec[4];
    c.assign(ni, 0.0); xlow.assign(ni, 0.0); xupp.assign(ni, 0.0); ixlow.assign(ni, 0.0); ixupp.assign(ni, 0.0);
    for (int r = 0, n = 0; r < x->count; ++r) {
-      if (x->keys[r] == obj_var || (int)x->vals[5 * r + V_SCALE] - offset != act_block) continue;
+      if (x->keys[r] == obj_var || to_int(x->vals[5 * r + V_SCALE]) - offset != act_block) continue;
       if (n >= ni) { err = "variable count mismatch"; return PIPS_ERR_ARG; }
       if (x->vals[5 * r + V_LOWER] != SV_MINF) { xlow[n] = x->vals[5 * r + V_LOWER]; ixlow[n] = 1.0; }
       if (x->vals[5 * r + V_UPPER] != SV_PINF) { xupp[n] = x->vals[5 * r + V_UPPER]; ixupp[n] = 1.0; }
@@ -252,7 +263,7 @@ static int read_block(const char* path, int num_blocks, int act_block, int offse
       const double lo = e->vals[5 * r + V_LOWER], up = e->vals[5 * r + V_UPPER];
       const bool lo_inf = lo == SV_MINF, up_inf = up == SV_PINF;
       if ((lo_inf && up_inf) || k == obj_row) continue;
-      const int blk = (int)e->vals[5 * r + V_SCALE] - offset;
+      const int blk = to_int(e->vals[5 * r + V_SCALE]) - offset;
       if (blk != act_block && blk != num_blocks) continue;
       const bool link = blk == num_blocks, ineq = lo_inf || up_inf;
       int m;
@@ -304,7 +315,8 @@ using namespace pips;
 extern "C" {
 
 int pips_gdx_read_block(void** block, const char* path, int num_blocks, int act_block, int offset) {
-   if (!block || !path || num_blocks <= 0 || act_block < 0 || act_block >= num_blocks) PIPS_FAIL(PIPS_ERR_ARG, "pips_gdx_read_block: bad arguments");
+   if (!block || !path || num_blocks <= 0 || num_blocks > 100000000 || act_block < 0 || act_block >= num_blocks || offset < -1000000 || offset > 1000000)
+      PIPS_FAIL(PIPS_ERR_ARG, "pips_gdx_read_block: bad arguments");
    auto b = std::make_unique<Block>();
    std::string err;
    const int rc = read_block(path, num_blocks, act_block, offset, *b, err);
@@ -325,7 +337,7 @@ int pips_gdx_block_vector(void* block, int which, double* out, int capacity, int
    *length = (int)v.size();
    if (out) {
       if (capacity < (int)v.size()) PIPS_FAIL(PIPS_ERR_ARG, "pips_gdx_block_vector: buffer too small");
-      std::memcpy(out, v.data(), v.size() * sizeof(double));
+      if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(double));
    }
    return PIPS_OK;
 }
