@@ -64,6 +64,12 @@ class GdxFile:
     def __init__(self, path):
         with open(path, "rb") as f:
             self.data = f.read()
+        try:
+            self._read_header()
+        except (struct.error, IndexError, UnicodeDecodeError, OverflowError) as e:
+            raise GdxError(f"damaged or truncated GDX file: {e}") from None
+
+    def _read_header(self):
         c = _Cursor(self.data)
         # stream signature: sizes and byte order probes of word / integer / double
         if c.take("B") != 2 or c.take("H") != 0x1234 or c.take("B") != 4 or c.take("I") != 0x12345678 or c.take("B") != 8:
@@ -107,7 +113,10 @@ class GdxFile:
         if s is None:
             raise GdxError(f"symbol {name!r} not in file")
         if s.keys is None:
-            self._read_records(s)
+            try:
+                self._read_records(s)
+            except (struct.error, IndexError, KeyError, OverflowError) as e:
+                raise GdxError(f"symbol {s.name}: damaged or truncated records: {e}") from None
         return s
 
     def has(self, name):
@@ -247,6 +256,14 @@ def _csr(rows, n_rows, n_cols):
 
 
 def read_block(path, num_blocks, act_block, offset=1):
+    """See `_read_block`; anything a damaged file can trigger surfaces as GdxError."""
+    try:
+        return _read_block(path, num_blocks, act_block, offset)
+    except (KeyError, IndexError, ValueError, OverflowError, struct.error) as e:
+        raise GdxError(f"{path}: inconsistent jacobian data ({type(e).__name__}: {e})") from None
+
+
+def _read_block(path, num_blocks, act_block, offset=1):
     """Block `act_block` (0 = the linking variables and their rows) of a `num_blocks`-block problem from one jacobian GDX file.
 
     Follows `readBlock` (gmspipsio.c:1357-2033): a variable belongs to block `stage - offset` (stage = the scale field of
