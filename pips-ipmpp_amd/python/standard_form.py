@@ -132,6 +132,7 @@ def block_standard_form(blocks, split_free=True):
     c0 = np.concatenate([M0.T @ np.asarray(root["c"], dtype=float), np.zeros(n0s - n0p)])
     offset = float(np.asarray(root["c"], dtype=float) @ xc0)
     out_blocks, cs, bs, recover = [], [], [], [(xc0, M0)]
+    row_layout = [dict(mBL=mBL, mDL=mDL, mA=mA0, mC=mC0, rows=n_link)]
     masks = [np.concatenate([mask0, np.ones(n0s - n0p)])]
     for k in kids:
         ni, mA, mC = k["ni"], k["mA"], k["mC"]
@@ -163,6 +164,7 @@ def block_standard_form(blocks, split_free=True):
                                   np.array([ww for _, ww in rng], dtype=float), w]))
         offset += float(np.asarray(k["c"], dtype=float) @ xc)
         recover.append((xc, M))
+        row_layout.append(dict(mA=mA, mC=mC, rows=W.shape[0]))
         masks.append(np.concatenate([maskk, np.ones(nloc - n1)]))
     c = np.concatenate([c0] + cs)
     b = np.concatenate([b_link] + bs)
@@ -173,7 +175,7 @@ def block_standard_form(blocks, split_free=True):
         rows.append(r)
     Afull = sp.bmat(rows, format="csr")
     return dict(n0=n0s, myl=n_link, blocks=out_blocks, F0=_to_pa(F0), c=c, b=b, A=Afull, offset=offset, recover=recover,
-                bounded_mask=np.concatenate(masks),
+                bounded_mask=np.concatenate(masks), row_layout=row_layout,
                 sizes=[n0s] + [f.to_scipy().shape[1] for (_, _, f) in out_blocks])
 
 
@@ -228,3 +230,105 @@ def general_lp(blocks):
     A_eq = sp.vstack(eq, format="csr")
     A_ub = sp.vstack(ub, format="csr") if ub else None
     return c, A_eq, np.concatenate(beq), A_ub, (np.array(bub, dtype=float) if ub else None), bounds
+
+
+def recover_duals(sf, y):
+    """Multipliers of the original rows from the dual solution y of the standard form (rows: [linking | block 1 | block 2 ...]).
+    Per block: `eq` (its own equality rows) and `ineq` (its own inequality rows); block 0 also has `link_eq` and `link_ineq`.
+    Convention: the multiplier is d objective / d right-hand side (for an inequality: of the side that is active) - what
+    GAMS calls the marginal; an equality row turned slack row keeps its multiplier (stationarity in the slack ties it to the
+    slack's reduced cost), range and bound rows are internal and dropped."""
+    out, at = [], 0
+    for k, lay in enumerate(sf["row_layout"]):
+        seg = y[at:at + lay["rows"]]
+        if k == 0:
+            a = lay["mBL"] + lay["mDL"]
+            out.append(dict(link_eq=seg[:lay["mBL"]], link_ineq=seg[lay["mBL"]:a], eq=seg[a:a + lay["mA"]], ineq=seg[a + lay["mA"]:a + lay["mA"] + lay["mC"]]))
+        else:
+            out.append(dict(eq=seg[:lay["mA"]], ineq=seg[lay["mA"]:lay["mA"] + lay["mC"]]))
+        at += lay["rows"]
+    return out
+
+
+def general_rows(blocks):
+    """The rows of the original problem as one matrix in the order recover_duals reports multipliers:
+    [link_eq | link_ineq | block 0 eq | block 0 ineq | block 1 eq | block 1 ineq | ...] over the variables [x0 | x1 | ...]."""
+    root, kids = blocks[0], blocks[1:]
+    n0, mBL, mDL = root["n0"], root["mBL"], root["mDL"]
+    sizes = [n0] + [k["ni"] for k in kids]
+    offs = np.cumsum([0] + sizes)
+    ntot = offs[-1]
+
+    def place(M, k):
+        return sp.hstack([sp.csr_matrix((M.shape[0], offs[k])), M, sp.csr_matrix((M.shape[0], ntot - offs[k + 1]))], format="csr")
+
+    L = place(_csr(root["BL"], mBL, n0), 0)
+    Dl = place(_csr(root["DL"], mDL, n0), 0)
+    rows = [None, None, place(_csr(root["A"], root["mA"], n0), 0), place(_csr(root["C"], root["mC"], n0), 0)]
+    for i, k in enumerate(kids, start=1):
+        ni = k["ni"]
+        L = L + place(_csr(k["BL"], mBL, ni), i)
+        Dl = Dl + place(_csr(k["DL"], mDL, ni), i)
+        rows.append(place(_csr(k["A"], k["mA"], n0), 0) + place(_csr(k["B"], k["mA"], ni), i))
+        rows.append(place(_csr(k["C"], k["mC"], n0), 0) + place(_csr(k["D"], k["mC"], ni), i))
+    rows[0], rows[1] = L, sp.csr_matrix(Dl)
+    return sp.vstack(rows, format="csr")
+
+
+def kkt_violation(blocks, x_blocks, duals, tol=1e-6):
+    """Largest violation of the optimality conditions of the ORIGINAL problem (bounded variables, two-sided rows) by a primal
+    point (list of per-block x) and the multipliers of recover_duals: stationarity with the right sign of every reduced cost
+    (>= 0 at a lower bound, <= 0 at an upper bound, 0 inside), sign and complementarity of the inequality multipliers
+    (<= 0 on a row at its upper side, >= 0 at its lower side, 0 strictly inside), primal feasibility."""
+    x = np.concatenate(x_blocks)
+    lam = np.concatenate([duals[0]["link_eq"], duals[0]["link_ineq"], duals[0]["eq"], duals[0]["ineq"]] +
+                         [np.concatenate([d["eq"], d["ineq"]]) for d in duals[1:]])
+    G = general_rows(blocks)
+    c = np.concatenate([np.asarray(b["c"], dtype=float) for b in blocks])
+    rc = c - G.T @ lam
+    act = G @ x
+    worst = 0.0
+    at = 0
+    for b in blocks:
+        n = b["n0"] if b["blockID"] == 0 else b["ni"]
+        for j in range(n):
+            xi, r = x[at + j], rc[at + j]
+            lo = b["xlow"][j] if b["ixlow"][j] else None
+            up = b["xupp"][j] if b["ixupp"][j] else None
+            scale = max(1.0, abs(xi))
+            at_lo = lo is not None and abs(xi - lo) <= tol * scale
+            at_up = up is not None and abs(xi - up) <= tol * scale
+            if lo is not None:
+                worst = max(worst, lo - xi)
+            if up is not None:
+                worst = max(worst, xi - up)
+            if at_lo and at_up:
+                continue
+            worst = max(worst, max(0.0, -r) if at_lo else (max(0.0, r) if at_up else abs(r)))
+        at += n
+    # rows, in the order of general_rows
+    root = blocks[0]
+    specs = [("eq", root["bL"], None, None, None), ("in", root["dlow"], root["idlow"], root["dupp"], root["idupp"]),
+             ("eq", root["b"], None, None, None), ("in", root["clow"], root["iclow"], root["cupp"], root["icupp"])]
+    for k in blocks[1:]:
+        specs += [("eq", k["b"], None, None, None), ("in", k["clow"], k["iclow"], k["cupp"], k["icupp"])]
+    r0 = 0
+    for kind, a1, i1, a2, i2 in specs:
+        m = len(a1)
+        for q in range(m):
+            v, mult = act[r0 + q], lam[r0 + q]
+            if kind == "eq":
+                worst = max(worst, abs(v - a1[q]))
+                continue
+            scale = max(1.0, abs(v))
+            at_lo = bool(i1[q]) and abs(v - a1[q]) <= tol * scale
+            at_up = bool(i2[q]) and abs(v - a2[q]) <= tol * scale
+            if i1[q]:
+                worst = max(worst, a1[q] - v)
+            if i2[q]:
+                worst = max(worst, v - a2[q])
+            if at_lo and at_up:
+                continue
+            worst = max(worst, max(0.0, -mult) if at_lo else (max(0.0, mult) if at_up else abs(mult)))
+        r0 += m
+    return worst

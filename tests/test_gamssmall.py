@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 import pytest
 
-from pips_ipmpp_amd.standard_form import block_standard_form, general_lp, recover_solution
+from pips_ipmpp_amd.standard_form import block_standard_form, general_lp, kkt_violation, recover_duals, recover_solution
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = json.load(open(os.path.join(HERE, "golden", "gamssmall.json")))["instances"]
@@ -96,6 +96,18 @@ def test_highs_reproduces_the_reference_objective(inst):
     assert all((lo is None or xi >= lo - 1e-7) and (up is None or xi <= up + 1e-7) for xi, (lo, up) in zip(x, bounds))
 
 
+@pytest.mark.parametrize("inst", DATA, ids=IDS)
+def test_recovered_duals_satisfy_the_original_optimality_conditions(inst):
+    """Primal point and row multipliers mapped back from the standard form (HiGHS solves it here) are a KKT point of the
+    bounded two-sided original: reduced-cost signs at the bounds, multiplier signs and complementarity on the rows."""
+    from scipy.optimize import linprog
+    sf = block_standard_form(inst["blocks"], split_free=False)
+    bnds = [(0, None) if m else (None, None) for m in sf["bounded_mask"]]
+    r = linprog(sf["c"], A_eq=sf["A"], b_eq=sf["b"], bounds=bnds, method="highs")
+    assert r.status == 0
+    assert kkt_violation(inst["blocks"], recover_solution(sf, r.x), recover_duals(sf, r.eqlin.marginals)) < 1e-7
+
+
 @pytest.mark.parametrize("free", ["split", "native"])
 @pytest.mark.parametrize("inst", DATA, ids=IDS)
 def test_ipm_oracle_reproduces_the_reference_objective(inst, free):
@@ -125,8 +137,10 @@ def test_device_harness_reproduces_the_reference_objective(inst, free):
     assert res["status"] == 0, res
     assert abs(res["objective"] + sf["offset"] - inst["expected_objective"]) < OBJ_TOL, res
     assert res["iterations"] <= 1.1 * inst["expected_iterations"] + 1
-    x, _ = ipm.solution()
+    x, y = ipm.solution()
     assert x[sf["bounded_mask"] == 1].min() > -1e-8 and np.linalg.norm(sf["A"] @ x - sf["b"], np.inf) < 1e-6 * max(1.0, np.abs(sf["b"]).max())
+    # primal point and multipliers in terms of the original problem
+    assert kkt_violation(inst["blocks"], recover_solution(sf, x), recover_duals(sf, y), tol=1e-5) < 1e-4
 
 
 def _same_block(got, want, tag):

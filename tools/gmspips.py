@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import pips_ipmpp_amd as pa  # noqa: E402
-from pips_ipmpp_amd.standard_form import block_standard_form, recover_solution  # noqa: E402
+from pips_ipmpp_amd.standard_form import block_standard_form, kkt_violation, recover_duals, recover_solution  # noqa: E402
 
 
 def main():
@@ -22,11 +22,14 @@ def main():
     ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=1e-9)
     ipm.set_free_variables(sf["bounded_mask"])
     res = ipm.solve(max_iter=200, mutol=mutol, artol=artol, verbose=1)
-    y, _ = ipm.solution()
+    y, duals_std = ipm.solution()
     x = recover_solution(sf, y)
+    duals = recover_duals(sf, duals_std)
     names = {0: "SUCCESSFUL_TERMINATION", 1: "MAX_ITS_EXCEEDED", 2: "NUMERICAL_BREAKDOWN", 3: "NUMERICAL_TROUBLES (best iterate)"}
     print(f"status {names.get(res['status'], res['status'])}  iterations {res['iterations']}  objective {res['objective'] + sf['offset']:.10g}")
     print("linking variables:", np.array2string(x[0], precision=6))
+    print("marginals of the linking rows: eq", np.array2string(duals[0]["link_eq"], precision=6), " ineq", np.array2string(duals[0]["link_ineq"], precision=6))
+    print(f"largest violation of the optimality conditions of the original problem: {kkt_violation(blocks, x, duals, tol=1e-5):.2e}")
     return 0 if res["status"] == 0 else 1
 
 
