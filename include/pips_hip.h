@@ -255,8 +255,9 @@ int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const
                     const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
                     const double* F0_val, const double* c, const double* b, double dual_reg, int device);
 /* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown before any
- * usable iterate, 3 numerical troubles: the best iterate so far is returned - its mu / residual are in [2] / [3])
- * [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
+ * usable iterate, 3 numerical troubles: the best iterate so far is returned - its mu / residual are in [2] / [3], 4 probably
+ * infeasible: phi = (||r|| + |gap|) / dnorm is >= 1e-8 and 1e4 times its best value after ten iterations, PIPSIPMppSolver.cpp:
+ * 128-170) [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
 /* the same on several ranks: this rank's N blocks; c = [c0 | blocks], b = [b_link | blocks] with the root parts
  * and F0 identical on every rank; comm as for pips_hip_kkt_create.  Scalars are reduced over the ranks (replicated parts
  * counted on rank 0 only, DistributedVector.C:1293-1303), the link rows of A x and the x0 rows of A^T y are summed

@@ -113,6 +113,12 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
         if mu <= mutol and rnorm <= artol * dnorm:
             status = 0
             break
+        # "probably infeasible" (PIPSIPMppSolver.cpp:128-170)
+        phi = (rnorm + abs(c @ x - b @ y)) / dnorm
+        phi_min = phi if it == 0 else min(phi_min, phi)
+        if it >= 10 and phi >= 1e-8 and phi >= 1e4 * phi_min:
+            status = 4
+            break
         dx, dy, dv, dg = solve(rQ, rA, rv, v * g)
         ap, ad = min(1.0, stepbound(v, dv)), min(1.0, stepbound(g, dg))
         mu_aff = (v + ap * dv) @ (g + ad * dg) / n_pairs

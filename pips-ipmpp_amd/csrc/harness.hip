@@ -163,7 +163,7 @@ struct Ipm {
    int bicg_max_iter = 75;      // OUTER_BICG_MAX_ITER
    bool regularize = true;      // REGULARIZATION: the inertia-correcting loop of factorize()
    long long n_precond = 0;
-   double outer_tol = 1e-10, last_outer_res = 0.0;
+   double outer_tol = 1e-10, last_outer_res = 0.0, last_outer_abs = 0.0;
    std::vector<void*> owned;
    double last[8] = {0};
 
@@ -315,7 +315,7 @@ struct Ipm {
    // terms and come out with the wrong sign, and split free variables (x = x+ - x-, both drifting) leave primal pivots of
    // 1e-10 - the reference's GAMSsmall instances are full of them.  The regularised factors only precondition: the outer
    // solve works on the unregularised system.
-   int n_regularised = 0, n_factorize = 0, verbose_run = 0;
+   int n_regularised = 0, n_factorize = 0, n_refactor_outer = 0, verbose_run = 0;
    double last_reg = 0.0;
    int perturbed_pivots(int* total) {
       int p_, n_, z_;
@@ -333,7 +333,7 @@ struct Ipm {
       *total += (int)leaves;
       return PIPS_OK;
    }
-   int factorize() {
+   int factorize(double reg_start = 0.0) {
       TRY(pips_hip_vec_copy(nx, g, dd, stream));
       TRY(pips_hip_vec_div(nx, v, dd, stream));
       const double* dfac = dd;
@@ -341,7 +341,7 @@ struct Ipm {
          hipLaunchKernelGGL(k_precond_diag, dim3(std::min<long long>(2048, (nx + 255) / 256)), dim3(256), 0, stream, (long long)nx, fmask, dd, free_reg, ddp);
          dfac = ddp;
       }
-      double reg = 0.0;
+      double reg = reg_start;
       for (int attempt = 0;; ++attempt) {
          hipLaunchKernelGGL(k_leaf_diag, dim3(32, N), dim3(256), 0, stream, N, d_xoff, d_yoff, d_koff, dfac, reg, dual_reg + reg, leaf_diag);
          TRY(pips_hip_kkt_set_root_regularization(kkt, reg, dual_reg + reg));
@@ -410,6 +410,7 @@ struct Ipm {
          if (!(rn < best)) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); break; }
          best = rn;
          last_outer_res = bn > 0 ? rn / bn : rn;
+         last_outer_abs = rn;
          TRY(pips_hip_vec_copy(nz(), x_, w_best, stream));
          if (rn <= target) break;
          ++last_outer_steps;
@@ -431,6 +432,7 @@ struct Ipm {
       TRY(pips_hip_vec_copy(nz(), x_, w_best, stream));
       last_outer_steps = 0;
       last_outer_res = bn > 0 ? rn / bn : rn;
+      last_outer_abs = rn;
       if (rn <= target) return PIPS_OK;                      // "skipped": the common case (LinearSystem.C:591-600)
       TRY(pips_hip_vec_copy(nz(), w_r, w_r0, stream));
       TRY(pips_hip_vec_scale(nz(), 1.0 / rn, w_r0, stream));
@@ -503,6 +505,7 @@ struct Ipm {
       if (min_rn < rn || bad(rn)) { TRY(pips_hip_vec_copy(nz(), w_best, x_, stream)); rn = min_rn; }
       last_outer_steps = it + 1;
       last_outer_res = bn > 0 ? rn / bn : rn;
+      last_outer_abs = rn;
       return PIPS_OK;
    }
 
@@ -516,8 +519,19 @@ struct Ipm {
       // joinRHS: z = [rx | ry]; outer solve on the ORIGINAL system [dd A^T; A 0] preconditioned by solveCompressed
       TRY(pips_hip_vec_copy(nx, tx, bz, stream));
       TRY(pips_hip_vec_copy(ny, ty, bz + nx, stream));
-      if (outer_mode == 2) TRY(bicgstab(bz, xz));
-      else TRY(iter_refine(bz, xz));
+      // A pivot whose value is rounding noise can keep the right sign and pass the inertia test; the factors are then useless as
+      // a preconditioner and the outer solve does not reach its tolerance.  The reference treats a failed outer solve as
+      // numerical trouble of the factorisation; here the system is factorised again with (more) regularisation - which also
+      // serves the later solves of the iteration - and the outer solve repeated, at most twice.
+      for (int retry = 0;; ++retry) {
+         if (outer_mode == 2) TRY(bicgstab(bz, xz));
+         else TRY(iter_refine(bz, xz));
+         const bool reached = last_outer_res <= std::max(1e3 * outer_tol, 1e-7) || last_outer_abs <= 1e-12;   // relative, or the absolute floor
+         if (!regularize || retry == 2 || reached || last_reg >= 1e-2) break;
+         if (verbose_run) printf("   outer solve stopped at rel.res %.1e: factorising again with regularisation\n", last_outer_res);
+         ++n_refactor_outer;
+         TRY(factorize(last_reg > 0.0 ? last_reg * 100.0 : 1e-8));
+      }
       TRY(pips_hip_vec_copy(nx, xz, sx, stream));       // separateVars
       TRY(pips_hip_vec_copy(ny, xz + nx, sy, stream));
       // solveXYZS: stepy.negate()
@@ -640,7 +654,7 @@ struct Ipm {
       HIP_TRYH(hipSetDevice(device));
       verbose_run = verbose = rank == 0 ? verbose : 0;
       n_gondzio = n_precond = 0;
-      n_regularised = n_factorize = 0;
+      n_regularised = n_factorize = n_refactor_outer = 0;
       // ---- start point: push_to_interior(sqrt(dnorm)), one affine solve, full step, shift (PIPSIPMppSolver.cpp:36-42, Solver.cpp:19-31)
       const double s0 = std::sqrt(dnorm);
       TRY(pips_hip_vec_set(nx, 0.0, x, stream));
@@ -677,7 +691,7 @@ struct Ipm {
       // from 1e-11 to 1); the reference answers with its "numerical troubles" logic (InteriorPointMethod.cpp:264-274,
       // PIPSIPMppSolver.cpp:163-185).  Here the iterate with the best merit max(mu / mutol, ||r|| / (artol dnorm)) is kept
       // and returned with status 3 when the iteration breaks down (NaN, residual blow-up, two stalled steps).
-      double best_merit = INFINITY, best_rnorm = INFINITY;
+      double best_merit = INFINITY, best_rnorm = INFINITY, phi_min = INFINITY;
       int n_stall = 0;
       auto merit = [&](double mm, double rr) { return std::max(mm / mutol, rr / (artol * dnorm)); };
       auto save_best = [&]() -> int {
@@ -714,6 +728,13 @@ struct Ipm {
          if (verbose) fflush(stdout);
          if (is_nan) { status = 2; break; }                                 // numerical breakdown before any usable iterate
          if (m <= mutol && rnorm <= artol * dnorm) { status = 0; break; }   // PIPSIPMppSolver.cpp:143-149
+         // "probably infeasible" (PIPSIPMppSolver.cpp:128-170): phi = (||r|| + |gap|) / dnorm, ten iterations in and four
+         // orders of magnitude above the best value seen
+         {
+            const double phi = (rnorm + std::fabs(pobj - dobj)) / dnorm;
+            phi_min = it == 0 ? phi : std::min(phi_min, phi);
+            if (it >= 10 && phi >= 1e-8 && phi >= 1e4 * phi_min) { status = 4; break; }
+         }
          // outer tolerance schedule (InteriorPointMethod.cpp:655-669): 1e-8 up to iteration 3, 1e-9 up to 7, then 1e-10
          outer_tol = it <= 3 ? 1e-8 : (it <= 7 ? 1e-9 : 1e-10);
          // ---- predictor (affine scaling): rgamma = V Gamma e
@@ -1000,7 +1021,7 @@ int pips_ipm_get_trace(void* handle, double* rows7, int max_rows, int* n_rows) {
 int pips_ipm_get_stats(void* handle, long long* stats4) {
    Ipm* p = (Ipm*)handle;
    if (!p || !stats4) PIPS_FAIL(PIPS_ERR_ARG, "pips_ipm_get_stats: bad arguments");
-   stats4[0] = p->n_factorize; stats4[1] = p->n_regularised; stats4[2] = p->n_precond; stats4[3] = p->n_gondzio;
+   stats4[0] = p->n_factorize; stats4[1] = p->n_regularised + p->n_refactor_outer; stats4[2] = p->n_precond; stats4[3] = p->n_gondzio;
    return PIPS_OK;
 }
 

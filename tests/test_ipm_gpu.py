@@ -128,3 +128,38 @@ def test_config1_trace_follows_the_oracle_capture():
         assert abs(tr[k, 4] - sigma) <= 10 * tol and abs(tr[k, 5] - ap) <= 10 * tol and abs(tr[k, 6] - ad) <= 10 * tol, (k, tr[k], gt[k])
     x, _ = ipm.solution()
     assert np.abs(x[:n0] - g["x0"]).max() <= 1e-6 * max(1.0, np.abs(g["x0"]).max())
+
+
+def _infeasible_lp():
+    """Two blocks whose linking row cannot hold: x >= 0, every block row forces sum(x_i) = 1, the linking row asks for
+    sum over all x = -3."""
+    n_i, my_i, n0, myl = 6, 1, 2, 1
+    blocks = []
+    for _ in range(2):
+        W = pa.Csr(my_i, n_i, np.array([0, n_i]), np.arange(n_i), np.ones(n_i))
+        T = pa.Csr(my_i, n0, np.array([0, 1]), np.array([0]), np.ones(1))
+        F = pa.Csr(myl, n_i, np.array([0, n_i]), np.arange(n_i), np.ones(n_i))
+        blocks.append((W, T, F))
+    F0 = pa.Csr(myl, n0, np.array([0, n0]), np.arange(n0), np.ones(n0))
+    c = np.ones(n0 + 2 * n_i)
+    b = np.array([-3.0, 1.0, 1.0])
+    rows = [[F0.to_scipy(), blocks[0][2].to_scipy(), blocks[1][2].to_scipy()],
+            [blocks[0][1].to_scipy(), blocks[0][0].to_scipy(), None], [blocks[1][1].to_scipy(), None, blocks[1][0].to_scipy()]]
+    return n0, myl, blocks, F0, c, b, sp.bmat(rows, format="csr")
+
+
+def test_infeasible_lp_is_reported():
+    """The reference's infeasibility test (PIPSIPMppSolver.cpp:128-170: phi = (||r|| + |gap|) / dnorm ten iterations in and 1e4
+    above its best value) on the device and in the CPU restatement: status 4 from both, HiGHS agrees that the LP is infeasible."""
+    from scipy.optimize import linprog
+    from oracle import ipm_oracle as io
+    n0, myl, blocks, F0, c, b, A = _infeasible_lp()
+    assert linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs").status == 2
+    ipm = pa.IpmSolver(n0, myl, blocks, F0, c, b, dual_reg=1e-9)
+    res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8)
+    assert res["status"] == 4, res
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = io.solve_lp(A, b, c, 200, 1e-8, 1e-8, dual_reg=1e-9)
+    assert o["status"] == 4

@@ -28,9 +28,12 @@ def main():
         if ref.status != 0:
             print(f"seed {seed}: HiGHS status {ref.status}, skipped")
             continue
-        sf = block_standard_form(bl)
+        native = bool(os.environ.get("NATIVE_FREE"))
+        sf = block_standard_form(bl, split_free=not native)
         ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=1e-9)
-        res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8)
+        if native:
+            ipm.set_free_variables(sf["bounded_mask"])
+        res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8, verbose=int(os.environ.get("VERB", "0")))
         st = ipm.stats()
         err = abs(res["objective"] + sf["offset"] - ref.fun) / max(1.0, abs(ref.fun))
         ok = res["status"] == 0 and err < 1e-6

@@ -25,7 +25,7 @@ def main():
     y, duals_std = ipm.solution()
     x = recover_solution(sf, y)
     duals = recover_duals(sf, duals_std)
-    names = {0: "SUCCESSFUL_TERMINATION", 1: "MAX_ITS_EXCEEDED", 2: "NUMERICAL_BREAKDOWN", 3: "NUMERICAL_TROUBLES (best iterate)"}
+    names = {0: "SUCCESSFUL_TERMINATION", 1: "MAX_ITS_EXCEEDED", 2: "NUMERICAL_BREAKDOWN", 3: "NUMERICAL_TROUBLES (best iterate)", 4: "INFEASIBLE (probably)"}
     print(f"status {names.get(res['status'], res['status'])}  iterations {res['iterations']}  objective {res['objective'] + sf['offset']:.10g}")
     print("linking variables:", np.array2string(x[0], precision=6))
     print("marginals of the linking rows: eq", np.array2string(duals[0]["link_eq"], precision=6), " ineq", np.array2string(duals[0]["link_ineq"], precision=6))
