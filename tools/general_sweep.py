@@ -33,6 +33,8 @@ def main():
         ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=1e-9)
         if native:
             ipm.set_free_variables(sf["bounded_mask"])
+            if os.environ.get("FREE_REG"):
+                ipm.set_option("FREE_VARIABLE_PROXIMAL_TERM", float(os.environ["FREE_REG"]))
         res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8, verbose=int(os.environ.get("VERB", "0")))
         st = ipm.stats()
         err = abs(res["objective"] + sf["offset"] - ref.fun) / max(1.0, abs(ref.fun))
