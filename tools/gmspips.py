@@ -18,9 +18,11 @@ def main():
     mutol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-6      # the reference's termination defaults (PIPSIPMppSolver.cpp:143-149)
     artol = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-4
     blocks = [pa.capi.gdx_read_block(f"{stem}{k}.gdx", nblocks, k) for k in range(nblocks)]
-    sf = block_standard_form(blocks, split_free=False)   # free variables stay single columns without a complementarity pair
+    native_free = bool(os.environ.get("PIPS_NATIVE_FREE"))   # free variables as single columns without a complementarity pair
+    sf = block_standard_form(blocks, split_free=not native_free)
     ipm = pa.IpmSolver(sf["n0"], sf["myl"], sf["blocks"], sf["F0"], sf["c"], sf["b"], dual_reg=1e-9)
-    ipm.set_free_variables(sf["bounded_mask"])
+    if native_free:
+        ipm.set_free_variables(sf["bounded_mask"])
     res = ipm.solve(max_iter=200, mutol=mutol, artol=artol, verbose=1)
     y, duals_std = ipm.solution()
     x = recover_solution(sf, y)
