@@ -19,7 +19,7 @@ MPI_INC = next((d for d in ("/opt/conda/include", "/usr/include/x86_64-linux-gnu
                     reason="needs the reference tree, mpi.h and g++")
 def test_adapters_match_the_reference_interface(tmp_path):
     tu = tmp_path / "adapter_tu.cpp"
-    tu.write_text('#include <type_traits>\n#include "HipLdlSolver.h"\n#include "HipDenseLdlSolver.h"\n'
+    tu.write_text('#include <type_traits>\n#include "HipLdlSolver.h"\n#include "HipDenseLdlSolver.h"\n#include "mpi_allreduce_callback.h"\n'
                   "// both are abstract-free: instantiable once a matrix exists\n"
                   "static_assert(!std::is_abstract<HipLdlSolver>::value && !std::is_abstract<HipDenseLdlSolver>::value, \"pure virtuals left\");\n")
     inc = ["-I" + d for d in sorted(p for p in glob.glob(REF_CORE + "/**/", recursive=True))]
