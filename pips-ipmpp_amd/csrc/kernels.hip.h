@@ -620,13 +620,16 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
 #if !defined(PIPS_EXPERIMENT_NO_BARRIER)
       __syncthreads();   // own DMA retired (vmcnt(0)) + everybody's DMA of this stage visible + buffer buf^1 free again
 #endif
-#if !defined(PIPS_EXPERIMENT_NO_DMA)
-      if (st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
-#endif
       const double* Ab = As[buf] + (lane >> 4) * LDSW + rlane;
       const double* Bb = Bs[buf] + (lane >> 4) * LDSW + clane;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+#if !defined(PIPS_EXPERIMENT_NO_DMA)
+         // the DMA of the next stage is issued after the first quarter of this stage's MFMAs, not right behind the barrier: the
+         // matrix pipe is already busy when the address arithmetic and the four LDS-DMA instructions go out (+1.5 %; issuing
+         // later still, or one instruction per quarter, loses 6-8 %: profiles/r1_fp64_issue_rates.txt)
+         if (q == 1 && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
+#endif
          double fr[4], fc[8];
 #pragma unroll
          for (int i = 0; i < 4; ++i) fr[i] = Ab[(4 * q) * LDSW + i * 16];
