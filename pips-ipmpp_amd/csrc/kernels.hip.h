@@ -15,7 +15,10 @@
 namespace pips {
 
 constexpr int TILE = 128;
-constexpr int KB = 16;          // k-depth of one LDS stage of the tile GEMM
+#ifndef PIPS_KB
+#define PIPS_KB 16
+#endif
+constexpr int KB = PIPS_KB;     // k-depth of one LDS stage of the tile GEMM (16; 32 needs 132 KB of LDS: one workgroup per CU)
 constexpr int LDS_PAD = 16;     // LDS row padding (doubles): 144*8 B = 1152 B -> half-wave k-groups hit disjoint banks
 constexpr int LDSW = TILE + LDS_PAD;
 
@@ -597,8 +600,8 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    const double* Bl = Bp + 2 * lane;
    auto issue = [&](int st, int buf) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-         const int k = wave + 8 * q;   // this wave's two k-columns of the stage
+      for (int q = 0; q < KB / 8; ++q) {
+         const int k = wave + 8 * q;   // this wave's k-columns of the stage (two at KB = 16)
          glds16(Al + (long long)(st * KB + k) * ld, &As[buf][k * LDSW]);
          glds16(Bl + (long long)(st * KB + k) * ldb, &Bs[buf][k * LDSW]);
       }
@@ -623,12 +626,12 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
       const double* Ab = As[buf] + (lane >> 4) * LDSW + rlane;
       const double* Bb = Bs[buf] + (lane >> 4) * LDSW + clane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < KB / 4; ++q) {
 #if !defined(PIPS_EXPERIMENT_NO_DMA)
          // the DMA of the next stage is issued after the first quarter of this stage's MFMAs, not right behind the barrier: the
          // matrix pipe is already busy when the address arithmetic and the four LDS-DMA instructions go out (+1.5 %; issuing
          // later still, or one instruction per quarter, loses 6-8 %: profiles/r1_fp64_issue_rates.txt)
-         if (q == 1 && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
+         if (q == KB / 16 && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
 #endif
          double fr[4], fc[8];
 #pragma unroll
