@@ -5,14 +5,31 @@ import os
 import numpy as np
 import pytest
 
-from tests.lp_standard_form import standard_form
+from pips_ipmpp_amd.standard_form import block_standard_form
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _blocks(data):
+    """The callback-convention nodes of the fixture in the reader's block layout (GMSPIPSBlockData_t): x >= 0 everywhere,
+    inequality rows bounded from above only."""
+    n0 = data["nodes"][0]["n"]
+    mBL, mDL = len(data["link_eq_rhs"]), len(data["link_ineq_upp"])
+    out = []
+    for k, nd in enumerate(data["nodes"]):
+        n, mz = nd["n"], nd["mz"]
+        out.append(dict(numBlocks=len(data["nodes"]), blockID=k, n0=n0, ni=n, mA=nd["my"], mC=mz, mBL=mBL, mDL=mDL, c=nd["c"],
+                        xlow=[0.0] * n, xupp=[0.0] * n, ixlow=[1] * n, ixupp=[0] * n, b=nd["b"], clow=[0.0] * mz, cupp=nd["cupp"],
+                        iclow=[0] * mz, icupp=[1] * mz, bL=data["link_eq_rhs"], dlow=[0.0] * mDL, dupp=data["link_ineq_upp"],
+                        idlow=[0] * mDL, idupp=[1] * mDL, A=nd["A"], B=nd["B"], C=nd["C"], D=nd["D"], BL=nd["Bl"], DL=nd["Dl"]))
+    return out
+
+
 def _load():
     data = json.load(open(os.path.join(HERE, "callback_example.json")))
-    return data, standard_form(data)
+    lp = block_standard_form(_blocks(data))
+    assert lp["offset"] == 0.0
+    return data, lp
 
 
 def test_highs_and_ipm_oracle_reproduce_the_reference_objective():
