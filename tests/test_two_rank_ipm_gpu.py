@@ -24,7 +24,18 @@ def _local(blocks, c, b, mine, n_i, my_i, n0, myl):
     return [blocks[k] for k in mine], cl, bl
 
 
-def _worker(rank, world, port, out):
+def _free_mask(c, b, A, n0):
+    """A tenth of the variables that are positive at the optimum (HiGHS) are declared free: the optimum stays (inactive bounds)."""
+    from scipy.optimize import linprog
+    ref = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
+    cand = np.nonzero(ref.x > 0.1)[0]
+    free = np.random.default_rng(3).choice(cand, size=max(4, len(cand) // 10), replace=False)
+    mask = np.ones(A.shape[1])
+    mask[free] = 0.0
+    return mask
+
+
+def _worker(rank, world, port, out, with_free=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,6 +55,9 @@ def _worker(rank, world, port, out):
     comm = pa.ExternalComm(allreduce)
     lb, lc, lbv = _local(blocks, c, b, mine, n_i, my_i, n0, myl)
     ipm = pa.IpmSolver(n0, myl, lb, F0, lc, lbv, comm=comm, rank=rank, n_ranks=world)
+    if with_free:
+        mask = _free_mask(c, b, A, n0)
+        ipm.set_free_variables(np.concatenate([mask[:n0]] + [mask[n0 + k * n_i:n0 + (k + 1) * n_i] for k in mine]))
     res = ipm.solve(max_iter=100, mutol=1e-9, artol=1e-8)
     x, y = ipm.solution()
     np.savez(os.path.join(out, f"rank{rank}.npz"), res=np.array([res[k] for k in ("status", "iterations", "objective", "dual_objective", "mu", "rnorm", "dnorm")]),
@@ -52,13 +66,16 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_ipm_matches_one_rank(tmp_path):
+@pytest.mark.parametrize("with_free", [False, True], ids=["bounded", "free_variables"])
+def test_two_rank_ipm_matches_one_rank(tmp_path, with_free):
     world = 2
-    port = 29500 + (os.getpid() % 2000) + 13
-    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    port = 29500 + (os.getpid() % 2000) + (13 if not with_free else 17)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), with_free), nprocs=world, join=True, start_method="spawn")
     seed, N, n_i, my_i, n0, myl, rho = SHAPE
     blocks, F0, c, b, A = build_lp(seed, N, n_i, my_i, n0, myl, rho)
     one = pa.IpmSolver(n0, myl, blocks, F0, c, b)
+    if with_free:
+        one.set_free_variables(_free_mask(c, b, A, n0))
     r1 = one.solve(max_iter=100, mutol=1e-9, artol=1e-8)
     x1, y1 = one.solution()
     t1 = one.trace()
