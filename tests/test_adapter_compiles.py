@@ -37,3 +37,42 @@ def test_integration_md_shows_the_same_adapter():
     start = md.index("class HipLdlSolver : public DoubleLinearSolver {")
     body = md[start:md.index("```", start)].strip()
     assert body in src
+
+
+GMSPIPS_INC = "/root/reference/PIPS-IPM/Drivers/gams/gmspips"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GMSPIPS_INC, "gmspipsio.h")) or shutil.which("gcc") is None,
+                    reason="needs the reference tree and gcc")
+def test_readblock_shim_fills_the_reference_struct(tmp_path):
+    """examples/adapter/read_block_compat.c implements `readBlock` with the reference's signature and GMSPIPSBlockData_t
+    (both from the reference's own gmspipsio.h) on top of pips_gdx_read_block.  Built here against that header, it reads every
+    block file of the 26 known-answer instances; each field must equal the committed fixture (= what the Python reader gives)."""
+    import json
+    import numpy as np
+    lib = os.path.join(ROOT, "pips-ipmpp_amd")
+    exe = str(tmp_path / "read_block_dump")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I" + GMSPIPS_INC, "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "adapter", "read_block_compat.c"), os.path.join(ROOT, "examples", "adapter", "read_block_dump.c"),
+           "-L" + lib, "-lpipship", "-Wl,-rpath," + lib]
+    if os.path.isdir("/opt/rocm/lib"):
+        cmd += ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd + ["-o", exe])
+    data = json.load(open(os.path.join(ROOT, "tests", "golden", "gamssmall.json")))["instances"]
+    n_files = 0
+    for d in data:
+        for k, want in enumerate(d["blocks"]):
+            out = subprocess.run([exe, f"/root/reference{d['source']}{k}.gdx", str(d["num_blocks"]), str(k)], capture_output=True, text=True)
+            assert out.returncode == 0, out.stdout + out.stderr
+            got = {line.split(":")[0]: [float(t) for t in line.split(":")[1].split()] for line in out.stdout.strip().splitlines()}
+            nnz = {m: (len(want[m]["val"]) if want[m] else 0) for m in ("A", "B", "C", "D", "BL", "DL")}
+            assert got["counts"] == [want["n0"], want["ni"], want["mA"], want["mC"], want["mBL"], want["mDL"]] + [nnz[m] for m in ("A", "B", "C", "D", "BL", "DL")]
+            for f in ("c", "xlow", "xupp", "ixlow", "ixupp", "b", "clow", "cupp", "iclow", "icupp", "bL", "dlow", "dupp", "idlow", "idupp"):
+                assert np.array_equal(got[f], np.asarray(want[f], dtype=float)), (d["name"], k, f)
+            for m in ("A", "B", "C", "D", "BL", "DL"):
+                if want[m] is None:
+                    assert got["rm" + m] == [] and got["ci" + m] == [] and got["val" + m] == []
+                else:
+                    assert got["rm" + m] == want[m]["rowptr"] and got["ci" + m] == want[m]["colidx"] and got["val" + m] == want[m]["val"], (d["name"], k, m)
+            n_files += 1
+    assert n_files == sum(d["num_blocks"] for d in data) == 108
