@@ -692,7 +692,8 @@ struct Ipm {
       // PIPSIPMppSolver.cpp:163-185).  Here the iterate with the best merit max(mu / mutol, ||r|| / (artol dnorm)) is kept
       // and returned with status 3 when the iteration breaks down (NaN, residual blow-up, two stalled steps).
       double best_merit = INFINITY, best_rnorm = INFINITY, phi_min = INFINITY;
-      int n_stall = 0;
+      int n_stall = 0, n_rstall = 0;
+      double prev_rnorm = INFINITY;
       auto merit = [&](double mm, double rr) { return std::max(mm / mutol, rr / (artol * dnorm)); };
       auto save_best = [&]() -> int {
          TRY(pips_hip_vec_copy(nx, x, bx, stream)); TRY(pips_hip_vec_copy(nx, v, bv, stream));
@@ -711,10 +712,14 @@ struct Ipm {
          TRY(mu(&m));
          const bool is_nan = !(m == m) || !(rnorm == rnorm) || !(pobj == pobj);
          const bool blown = !is_nan && best_merit < INFINITY && rnorm > 1e4 * std::max(best_rnorm, artol * dnorm);
-         if ((is_nan || blown || n_stall >= 2) && best_merit < INFINITY) {
+         // complementarity long converged, residual not moving any more (seen with the inexact preconditioner of the native
+         // free-variable route): nothing further will come of it
+         n_rstall = (!is_nan && m <= 1e-3 * mutol && rnorm > artol * dnorm && rnorm >= 0.99 * prev_rnorm) ? n_rstall + 1 : 0;
+         prev_rnorm = rnorm;
+         if ((is_nan || blown || n_stall >= 2 || n_rstall >= 3) && best_merit < INFINITY) {
             if (verbose)
                printf("ipm it %3d  numerical troubles (%s: mu %.3e ||r||inf %.3e), falling back to the best iterate\n", it,
-                      is_nan ? "nan" : (blown ? "residual blow-up" : "stalled"), m, rnorm);
+                      is_nan ? "nan" : (blown ? "residual blow-up" : (n_rstall >= 3 ? "residual stagnates, mu far below its tolerance" : "stalled")), m, rnorm);
             TRY(restore_best());
             trace.insert(trace.end(), {m, rnorm, pobj, dobj, 0.0, 0.0, 0.0});
             status = (m <= mutol && rnorm <= artol * dnorm) ? 0 : 3;
