@@ -314,7 +314,7 @@ int pips_map_children_to_ranks(int n_children, int n_ranks, int* map);
 int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, int S, const int* Bt_rowptr,
                         const int* Bt_colidx, int force_n_head, int64_t* what, int n_what, int* perm, int* colcount);
 
-/* ---- 7. input files ---------------------------------------------------------------------------------------------------
+/* ---- 6. input files ---------------------------------------------------------------------------------------------------
  * One block of a block-structured LP from a "jacobian" GDX file, the format gmspips_reader opens per block
  * (Drivers/gams/gmspips/gmspips_reader.cpp:30-60; extraction rules of readBlock, gmspipsio.c:1357-2033; fields of
  * GMSPIPSBlockData_t, gmspipsio.h:5-58).  Uncompressed GDX version 7 files.  offset = stage number of block 0 (the
