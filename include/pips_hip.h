@@ -237,6 +237,11 @@ int pips_hip_vec_sumsq_scaled(long long n, long long skip_root, double scale_inv
 int pips_hip_vec_stepbound(long long n, const double* x_dev, const double* dx_dev, const double* mask_dev, double* result, void* stream);
 /* Variables::find_blocking (Variables.C:227-308) for one pair of complementary vectors: out5 = [min ratio -x_i/dx_i over
  * dx_i < 0 (inf if no entry blocks), then x, dx, y, dy at the blocking index (smallest index on ties)] */
+/* the step bounds of nw <= 16 blended directions in one pass: out[k] = largest alpha with x + alpha (dx + w_k cx) >= 0 (inf if
+ * unbounded), out[nw + k] the same for (y, dy, cy), w_k = min(1, wmin + (1 - wmin) k / (nw - 1)) - the corrector weight search
+ * calculate_alpha_pd_weight_candidate (InteriorPointMethod.cpp:486-523); out2nw is a host array */
+int pips_hip_vec_weighted_stepbounds(long long n, const double* x_dev, const double* dx_dev, const double* cx_dev, const double* y_dev,
+                                     const double* dy_dev, const double* cy_dev, double wmin, int nw, double* out2nw, void* stream);
 int pips_hip_vec_find_blocking(long long n, const double* x_dev, const double* dx_dev, const double* y_dev, const double* dy_dev,
                                double* out5, void* stream);
 /* sum (x + a dx)(y + b dy)  (mustep_pd, Variables.C:109) */

@@ -562,19 +562,29 @@ struct Ipm {
       return PIPS_OK;
    }
 
-   // 10-point search for the corrector weight in [alpha_p alpha_d, 1] that allows the longest steps
+   // 11-point search (one fused device pass) for the corrector weight in [alpha_p alpha_d, 1] that allows the longest steps
    // (calculate_alpha_pd_weight_candidate, InteriorPointMethod.cpp:486-523); step bounds are plain ratios capped at 1
    int weight_search(double apt, double adt, double* ape, double* ade, double* wp, double* wd) {
+      constexpr int NW = 11;
       const double wmin = apt * adt;
+      double bounds[2 * NW];   // one fused pass: primal bounds of the 11 blends, then the dual ones
+      TRY(pips_hip_vec_weighted_stepbounds(nx, v, dv, cv, g, dg, cg, wmin, NW, bounds, stream));
+      if (n_ranks > 1) {       // minimum over the ranks, one slot per rank and value (infinities do not travel through a sum)
+         std::vector<double> slots((size_t)2 * NW * n_ranks, 0.0);
+         for (int q = 0; q < 2 * NW; ++q) slots[(size_t)2 * NW * rank + q] = bounds[q] < INFINITY ? bounds[q] : -1.0;
+         TRY(reduce_host(slots.data(), 2 * NW * n_ranks));
+         for (int q = 0; q < 2 * NW; ++q) {
+            bounds[q] = INFINITY;
+            for (int r = 0; r < n_ranks; ++r) {
+               const double t = slots[(size_t)2 * NW * r + q];
+               if (t >= 0.0) bounds[q] = std::min(bounds[q], t);
+            }
+         }
+      }
       *ape = *ade = *wp = *wd = -1.0;
-      for (int k = 0; k <= 10; ++k) {
-         const double w = std::min(1.0, wmin + (1.0 - wmin) / 10.0 * k);
-         TRY(pips_hip_vec_copy(nx, dv, gv, stream));
-         TRY(pips_hip_vec_axpy(nx, w, cv, gv, stream));
-         TRY(pips_hip_vec_copy(nx, dg, gg, stream));
-         TRY(pips_hip_vec_axpy(nx, w, cg, gg, stream));
-         double a1, a2;
-         TRY(step_lengths(gv, gg, 1.0, &a1, &a2));
+      for (int k = 0; k < NW; ++k) {
+         const double w = std::min(1.0, wmin + (1.0 - wmin) / (NW - 1) * k);
+         const double a1 = std::min(1.0, bounds[k]), a2 = std::min(1.0, bounds[NW + k]);
          if (a1 > *ape) { *ape = a1; *wp = w; }
          if (a2 > *ade) { *ade = a2; *wd = w; }
       }
@@ -907,7 +917,7 @@ int pips_ipm_create_rank(void** handle, int N, int n0, int myl, const int* n_i, 
                                comm, rank, n_ranks);
    if (rc) return rc;
    HIP_TRYH(hipGetDevice(&p->device));
-   if ((rc = p->alloc(&p->d_red, 8 * (long long)n_ranks))) return rc;
+   if ((rc = p->alloc(&p->d_red, 24 * (long long)n_ranks))) return rc;
    // data norm and number of complementarity pairs over all ranks
    if ((rc = p->gext(&p->dnorm, true))) return rc;
    {

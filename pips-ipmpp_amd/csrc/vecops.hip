@@ -151,6 +151,49 @@ __global__ void k_gather_blocking(const unsigned long long* __restrict__ idx, co
    out[1] = x[i]; out[2] = dx[i]; out[3] = y[i]; out[4] = dy[i];
 }
 
+// Step bounds of nw blended directions at once: for w_k = min(1, wmin + (1 - wmin) k / (nw - 1)) the largest alpha with
+// x + alpha (dx + w_k cx) >= 0, for two vector triples (the 11-point corrector weight search of the IPM, InteriorPointMethod.cpp:
+// 486-523: 22 reductions and 44 vector passes in one kernel).  out holds 2 nw doubles preset to +inf; the ratios are non-negative,
+// so the order of their bit patterns is the order of the numbers and an integer atomicMin finishes the reduction.
+constexpr int WS_MAX = 16;
+__global__ __launch_bounds__(256) void k_weighted_stepbounds(long long n, const double* __restrict__ x, const double* __restrict__ dx,
+                                                            const double* __restrict__ cx, const double* __restrict__ y,
+                                                            const double* __restrict__ dy, const double* __restrict__ cy, double wmin,
+                                                            int nw, double* __restrict__ out) {
+   double bx[WS_MAX], by[WS_MAX];
+#pragma unroll
+   for (int k = 0; k < WS_MAX; ++k) bx[k] = by[k] = INFINITY;
+   const double step = nw > 1 ? (1.0 - wmin) / (nw - 1) : 0.0;
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+      const double xi = x[i], dxi = dx[i], cxi = cx[i], yi = y[i], dyi = dy[i], cyi = cy[i];
+#pragma unroll
+      for (int k = 0; k < WS_MAX; ++k) {
+         if (k < nw) {
+            const double w = fmin(1.0, wmin + step * k);
+            const double sx = dxi + w * cxi, sy = dyi + w * cyi;
+            if (sx < 0.0) bx[k] = fmin(bx[k], -xi / sx);
+            if (sy < 0.0) by[k] = fmin(by[k], -yi / sy);
+         }
+      }
+   }
+   __shared__ double red[256];
+   for (int k = 0; k < 2 * nw; ++k) {
+      double t = k < nw ? INFINITY : INFINITY;
+#pragma unroll
+      for (int q = 0; q < WS_MAX; ++q) {   // register arrays need constant indices
+         if (q == (k < nw ? k : k - nw)) t = k < nw ? bx[q] : by[q];
+      }
+      red[threadIdx.x] = t;
+      __syncthreads();
+      for (int sft = 128; sft > 0; sft >>= 1) {
+         if ((int)threadIdx.x < sft) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + sft]);
+         __syncthreads();
+      }
+      if (threadIdx.x == 0 && red[0] < INFINITY) atomicMin((unsigned long long*)(out + k), (unsigned long long)__double_as_longlong(red[0]));
+      __syncthreads();
+   }
+}
+
 static double red_identity_host(int op) { return (op == RED_MIN || op == RED_STEPBOUND) ? INFINITY : 0.0; }
 
 struct VecWorkspace {
@@ -281,6 +324,22 @@ int pips_hip_vec_find_blocking(long long n, const double* x_dev, const double* d
    HIP_TRYV(hipMemcpyAsync(g_ws.h_out, g_ws.d_partial + 2050, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
    HIP_TRYV(hipStreamSynchronize(s));
    for (int i = 1; i < 5; ++i) out5[i] = g_ws.h_out[i];
+   return PIPS_OK;
+}
+int pips_hip_vec_weighted_stepbounds(long long n, const double* x_dev, const double* dx_dev, const double* cx_dev, const double* y_dev,
+                                     const double* dy_dev, const double* cy_dev, double wmin, int nw, double* out2nw, void* stream) {
+   if (nw < 1 || nw > WS_MAX || !out2nw) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_vec_weighted_stepbounds: 1 <= nw <= 16");
+   hipStream_t s = (hipStream_t)stream;
+   int rc = g_ws.init();
+   if (rc) return rc;
+   for (int k = 0; k < 2 * nw; ++k) out2nw[k] = INFINITY;
+   if (n <= 0) return PIPS_OK;
+   double* d_out = g_ws.d_partial;   // the first 2 nw slots of the reduction workspace
+   HIP_TRYV(hipMemcpyAsync(d_out, out2nw, 2 * nw * sizeof(double), hipMemcpyHostToDevice, s));
+   hipLaunchKernelGGL(k_weighted_stepbounds, dim3(vgrid(n) < 1024 ? vgrid(n) : 1024), dim3(256), 0, s, n, x_dev, dx_dev, cx_dev, y_dev, dy_dev,
+                      cy_dev, wmin, nw, d_out);
+   HIP_TRYV(hipMemcpyAsync(out2nw, d_out, 2 * nw * sizeof(double), hipMemcpyDeviceToHost, s));
+   HIP_TRYV(hipStreamSynchronize(s));
    return PIPS_OK;
 }
 /* sum (x + a dx)(y + b dy)  (complementarity after a trial step) */

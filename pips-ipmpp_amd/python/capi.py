@@ -66,7 +66,7 @@ SYMBOLS = [
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_find_blocking", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_set_free_variables", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
+    "pips_hip_vec_find_blocking", "pips_hip_vec_weighted_stepbounds", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_set_free_variables", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
     "pips_gdx_read_block", "pips_gdx_block_counts", "pips_gdx_block_vector", "pips_gdx_block_matrix", "pips_gdx_block_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
@@ -663,6 +663,13 @@ class vec:
         out = np.zeros(5)
         _check(lib.pips_hip_vec_find_blocking(vec._n(x), _ptr(x), _ptr(dx), _ptr(y), _ptr(dy), _ptr(out), None), "vec_find_blocking")
         return out
+
+    @staticmethod
+    def weighted_stepbounds(x, dx, cx, y, dy, cy, wmin, nw=11):
+        out = np.zeros(2 * nw)
+        _check(lib.pips_hip_vec_weighted_stepbounds(vec._n(x), _ptr(x), _ptr(dx), _ptr(cx), _ptr(y), _ptr(dy), _ptr(cy), C.c_double(wmin),
+                                                    C.c_int(nw), _ptr(out), None), "vec_weighted_stepbounds")
+        return out[:nw], out[nw:]
 
     @staticmethod
     def gondzio_projection(rmin, rmax, y):

@@ -119,3 +119,25 @@ def test_find_blocking_matches_numpy():
     z = torch.tensor(np.abs(dv), device="cuda")
     out = V.find_blocking(t[0], z, t[2], t[3])
     assert out[0] == np.inf and not out[1:].any()
+
+
+def test_weighted_stepbounds_match_numpy():
+    """One pass for the 11 blended directions of the corrector weight search (InteriorPointMethod.cpp:486-523) = 22 separate
+    step bounds."""
+    import torch
+    V = pa.capi.vec
+    for seed, n in ((1, 5), (2, 3000), (3, 400001)):
+        rng = np.random.default_rng(seed)
+        v, g = rng.random(n) + 0.05, rng.random(n) + 0.05
+        dv, cv, dg, cg = (rng.standard_normal(n) for _ in range(4))
+        if seed == 1:
+            dg, cg = np.abs(dg), np.abs(cg)      # no blocking entry on the second triple: infinities
+        t = [torch.tensor(a, device="cuda") for a in (v, dv, cv, g, dg, cg)]
+        wmin = 0.37
+        bp, bd = V.weighted_stepbounds(*t, wmin, 11)
+        for k in range(11):
+            w = min(1.0, wmin + (1.0 - wmin) / 10.0 * k)
+            for got, x, dx, cx in ((bp[k], v, dv, cv), (bd[k], g, dg, cg)):
+                s = dx + w * cx
+                want = np.min(-x[s < 0] / s[s < 0]) if (s < 0).any() else np.inf
+                assert got == want or abs(got - want) <= 1e-14 * want, (seed, k, got, want)
