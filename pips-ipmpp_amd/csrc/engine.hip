@@ -213,21 +213,22 @@ struct TailCtx {
    hipEvent_t ev_rest = nullptr;        // side -> main: trailing update of panel j is done
    bool is_root = false;                // dense root: same update kernel under its own name (k_tile_gemm<3>)
    const int* d_sctab = nullptr;        // sparse Schur complement: per-block position tables (kernels.hip.h sc_entry)
+   double* d_uarena = nullptr;          // scaled copies U = L D of the tail rows (BlkDesc::U), B operand of the updates
 };
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
    auto gemm_diag_tiles = [&](const TaskList& l, hipStream_t st) {
       hipLaunchKernelGGL(k_tile_gemm<4>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                         c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+                         c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
    };
    auto gemm0 = [&](const TaskList& l, hipStream_t st) {
       if (c.is_root)
          hipLaunchKernelGGL(k_tile_gemm<3>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
       else
          hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
    };
    // Lookahead bookkeeping (right-looking modes with a side stream): while the side stream applies a finished panel to
    // the tile columns >= side_from, the main stream may only write columns left of that.
@@ -272,7 +273,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       if (p.trsm[j].cnt > 0) {
          if (c.timer) c.timer->begin(c.stream, 4);
          hipLaunchKernelGGL(k_tile_gemm<1>, dim3((p.trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trsm[j].off, p.trsm[j].cnt,
-                            c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0);
+                            c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
          if (c.timer) c.timer->end(c.stream);
       }
       // right-looking modes: trailing update with the panel that ends at column j.  With a side stream the bulk of it
@@ -299,7 +300,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    if (SC && p.schur.cnt > 0) {
       if (c.timer) c.timer->begin(c.stream, 5);
       hipLaunchKernelGGL(k_tile_gemm<2>, dim3((p.schur.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
-                         c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab);
+                         c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena);
       if (c.timer) c.timer->end(c.stream);
    }
    HIP_TRY(hipGetLastError());
@@ -387,6 +388,8 @@ struct Engine {
    TailPlan plan;
    PhaseTimer timer;
 
+   double* d_uarena = nullptr;   // U = L D copies of the tails (see k_tile_gemm)
+   long long uarena_total = 0;
    double *d_arena = nullptr, *d_kval = nullptr, *d_bval = nullptr, *d_winv = nullptr, *d_dtail = nullptr, *d_xw = nullptr;
    double *d_rhs = nullptr, *d_res = nullptr, *d_stage = nullptr, *d_pref = nullptr;
    long long *d_kdst = nullptr, *d_bdst = nullptr, *d_kdiag = nullptr, *d_kptr = nullptr, *d_psign_off = nullptr,
@@ -406,6 +409,8 @@ struct Engine {
       if (ev_diag_out) (void)hipEventDestroy(ev_diag_out);
    }
    void release() {
+      if (d_uarena) (void)hipFree(d_uarena);
+      d_uarena = nullptr;
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc, d_flong,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
@@ -430,7 +435,7 @@ struct Engine {
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
    TailCtx ctx() {
       return TailCtx{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
-                     timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab};
+                     timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
    }
 
    int analyze_host(int n_threads, bool with_border = true) {
@@ -510,7 +515,7 @@ struct Engine {
       x_off.assign(nblk + 1, 0);
       std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0),
          upd_base(nblk + 1, 0);
-      long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0;
+      long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0, uar = 0;
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
          BlkDesc& d = h_blks[b];
@@ -526,6 +531,8 @@ struct Engine {
          d.ntc = s.m_pad / TILE;
          d.ntr = s.m > 0 ? s.ldT / TILE : 0;
          d.pad0 = 0;
+         d.U = uar;
+         uar += (long long)s.m_pad * s.m_pad;
          d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
          arena += s.arena;
          xw += s.n_head + s.m_pad;
@@ -540,7 +547,7 @@ struct Engine {
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
          bmap_off[b + 1] = bmap_off[b] + s.nb;
       }
-      arena_total = arena; xw_total = xw; n_total = x_off[nblk]; nnzK_total = kptr[nblk]; nnzB_total = bptr[nblk];
+      arena_total = arena; uarena_total = uar; xw_total = xw; n_total = x_off[nblk]; nnzK_total = kptr[nblk]; nnzB_total = bptr[nblk];
       nsn_total = (int)sn_base[nblk];
 
       // ---- supernodes sorted by (level, size class)
@@ -693,6 +700,7 @@ struct Engine {
 
       // ---- device allocation / upload
       HIP_TRY(hipMalloc((void**)&d_arena, std::max<long long>(arena_total, 1) * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_uarena, std::max<long long>(uarena_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_kval, std::max<long long>(nnzK_total, 1) * sizeof(double)));
       HIP_TRY(hipMemset(d_kval, 0, std::max<long long>(nnzK_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_winv, std::max<long long>(winv, 1) * sizeof(double)));
@@ -1060,18 +1068,24 @@ struct DenseLdl {
    TailPlan plan;
    BlkDesc* d_blks = nullptr;
    double *d_R = nullptr, *d_winv = nullptr, *d_dtail = nullptr, *d_xw = nullptr, *d_in = nullptr, *d_pref = nullptr;
+   double* d_U = nullptr;   // U = L D (npad x npad), B operand of the updates
    signed char* d_psign = nullptr;
    long long *d_psign_off = nullptr, *d_kptr = nullptr;
    int* d_inertia = nullptr;
    int h_inertia[3] = {0, 0, 0};
    hipStream_t side = nullptr;
    hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
+   // staging copy of a host matrix: only the host-pointer entry points need it (the fused KKT path hands over d_SC)
+   int ensure_input_buffer() {
+      if (!d_in) HIP_TRY(hipMalloc((void**)&d_in, (size_t)std::max(n, 1) * std::max(n, 1) * sizeof(double)));
+      return PIPS_OK;
+   }
 
    ~DenseLdl() {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -1107,7 +1121,7 @@ struct DenseLdl {
       if ((rc = dev_upload(&d_psign_off, zero, stream))) return rc;
       if ((rc = dev_upload(&d_kptr, kp, stream))) return rc;
       HIP_TRY(hipMalloc((void**)&d_R, (size_t)npad * npad * sizeof(double)));
-      HIP_TRY(hipMalloc((void**)&d_in, (size_t)n * n * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_U, (size_t)npad * npad * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_winv, (size_t)npad * TILE * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_dtail, (size_t)npad * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_xw, (size_t)npad * sizeof(double)));
@@ -1116,7 +1130,7 @@ struct DenseLdl {
       return PIPS_OK;
    }
    TailCtx ctx() {
-      return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true};
+      return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
    }
 
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)
@@ -1692,6 +1706,7 @@ int pips_hip_dense_ldl_factor(void* handle, const double* A_host, int lda) {
    HIP_TRY(hipSetDevice(d->device));
    // DenseStorage is row-major with the lower triangle authoritative (DeSymIndefSolver.h:41-42 hands exactly this to
    // dsytrf_('U') as a column-major matrix); upload and let the copy kernel read it transposed.
+   if (int rc0 = d->ensure_input_buffer()) return rc0;
    HIP_TRY(hipMemcpy2DAsync(d->d_in, (size_t)d->n * sizeof(double), A_host, (size_t)lda * sizeof(double),
                             (size_t)d->n * sizeof(double), (size_t)d->n, hipMemcpyHostToDevice, d->stream));
    int rc = d->factor_dev(d->d_in, d->n, 1);
@@ -1716,6 +1731,7 @@ int pips_hip_dense_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    DenseLdl* d = (DenseLdl*)handle;
    if (!d || !rhs || nrhs < 0 || ld < d->n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_dense_ldl_solve: bad arguments");
    HIP_TRY(hipSetDevice(d->device));
+   if (int rc0 = d->ensure_input_buffer()) return rc0;
    for (int k = 0; k < nrhs; ++k) {
       double* x = rhs + (size_t)k * ld;
       HIP_TRY(hipMemcpyAsync(d->d_in, x, (size_t)d->n * sizeof(double), hipMemcpyHostToDevice, d->stream));

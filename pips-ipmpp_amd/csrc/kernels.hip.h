@@ -18,6 +18,9 @@ constexpr int TILE = 128;
 #ifndef PIPS_KB
 #define PIPS_KB 16
 #endif
+#ifndef PIPS_DMA_QUARTER
+#define PIPS_DMA_QUARTER (PIPS_KB / 16)
+#endif
 constexpr int KB = PIPS_KB;     // k-depth of one LDS stage of the tile GEMM (16; 32 needs 132 KB of LDS: one workgroup per CU)
 constexpr int LDS_PAD = 16;     // LDS row padding (doubles): 144*8 B = 1152 B -> half-wave k-groups hit disjoint banks
 constexpr int LDSW = TILE + LDS_PAD;
@@ -42,6 +45,7 @@ struct BlkDesc {
    long long sctab_off;  // offset of this block's nb x nb position table inside sctab (sparse Schur complement), else 0
    int n, n_head, m, m_pad, nb, nb_pad, ldT, ntc, ntr;
    int pad0;
+   long long U;          // offset of the block's scaled tail copy U = L D (m_pad x m_pad, ld = m_pad) inside the U arena
    double thr_rel, repl_rel;  // pivot threshold / replacement relative to the pivot's reference magnitude pref[k]
    double repl_abs;           // replacement when no reference magnitude exists (structurally zero diagonal)
 };
@@ -507,8 +511,10 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
 
 // ------------------------------------------------------------------------------------------------
 // tile GEMM on the FP64 matrix cores.
-//   MODE 0 (update): C(ti,tj) -= A(ti,0:K) diag(d) B(tj,0:K)^T     K = tj*TILE, A/B/C tiles of the tail panel
-//   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE
+//   MODE 0 (update): C(ti,tj) -= L(ti,0:K) U(tj,0:K)^T             K = tj*TILE, L/C tiles of the tail panel, U = L D its
+//                    scaled copy (tail rows only): the diagonal scaling costs no v_mul_f64 in the inner loop - FP64 VALU
+//                    instructions share the matrix pipe's issue slots, four per 32 MFMAs were 3 % of the kernel
+//   MODE 1 (trsm)  : C(ti,tj)  = C(ti,tj) Winv(tj)^T               K = TILE; tail rows also store U(ti,tj) = C(ti,tj) D(tj)
 //   MODE 2 (schur) : SC[bmap(ti), bmap(tj)] -= A(ti,0:K) diag(d) B(tj,0:K)^T   ti,tj border tile rows, K = m_pad
 //   MODE 3 / 4     : MODE 0 under names of their own - 3 the dense root, 4 the diagonal tiles of a leaf column that are
 //                    updated ahead of the rest (so that profiles keep the leaf update kernel apart)
@@ -524,10 +530,23 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
 // the column-panel fragment is 4 columns x 4 k broadcast to the four blocks (LDS broadcast read, no conflict).
 // ------------------------------------------------------------------------------------------------
 // 16-byte-per-lane LDS-DMA: the wave writes 1 KiB contiguously at lds_base (wave-uniform) + 16 * lane
+// Written as inline assembly, not with __builtin_amdgcn_global_load_lds: the compiler cannot prove that the LDS image the
+// DMA fills is disjoint from the one the MFMA fragments are read from and puts an s_waitcnt vmcnt(0) in front of the next
+// ds_read, i.e. every wave sat out the full global-memory latency in the middle of every stage.  The asm form is invisible
+// to that bookkeeping; the wait is placed by hand (dma_wait) right before the barrier that hands the buffer over.
+#if defined(PIPS_DMA_BUILTIN)
 __device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base) {
    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr_lane,
                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+__device__ __forceinline__ void dma_wait() {}
+#else
+__device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base) {
+   const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base;
+   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 // Staging: both panels are column-major with the tile's 128 rows contiguous, so one LDS-DMA wave-instruction moves one
 // k-column (1 KiB) straight into the [k][row] LDS image (no VGPR round trip, no ds_write).  Two LDS buffers: the DMA of
@@ -538,10 +557,11 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
                                                      const BlkDesc* __restrict__ blks, double* __restrict__ arena,
                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
                                                      const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
-                                                     const int* __restrict__ sctab = nullptr) {
+                                                     const int* __restrict__ sctab = nullptr, double* __restrict__ uarena = nullptr) {
+   constexpr bool SCALE = (MODE == 2);   // in-loop diagonal scaling: only the Schur SYRK (border rows have no U copy)
    __shared__ __attribute__((aligned(16))) double As[2][KB * LDSW];
    __shared__ __attribute__((aligned(16))) double Bs[2][KB * LDSW];
-   __shared__ double Ds[2][KB];   // diagonal scaling d_k of the stage
+   __shared__ __attribute__((aligned(16))) double Ds[2][KB];   // diagonal scaling d_k of the stage
 
    // XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
    // slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
@@ -552,6 +572,9 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 #endif
    if (tix >= n_tasks) return;
+#if defined(PIPS_EXPERIMENT_CLOCK)
+   const unsigned long long re_ = __builtin_amdgcn_s_memrealtime();   // workgroup entry
+#endif
    const TileTask task = tasks[tix];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
@@ -570,9 +593,8 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
       const int k0 = task.pad & 0xffff, k1 = (task.pad >> 16) ? (task.pad >> 16) : task.tj;
       K = (k1 - k0) * TILE;
       Ap = T + (long long)task.ti * TILE + (long long)k0 * TILE * ld;
-      Bp = T + (long long)task.tj * TILE + (long long)k0 * TILE * ld;
-      ldb = ld;
-      dv = dtail + bd.dt_off + k0 * TILE;
+      Bp = uarena + bd.U + (long long)task.tj * TILE + (long long)k0 * TILE * bd.m_pad;
+      ldb = bd.m_pad;
    } else if (MODE == 1) {
       K = TILE;
       Ap = T + (long long)task.ti * TILE + (long long)task.tj * TILE * ld;
@@ -606,22 +628,21 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
          glds16(Bl + (long long)(st * KB + k) * ldb, &Bs[buf][k * LDSW]);
       }
    };
-   // the 16 scaling factors of a stage travel through one register of the first 16 threads into LDS
-   double dreg = 1.0;
-   auto load_d = [&](int st) {
-      if (MODE != 1 && tid < KB) dreg = dv[st * KB + tid];
+   // the KB scaling factors of a stage: one more LDS-DMA, KB/2 lanes of the last wave (16 bytes each)
+   auto load_d = [&](int st, int buf) {
+      if (SCALE && wave == 7 && lane < KB / 2) glds16(dv + st * KB + 2 * lane, &Ds[buf][0]);
    };
    if (nst > 0) {
       issue(0, 0);
-      load_d(0);
-      if (tid < KB) Ds[0][tid] = dreg;
+      load_d(0, 0);
    }
    const int rlane = wr * 64 + (lane & 15);   // row-panel fragment offset
    const int clane = wc * 32 + (lane & 3);    // column-panel fragment offset (broadcast over the 4 blocks)
    for (int st = 0; st < nst; ++st) {
       const int buf = st & 1;
 #if !defined(PIPS_EXPERIMENT_NO_BARRIER)
-      __syncthreads();   // own DMA retired (vmcnt(0)) + everybody's DMA of this stage visible + buffer buf^1 free again
+      dma_wait();        // own DMA of this stage retired
+      __syncthreads();   // everybody's DMA of this stage visible + buffer buf^1 free again
 #endif
       const double* Ab = As[buf] + (lane >> 4) * LDSW + rlane;
       const double* Bb = Bs[buf] + (lane >> 4) * LDSW + clane;
@@ -631,14 +652,14 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
          // the DMA of the next stage is issued after the first quarter of this stage's MFMAs, not right behind the barrier: the
          // matrix pipe is already busy when the address arithmetic and the four LDS-DMA instructions go out (+1.5 %; issuing
          // later still, or one instruction per quarter, loses 6-8 %: profiles/r1_fp64_issue_rates.txt)
-         if (q == KB / 16 && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1); }
+         if (q == PIPS_DMA_QUARTER && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1, buf ^ 1); }
 #endif
          double fr[4], fc[8];
 #pragma unroll
          for (int i = 0; i < 4; ++i) fr[i] = Ab[(4 * q) * LDSW + i * 16];
 #pragma unroll
          for (int c = 0; c < 8; ++c) fc[c] = Bb[(4 * q) * LDSW + c * 4];
-         if (MODE != 1) {
+         if (SCALE) {
             const double dq = Ds[buf][4 * q + (lane >> 4)];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fr[i] *= dq;   // A diag(d) B^T: scale the 4 row fragments, not the column ones
@@ -649,16 +670,70 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
             for (int c = 0; c < 8; ++c)
                acc[i][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], fr[i], acc[i][c], 0, 0, 0);
       }
-      if (MODE != 1 && st + 1 < nst && tid < KB) Ds[buf ^ 1][tid] = dreg;   // visible after the next barrier
    }
 
 #if defined(PIPS_EXPERIMENT_CLOCK)
-   if (tid == 0 && SC) {   // diagnostic build only: shader cycles and 100 MHz ticks of the main loop into a debug buffer
-      SC[2 * tix] = (double)(__builtin_amdgcn_s_memtime() - t0_);
-      SC[2 * tix + 1] = (double)(__builtin_amdgcn_s_memrealtime() - r0_);
-   }
+   // diagnostic build only, 8 doubles per workgroup: shader cycles and 100 MHz ticks of the main loop, absolute ticks of
+   // entry / loop begin / loop end / exit, hardware id (XCC, SE, CU)
+   const unsigned long long t1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();
 #endif
    // epilogue: lane holds C(row = wr*64 + 16 i + (lane&15), col = wc*32 + 4 c + (lane>>4))
+   if (MODE == 0 || MODE >= 3) {
+      // read-modify-write of the C tile: all 32 loads go out before the first store (written as `*cp -= v` per element the
+      // compiler serialises load -> wait -> store 32 times, a global round trip each)
+      double* c0 = T + (long long)task.ti * TILE + wr * 64 + (lane & 15) + ((long long)task.tj * TILE + wc * 32 + (lane >> 4)) * ld;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {   // 8 elements at a time: the accumulators leave 40-odd registers
+         double cv[4][2];
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) cv[i][c] = c0[i * 16 + (long long)((2 * h + c) * 4) * ld];
+         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) c0[i * 16 + (long long)((2 * h + c) * 4) * ld] = cv[i][c] - acc[i][2 * h + c];
+         __builtin_amdgcn_sched_barrier(0);
+      }
+#if defined(PIPS_EXPERIMENT_CLOCK)
+      if (SC) {
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         if (tid == 0) {
+            double* o = SC + 8 * (long long)tix;
+            o[0] = (double)(t1_ - t0_); o[1] = (double)(r1_ - r0_);
+            o[2] = (double)re_; o[3] = (double)r0_; o[4] = (double)r1_; o[5] = (double)__builtin_amdgcn_s_memrealtime();
+            o[6] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4 /*HW_ID*/);
+            o[7] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20 /*XCC_ID*/);
+         }
+      }
+#endif
+      return;
+   }
+   if (MODE == 1) {
+      // L tile, and for tail rows its scaled copy U = L D (B operand of the updates); the eight d_j a lane needs are
+      // fetched in one go before the stores
+      const int col0 = task.tj * TILE + wc * 32 + (lane >> 4), row0 = task.ti * TILE + wr * 64 + (lane & 15);
+      const bool tail_row = task.ti < bd.ntc;
+      double dsc[8];
+      if (tail_row) {
+#pragma unroll
+         for (int c = 0; c < 8; ++c) dsc[c] = dtail[bd.dt_off + col0 + 4 * c];
+      }
+      double* c0 = T + row0 + (long long)col0 * ld;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+         for (int c = 0; c < 8; ++c) c0[i * 16 + (long long)(c * 4) * ld] = acc[i][c];
+      if (tail_row) {
+         double* u0 = uarena + bd.U + row0 + (long long)col0 * bd.m_pad;
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) u0[i * 16 + (long long)(c * 4) * bd.m_pad] = acc[i][c] * dsc[c];
+      }
+      return;
+   }
 #pragma unroll
    for (int i = 0; i < 4; ++i) {
       const int row = wr * 64 + i * 16 + (lane & 15);
@@ -666,17 +741,7 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
       for (int c = 0; c < 8; ++c) {
          const int col = wc * 32 + c * 4 + (lane >> 4);
          const double v = acc[i][c];
-         if (MODE == 0 || MODE >= 3) {
-            double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
-#if defined(PIPS_EXPERIMENT_NO_EPILOGUE)
-            if (v == 1.2345e300) *cp = v;
-#else
-            *cp -= v;
-#endif
-         } else if (MODE == 1) {
-            double* cp = T + (long long)task.ti * TILE + row + ((long long)task.tj * TILE + col) * ld;
-            *cp = v;
-         } else {
+         {
             const int gi = task.ti * TILE + row, gj = task.tj * TILE + col;
             if (gi < bd.nb && gj < bd.nb && gi >= gj) {
                const int* bm = bmap + bd.bmap_off;
