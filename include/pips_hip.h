@@ -249,49 +249,94 @@ int pips_hip_vec_dot_shifted(long long n, long long skip_root, const double* x_d
                              const double* y_dev, double b, const double* dy_dev, double* result, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * 4c. Host harness: Mehrotra predictor-corrector IPM for  min c^T x, A x = b, x >= 0  with block-angular A, driving the
- *     fused KKT path (counterpart of PIPSIPMppSolver::solve / InteriorPointMethod / LinearSystem::solve /
- *     Residuals::evaluate for this problem class).  Single rank.
- *     Block data are concatenated: W/T/F rowptr arrays hold N block-local row pointers (each starting at 0) back to back.
- *     x order [x_0 | x_1 .. x_N], b/y order [linking rows | block 1 rows .. block N rows].
+ * 4c. Host harness: Mehrotra predictor-corrector IPM with Gondzio correctors for the reference's full problem class
+ *        min c^T x   s.t.  A x = b,  clow <= C x <= cupp,  xlow <= x <= xupp      (every bound optional per row / entry)
+ *     with block-angular A and C, driving the fused KKT path (counterpart of PIPSIPMppSolver::solve / InteriorPointMethod /
+ *     LinearSystem::computeDiagonals, solve, solveXYZS, solveCompressedBiCGStab, system_mult / Residuals::evaluate /
+ *     DistributedMatrix::mult).  One or several ranks.
+ *     Input = the reader's per-block layout (GMSPIPSBlockData_t, Drivers/gams/gmspips/gmspipsio.h:5-58): block 0 is the root
+ *     (n0 variables; A = A0, C = C0, BL = F0, DL = G0; B, D absent), block k >= 1 has n variables, A (my x n0) and B (my x n)
+ *     for its equality rows, C (mz x n0) and D (mz x n) for its inequality rows, BL (myl x n) / DL (mzl x n) its part of the
+ *     linking rows.  Row pointers are block-local and start at 0.  Indicators are 0.0 / 1.0.
+ *     Vector orders: x = [x0 | x_1 .. x_N]; equality rows / y = [root rows | linking rows | block 1 .. N];
+ *     inequality rows / s, z, t, u, lambda, pi = [root rows | linking rows | block 1 .. N].
  * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+   int rows, cols;
+   const int* rowptr;      /* NULL: matrix absent (all zero) */
+   const int* colidx;
+   const double* val;
+} pips_csr_view;
+typedef struct {
+   int n, my, mz;                                        /* variables, own equality rows, own inequality rows */
+   pips_csr_view A, B, C, D, BL, DL;
+   const double *c, *xlow, *xupp, *ixlow, *ixupp;        /* n entries each */
+   const double* b;                                      /* my */
+   const double *clow, *cupp, *iclow, *icupp;            /* mz */
+} pips_ipm_block;
+/* n_blocks counts the root (block 0).  bL: right-hand side of the myl linking equalities; dlow / dupp / idlow / idupp: bounds
+ * of the mzl linking inequalities.  Several ranks: blocks[1..] are this rank's blocks, the root block and
+ * the linking data are identical on every rank; comm as for pips_hip_kkt_create.  Scalars are reduced over the ranks
+ * (replicated parts counted on rank 0 only, DistributedVector.C:1293-1303), replicated rows of the SpMVs are summed
+ * (DistributedMatrix.C:224-326); every rank returns the same result and holds the root part and its blocks' part of the
+ * solution. */
+int pips_ipm_create_general(void** handle, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, const double* bL,
+                            const double* dlow, const double* dupp, const double* idlow, const double* idupp, double dual_reg,
+                            int device, void* comm, int rank, int n_ranks);
+/* the generator's class  min c^T x, A x = b, x >= 0   as a shorthand for the general entry: W/T/F rowptr
+ * arrays hold N block-local row pointers back to back; x order [x_0 | x_1 .. x_N], b/y order [linking rows | block rows] */
 int pips_ipm_create(void** handle, int N, int n0, int myl, const int* n_i, const int* my_i, const int* W_rowptr,
                     const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
                     const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
                     const double* F0_val, const double* c, const double* b, double dual_reg, int device);
-/* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical breakdown before any
- * usable iterate, 3 numerical troubles: the best iterate so far is returned - its mu / residual are in [2] / [3], 4 probably
- * infeasible: phi = (||r|| + |gap|) / dnorm is >= 1e-8 and 1e4 times its best value after ten iterations, PIPSIPMppSolver.cpp:
- * 128-170) [5] b^T y [6] data norm.  Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
-/* the same on several ranks: this rank's N blocks; c = [c0 | blocks], b = [b_link | blocks] with the root parts
- * and F0 identical on every rank; comm as for pips_hip_kkt_create.  Scalars are reduced over the ranks (replicated parts
- * counted on rank 0 only, DistributedVector.C:1293-1303), the link rows of A x and the x0 rows of A^T y are summed
- * (DistributedMatrix.C:224-326); every rank returns the same result and holds x0 / y_link and its blocks' part of the solution */
 int pips_ipm_create_rank(void** handle, int N, int n0, int myl, const int* n_i, const int* my_i, const int* W_rowptr,
                          const int* W_colidx, const double* W_val, const int* T_rowptr, const int* T_colidx, const double* T_val,
                          const int* F_rowptr, const int* F_colidx, const double* F_val, const int* F0_rowptr, const int* F0_colidx,
                          const double* F0_val, const double* c, const double* b, double dual_reg, int device, void* comm, int rank,
                          int n_ranks);
+/* result7: [0] primal objective [1] iterations [2] mu [3] residual inf-norm [4] status (0 converged, 1 max iterations, 2 numerical
+ * breakdown before any usable iterate, 3 numerical troubles: the best iterate so far is returned - its mu / residual are in
+ * [2] / [3], 4 probably infeasible: phi = (||r|| + |gap|) / dnorm is >= 1e-8 and 1e4 times its best value after ten iterations,
+ * PIPSIPMppSolver.cpp:128-170) [5] dual objective b^T y + clow^T lambda - cupp^T pi + xlow^T gamma - xupp^T phi [6] data norm.
+ * Termination as PIPSIPMppSolver.cpp:143-149: mu <= mutol and ||r||inf <= artol * dnorm. */
 int pips_ipm_solve(void* handle, int max_iter, double mutol, double artol, int verbose, double* result7);
 /* Gondzio multiple centrality correctors per iteration (InteriorPointMethod.cpp:236-358): 0 = plain Mehrotra predictor-
  * corrector; default 2, i.e. 4 solves per iteration like the work unit of bench.py */
 int pips_ipm_set_gondzio(void* handle, int max_correctors);
-/* harness settings under the reference's option identifiers (Options.C:18-73, PIPSIPMppOptions.C:170-264): GONDZIO_MAX_CORRECTORS,
- * OUTER_SOLVE (1 iterative refinement, 2 BiCGStab), OUTER_BICG_MAX_ITER, REGULARIZATION (0/1: the inertia-correcting loop);
- * anything else returns an error */
+/* harness settings under the reference's option identifiers (Options.C:18-73, PIPSIPMppOptions.C:170-264,303-310):
+ * GONDZIO_MAX_CORRECTORS, OUTER_SOLVE (1 iterative refinement, 2 BiCGStab), OUTER_BICG_MAX_ITER,
+ * OUTER_BICG_MAX_NORMR_DIVERGENCES, OUTER_BICG_MAX_STAGNATIONS, REGULARIZATION (0/1: the inertia-correcting loop); anything else
+ * returns an error */
 int pips_ipm_set_option(void* handle, const char* name, double value);
-/* free variables: bounded_mask (nx host doubles, this rank's layout) is 1 for x_j >= 0 and 0 for a free x_j (the reference's
- * ixlow = ixupp = 0, whose computeDiagonals leaves dd_j = 0: LinearSystem.C:262-294).  Free entries carry no complementarity pair;
- * the preconditioner gets a proximal term on their diagonal (1e-6, option FREE_VARIABLE_PROXIMAL_TERM), the outer solve none.
- * Call before pips_ipm_solve; with several ranks on every rank. */
+/* shorthand for the x >= 0 class: bounded_mask (nx host doubles) is 1 for x_j >= 0 and 0 for a free x_j (ixlow = ixupp = 0, whose
+ * computeDiagonals leaves dd_j = 0: LinearSystem.C:262-294).  Free entries carry no complementarity pair; the preconditioner gets
+ * a proximal term on their diagonal (1e-6, option FREE_VARIABLE_PROXIMAL_TERM), the outer solve none.  Call before
+ * pips_ipm_solve; with several ranks on every rank.  (The general entry takes free variables through ixlow = ixupp = 0.) */
 int pips_ipm_set_free_variables(void* handle, const double* bounded_mask_host);
 int pips_ipm_get_solution(void* handle, double* x_host, double* y_host);
+/* dims4 = {nx, my, mz, complementarity pairs over all ranks}; iterate: any pointer may be NULL (sizes nx: x v w gamma phi,
+ * my: y, mz: s z t u lambda pi) */
+int pips_ipm_get_dims(void* handle, long long* dims4);
+int pips_ipm_get_iterate(void* handle, double* x, double* s, double* y, double* z, double* t, double* u, double* v, double* w,
+                         double* lambda, double* pi, double* gamma, double* phi);
 /* history of the last pips_ipm_solve, one row of 7 doubles per iterate: mu, ||r||inf, primal objective, dual objective, and the
  * step taken from it: sigma, alpha_primal, alpha_dual (zeros in the final row).  rows7 may be NULL to query *n_rows. */
 int pips_ipm_get_trace(void* handle, double* rows7, int max_rows, int* n_rows);
-/* counters of the last pips_ipm_solve: [0] KKT factorisations, [1] of which repeats with added dual regularisation (the inertia
- * loop, LinearSystem.C:295-325), [2] solveCompressed calls (preconditioner applications), [3] Gondzio correctors accepted */
+/* counters of the last pips_ipm_solve: [0] KKT factorisations, [1] of which repeats with added regularisation (the inertia
+ * loop, LinearSystem.C:295-325), [2] solveCompressed calls (preconditioner applications), [3] Gondzio correctors accepted;
+ * stats2: [0] BiCGStab iterations, [1] host synchronisations (scalar read-backs) */
 int pips_ipm_get_stats(void* handle, long long* stats4);
+int pips_ipm_get_stats2(void* handle, long long* stats2);
+/* direct entries to the rows either side of the path, for parity tests.  pips_ipm_mult: out = J in (transposed = 0; in: nx, out:
+ * my + mz = [A x | C x]) or out = J^T in (transposed = 1) - DistributedMatrix::mult / transpose_mult; with several ranks the
+ * replicated rows are summed.  pips_ipm_outer_solve: factorises with the diagonals of the pair vectors G = [t|u|v|w],
+ * L = [lambda|pi|gamma|phi] (host, 2 mz + 2 nx entries each) and runs the outer solve (OUTER_SOLVE option) on
+ * [dd J^T; J diag(0, nOmegaInv)] sol = rhs ([x | y | z] order) to tolerance tol * ||rhs||; info6 = {status (1 converged, 2 skipped,
+ * 3 max iterations, 4 breakdown, 5 diverged, 6 stagnation), iterations, ||r||_2, ||rhs||_2, preconditioner applications, host
+ * synchronisations} */
+int pips_ipm_mult(void* handle, int transposed, const double* in_host, double* out_host);
+int pips_ipm_outer_solve(void* handle, const double* G_host, const double* L_host, const double* rhs_host, double tol, double* sol_host,
+                         double* info6);
 void pips_ipm_destroy(void* handle);
 
 /* ---------------------------------------------------------------------------------------------------------------

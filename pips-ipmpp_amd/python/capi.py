@@ -66,7 +66,7 @@ SYMBOLS = [
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
     "pips_hip_vec_one_norm", "pips_hip_vec_inf_norm", "pips_hip_vec_min", "pips_hip_vec_sumsq_scaled", "pips_hip_vec_stepbound",
-    "pips_hip_vec_find_blocking", "pips_hip_vec_weighted_stepbounds", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_set_free_variables", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
+    "pips_hip_vec_find_blocking", "pips_hip_vec_weighted_stepbounds", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_create_general", "pips_ipm_get_dims", "pips_ipm_get_iterate", "pips_ipm_get_stats2", "pips_ipm_mult", "pips_ipm_outer_solve", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_set_free_variables", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
     "pips_gdx_read_block", "pips_gdx_block_counts", "pips_gdx_block_vector", "pips_gdx_block_matrix", "pips_gdx_block_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
     "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
@@ -797,6 +797,89 @@ class IpmSolver:
             self.close()
         except Exception:
             pass
+
+
+class _CsrView(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("val", C.c_void_p)]
+
+
+class _IpmBlock(C.Structure):
+    _fields_ = [("n", C.c_int), ("my", C.c_int), ("mz", C.c_int)] + [(k, _CsrView) for k in ("A", "B", "C", "D", "BL", "DL")] + \
+               [(k, C.c_void_p) for k in ("c", "xlow", "xupp", "ixlow", "ixupp", "b", "clow", "cupp", "iclow", "icupp")]
+
+
+class GeneralIpmSolver(IpmSolver):
+    """The device IPM on the reference's full problem class (bounds of either side on variables and rows, inequality rows, root
+    and linking rows), fed with the reader's per-block dicts (fields of GMSPIPSBlockData_t as gdx.read_block / gdx_read_block
+    return them): blocks[0] is the root.  Several ranks: blocks = [root] + this rank's blocks."""
+
+    def __init__(self, blocks, dual_reg=0.0, device=-1, comm=None, rank=0, n_ranks=1):
+        keep = []
+
+        def arr(a, dtype=np.float64):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p).value if a.size else None
+
+        def view(m):
+            if m is None:
+                return _CsrView(0, 0, None, None, None)
+            if isinstance(m, Csr):
+                m = dict(rows=m.nrows, cols=m.ncols, rowptr=m.rowptr, colidx=m.colidx, val=m.val)
+            rp = np.ascontiguousarray(m["rowptr"], dtype=np.int32)
+            keep.append(rp)
+            return _CsrView(int(m["rows"]), int(m["cols"]), rp.ctypes.data_as(C.c_void_p).value, arr(m["colidx"], np.int32), arr(m["val"]))
+
+        root = blocks[0]
+        myl, mzl = int(root["mBL"]), int(root["mDL"])
+        cb = (_IpmBlock * len(blocks))()
+        for k, b in enumerate(blocks):
+            n = int(b["n0"] if k == 0 else b["ni"])
+            cb[k].n, cb[k].my, cb[k].mz = n, int(b["mA"]), int(b["mC"])
+            cb[k].A, cb[k].C, cb[k].BL, cb[k].DL = view(b["A"]), view(b["C"]), view(b["BL"]), view(b["DL"])
+            cb[k].B, cb[k].D = (view(None), view(None)) if k == 0 else (view(b["B"]), view(b["D"]))
+            for f in ("c", "xlow", "xupp", "ixlow", "ixupp", "b", "clow", "cupp", "iclow", "icupp"):
+                setattr(cb[k], f, arr(b[f]))
+        self.n_blocks = len(blocks)
+        self._keep = (keep, cb)
+        self._comm = comm
+        self._h = C.c_void_p()
+        _check(lib.pips_ipm_create_general(C.byref(self._h), C.c_int(len(blocks)), cb, C.c_int(myl), C.c_int(mzl),
+                                           C.c_void_p(arr(root["bL"])), C.c_void_p(arr(root["dlow"])), C.c_void_p(arr(root["dupp"])),
+                                           C.c_void_p(arr(root["idlow"])), C.c_void_p(arr(root["idupp"])), C.c_double(dual_reg), C.c_int(device),
+                                           comm._h if comm is not None else None, C.c_int(rank), C.c_int(n_ranks)), "pips_ipm_create_general")
+        d = (C.c_longlong * 4)()
+        _check(lib.pips_ipm_get_dims(self._h, d), "pips_ipm_get_dims")
+        self.nx, self.ny, self.nzr, self.n_pairs = int(d[0]), int(d[1]), int(d[2]), int(d[3])
+
+    def iterate(self):
+        """All twelve parts of the current iterate as a dict of host arrays."""
+        nx, my, mz = self.nx, self.ny, self.nzr
+        out = dict(x=np.zeros(nx), s=np.zeros(mz), y=np.zeros(my), z=np.zeros(mz), t=np.zeros(mz), u=np.zeros(mz), v=np.zeros(nx), w=np.zeros(nx),
+                   lam=np.zeros(mz), pi=np.zeros(mz), gamma=np.zeros(nx), phi=np.zeros(nx))
+        _check(lib.pips_ipm_get_iterate(self._h, *[_ptr(out[k]) for k in ("x", "s", "y", "z", "t", "u", "v", "w", "lam", "pi", "gamma", "phi")]),
+               "pips_ipm_get_iterate")
+        return out
+
+    def mult(self, vec, transposed=False):
+        """J vec ([A x | C x]) or J^T vec for J = [A; C] in the harness' row / column order (DistributedMatrix::mult / transpose_mult)."""
+        vec = _f64(vec)
+        out = np.zeros(self.nx if transposed else self.ny + self.nzr)
+        _check(lib.pips_ipm_mult(self._h, C.c_int(1 if transposed else 0), _ptr(vec), _ptr(out)), "pips_ipm_mult")
+        return out
+
+    def outer_solve(self, G, L, rhs, tol=1e-10):
+        """Outer solve of [dd J^T; J diag(0, nOmegaInv)] sol = rhs with the diagonals of the pair vectors G = [t|u|v|w], L = [lambda|pi|gamma|phi]."""
+        G, L, rhs = _f64(G), _f64(L), _f64(rhs)
+        sol, info = np.zeros(self.nx + self.ny + self.nzr), np.zeros(6)
+        _check(lib.pips_ipm_outer_solve(self._h, _ptr(G), _ptr(L), _ptr(rhs), C.c_double(tol), _ptr(sol), _ptr(info)), "pips_ipm_outer_solve")
+        return sol, dict(status=int(info[0]), iterations=int(info[1]), residual=info[2], rhs_norm=info[3], preconditioner_calls=int(info[4]),
+                         host_syncs=int(info[5]))
+
+    def stats2(self):
+        out = (C.c_longlong * 2)()
+        _check(lib.pips_ipm_get_stats2(self._h, out), "pips_ipm_get_stats2")
+        return dict(bicgstab_iterations=out[0], host_syncs=out[1])
 
 
 def gdx_read_block(path, num_blocks, act_block, offset=1):
