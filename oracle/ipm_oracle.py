@@ -242,3 +242,112 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
     z0 = np.zeros(0)
     return solve_general(A, b, sp.csr_matrix((0, nx)), z0, z0, z0, z0, c, np.zeros(nx), ixlow, np.zeros(nx), np.zeros(nx), max_iter=max_iter,
                          mutol=mutol, artol=artol, trace=trace, dual_reg=dual_reg, gondzio=gondzio, free_diag=free_diag)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# f-1: the outer BiCGStab
+# ----------------------------------------------------------------------------------------------------------------------------
+BICG_STATUS = {1: "converged", 2: "skipped", 3: "max iterations", 4: "breakdown", 5: "diverged", 6: "stagnation"}
+
+
+def bicgstab(matvec, precond, b, tol=1e-10, max_iter=75, max_div=4, max_stag=4, eps=1e-15, history=None):
+    """LinearSystem::solveCompressedBiCGStab (LinearSystem.C:550-798) restated: right-preconditioned BiCGStab with
+    precond = solveCompressed, convergence tests on the predicted residual confirmed by the true one (:671-690,:722-738), the
+    best-iterate rollback (:692-697,:741-760), divergence (:741-753) and stagnation (:625-630,:763-775) counters, breakdown tests
+    with PIPSisZero(pips_eps0 = 1e-40) on rho, beta, r0^T v, t^T t, omega.  Returns (x, status, iterations, residual norm)."""
+    def is_zero(v):
+        return abs(v) < 1e-40
+
+    def true_res(x):
+        r = b - matvec(x)
+        return r, np.linalg.norm(r)
+
+    bn = np.linalg.norm(b)
+    target = max(bn * tol, eps)
+    x = precond(b.copy())
+    r, rn = true_res(x)
+    min_rn, best_x = rn, x.copy()
+    if rn <= target:
+        return x, 2, 0, rn
+    r0 = r / rn
+    rho = alpha = omega = 1.0
+    ndiv = nstag = 0
+    status = 3
+    p = v = None
+    it = 0
+
+    def stagn(step, dxn):
+        nonlocal nstag
+        nstag = nstag + 1 if abs(step) * dxn <= eps * np.linalg.norm(x) else 0
+
+    for it in range(max_iter):
+        rho_last, rho = rho, r0 @ r
+        if is_zero(rho):
+            status = 4
+            break
+        if it == 0:
+            p = r.copy()
+        else:
+            beta = (rho / rho_last) * (alpha / omega)
+            if is_zero(beta):
+                status = 4
+                break
+            p = r + beta * (p - omega * v)
+        dx = precond(p.copy())
+        v = matvec(dx)
+        rtv = r0 @ v
+        if is_zero(rtv):
+            status = 4
+            break
+        alpha = rho / rtv
+        stagn(alpha, np.linalg.norm(dx))
+        x = x + alpha * dx
+        r = r - alpha * v
+        rn = np.linalg.norm(r)
+        if rn <= target:
+            r, tr = true_res(x)
+            if tr <= target:
+                rn, status = tr, 1
+                break
+            min_rn = true_res(best_x)[1]
+            rn = tr
+        if rn < min_rn:
+            min_rn, best_x = rn, x.copy()
+        dx = precond(r.copy())
+        t = matvec(dx)
+        tt = t @ t
+        if is_zero(tt):
+            status = 4
+            break
+        omega = (t @ r) / tt
+        stagn(omega, np.linalg.norm(dx))
+        x = x + omega * dx
+        r = r - omega * t
+        rn = np.linalg.norm(r)
+        if rn <= target or nstag >= max_stag:
+            r, tr = true_res(x)
+            if tr <= target:
+                rn, status = tr, 1
+                break
+            min_rn = true_res(best_x)[1]
+            rn = tr
+        else:
+            ndiv = ndiv + 1 if rn >= min_rn else 0
+            if ndiv > max_div:
+                x, rn, status = best_x.copy(), min_rn, 5
+                break
+        if rn < min_rn:
+            min_rn, best_x = rn, x.copy()
+        if history is not None:
+            history.append(rn)
+        if nstag >= max_stag:
+            if min_rn < rn:
+                rn, x = min_rn, best_x.copy()
+            status = 6
+            break
+        if is_zero(omega):
+            status = 4
+            break
+    else:
+        it = max_iter - 1
+    return x, status, it + 1, rn
