@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "common.h"
 #include "pips_hip.h"
@@ -196,17 +198,52 @@ __global__ __launch_bounds__(256) void k_weighted_stepbounds(long long n, const 
 
 static double red_identity_host(int op) { return (op == RED_MIN || op == RED_STEPBOUND) ? INFINITY : 0.0; }
 
+// Reduction workspace: one per (thread, device).  The entry points take device pointers only, so the workspace of the device
+// that is current at the call is used - a workspace allocated on another device would be written across the fabric (or
+// fault without peer access).  Freed when a worker thread ends.
 struct VecWorkspace {
    double* d_partial = nullptr;  // 2048 partials + 8 result slots
    double* h_out = nullptr;      // pinned
-   int init() {
-      if (d_partial) return PIPS_OK;
-      HIP_TRYV(hipMalloc((void**)&d_partial, (2048 + 8) * sizeof(double)));
-      HIP_TRYV(hipHostMalloc((void**)&h_out, 8 * sizeof(double), hipHostMallocDefault));
-      return PIPS_OK;
+};
+constexpr int VEC_MAX_DEVICES = 64;
+struct VecWorkspaces {
+   VecWorkspace ws[VEC_MAX_DEVICES];
+   ~VecWorkspaces() {
+      // the main thread's copy goes away at process exit, when the HIP runtime may already be shutting down: leave it to the OS
+      if (getpid() == (pid_t)syscall(SYS_gettid)) return;
+      int cur = 0;
+      const bool have = hipGetDevice(&cur) == hipSuccess;
+      for (int d = 0; d < VEC_MAX_DEVICES; ++d) {
+         if (!ws[d].d_partial) continue;
+         if (hipSetDevice(d) == hipSuccess) {
+            (void)hipFree(ws[d].d_partial);
+            (void)hipHostFree(ws[d].h_out);
+         }
+      }
+      if (have) (void)hipSetDevice(cur);
    }
 };
-static thread_local VecWorkspace g_ws;
+static thread_local VecWorkspaces g_wss;
+static thread_local VecWorkspace* g_cur = nullptr;
+struct WsRef {   // g_ws.member resolves to the current device's workspace (set by g_ws.init())
+   int init() {
+      int dev = 0;
+      HIP_TRYV(hipGetDevice(&dev));
+      if (dev < 0 || dev >= VEC_MAX_DEVICES) PIPS_FAIL(PIPS_ERR_ARG, "vector layer: device index %d out of range", dev);
+      VecWorkspace& w = g_wss.ws[dev];
+      if (!w.d_partial) {
+         HIP_TRYV(hipMalloc((void**)&w.d_partial, (2048 + 8) * sizeof(double)));
+         HIP_TRYV(hipHostMalloc((void**)&w.h_out, 8 * sizeof(double), hipHostMallocDefault));
+      }
+      g_cur = &w;
+      d_partial = w.d_partial;
+      h_out = w.h_out;
+      return PIPS_OK;
+   }
+   double* d_partial = nullptr;
+   double* h_out = nullptr;
+};
+static thread_local WsRef g_ws;
 
 int vec_apply(int op, long long n, double a, double b, const double* x, const double* z, const double* mask, double* y,
               hipStream_t s) {

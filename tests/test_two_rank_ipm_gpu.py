@@ -100,3 +100,83 @@ def test_two_rank_ipm_matches_one_rank(tmp_path, with_free):
             seen.append(int(k))
         assert g["ncalls"] > 50
     assert sorted(seen) == list(range(N))
+
+
+# ---- the general problem class on two ranks: root equality / inequality rows, block inequality rows, linking rows of both kinds
+GEN = dict(seed=411, nb=5, n0=7, ni=26, mA=8, mC=5, mBL=3, mDL=3)
+
+
+def _gen_blocks():
+    from tests.general_lp_gen import random_block_lp
+    g = GEN
+    return random_block_lp(g["seed"], g["nb"], g["n0"], g["ni"], g["mA"], g["mC"], g["mBL"], g["mDL"], free_fraction=0.0)
+
+
+def _general_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blocks = _gen_blocks()
+    N = len(blocks) - 1
+    mine = np.nonzero(pa.map_children_to_ranks(N, world) == rank)[0]
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        torch.cuda.synchronize()
+
+    comm = pa.ExternalComm(allreduce)
+    ipm = pa.GeneralIpmSolver([blocks[0]] + [blocks[1 + k] for k in mine], comm=comm, rank=rank, n_ranks=world)
+    # f-2 on two ranks: replicated rows of J x and J^T [y; z] are summed over the ranks (DistributedMatrix.C:224-326)
+    rng = np.random.default_rng(9)
+    xg = rng.standard_normal(GEN["n0"] + N * GEN["ni"])
+    xl = np.concatenate([xg[:GEN["n0"]]] + [xg[GEN["n0"] + k * GEN["ni"]:GEN["n0"] + (k + 1) * GEN["ni"]] for k in mine])
+    jx = ipm.mult(xl)
+    res = ipm.solve(max_iter=100, mutol=1e-9, artol=1e-8)
+    itr = ipm.iterate()
+    np.savez(os.path.join(out, f"grank{rank}.npz"), res=np.array([res[k] for k in ("status", "iterations", "objective", "dual_objective", "mu", "rnorm", "dnorm")]),
+             trace=ipm.trace(), mine=mine, jx=jx, pairs=ipm.n_pairs, **{k: v for k, v in itr.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_general_ipm_matches_one_rank(tmp_path):
+    import scipy.sparse as sp
+    from oracle import ipm_oracle as io
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + 23
+    mp.start_processes(_general_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    blocks = _gen_blocks()
+    d = io.assemble(blocks)
+    N, n0, ni = len(blocks) - 1, GEN["n0"], GEN["ni"]
+    one = pa.GeneralIpmSolver(blocks)
+    r1 = one.solve(max_iter=100, mutol=1e-9, artol=1e-8)
+    i1, t1 = one.iterate(), one.trace()
+    assert r1["status"] == 0
+    got = [np.load(os.path.join(str(tmp_path), f"grank{r}.npz")) for r in range(world)]
+    assert np.array_equal(got[0]["res"], got[1]["res"]) and np.array_equal(got[0]["trace"], got[1]["trace"])
+    rng = np.random.default_rng(9)
+    xg = rng.standard_normal(n0 + N * ni)
+    J = sp.vstack([d["A"], d["C"]], format="csr")
+    want = J @ xg
+    my0, myl, mz0, mzl = blocks[0]["mA"], blocks[0]["mBL"], blocks[0]["mC"], blocks[0]["mDL"]
+    my_tot = d["A"].shape[0]
+    for g in got:
+        assert int(g["pairs"]) == one.n_pairs
+        status, its, obj = int(g["res"][0]), int(g["res"][1]), g["res"][2]
+        assert status == 0 and abs(its - r1["iterations"]) <= 1
+        assert abs(obj - r1["objective"]) <= 1e-8 * max(1.0, abs(r1["objective"]))
+        # same path; the summation order of the two ranks differs from the single rank's, and the last iterations amplify that
+        n_cmp = min(g["trace"].shape[0], t1.shape[0]) - 6
+        assert n_cmp >= 5 and np.allclose(g["trace"][:n_cmp, [0, 2, 3]], t1[:n_cmp, [0, 2, 3]], rtol=1e-4, atol=1e-9)
+        # replicated parts of the iterate equal the one-rank run
+        assert np.abs(g["x"][:n0] - i1["x"][:n0]).max() <= 1e-6 * max(1.0, np.abs(i1["x"]).max())
+        assert np.abs(g["z"][:mz0 + mzl] - i1["z"][:mz0 + mzl]).max() <= 1e-3 * max(1.0, np.abs(i1["z"]).max())   # multipliers of degenerate rows are large and loosely determined
+        # J x: replicated rows (root and linking rows of both kinds) carry the global sums on every rank
+        assert np.abs(g["jx"][:my0 + myl] - want[:my0 + myl]).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        assert np.abs(g["jx"][g["y"].shape[0]:g["y"].shape[0] + mz0 + mzl] - want[my_tot:my_tot + mz0 + mzl]).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        for i, k in enumerate(g["mine"]):
+            xs = g["x"][n0 + i * ni:n0 + (i + 1) * ni]
+            assert np.abs(xs - i1["x"][n0 + k * ni:n0 + (k + 1) * ni]).max() <= 1e-6 * max(1.0, np.abs(i1["x"]).max())
