@@ -45,7 +45,7 @@ def update_kernel_algorithmic_flops(m, nb):
 def update_kernel_traffic(n_blocks, n_i, S, world):
     """HBM bytes of the update kernel per factorize from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes over this very command, FETCH_SIZE doubled per MI355X_MICROARCH.md); only valid for the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r1_bench_update_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_bench_update_traffic.json")
     if world != 1 or n_blocks != 64 or n_i != 10000 or S != 2000 or not os.path.exists(path):
         return None
     try:
@@ -289,7 +289,10 @@ def main():
     upd_ms, upd_launches = tm["tail_update"]
     # per-block tail sizes are statistically equal; use the exact aggregate from the symbolic phase
     m_avg = info["m"] / len(blocks)
-    alg_flops = len(blocks) * update_kernel_algorithmic_flops(int(round(m_avg)), S)
+    # border rows that ride along = the NON-EMPTY border columns of a block (info["nb"]), not S: on configurations whose blocks
+    # touch only part of the linking columns the difference is large (configs[4] share: S = 16000, ~3700 non-empty per block)
+    nb_avg = info["nb"] / len(blocks)
+    alg_flops = len(blocks) * update_kernel_algorithmic_flops(int(round(m_avg)), int(round(nb_avg)))
     achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
     traffic = update_kernel_traffic(n_blocks_total, n_i, S, world)
     roofline = {
@@ -316,7 +319,7 @@ def main():
             "config": {"workload": f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""),
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(), "iter_per_s": round(a.steps / dt, 4),
-                       "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1),
+                       "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},
             "roofline": roofline,
         }

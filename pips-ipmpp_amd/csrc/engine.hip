@@ -1495,15 +1495,17 @@ int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero) {
 }
 
 static void sym_info(const std::vector<BlockSym>& sym, int64_t* what, int n_what) {
-   int64_t v[11] = {0};
+   int64_t v[13] = {0};
    for (const BlockSym& s : sym) {
       v[10] += (int64_t)s.upd.size() * 4;
+      v[11] += s.nb;
+      v[12] += (int64_t)s.a_dst.size();
       v[0] += s.nnzL; v[1] += s.n; v[2] += s.n_head; v[3] += s.m; v[4] += (int64_t)s.sn.size();
       v[5] = std::max<int64_t>(v[5], s.n_levels);
       v[6] += (int64_t)s.flops_factor; v[7] += (int64_t)s.flops_border; v[8] += s.arena * 8;
       v[9] = std::max<int64_t>(v[9], s.m_pad / TILE);
    }
-   for (int i = 0; i < n_what && i < 11; ++i) what[i] = v[i];
+   for (int i = 0; i < n_what && i < 13; ++i) what[i] = v[i];
 }
 
 int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {

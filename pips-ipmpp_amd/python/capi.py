@@ -418,9 +418,9 @@ class LeafBatch:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(10, np.int64)
-        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(10)), "pips_hip_batch_info")
-        keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc"]
+        what = np.zeros(13, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(13)), "pips_hip_batch_info")
+        keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK"]
         return {k: int(v) for k, v in zip(keys, what)}
 
     def sync(self):

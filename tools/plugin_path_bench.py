@@ -1,0 +1,63 @@
+"""What a stock PIPS-IPM++ gets from the drop-in DoubleLinearSolver adapters alone (INTEGRATION.md level 1), timed beside the fused
+path: per block pips_hip_ldl_factor with the values coming from host memory, the reference's own K4-K6 loop on the host
+(DistributedLinearSystem.C:766-1175: chunks of 20 x T border columns dense-ified on the host, multi-RHS pips_hip_ldl_solve through
+host pointers, sparse product back into the host Schur complement), the dense root through pips_hip_dense_ldl_factor / _solve with
+host pointers, and solveCompressed as host loops around single solves.  Config: BASELINE.json configs[1] (64 x 10 000, S = 2000);
+--blocks B of the 64 are run and scaled by 64 / B.   usage: plugin_path_bench.py [--blocks 4] [--chunk 160]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp
+import pips_ipmpp_amd as pa
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--blocks", type=int, default=4)
+ap.add_argument("--chunk", type=int, default=160, help="border columns per multi-RHS solve (the reference: 20 x OMP threads)")
+a = ap.parse_args()
+seed, N_total, n_i, S, rho = 20261002, 64, 10000, 2000, 1e-3
+my_i, n0, myl = n_i // 2, S // 2, S // 2
+solvers, Bts = [], []
+t_an = t_fac = t_schur = 0.0
+SC = np.zeros((S, S))
+for b in range(a.blocks):
+    W, T, F, c, xs = pa.gen_block(seed, b + 1, n_i, my_i, n0, myl, rho)
+    K, dpos = pa.kkt_leaf_assemble(n_i, W)
+    K.val[dpos] = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
+    Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F).to_scipy()
+    s = pa.HipLdlSolver(K, n_primal=n_i, refine_steps=1)
+    t0 = time.perf_counter(); s.analyze(); t_an += time.perf_counter() - t0
+    s.matrixChanged()                                   # warm-up (first-touch allocations)
+    t0 = time.perf_counter(); s.matrixChanged(); t_fac += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cols = np.nonzero(np.diff(Bt.indptr) > 0)[0]
+    for k in range(0, len(cols), a.chunk):               # K4: dense-ify, K5: multi-RHS solve, K6: sparse product
+        ids = cols[k:k + a.chunk]
+        dense = np.ascontiguousarray(Bt[ids].toarray())
+        s.solve(dense)
+        SC[ids, :] -= (Bt @ dense.T).T
+    t_schur += time.perf_counter() - t0
+    solvers.append(s); Bts.append(Bt)
+    print(f"block {b}: factor {t_fac / (b + 1) * 1e3:.1f} ms, Schur term {t_schur / (b + 1):.2f} s (running means)", file=sys.stderr, flush=True)
+F0, c0, x0s = pa.gen_root(seed, n0, myl)
+from oracle import oracle as orc   # only finalize_kkt_dense: host-side assembly of the root rows, as the reference's host does
+SCf = orc.finalize_kkt_dense(np.tril(SC) * (N_total / a.blocks), n0, 0, myl, 0, pa.gen_diagonal(seed, 0, n0), F0=F0.to_scipy())
+root = pa.HipDenseLdlSolver(S, n_primal=n0)
+A = np.tril(SCf); A = A + np.tril(A, -1).T
+root.matrixChanged(np.ascontiguousarray(A))
+t0 = time.perf_counter(); root.matrixChanged(np.ascontiguousarray(A)); t_root = time.perf_counter() - t0
+rng = np.random.default_rng(0)
+t_sc = []
+for r in range(4):
+    b0 = rng.standard_normal(S); bs = [rng.standard_normal(n_i + my_i) for _ in range(a.blocks)]
+    t0 = time.perf_counter()
+    for bi, sol, Bt in zip(bs, solvers, Bts):
+        sol.solve(bi); b0 -= Bt @ bi
+    root.solve(b0)
+    for bi, sol, Bt in zip(bs, solvers, Bts):
+        t = Bt.T @ b0; sol.solve(t); bi -= t
+    t_sc.append(time.perf_counter() - t0)
+scale = N_total / a.blocks
+unit = (t_fac + t_schur) * scale + t_root + 4 * np.median(t_sc) * scale
+print(json.dumps({"path": "drop-in DoubleLinearSolver adapters only (host pointers, reference K4-K6 host loop)", "blocks_run": a.blocks, "chunk_columns": a.chunk,
+                  "seconds_per_block": {"analyze_once": t_an / a.blocks, "factor": t_fac / a.blocks, "schur_term": t_schur / a.blocks},
+                  "seconds_per_unit": {"leaf_factor": t_fac * scale, "leaf_schur": t_schur * scale, "root_factor": t_root, "solve_compressed_x4": 4 * float(np.median(t_sc)) * scale,
+                                       "total": unit}, "units_per_s": 1.0 / unit}))
