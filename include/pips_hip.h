@@ -203,6 +203,16 @@ void pips_hip_comm_destroy(void* comm);
  * from any stream; the library synchronises its own stream before calling it. */
 typedef int (*pips_hip_allreduce_cb)(void* user, double* buf_dev, size_t n);
 int pips_hip_comm_create_external(void** comm, pips_hip_allreduce_cb allreduce, void* user);
+/* The same sum as reduce-scatter + all-gather (ncclReduceScatter + ncclAllGather; the slice a rank owns after the first phase is
+ * what a distributed root would keep): buf_dev must have room for ceil(n / n_ranks) * n_ranks doubles.  Host-supplied pair for an
+ * external communicator (MPI_Reduce_scatter_block / MPI_Allgather, in place on buf_dev: reduce_scatter leaves the sum of slice
+ * `rank` at buf_dev + rank * chunk, all_gather replicates every slice); without it the external all-reduce is used.
+ * PIPS_HIP_SC_REDUCE=rsag makes pips_hip_kkt_factorize reduce the Schur complement this way. */
+typedef int (*pips_hip_reduce_scatter_cb)(void* user, double* buf_dev, size_t chunk);
+typedef int (*pips_hip_all_gather_cb)(void* user, double* buf_dev, size_t chunk);
+int pips_hip_comm_set_external_rsag(void* comm, int n_ranks, int rank, pips_hip_reduce_scatter_cb reduce_scatter, pips_hip_all_gather_cb all_gather);
+int pips_hip_allreduce_sum_rsag(void* comm, double* buf_dev, size_t n, void* stream);
+int pips_hip_comm_size(void* comm);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * 4b. Flat-arena vector kernels: DistributedVector<T>/DenseVector<T> operations used around the path

@@ -16,6 +16,8 @@ typedef void* nccl_comm_t;
 typedef int (*fn_get_id)(nccl_id_t*);
 typedef int (*fn_init_rank)(nccl_comm_t*, int, nccl_id_t, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_reduce_scatter)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef const char* (*fn_errstr)(int);
 
@@ -24,6 +26,8 @@ struct Rccl {
    fn_get_id get_id = nullptr;
    fn_init_rank init_rank = nullptr;
    fn_allreduce allreduce = nullptr;
+   fn_reduce_scatter reduce_scatter = nullptr;
+   fn_all_gather all_gather = nullptr;
    fn_destroy destroy = nullptr;
    fn_errstr errstr = nullptr;
    bool load() {
@@ -37,6 +41,8 @@ struct Rccl {
       get_id = (fn_get_id)dlsym(lib, "ncclGetUniqueId");
       init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
       allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
+      reduce_scatter = (fn_reduce_scatter)dlsym(lib, "ncclReduceScatter");
+      all_gather = (fn_all_gather)dlsym(lib, "ncclAllGather");
       destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
       errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
       return get_id && init_rank && allreduce && destroy;
@@ -48,6 +54,9 @@ struct Comm {
    int device;
    pips_hip_allreduce_cb external = nullptr;   // host-supplied reduction (GPU-aware MPI, torch.distributed, ...)
    void* user = nullptr;
+   int n_ranks = 1, rank = 0;
+   pips_hip_reduce_scatter_cb ext_reduce_scatter = nullptr;   // optional: MPI_Reduce_scatter_block / MPI_Allgather of the host
+   pips_hip_all_gather_cb ext_all_gather = nullptr;
 };
 constexpr int kNcclDouble = 8;  // ncclFloat64
 constexpr int kNcclSum = 0;
@@ -72,6 +81,7 @@ int pips_hip_comm_create(void** comm, const void* id128, int n_ranks, int rank, 
    nccl_id_t id;
    std::memcpy(&id, id128, 128);
    Comm* c = new Comm{nullptr, device};
+   c->n_ranks = n_ranks; c->rank = rank;
    const int rc = g_rccl.init_rank(&c->comm, n_ranks, id, rank);
    if (rc) {
       delete c;
@@ -104,6 +114,45 @@ int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream) 
    if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclAllReduce failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
    return 0;
 }
+
+int pips_hip_comm_set_external_rsag(void* comm, int n_ranks, int rank, pips_hip_reduce_scatter_cb reduce_scatter, pips_hip_all_gather_cb all_gather) {
+   Comm* c = (Comm*)comm;
+   if (!c || !c->external || n_ranks < 1 || rank < 0 || rank >= n_ranks || !reduce_scatter || !all_gather)
+      PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_comm_set_external_rsag: bad arguments");
+   c->n_ranks = n_ranks; c->rank = rank;
+   c->ext_reduce_scatter = reduce_scatter;
+   c->ext_all_gather = all_gather;
+   return 0;
+}
+
+/* Sum over the ranks as reduce-scatter + all-gather: rank r ends up owning the reduced slice [r * chunk, (r + 1) * chunk) after the
+ * first phase (what a distributed root factorisation would keep), the second phase replicates it.  On xGMI (point-to-point
+ * links, 7 per GPU) both phases are one direct exchange with every peer; the ring all-reduce RCCL may pick instead is bound by
+ * a single link.  buf_dev must hold n_padded = chunk * n_ranks doubles, chunk = ceil(n / n_ranks); entries n .. n_padded are
+ * scratch. */
+int pips_hip_allreduce_sum_rsag(void* comm, double* buf_dev, size_t n, void* stream) {
+   Comm* c = (Comm*)comm;
+   if (!c || !buf_dev) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_allreduce_sum_rsag: bad arguments");
+   const size_t P = (size_t)c->n_ranks, chunk = (n + P - 1) / P;
+   if (c->external) {
+      if (!c->ext_reduce_scatter || !c->ext_all_gather) return pips_hip_allreduce_sum(comm, buf_dev, n, stream);   // host has no such pair
+      if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) PIPS_FAIL(pips::PIPS_ERR_HIP, "stream sync before the external reduce-scatter failed");
+      int rc = c->ext_reduce_scatter(c->user, buf_dev, chunk);
+      if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "external reduce-scatter callback returned %d", rc);
+      rc = c->ext_all_gather(c->user, buf_dev, chunk);
+      if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "external all-gather callback returned %d", rc);
+      return 0;
+   }
+   if (!g_rccl.reduce_scatter || !g_rccl.all_gather) return pips_hip_allreduce_sum(comm, buf_dev, n, stream);
+   double* mine = buf_dev + (size_t)c->rank * chunk;
+   int rc = g_rccl.reduce_scatter(buf_dev, mine, chunk, kNcclDouble, kNcclSum, c->comm, (hipStream_t)stream);
+   if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclReduceScatter failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+   rc = g_rccl.all_gather(mine, buf_dev, chunk, kNcclDouble, c->comm, (hipStream_t)stream);
+   if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclAllGather failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+   return 0;
+}
+
+int pips_hip_comm_size(void* comm) { return comm ? ((Comm*)comm)->n_ranks : 1; }
 
 void pips_hip_comm_destroy(void* comm) {
    Comm* c = (Comm*)comm;

@@ -214,6 +214,11 @@ struct TailCtx {
    bool is_root = false;                // dense root: same update kernel under its own name (k_tile_gemm<3>)
    const int* d_sctab = nullptr;        // sparse Schur complement: per-block position tables (kernels.hip.h sc_entry)
    double* d_uarena = nullptr;          // scaled copies U = L D of the tail rows (BlkDesc::U), B operand of the updates
+   // Schur SYRK in row-panel groups (several ranks): group p holds the tile rows whose first Schur row lies in panel p; after
+   // its launch ev_sc[p] is recorded and rows of panel p are final on this rank (Engine::set_sc_panels)
+   const std::vector<TaskList>* sc_groups = nullptr;
+   const TileTask* d_sc_tasks = nullptr;
+   const std::vector<hipEvent_t>* ev_sc = nullptr;
 };
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
@@ -297,7 +302,17 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       }
    }
    if ((rc = main_writes(1 << 30))) return rc;   // join the side stream
-   if (SC && p.schur.cnt > 0) {
+   if (SC && c.sc_groups && !c.d_sctab) {
+      if (c.timer) c.timer->begin(c.stream, 5);
+      for (size_t g = 0; g < c.sc_groups->size(); ++g) {
+         const TaskList& l = (*c.sc_groups)[g];
+         if (l.cnt > 0)
+            hipLaunchKernelGGL(k_tile_gemm<2>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, c.d_sc_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                               c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena);
+         HIP_TRY(hipEventRecord((*c.ev_sc)[g], c.stream));
+      }
+      if (c.timer) c.timer->end(c.stream);
+   } else if (SC && p.schur.cnt > 0) {
       if (c.timer) c.timer->begin(c.stream, 5);
       hipLaunchKernelGGL(k_tile_gemm<2>, dim3((p.schur.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
                          c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena);
@@ -433,9 +448,50 @@ struct Engine {
 
    hipStream_t side = nullptr;                       // diagonal tiles of the tail are factorised here, beside the column update
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
+   // ---- Schur SYRK in row-panel groups, so that a multi-rank root can reduce panel p while the leaves still compute p + 1 ..
+   std::vector<TaskList> sc_groups;
+   std::vector<int> sc_row_begin;          // panel p = Schur rows [sc_row_begin[p], sc_row_begin[p + 1])
+   std::vector<hipEvent_t> ev_sc;
+   TileTask* d_sc_tasks = nullptr;
+   int set_sc_panels(int n_panels) {
+      if (!analyzed) PIPS_FAIL(PIPS_ERR_STATE, "set_sc_panels: analyze first");
+      for (auto ev : ev_sc) (void)hipEventDestroy(ev);
+      ev_sc.clear(); sc_groups.clear(); sc_row_begin.clear();
+      if (d_sc_tasks) { (void)hipFree(d_sc_tasks); d_sc_tasks = nullptr; }
+      n_panels = std::min(n_panels, std::max(1, S / (2 * TILE)));
+      if (n_panels <= 1 || schur_mode_eff != 1) return PIPS_OK;
+      for (int q = 0; q <= n_panels; ++q) sc_row_begin.push_back(q == n_panels ? S : (int)((long long)S * q / n_panels) / TILE * TILE);
+      std::vector<std::vector<TileTask>> g(n_panels);
+      for (int b = 0; b < nblk; ++b) {
+         if (h_blks[b].ntc <= 0 || h_blks[b].nb <= 0) continue;
+         const int nt = h_blks[b].nb_pad / TILE;
+         for (int ti = 0; ti < nt; ++ti) {
+            // a tile row belongs to the panel of its FIRST Schur row: every tile row that touches panel q then sits in a group <= q
+            // (compressed border ids ascend like the Schur ids), so panel q is final once group q has run
+            const int first = sym[b].bmap[std::min(ti * TILE, h_blks[b].nb - 1)];
+            int q = (int)(std::upper_bound(sc_row_begin.begin(), sc_row_begin.end(), first) - sc_row_begin.begin()) - 1;
+            q = std::max(0, std::min(q, n_panels - 1));
+            for (int tj = 0; tj <= ti; ++tj) g[q].push_back({b, ti, tj, 0});
+         }
+      }
+      std::vector<TileTask> all;
+      for (int q = 0; q < n_panels; ++q) {
+         TaskList l;
+         l.off = (long long)all.size(); l.cnt = (int)g[q].size();
+         all.insert(all.end(), g[q].begin(), g[q].end());
+         sc_groups.push_back(l);
+         hipEvent_t ev;
+         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+         ev_sc.push_back(ev);
+      }
+      if (all.empty()) all.push_back({-1, 0, 0, 0});
+      return dev_upload(&d_sc_tasks, all, stream);
+   }
    TailCtx ctx() {
-      return TailCtx{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
-                     timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
+      TailCtx c{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
+                timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
+      if (!sc_groups.empty()) { c.sc_groups = &sc_groups; c.d_sc_tasks = d_sc_tasks; c.ev_sc = &ev_sc; }
+      return c;
    }
 
    int analyze_host(int n_threads, bool with_border = true) {
@@ -1183,6 +1239,10 @@ struct KktSystem {
    int *d_c0_rp = nullptr, *d_c0_ci = nullptr;
    const double* d_zdiag0 = nullptr;   // caller-owned, set per iteration
    double root_reg_primal = 0.0, root_reg_dual = 0.0;   // pips_hip_kkt_set_root_regularization
+   hipStream_t comm_stream = nullptr;   // panel-wise Schur reduction beside the leaf work
+   hipEvent_t ev_reduced = nullptr;
+   size_t packed_cap = 0;
+   bool use_rsag = false;
    // sparse root: SC lives as the value array of a lower-triangular CSR pattern inside a one-block sparse
    // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
    bool sparse = false;
@@ -1191,6 +1251,8 @@ struct KktSystem {
    long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
    int* d_sc_rowptr = nullptr;
    ~KktSystem() {
+      if (comm_stream) (void)hipStreamDestroy(comm_stream);
+      if (ev_reduced) (void)hipEventDestroy(ev_reduced);
       void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -1253,6 +1315,20 @@ __global__ void k_pack_lower(const double* __restrict__ M, int ld, int S, double
    for (int r = c + blockIdx.x * blockDim.x + threadIdx.x; r < S; r += gridDim.x * blockDim.x) {
       if (unpack) col[r] = packed[base + (r - c)];
       else packed[base + (r - c)] = col[r];
+   }
+}
+
+// the same for a row panel [R0, R1) of the lower triangle: column c < R1 contributes its rows max(c, R0) .. R1 - 1
+__global__ void k_pack_rows(const double* __restrict__ M, int ld, int R0, int R1, double* __restrict__ packed, int unpack) {
+   const int c = blockIdx.y;
+   const long long h = R1 - R0;
+   const long long base = c <= R0 ? (long long)c * h
+                                  : (long long)R0 * h + (long long)(c - R0) * R1 - ((long long)c * (c - 1) / 2 - (long long)R0 * (R0 - 1) / 2);
+   const int r_first = c > R0 ? c : R0;
+   double* col = const_cast<double*>(M) + (long long)c * ld;
+   for (int r = r_first + blockIdx.x * blockDim.x + threadIdx.x; r < R1; r += gridDim.x * blockDim.x) {
+      if (unpack) col[r] = packed[base + (r - r_first)];
+      else packed[base + (r - r_first)] = col[r];
    }
 }
 
@@ -1824,6 +1900,14 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    k->n_fin = (long long)idx.size();
    if ((rc = dev_upload(&k->d_fin_idx, idx, nullptr))) return rc;
    if ((rc = dev_upload(&k->d_fin_val, val, nullptr))) return rc;
+   // several ranks: Schur SYRK in row panels, each reduced as soon as it is final (PIPS_HIP_SC_PANELS, default 4 for S >= 1024; 1 =
+   // one reduction after all leaf work); PIPS_HIP_SC_REDUCE=rsag: reduce-scatter + all-gather instead of the all-reduce
+   if (comm && (n_ranks > 1 || getenv("PIPS_HIP_FORCE_REDUCE"))) {
+      int panels = S >= 1024 ? 4 : 1;
+      if (const char* pp = getenv("PIPS_HIP_SC_PANELS")) panels = atoi(pp);
+      if ((rc = e->set_sc_panels(panels))) return rc;
+      if (const char* m = getenv("PIPS_HIP_SC_REDUCE")) k->use_rsag = std::string(m) == "rsag";
+   }
    *handle = k.release();
    return PIPS_OK;
 }
@@ -2012,11 +2096,47 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       // only the lower triangle is authoritative: reduce S(S+1)/2 packed doubles instead of S^2
       const size_t np = (size_t)k->S * (k->S + 1) / 2;
-      if (!k->d_packed) HIP_TRY(hipMalloc((void**)&k->d_packed, np * sizeof(double)));
-      const dim3 pg(std::max(1, std::min(64, (k->S + 255) / 256)), k->S);
-      hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 0);
-      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_packed, np, e->stream))) return rc;
-      hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 1);
+      const size_t n_groups = std::max<size_t>(e->sc_groups.size(), 1);
+      const size_t P = (size_t)std::max(1, pips_hip_comm_size(k->comm));
+      const size_t cap = np + (n_groups + 1) * P;   // reduce-scatter pads every piece to a multiple of the rank count
+      if (!k->d_packed || k->packed_cap < cap) {
+         if (k->d_packed) (void)hipFree(k->d_packed);
+         HIP_TRY(hipMalloc((void**)&k->d_packed, cap * sizeof(double)));
+         k->packed_cap = cap;
+      }
+      auto reduce_piece = [&](double* buf, size_t cnt, hipStream_t st) -> int {
+         return k->use_rsag ? pips_hip_allreduce_sum_rsag(k->comm, buf, cnt, st) : pips_hip_allreduce_sum(k->comm, buf, cnt, st);
+      };
+      if (!e->sc_groups.empty()) {
+         // Panel-wise: the Schur SYRK ran in row-panel groups (Engine::set_sc_panels); the rows of panel q are final on this rank
+         // once group q has run, so their reduction goes out on a second stream while the leaves compute the later groups -
+         // the overlap of leaf work with MPI_Allreduce that DistributedRootLinearSystem.C:860-881 cannot have (it reduces
+         // after all children are done).  Everything was enqueued by e->factor(); here only the reductions are issued, in order.
+         if (!k->comm_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&k->comm_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&k->ev_reduced, hipEventDisableTiming));
+         }
+         size_t off = 0;
+         for (size_t q = 0; q < e->sc_groups.size(); ++q) {
+            const int R0 = e->sc_row_begin[q], R1 = e->sc_row_begin[q + 1];
+            if (R1 <= R0) continue;
+            const size_t h = (size_t)(R1 - R0);
+            const size_t cnt = (size_t)R0 * h + h * (h + 1) / 2;
+            HIP_TRY(hipStreamWaitEvent(k->comm_stream, e->ev_sc[q], 0));
+            const dim3 pg(std::max(1, std::min(64, (R1 - R0 + 255) / 256)), R1);
+            hipLaunchKernelGGL(k_pack_rows, pg, dim3(256), 0, k->comm_stream, k->d_SC, k->S, R0, R1, k->d_packed + off, 0);
+            if ((rc = reduce_piece(k->d_packed + off, cnt, k->comm_stream))) return rc;
+            hipLaunchKernelGGL(k_pack_rows, pg, dim3(256), 0, k->comm_stream, k->d_SC, k->S, R0, R1, k->d_packed + off, 1);
+            off += (cnt + P - 1) / P * P;
+         }
+         HIP_TRY(hipEventRecord(k->ev_reduced, k->comm_stream));
+         HIP_TRY(hipStreamWaitEvent(e->stream, k->ev_reduced, 0));
+      } else {
+         const dim3 pg(std::max(1, std::min(64, (k->S + 255) / 256)), k->S);
+         hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 0);
+         if ((rc = reduce_piece(k->d_packed, np, e->stream))) return rc;
+         hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 1);
+      }
    }
    // finalizeKKTdense
    if (xdiag0_dev && k->n0 > 0)

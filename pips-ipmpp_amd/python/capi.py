@@ -61,7 +61,7 @@ SYMBOLS = [
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
-    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
+    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
@@ -487,7 +487,10 @@ class ExternalComm(Comm):
     """Communicator whose all-reduce is supplied by the host program (the reference would hand in its MPI communicator's
     `PIPS_MPIsumArrayInPlace`); `torch_distributed()` builds one on an initialised torch.distributed process group."""
 
-    def __init__(self, allreduce):
+    def __init__(self, allreduce, reduce_scatter=None, all_gather=None, n_ranks=1, rank=0):
+        """allreduce(ptr, n): in-place sum of n device doubles at ptr over all ranks.  Optional pair for the reduce-scatter +
+        all-gather formulation (pips_hip_allreduce_sum_rsag): reduce_scatter(ptr, chunk) leaves the summed slice `rank` at
+        ptr + rank * chunk doubles, all_gather(ptr, chunk) replicates every rank's slice."""
         def _cb(_user, ptr, n):
             try:
                 allreduce(int(ptr), int(n))
@@ -499,6 +502,18 @@ class ExternalComm(Comm):
         self._cb = _ALLREDUCE_CB(_cb)   # keep the trampoline alive as long as the communicator
         self._h = C.c_void_p()
         _check(lib.pips_hip_comm_create_external(C.byref(self._h), self._cb, None), "pips_hip_comm_create_external")
+        if reduce_scatter is not None and all_gather is not None:
+            def _wrap(fn, what):
+                def _f(_user, ptr, chunk):
+                    try:
+                        fn(int(ptr), int(chunk))
+                        return 0
+                    except Exception as e:
+                        sys.stderr.write(f"external {what} failed: {e}\n")
+                        return 1
+                return _ALLREDUCE_CB(_f)
+            self._rs, self._ag = _wrap(reduce_scatter, "reduce-scatter"), _wrap(all_gather, "all-gather")
+            _check(lib.pips_hip_comm_set_external_rsag(self._h, C.c_int(n_ranks), C.c_int(rank), self._rs, self._ag), "pips_hip_comm_set_external_rsag")
 
     @classmethod
     def torch_distributed(cls, group=None):
