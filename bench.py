@@ -214,16 +214,28 @@ def main():
         want_own = os.environ.get("PIPS_BENCH_COMM", "rccl") != "torch" and not share_gpu
         ok = torch.ones(1, dtype=torch.int32, device="cpu" if share_gpu else "cuda")
         if want_own:
+            # ncclCommInitRank is collective: a rank that fails BEFORE it (librccl not loadable, bad device) would leave the others
+            # blocked inside it.  So every rank first checks locally what can be checked locally and the ranks vote; only a
+            # unanimous yes enters the collective initialisation.
             try:
-                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(pa.Comm.unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, 0)
-                comm = pa.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+                my_id = pa.Comm.unique_id()          # loads librccl, touches the device
+                torch.zeros(1, device="cuda").item()
             except Exception as e:
                 sys.stderr.write(f"[rank {rank}] own RCCL communicator unavailable ({e}); using torch.distributed\n")
+                my_id = None
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                try:
+                    idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if rank == 0:
+                        idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+                    dist.broadcast(idt, 0)
+                    comm = pa.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+                except Exception as e:
+                    sys.stderr.write(f"[rank {rank}] ncclCommInitRank failed ({e}); using torch.distributed\n")
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if want_own and int(ok.item()) == 1:
             comm_kind = "rccl (library communicator)"
         else:

@@ -604,6 +604,10 @@ struct Engine {
          bmap_off[b + 1] = bmap_off[b] + s.nb;
       }
       arena_total = arena; uarena_total = uar; xw_total = xw; n_total = x_off[nblk]; nnzK_total = kptr[nblk]; nnzB_total = bptr[nblk];
+      // the concatenated CSR copies of K (refinement residual: both triangles) and of the borders are indexed with int32
+      if (2 * nnzK_total > (long long)INT32_MAX || nnzB_total > (long long)INT32_MAX || n_total > (long long)INT32_MAX)
+         PIPS_FAIL(PIPS_ERR_ARG, "batch too large for the 32-bit index arrays of one rank: sum nnz(K) %lld (limit 2^30), sum nnz(border) %lld, sum n %lld - "
+                                 "use more ranks or fewer blocks per batch", nnzK_total, nnzB_total, n_total);
       nsn_total = (int)sn_base[nblk];
 
       // ---- supernodes sorted by (level, size class)
@@ -1242,7 +1246,7 @@ struct KktSystem {
    hipStream_t comm_stream = nullptr;   // panel-wise Schur reduction beside the leaf work
    hipEvent_t ev_reduced = nullptr;
    size_t packed_cap = 0;
-   bool use_rsag = false;
+   bool use_rsag = false, force_reduce = false;
    // sparse root: SC lives as the value array of a lower-triangular CSR pattern inside a one-block sparse
    // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
    bool sparse = false;
@@ -1873,6 +1877,7 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    k->leaves = e;
    k->n0 = n0; k->my0 = my0; k->myl = myl; k->mzl = mzl; k->S = S;
    k->comm = comm; k->rank = rank; k->n_ranks = n_ranks;
+   k->force_reduce = comm && getenv("PIPS_HIP_FORCE_REDUCE") != nullptr;
    HIP_TRY(hipSetDevice(e->device));
    k->root = std::make_unique<DenseLdl>();
    k->root->n = S;
@@ -1902,8 +1907,9 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    if ((rc = dev_upload(&k->d_fin_val, val, nullptr))) return rc;
    // several ranks: Schur SYRK in row panels, each reduced as soon as it is final (PIPS_HIP_SC_PANELS, default 4 for S >= 1024; 1 =
    // one reduction after all leaf work); PIPS_HIP_SC_REDUCE=rsag: reduce-scatter + all-gather instead of the all-reduce
-   if (comm && (n_ranks > 1 || getenv("PIPS_HIP_FORCE_REDUCE"))) {
-      int panels = S >= 1024 ? 4 : 1;
+   if (comm && (n_ranks > 1 || k->force_reduce)) {
+      // default: panels only where the reduction is worth hiding (S >= 4096: >= 64 MB packed; splitting the SYRK costs ~1 ms)
+      int panels = S >= 4096 ? 4 : 1;
       if (const char* pp = getenv("PIPS_HIP_SC_PANELS")) panels = atoi(pp);
       if ((rc = e->set_sc_panels(panels))) return rc;
       if (const char* m = getenv("PIPS_HIP_SC_REDUCE")) k->use_rsag = std::string(m) == "rsag";
@@ -1931,6 +1937,7 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
    k->leaves = e;
    k->n0 = n0; k->my0 = my0; k->myl = myl; k->mzl = mzl; k->S = S;
    k->comm = comm; k->rank = rank; k->n_ranks = n_ranks;
+   k->force_reduce = comm && getenv("PIPS_HIP_FORCE_REDUCE") != nullptr;
    k->sparse = true;
    HIP_TRY(hipSetDevice(e->device));
    // ---- pattern, row by row (lower triangle, sorted, explicit diagonal)
@@ -2053,7 +2060,7 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    const size_t nnz = (size_t)k->sc_rowptr[k->S];
    HIP_TRY(hipMemsetAsync(r->d_kval, 0, nnz * sizeof(double), e->stream));
    if ((rc = e->factor(r->d_kval, 0))) return rc;
-   const bool reduce = k->n_ranks > 1 || (k->comm && getenv("PIPS_HIP_FORCE_REDUCE"));
+   const bool reduce = k->n_ranks > 1 || k->force_reduce;
    if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       if ((rc = pips_hip_allreduce_sum(k->comm, r->d_kval, nnz, e->stream))) return rc;
@@ -2091,7 +2098,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    HIP_TRY(hipMemsetAsync(k->d_SC, 0, n * sizeof(double), e->stream));            // initializeKKT (:840-847)
    if ((rc = e->factor(k->d_SC, k->S))) return rc;                               // children factor2 + assembleLocalKKT
    // reduceKKT (:860-881).  PIPS_HIP_FORCE_REDUCE exercises the reduction path with a one-rank communicator (tests).
-   const bool reduce = k->n_ranks > 1 || (k->comm && getenv("PIPS_HIP_FORCE_REDUCE"));
+   const bool reduce = k->n_ranks > 1 || k->force_reduce;
    if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       // only the lower triangle is authoritative: reduce S(S+1)/2 packed doubles instead of S^2
@@ -2189,7 +2196,7 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
    if ((rc = e->solve(b_leaf_dev))) return rc;
    if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
-   if ((k->n_ranks > 1 || (k->comm && getenv("PIPS_HIP_FORCE_REDUCE"))) && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream)))
+   if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream)))
       return rc;
    // Dsolve: eliminate z0 through C0, solve with the Schur complement, recover z0 (solveReducedLinkCons :384-466)
    if (k->mz0 > 0)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -44,28 +45,61 @@ enum VecOp : int {
    OP_GONDZIO,       // y = projection step onto [a, b] (gondzioProjection, DenseVector.cpp:405-420)
 };
 
-__global__ void k_vec_op(int op, long long n, double a, double b, const double* __restrict__ x, const double* __restrict__ z,
-                         const double* __restrict__ mask, double* __restrict__ y) {
-   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-      const bool on = mask == nullptr || mask[i] != 0.0;
-      double v = y[i];
-      switch (op) {
-         case OP_AXPY: v += a * x[i]; break;
-         case OP_SCALE: v *= a; break;
-         case OP_COPY: v = x[i]; break;
-         case OP_SET: v = a; break;
-         case OP_MUL: v *= x[i]; break;
-         case OP_DIV: v /= x[i]; break;
-         case OP_ADD_PRODUCT: v += a * x[i] * z[i]; break;
-         case OP_ADD_QUOTIENT: if (on) v += a * x[i] / z[i]; break;
-         case OP_DIVIDE_SOME: if (on) v /= x[i]; break;
-         case OP_SELECT: if (!on) v = 0.0; break;
-         case OP_SAFE_INVERT: v = v != 0.0 ? 1.0 / v : 0.0; break;
-         case OP_ADD_CONST: v += a; break;
-         case OP_AXPBY: v = a * x[i] + b * v; break;
-         case OP_GONDZIO: v = v < a ? a - v : (v > b ? b - v : 0.0); v = v < -b ? -b : v; break;
+// one element of operation OP; `v` is y_i on entry where the operation reads it
+template <int OP>
+__device__ __forceinline__ double vec_elem(double v, double a, double b, double x, double z, bool on) {
+   switch (OP) {
+      case OP_AXPY: return v + a * x;
+      case OP_SCALE: return v * a;
+      case OP_COPY: return x;
+      case OP_SET: return a;
+      case OP_MUL: return v * x;
+      case OP_DIV: return v / x;
+      case OP_ADD_PRODUCT: return v + a * x * z;
+      case OP_ADD_QUOTIENT: return on ? v + a * x / z : v;
+      case OP_DIVIDE_SOME: return on ? v / x : v;
+      case OP_SELECT: return on ? v : 0.0;
+      case OP_SAFE_INVERT: return v != 0.0 ? 1.0 / v : 0.0;
+      case OP_ADD_CONST: return v + a;
+      case OP_AXPBY: return a * x + b * v;
+      default: { double t = v < a ? a - v : (v > b ? b - v : 0.0); return t < -b ? -b : t; }   // OP_GONDZIO
+   }
+}
+template <int OP> constexpr bool vec_reads_y() { return OP != OP_COPY && OP != OP_SET; }
+template <int OP> constexpr bool vec_reads_x() { return OP == OP_AXPY || OP == OP_COPY || OP == OP_MUL || OP == OP_DIV || OP == OP_ADD_PRODUCT || OP == OP_ADD_QUOTIENT || OP == OP_DIVIDE_SOME || OP == OP_AXPBY; }
+template <int OP> constexpr bool vec_reads_z() { return OP == OP_ADD_PRODUCT || OP == OP_ADD_QUOTIENT; }
+template <int OP> constexpr bool vec_uses_mask() { return OP == OP_ADD_QUOTIENT || OP == OP_DIVIDE_SOME || OP == OP_SELECT; }
+
+// Element-wise kernels are pure streaming: one specialisation per operation (no switch in the loop, operands an operation does
+// not use are never read - y itself for SET / COPY), 16-byte accesses (two doubles per lane and step) when every pointer is
+// 16-byte aligned, a scalar tail.
+typedef double double2v __attribute__((ext_vector_type(2)));
+template <int OP, bool VEC2>
+__global__ __launch_bounds__(256) void k_vec_op(long long n, double a, double b, const double* __restrict__ x, const double* __restrict__ z,
+                                                const double* __restrict__ mask, double* __restrict__ y) {
+   const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+   if (VEC2) {
+      const long long n2 = n / 2;
+      for (long long i = tid; i < n2; i += stride) {
+         double2v yv = {0.0, 0.0}, xv = {0.0, 0.0}, zv = {0.0, 0.0}, mv = {1.0, 1.0};
+         if (vec_reads_y<OP>()) yv = ((const double2v*)y)[i];
+         if (vec_reads_x<OP>()) xv = ((const double2v*)x)[i];
+         if (vec_reads_z<OP>()) zv = ((const double2v*)z)[i];
+         if (vec_uses_mask<OP>() && mask) mv = ((const double2v*)mask)[i];
+         double2v r;
+         r.x = vec_elem<OP>(yv.x, a, b, xv.x, zv.x, mv.x != 0.0);
+         r.y = vec_elem<OP>(yv.y, a, b, xv.y, zv.y, mv.y != 0.0);
+         ((double2v*)y)[i] = r;
       }
-      y[i] = v;
+      if (tid == 0 && (n & 1)) {
+         const long long i = n - 1;
+         y[i] = vec_elem<OP>(vec_reads_y<OP>() ? y[i] : 0.0, a, b, vec_reads_x<OP>() ? x[i] : 0.0, vec_reads_z<OP>() ? z[i] : 0.0,
+                             !(vec_uses_mask<OP>() && mask) || mask[i] != 0.0);
+      }
+   } else {
+      for (long long i = tid; i < n; i += stride)
+         y[i] = vec_elem<OP>(vec_reads_y<OP>() ? y[i] : 0.0, a, b, vec_reads_x<OP>() ? x[i] : 0.0, vec_reads_z<OP>() ? z[i] : 0.0,
+                             !(vec_uses_mask<OP>() && mask) || mask[i] != 0.0);
    }
 }
 
@@ -245,10 +279,26 @@ struct WsRef {   // g_ws.member resolves to the current device's workspace (set 
 };
 static thread_local WsRef g_ws;
 
+template <int OP>
+static void vec_launch(long long n, double a, double b, const double* x, const double* z, const double* mask, double* y, hipStream_t s) {
+   auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+   if (al(x) && al(z) && al(mask) && al(y) && n >= 2)
+      hipLaunchKernelGGL((k_vec_op<OP, true>), dim3(vgrid((n + 1) / 2)), dim3(256), 0, s, n, a, b, x, z, mask, y);
+   else
+      hipLaunchKernelGGL((k_vec_op<OP, false>), dim3(vgrid(n)), dim3(256), 0, s, n, a, b, x, z, mask, y);
+}
+
 int vec_apply(int op, long long n, double a, double b, const double* x, const double* z, const double* mask, double* y,
               hipStream_t s) {
    if (n <= 0) return PIPS_OK;
-   hipLaunchKernelGGL(k_vec_op, dim3(vgrid(n)), dim3(256), 0, s, op, n, a, b, x, z, mask, y);
+   switch (op) {
+#define PIPS_VEC_CASE(OP) case OP: vec_launch<OP>(n, a, b, x, z, mask, y, s); break;
+      PIPS_VEC_CASE(OP_AXPY) PIPS_VEC_CASE(OP_SCALE) PIPS_VEC_CASE(OP_COPY) PIPS_VEC_CASE(OP_SET) PIPS_VEC_CASE(OP_MUL) PIPS_VEC_CASE(OP_DIV)
+      PIPS_VEC_CASE(OP_ADD_PRODUCT) PIPS_VEC_CASE(OP_ADD_QUOTIENT) PIPS_VEC_CASE(OP_DIVIDE_SOME) PIPS_VEC_CASE(OP_SELECT)
+      PIPS_VEC_CASE(OP_SAFE_INVERT) PIPS_VEC_CASE(OP_ADD_CONST) PIPS_VEC_CASE(OP_AXPBY) PIPS_VEC_CASE(OP_GONDZIO)
+#undef PIPS_VEC_CASE
+      default: PIPS_FAIL(PIPS_ERR_ARG, "vec_apply: unknown operation %d", op);
+   }
    HIP_TRYV(hipGetLastError());
    return PIPS_OK;
 }
