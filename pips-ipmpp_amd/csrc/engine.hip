@@ -219,7 +219,13 @@ struct TailCtx {
    const std::vector<TaskList>* sc_groups = nullptr;
    const TileTask* d_sc_tasks = nullptr;
    const std::vector<hipEvent_t>* ev_sc = nullptr;
+   // persistent update kernel (k_tile_gemm_persist): pool of 8-counter slots, zeroed at the start of a factorisation; every
+   // update launch takes the next slot
+   int* d_ctr_pool = nullptr;
+   int* ctr_cursor = nullptr;
 };
+constexpr int GEMM_CTR_SLOTS = 4096;
+constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
@@ -228,12 +234,23 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
                          c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
    };
    auto gemm0 = [&](const TaskList& l, hipStream_t st) {
-      if (c.is_root)
-         hipLaunchKernelGGL(k_tile_gemm<3>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
-      else
-         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+      const bool persist = c.d_ctr_pool && l.cnt >= GEMM_PERSIST_MIN_TASKS && *c.ctr_cursor < GEMM_CTR_SLOTS;
+      int* ctr = persist ? c.d_ctr_pool + 8 * (*c.ctr_cursor)++ : nullptr;
+      if (c.is_root) {
+         if (persist)
+            hipLaunchKernelGGL(k_tile_gemm_persist<3>, dim3(512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
+                               c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
+         else
+            hipLaunchKernelGGL(k_tile_gemm<3>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                               c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+      } else {
+         if (persist)
+            hipLaunchKernelGGL(k_tile_gemm_persist<0>, dim3(512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
+                               c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
+         else
+            hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                               c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+      }
    };
    // Lookahead bookkeeping (right-looking modes with a side stream): while the side stream applies a finished panel to
    // the tile columns >= side_from, the main stream may only write columns left of that.
@@ -426,6 +443,8 @@ struct Engine {
    void release() {
       if (d_uarena) (void)hipFree(d_uarena);
       d_uarena = nullptr;
+      if (d_gemm_ctr) (void)hipFree(d_gemm_ctr);
+      d_gemm_ctr = nullptr;
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc, d_flong,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
@@ -448,6 +467,9 @@ struct Engine {
 
    hipStream_t side = nullptr;                       // diagonal tiles of the tail are factorised here, beside the column update
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
+   int* d_gemm_ctr = nullptr;     // counter slots of the persistent update kernel
+   int gemm_ctr_cursor = 0;
+   bool persistent_gemm = false;   // measured: no gain, and it starves the side stream (see k_tile_gemm_persist); PIPS_HIP_PERSISTENT_GEMM=1
    // ---- Schur SYRK in row-panel groups, so that a multi-rank root can reduce panel p while the leaves still compute p + 1 ..
    std::vector<TaskList> sc_groups;
    std::vector<int> sc_row_begin;          // panel p = Schur rows [sc_row_begin[p], sc_row_begin[p + 1])
@@ -491,6 +513,7 @@ struct Engine {
       TailCtx c{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
                 timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
       if (!sc_groups.empty()) { c.sc_groups = &sc_groups; c.d_sc_tasks = d_sc_tasks; c.ev_sc = &ev_sc; }
+      if (persistent_gemm) { c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor; }
       return c;
    }
 
@@ -553,6 +576,7 @@ struct Engine {
          if (in[b].n <= 0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_analyze: block %d was never set", b);
       apply_tuning(opt);
       if (const char* sm = getenv("PIPS_HIP_SCHUR_MODE")) schur_mode = atoi(sm);
+      if (const char* pg = getenv("PIPS_HIP_PERSISTENT_GEMM")) persistent_gemm = atoi(pg) != 0;
       bool any_border = false;
       for (int b = 0; b < nblk; ++b) any_border = any_border || !in[b].btrow.empty();
       int rc = analyze_host(n_threads, schur_mode != 2);
@@ -847,6 +871,11 @@ struct Engine {
       hipLaunchKernelGGL(k_block_absmax_finish, dim3((nblk + 255) / 256), dim3(256), 0, stream, d_blks, nblk, thr_rel, repl_rel);
       hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
+      if (persistent_gemm) {
+         if (!d_gemm_ctr) HIP_TRY(hipMalloc((void**)&d_gemm_ctr, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int)));
+         HIP_TRY(hipMemsetAsync(d_gemm_ctr, 0, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int), stream));
+         gemm_ctr_cursor = 0;
+      }
       if (nnzK_total > 0)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzK_total, 256)), dim3(256), 0, stream, d_kdst, d_kval, d_arena, nnzK_total);
       if (nnzB_total > 0 && schur_mode_eff == 1)

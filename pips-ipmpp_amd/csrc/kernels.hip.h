@@ -552,25 +552,23 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // k-column (1 KiB) straight into the [k][row] LDS image (no VGPR round trip, no ds_write).  Two LDS buffers: the DMA of
 // stage s+1 is in flight while stage s is multiplied; one barrier per stage.  The diagonal scaling d_k of the update is
 // applied to the column-panel fragment after the LDS read (one v_mul_f64 per fragment, hidden beside the MFMAs).
-template <int MODE>
-__global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
-                                                     const BlkDesc* __restrict__ blks, double* __restrict__ arena,
-                                                     const double* __restrict__ dtail, const double* __restrict__ winv,
-                                                     const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
-                                                     const int* __restrict__ sctab = nullptr, double* __restrict__ uarena = nullptr) {
-   constexpr bool SCALE = (MODE == 2);   // in-loop diagonal scaling: only the Schur SYRK (border rows have no U copy)
-   __shared__ __attribute__((aligned(16))) double As[2][KB * LDSW];
-   __shared__ __attribute__((aligned(16))) double Bs[2][KB * LDSW];
-   __shared__ __attribute__((aligned(16))) double Ds[2][KB];   // diagonal scaling d_k of the stage
+struct GemmShared {
+   __attribute__((aligned(16))) double As[2][KB * LDSW];
+   __attribute__((aligned(16))) double Bs[2][KB * LDSW];
+   __attribute__((aligned(16))) double Ds[2][KB];   // diagonal scaling d_k of the stage
+};
 
-   // XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
-   // slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
-#if defined(PIPS_EXPERIMENT_NO_XCD)
-   const int tix = (int)blockIdx.x;
-#else
-   const int per = (n_tasks + 7) >> 3;
-   const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-#endif
+// one tile task (index tix of the list); every thread of the workgroup calls it with the same tix
+template <int MODE>
+__device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const TileTask* __restrict__ tasks, int n_tasks,
+                                               const BlkDesc* __restrict__ blks, double* __restrict__ arena,
+                                               const double* __restrict__ dtail, const double* __restrict__ winv,
+                                               const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
+                                               const int* __restrict__ sctab, double* __restrict__ uarena) {
+   constexpr bool SCALE = (MODE == 2);   // in-loop diagonal scaling: only the Schur SYRK (border rows have no U copy)
+   auto& As = sh.As;
+   auto& Bs = sh.Bs;
+   auto& Ds = sh.Ds;
    if (tix >= n_tasks) return;
 #if defined(PIPS_EXPERIMENT_CLOCK)
    const unsigned long long re_ = __builtin_amdgcn_s_memrealtime();   // workgroup entry
@@ -749,6 +747,68 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
             }
          }
       }
+   }
+}
+
+// one workgroup per task.  XCD-aware task order: workgroups w and w+8 share an XCD (round-robin dispatch), so each XCD gets a
+// contiguous slice of the task list: tasks of one block (which share the B panel) then meet in one L2.
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict__ tasks, int n_tasks,
+                                                     const BlkDesc* __restrict__ blks, double* __restrict__ arena,
+                                                     const double* __restrict__ dtail, const double* __restrict__ winv,
+                                                     const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
+                                                     const int* __restrict__ sctab = nullptr, double* __restrict__ uarena = nullptr) {
+   __shared__ GemmShared sh;
+#if defined(PIPS_EXPERIMENT_NO_XCD)
+   const int tix = (int)blockIdx.x;
+#else
+   const int per = (n_tasks + 7) >> 3;
+   const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+#endif
+   tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena);
+}
+
+// Persistent variant for the deep-K updates: as many workgroups as the chip holds (two per CU), each pulls tiles from the slice
+// of its own XCD (read from the hardware register, not assumed from blockIdx) through a counter and, when that is empty,
+// steals from the other XCDs' slices.  Measured reasons (profiles/r2_gemm_experiments.txt): under FP64 matrix load the XCDs run
+// at different clocks (1.83 .. 1.92 GHz on one box), so a static 1/8 share finishes 5 % apart, and identical tiles take
+// 500 .. 790 us depending on how a CU's two workgroups share its matrix pipes.  The next tile's index is fetched while the
+// current one is being multiplied.  ctr: 8 counters of this launch, zero on entry.
+// OFF by default (PIPS_HIP_PERSISTENT_GEMM=1): on config 2 the 34 update launches take 74.9-76.2 ms against 74.0-74.2 ms with one
+// workgroup per tile (the drain it removes is already cheap - a CU left with one workgroup runs that one faster), and because
+// its workgroups hold every slot until the launch ends, the diagonal-tile chain on the side stream is no longer hidden behind the
+// column update: the factorisation went from 110 to 118 ms.
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_tile_gemm_persist(const TileTask* __restrict__ tasks, int n_tasks,
+                                                             const BlkDesc* __restrict__ blks, double* __restrict__ arena,
+                                                             const double* __restrict__ dtail, const double* __restrict__ winv,
+                                                             const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
+                                                             const int* __restrict__ sctab, double* __restrict__ uarena,
+                                                             int* __restrict__ ctr) {
+   __shared__ GemmShared sh;
+   __shared__ int s_tix[2];
+   const int per = (n_tasks + 7) >> 3;
+   auto grab = [&]() -> int {   // thread 0 only
+      const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID[3:0] */) & 7);
+      for (int d = 0; d < 8; ++d) {
+         const int x = (xcc + d) & 7;
+         if (__hip_atomic_load(ctr + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per) continue;   // slice known to be empty
+         const int t = __hip_atomic_fetch_add(ctr + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         const int tix = x * per + t;
+         if (t < per && tix < n_tasks) return tix;
+      }
+      return -1;
+   };
+   if (threadIdx.x == 0) s_tix[0] = grab();
+   __syncthreads();
+   int cur = 0;
+   while (true) {
+      const int tix = s_tix[cur];
+      if (tix < 0) break;
+      if (threadIdx.x == 0) s_tix[cur ^ 1] = grab();   // latency hidden behind this tile
+      tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena);
+      __syncthreads();   // all waves are out of the LDS buffers, s_tix[cur ^ 1] is visible
+      cur ^= 1;
    }
 }
 
