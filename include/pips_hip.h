@@ -89,6 +89,11 @@ int pips_hip_batch_set_options(void* handle, int force_n_head, int refine_steps,
  * Call before analyze; get_schur_mode reports the choice. */
 int pips_hip_batch_set_schur_mode(void* handle, int mode);
 int pips_hip_batch_get_schur_mode(void* handle, int* mode);
+/* Deterministic mode (call before analyze): bit-identical factors, Schur complement, inertia and solutions from run to run, at a
+ * cost in time and memory ("deterministic mode").  By default the head scatter, the Schur accumulation over the
+ * blocks and the head substitution use hardware FP64 atomics, whose order of arrival decides the last bits - the reference's
+ * breakdown tests (PIPSisZero, pipsdef.h:35,108) and any bitwise comparison between runs see that. */
+int pips_hip_batch_set_deterministic(void* handle, int on);
 /* add_regularization_local_kkt (DistributedLeafLinearSystem.C:108-143): K diagonal += primal on the leading n_primal rows
  * of every block, -= dual on the remaining rows; used by the inertia-correcting loop (LinearSystem.C:296-325) */
 int pips_hip_batch_add_regularization(void* handle, double primal, double dual);

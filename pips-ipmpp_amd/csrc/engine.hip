@@ -445,6 +445,13 @@ struct Engine {
       d_uarena = nullptr;
       if (d_gemm_ctr) (void)hipFree(d_gemm_ctr);
       d_gemm_ctr = nullptr;
+      for (auto& g : g_levels) g.release();
+      for (auto& g : gv_levels) g.release();
+      g_levels.clear(); gv_levels.clear();
+      g_tail.release(); g_sc.release(); gv_tail.release();
+      if (d_slot_val) (void)hipFree(d_slot_val);
+      if (d_vslot_val) (void)hipFree(d_vslot_val);
+      d_slot_val = d_vslot_val = nullptr;
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc, d_flong,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
@@ -467,6 +474,24 @@ struct Engine {
 
    hipStream_t side = nullptr;                       // diagonal tiles of the tail are factorised here, beside the column update
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
+   // ---- deterministic mode (pips_hip_batch_set_deterministic): no FP64 atomics on the path.  Every scattered contribution of
+   // the head owns a slot; at analyze time the kernels run once in recording mode, the host groups the slots by target (per
+   // elimination-tree level, then the tail, then the Schur complement) and the factorisation gathers them in that fixed order.
+   struct GatherList {
+      long long n_targets = 0, n_slots = 0;
+      long long *d_tgt = nullptr, *d_off = nullptr, *d_slots = nullptr;
+      void release() {
+         for (void* p : {(void*)d_tgt, (void*)d_off, (void*)d_slots})
+            if (p) (void)hipFree(p);
+         d_tgt = d_off = d_slots = nullptr;
+         n_targets = n_slots = 0;
+      }
+   };
+   bool deterministic = false;
+   long long slots_total = 0, vslots_total = 0;
+   double *d_slot_val = nullptr, *d_vslot_val = nullptr;
+   std::vector<GatherList> g_levels, gv_levels;   // targets inside the head, per level (factorisation / forward substitution)
+   GatherList g_tail, g_sc, gv_tail;
    int* d_gemm_ctr = nullptr;     // counter slots of the persistent update kernel
    int gemm_ctr_cursor = 0;
    bool persistent_gemm = false;   // measured: no gain, and it starves the side stream (see k_tile_gemm_persist); PIPS_HIP_PERSISTENT_GEMM=1
@@ -666,9 +691,10 @@ struct Engine {
          }
          while (lstar > 0 && width[lstar - 1] <= 2) --lstar;
          const char* env = getenv("PIPS_HIP_SPINE");
-         if (nlev - lstar < 8 || (env && atoi(env) == 0)) lstar = nlev;
+         if (nlev - lstar < 8 || (env && atoi(env) == 0) || deterministic) lstar = nlev;   // the spine kernels hand over through atomics
       }
       std::vector<SnDesc> h_sns(nsn_total);
+      long long slots_acc = 0, vslots_acc = 0;
       std::vector<std::vector<int>> sorted_id(nblk);
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
       levels.assign(lstar, LevelRange{0, 0, 0, 0, 0, 0});
@@ -677,7 +703,9 @@ struct Engine {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
-                           s.n_useg, s.rb};
+                           s.n_useg, s.rb, slots_acc, vslots_acc};
+         slots_acc += (long long)s.r * (s.r + 1) / 2;
+         vslots_acc += s.r;
          sorted_id[k.blk][k.loc] = i;
          LevelRange& L = k.level >= lstar ? levels_top[k.level - lstar] : levels[k.level];
          if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
@@ -840,8 +868,138 @@ struct Engine {
          HIP_TRY(hipEventCreateWithFlags(&ev_diag_out, hipEventDisableTiming));
       }
       h_inertia.assign(3 * nblk, 0);
+      slots_total = slots_acc; vslots_total = vslots_acc;
+      h_sns_keep = h_sns;
       analyzed = true;
       factored = false;
+      if (deterministic && (rc = build_deterministic(n_threads))) return rc;
+      return PIPS_OK;
+   }
+
+   std::vector<SnDesc> h_sns_keep;
+   ScatterCtx sx_atomic() const { return ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}; }
+   void launch_head_level(const LevelRange& L, double* SC, int ldSC, const ScatterCtx& sx) {
+      if (L.simple_cnt > 0)
+         hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
+                            L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
+      if (L.small_cnt > 0)
+         hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
+                            d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
+      if (L.large_cnt > 0)
+         hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
+                            L.large_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
+                            d_inertia, d_pref, d_sctab, sx);
+   }
+   void gather(const GatherList& g, const double* vals, double* target) {
+      if (g.n_targets > 0)
+         hipLaunchKernelGGL(k_gather_slots, dim3(grid_for(g.n_targets, 256)), dim3(256), 0, stream, g.n_targets, g.d_tgt, g.d_off, g.d_slots, vals, target);
+   }
+
+   // One entry per recorded contribution: (target, slot), sorted; then the CSR "target -> its slots"
+   struct SlotEntry { long long target, slot; };
+   int upload_gather(std::vector<SlotEntry>& e, GatherList& g) {
+      std::sort(e.begin(), e.end(), [](const SlotEntry& a, const SlotEntry& b) { return a.target != b.target ? a.target < b.target : a.slot < b.slot; });
+      std::vector<long long> tgt, off, sl(e.size());
+      for (size_t i = 0; i < e.size(); ++i) {
+         if (i == 0 || e[i].target != e[i - 1].target) { tgt.push_back(e[i].target); off.push_back((long long)i); }
+         sl[i] = e[i].slot;
+      }
+      off.push_back((long long)e.size());
+      g.n_targets = (long long)tgt.size(); g.n_slots = (long long)e.size();
+      if (tgt.empty()) return PIPS_OK;
+      int rc;
+      if ((rc = dev_upload(&g.d_tgt, tgt, stream)) || (rc = dev_upload(&g.d_off, off, stream)) || (rc = dev_upload(&g.d_slots, sl, stream))) return rc;
+      return PIPS_OK;
+   }
+   int build_deterministic(int n_threads) {
+      if (d_sctab) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: not available with the sparse Schur complement");
+      if (schur_mode_eff != 1) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode needs Schur mode 1 (augmented factorisation)");
+      const int nlev = (int)levels.size();
+      g_levels.assign(nlev, GatherList());
+      gv_levels.assign(nlev, GatherList());
+      int rc = PIPS_OK;
+      // ---- factorisation scatter: record where every slot goes (structure only; the numbers this pass produces are discarded)
+      std::vector<long long> rec((size_t)std::max<long long>(slots_total, 1), -1);
+      if (slots_total > 0) {
+         long long* d_rec = nullptr;
+         HIP_TRY(hipMalloc((void**)&d_rec, (size_t)slots_total * sizeof(long long)));
+         HIP_TRY(hipMemsetAsync(d_rec, 0xff, (size_t)slots_total * sizeof(long long), stream));
+         double* fakeSC = d_arena;   // only offsets relative to it are formed (S > 0 blocks have border rows)
+         const ScatterCtx sx{1, d_rec, nullptr, d_arena, fakeSC};
+         for (const LevelRange& L : levels) launch_head_level(L, fakeSC, S, sx);
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipStreamSynchronize(stream));
+         HIP_TRY(hipMemcpy(rec.data(), d_rec, (size_t)slots_total * sizeof(long long), hipMemcpyDeviceToHost));
+         (void)hipFree(d_rec);
+         HIP_TRY(hipMalloc((void**)&d_slot_val, (size_t)slots_total * sizeof(double)));
+      }
+      // classify: Schur complement / tail of block b / head panel of a supernode at level l (targets of different blocks are disjoint)
+      std::vector<std::vector<SlotEntry>> per_level(nlev);
+      std::vector<SlotEntry> tail_e, sc_e;
+      std::vector<std::vector<std::pair<long long, int>>> panel_level(nblk);   // (panel offset inside the block arena, level), ascending
+      for (int b = 0; b < nblk; ++b) {
+         for (const HeadSupernode& hs : sym[b].sn) panel_level[b].push_back({hs.panel, hs.level});
+         std::sort(panel_level[b].begin(), panel_level[b].end());
+      }
+      for (int i = 0; i < nsn_total; ++i) {
+         const SnDesc& sn = h_sns_keep[i];
+         const long long cnt = (long long)sn.r * (sn.r + 1) / 2;
+         const BlkDesc& bd = h_blks[sn.blk];
+         for (long long q = 0; q < cnt; ++q) {
+            const long long t = rec[(size_t)(sn.slot + q)];
+            if (t < 0) continue;
+            if (t & SCATTER_SC_FLAG) { sc_e.push_back({t & ~SCATTER_SC_FLAG, sn.slot + q}); continue; }
+            if (t >= bd.T) { tail_e.push_back({t, sn.slot + q}); continue; }
+            const long long rel = t - bd.arena_off;
+            auto& pl = panel_level[sn.blk];
+            auto it = std::upper_bound(pl.begin(), pl.end(), std::make_pair(rel, INT32_MAX));
+            if (it == pl.begin()) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: a recorded target lies outside every head panel");
+            per_level[std::prev(it)->second].push_back({t, sn.slot + q});
+         }
+      }
+      std::vector<long long>().swap(rec);
+      for (int l = 0; l < nlev; ++l)
+         if ((rc = upload_gather(per_level[l], g_levels[l]))) return rc;
+      if ((rc = upload_gather(tail_e, g_tail)) || (rc = upload_gather(sc_e, g_sc))) return rc;
+      // ---- forward-substitution scatter: same recording, targets are entries of the permuted work vector
+      if (vslots_total > 0) {
+         long long* d_rec = nullptr;
+         HIP_TRY(hipMalloc((void**)&d_rec, (size_t)vslots_total * sizeof(long long)));
+         HIP_TRY(hipMemsetAsync(d_rec, 0xff, (size_t)vslots_total * sizeof(long long), stream));
+         const ScatterCtx sxv{1, d_rec, nullptr, d_xw, nullptr};
+         for (const LevelRange& L : levels) {
+            if (L.simple_cnt > 0)
+               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
+                                  L.simple_cnt, d_blks, d_rowidx, d_arena, d_xw, 0LL, 0, sxv);
+            const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+            const int cnt = L.small_cnt + L.large_cnt;
+            if (cnt > 0) hipLaunchKernelGGL(k_head_fwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, sxv);
+         }
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipStreamSynchronize(stream));
+         std::vector<long long> vrec((size_t)vslots_total);
+         HIP_TRY(hipMemcpy(vrec.data(), d_rec, (size_t)vslots_total * sizeof(long long), hipMemcpyDeviceToHost));
+         (void)hipFree(d_rec);
+         HIP_TRY(hipMalloc((void**)&d_vslot_val, (size_t)vslots_total * sizeof(double)));
+         std::vector<std::vector<SlotEntry>> v_level(nlev);
+         std::vector<SlotEntry> v_tail;
+         for (int i = 0; i < nsn_total; ++i) {
+            const SnDesc& sn = h_sns_keep[i];
+            const BlkDesc& bd = h_blks[sn.blk];
+            for (int a = 0; a < sn.r; ++a) {
+               const long long t = vrec[(size_t)(sn.vslot + a)];
+               if (t < 0) continue;
+               const long long col = t - bd.xw_off;
+               if (col >= bd.n_head) { v_tail.push_back({t, sn.vslot + a}); continue; }
+               const int loc = sym[sn.blk].sn_of_col[(size_t)col];
+               v_level[sym[sn.blk].sn[loc].level].push_back({t, sn.vslot + a});
+            }
+         }
+         for (int l = 0; l < nlev; ++l)
+            if ((rc = upload_gather(v_level[l], gv_levels[l]))) return rc;
+         if ((rc = upload_gather(v_tail, gv_tail))) return rc;
+      }
+      (void)n_threads;
       return PIPS_OK;
    }
 
@@ -886,19 +1044,16 @@ struct Engine {
       if (timer.on) timer.end(stream);
       // the whole-factor record (phase 6) was pushed first; close it at the end
       const size_t total_rec = 0;
-      for (const LevelRange& L : levels) {
+      const ScatterCtx sx = deterministic ? ScatterCtx{2, nullptr, d_slot_val, d_arena, SC} : sx_atomic();
+      for (size_t li = 0; li < levels.size(); ++li) {
          if (timer.on) timer.begin(stream, 1);
-         if (L.simple_cnt > 0)
-            hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
-                               L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab);
-         if (L.small_cnt > 0)
-            hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
-                               d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab);
-         if (L.large_cnt > 0)
-            hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
-                               L.large_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
-                               d_inertia, d_pref, d_sctab);
+         if (deterministic) gather(g_levels[li], d_slot_val, d_arena);   // contributions of the lower levels, in fixed order
+         launch_head_level(levels[li], SC, ldSC, sx);
          if (timer.on) timer.end(stream);
+      }
+      if (deterministic) {
+         gather(g_tail, d_slot_val, d_arena);
+         if (SC) gather(g_sc, d_slot_val, SC);
       }
       if (spine_total > 0) {
          if (timer.on) timer.begin(stream, 1);
@@ -948,6 +1103,23 @@ struct Engine {
       const long long xws = nrhs > 1 ? xw_total : 0;
       const dim3 pg(64, nblk, nrhs);
       hipLaunchKernelGGL(k_permute_in, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
+      if (deterministic) {
+         // forward substitution without atomics: the contributions go to their slots, every level first gathers what the lower
+         // levels left for its own columns, the tail rows are gathered before the dense sweep
+         if (nrhs != 1) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode solves one right-hand side at a time");
+         const ScatterCtx sxv{2, nullptr, d_vslot_val, xw, nullptr};
+         for (size_t li = 0; li < levels.size(); ++li) {
+            const LevelRange& L = levels[li];
+            gather(gv_levels[li], d_vslot_val, xw);
+            if (L.simple_cnt > 0)
+               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
+                                  L.simple_cnt, d_blks, d_rowidx, d_arena, xw, 0LL, 0, sxv);
+            const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+            const int cnt = L.small_cnt + L.large_cnt;
+            if (cnt > 0) hipLaunchKernelGGL(k_head_fwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, 0LL, sxv);
+         }
+         gather(gv_tail, d_vslot_val, xw);
+      } else
       for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
@@ -1054,6 +1226,11 @@ struct Engine {
    int solve_multi(double* X_dev, int nrhs, long long x_stride) {
       if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
       HIP_TRY(hipSetDevice(device));
+      if (deterministic) {   // one right-hand side at a time through the atomics-free sweeps
+         for (int r = 0; r < nrhs; ++r)
+            if (int rc = solve(X_dev + (long long)r * x_stride)) return rc;
+         return PIPS_OK;
+      }
       const int chunk_max = 32;
       int rc0 = ensure_multi_buffers();
       if (rc0) return rc0;
@@ -1455,6 +1632,14 @@ int pips_hip_batch_set_schur_mode(void* handle, int mode) {
    if (!e || mode < 0 || mode > 2) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_batch_set_schur_mode: mode must be 0 (auto), 1 or 2");
    if (e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_set_schur_mode: call before analyze");
    e->schur_mode = mode;
+   return PIPS_OK;
+}
+
+int pips_hip_batch_set_deterministic(void* handle, int on) {
+   Engine* e = (Engine*)handle;
+   if (!e) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_set_deterministic: call before pips_hip_batch_analyze");
+   e->deterministic = on != 0;
    return PIPS_OK;
 }
 

@@ -31,7 +31,11 @@ struct SnDesc {
    long long upd;    // global offset into upd (head-to-head update segments)
    int w, r, c0, blk;
    int n_useg, rb;   // number of update segments; index of the first border row among the r below-rows
+   long long slot;   // deterministic mode: first contribution slot of the factorisation scatter (r (r + 1) / 2 slots: pair (a, b),
+                     // a >= b, has slot + b r - b (b - 1) / 2 + a - b)
+   long long vslot;  // ... and of the forward-substitution scatter (r slots)
 };
+
 
 struct BlkDesc {
    long long arena_off;  // block arena base (doubles)
@@ -57,6 +61,37 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// How a scattered contribution reaches its target.  mode 0: hardware FP64 atomic (order of arrival decides the last bits).
+// Deterministic mode: every contribution owns a slot; mode 1 (once, at analyze time) records where slot k goes, mode 2 stores
+// the value into its slot, and k_gather_slots adds the slots of every target in a fixed order.
+struct ScatterCtx {
+   int mode;
+   long long* rec;
+   double* val;
+   const double* base;      // arena (factorisation) / work vector (solve)
+   const double* sc_base;   // Schur complement
+};
+constexpr long long SCATTER_SC_FLAG = 1LL << 62;
+__device__ __forceinline__ void scatter_add(const ScatterCtx& sx, double* ptr, bool is_sc, long long slot, double v) {
+   if (sx.mode == 0) atomic_add_f64(ptr, v);
+   else if (sx.mode == 1) sx.rec[slot] = is_sc ? (SCATTER_SC_FLAG | (long long)(ptr - sx.sc_base)) : (long long)(ptr - sx.base);
+   else sx.val[slot] = v;
+}
+__device__ __forceinline__ long long pair_slot(long long base, int a, int b, int r) {
+   return base + (long long)b * r - (long long)b * (b - 1) / 2 + (a - b);
+}
+
+// target[tgt[t]] += sum of the slots off[t] .. off[t+1] in list order
+__global__ void k_gather_slots(long long n_targets, const long long* __restrict__ tgt, const long long* __restrict__ off,
+                               const long long* __restrict__ slots, const double* __restrict__ val, double* __restrict__ target) {
+   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n_targets; t += (long long)gridDim.x * blockDim.x) {
+      double s = 0.0;
+      for (long long p = off[t]; p < off[t + 1]; ++p) s += val[slots[p]];
+      target[tgt[t]] += s;
+   }
+}
+
 
 // Where the (la, lb) entry of a block's Schur contribution lives (la >= lb: compressed border ids, ascending like the Schur
 // column ids they map to).  Dense root: column-major S x S array, bm = the block's bmap.  Sparse root (sctab != nullptr): the
@@ -235,7 +270,7 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
                                                  const long long* __restrict__ psign_off, const int* __restrict__ bmap,
                                                  double* __restrict__ arena, double* __restrict__ SC, int ldSC,
                                                  int* __restrict__ inertia, const double* __restrict__ pref,
-                                                 const int* __restrict__ sctab) {
+                                                 const int* __restrict__ sctab, const ScatterCtx& sx) {
    __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w; column k keeps l_ik * d_k (unscaled)
    __shared__ double dk[WMAX];
    __shared__ double prf[WMAX];
@@ -354,7 +389,9 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
       const long long tpanel = (long long)(((unsigned long long)(unsigned)U[5] << 32) | (unsigned long long)(unsigned)U[4]);
       const int* pp = U + USEG_HDR;
       double* TP = arena + bd.arena_off + tpanel;
-      for_pairs(sb0, sb1, [&](int a, int b) { atomic_add_f64(TP + pp[a - sb0] + (long long)pp[b - sb0] * tld, -entry(a, b)); });
+      for_pairs(sb0, sb1, [&](int a, int b) {
+         scatter_add(sx, TP + pp[a - sb0] + (long long)pp[b - sb0] * tld, false, pair_slot(sn.slot, a, b, r), -entry(a, b));
+      });
       U += USEG_HDR + (r - sb0);
       b0 = sb1;
    }
@@ -364,14 +401,14 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
       for_pairs(b0, sn.rb, [&](int a, int b) {
          const int ra = rows[a], cb = rows[b];
          const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
-         atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -entry(a, b));
+         scatter_add(sx, T + tr + (long long)(cb - n_head) * bd.ldT, false, pair_slot(sn.slot, a, b, r), -entry(a, b));
       });
       b0 = sn.rb;
    }
    if (b0 < r && SC) {   // border x border: the Schur complement itself (SC == nullptr: factor-only call)
       const int* bm = bmap + bd.bmap_off;
       for_pairs(b0, r, [&](int a, int b) {
-         atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, rows[a] - n, rows[b] - n), -entry(a, b));
+         scatter_add(sx, sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, rows[a] - n, rows[b] - n), true, pair_slot(sn.slot, a, b, r), -entry(a, b));
       });
    }
 }
@@ -384,10 +421,11 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
                                                       const long long* __restrict__ psign_off,
                                                       const int* __restrict__ bmap, double* __restrict__ arena,
                                                       double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
-                                                      const double* __restrict__ pref, const int* __restrict__ sctab) {
+                                                      const double* __restrict__ pref, const int* __restrict__ sctab,
+                                                      ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab);
+   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab, sx);
 }
 
 // "Spine" of a chain-like elimination tree: the top levels that hold at most two supernodes per block.  Level scheduling
@@ -409,7 +447,8 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor_spine(const int* __restri
    const BlkDesc bd = blks[blockIdx.x];
    for (int p = p0; p < p1; ++p) {
       const SnDesc sn = sns[spine[p]];
-      head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab);
+      head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab,
+                                          ScatterCtx{0, nullptr, nullptr, nullptr, nullptr});
       __threadfence();
       __syncthreads();
    }
@@ -428,7 +467,8 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                                                            const long long* __restrict__ psign_off, const int* __restrict__ bmap,
                                                            double* __restrict__ arena, double* __restrict__ SC, int ldSC,
                                                            int* __restrict__ inertia, const double* __restrict__ pref,
-                                                           const int* __restrict__ sctab) {
+                                                           const int* __restrict__ sctab,
+                                                           ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
    __shared__ int cnt_s[3];
    __shared__ int blk_s;
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -466,9 +506,9 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                   const double u = l[a] * lbd;
                   if (cb < n) {
                      const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
-                     atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, -u);
+                     scatter_add(sx, T + tr + (long long)(cb - n_head) * bd.ldT, false, pair_slot(sn.slot, a, b, r), -u);
                   } else if (SC) {
-                     atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n), -u);
+                     scatter_add(sx, sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n), true, pair_slot(sn.slot, a, b, r), -u);
                   }
                }
             }
@@ -483,7 +523,8 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
 __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                                           const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                           const double* __restrict__ arena, double* __restrict__ xw,
-                                                          long long xw_stride, int backward) {
+                                                          long long xw_stride, int backward,
+                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= cnt) return;
    const SnDesc sn = sns[sn_begin + t];
@@ -496,7 +537,7 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
       for (int a = 0; a < sn.r; ++a) {
          const int ra = rows[a];
          if (ra >= bd.n) break;
-         atomic_add_f64(xb + ra, -P[1 + a] * y);
+         scatter_add(sx, xb + ra, false, sn.vslot + a, -P[1 + a] * y);
       }
    } else {
       double s = 0.0;
@@ -995,7 +1036,8 @@ __global__ void k_permute_out(const BlkDesc* __restrict__ blks, const int* __res
 // registers, high occupancy) for launches with many supernodes
 __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
+                                                ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
    __shared__ double y[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
@@ -1016,7 +1058,7 @@ __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns,
       if (ra >= bd.n) break;  // border rows do not take part in solves with K_i
       double s = 0.0;
       for (int k = 0; k < w; ++k) s += P[w + a + (long long)k * ld] * y[k];
-      atomic_add_f64(xb + ra, -s);
+      scatter_add(sx, xb + ra, false, sn.vslot + a, -s);
    }
 }
 

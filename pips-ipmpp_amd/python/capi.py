@@ -50,7 +50,7 @@ SYMBOLS = [
     "pips_hip_ldl_get_perm", "pips_hip_ldl_destroy",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
     "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_destroy",
-    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
+    "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
     "pips_hip_batch_last_refinement_steps", "pips_hip_batch_set_refinement_backward_error",
     "pips_hip_batch_last_refinement_measure", "pips_hip_batch_analyze",
     "pips_hip_batch_set_values", "pips_hip_batch_set_diagonals_dev", "pips_hip_batch_set_diagonals", "pips_hip_batch_factor",
@@ -383,6 +383,10 @@ class LeafBatch:
     def set_schur_mode(self, mode):
         """0 auto, 1 augmented partial factorisation, 2 blocked multi-RHS solves (the reference's K4-K6); before analyze."""
         _check(lib.pips_hip_batch_set_schur_mode(self._h, C.c_int(mode)), "pips_hip_batch_set_schur_mode")
+
+    def set_deterministic(self, on=True):
+        """Before analyze(): no FP64 atomics on the path - bit-identical results from run to run."""
+        _check(lib.pips_hip_batch_set_deterministic(self._h, C.c_int(1 if on else 0)), "pips_hip_batch_set_deterministic")
 
     def schur_mode(self):
         m = C.c_int()
