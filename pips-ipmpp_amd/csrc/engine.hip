@@ -223,6 +223,15 @@ struct TailCtx {
    // update launch takes the next slot
    int* d_ctr_pool = nullptr;
    int* ctr_cursor = nullptr;
+   // deterministic Schur accumulation (Engine::set_det_groups): the blocks are cut into at most eight contiguous groups with a
+   // buffer each; round k of the SYRK handles the k-th block of every group, so a launch never has two workgroups on the same
+   // entry of a buffer and the blocks of a group arrive in their order; k_reduce_groups then adds the buffers in a fixed tree
+   const std::vector<TaskList>* det_rounds = nullptr;
+   const TileTask* d_det_tasks = nullptr;
+   double* d_gbuf = nullptr;
+   long long gstride = 0;
+   const int* d_blk_group = nullptr;
+   int n_groups = 0, first_slot = 0;
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
 constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
@@ -319,7 +328,17 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       }
    }
    if ((rc = main_writes(1 << 30))) return rc;   // join the side stream
-   if (SC && c.sc_groups && !c.d_sctab) {
+   if (SC && c.det_rounds && !c.d_sctab) {
+      if (c.timer) c.timer->begin(c.stream, 5);
+      for (const TaskList& l : *c.det_rounds)   // the group buffers were zeroed (and took the head's contributions) in Engine::factor
+         if (l.cnt > 0)
+            hipLaunchKernelGGL(k_tile_gemm<2>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, c.d_det_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                               c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena, c.d_gbuf, c.gstride, c.d_blk_group);
+      const int S_ = ldSC;
+      hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (S_ + 255) / 256)), S_), dim3(256), 0, c.stream, SC, ldSC, S_, c.d_gbuf,
+                         c.gstride, c.n_groups, c.first_slot);
+      if (c.timer) c.timer->end(c.stream);
+   } else if (SC && c.sc_groups && !c.d_sctab) {
       if (c.timer) c.timer->begin(c.stream, 5);
       for (size_t g = 0; g < c.sc_groups->size(); ++g) {
          const TaskList& l = (*c.sc_groups)[g];
@@ -448,7 +467,13 @@ struct Engine {
       for (auto& g : g_levels) g.release();
       for (auto& g : gv_levels) g.release();
       g_levels.clear(); gv_levels.clear();
-      g_tail.release(); g_sc.release(); gv_tail.release();
+      g_tail.release(); g_sc.release(); gv_tail.release(); g_btm.release(); g_bm.release();
+      if (d_bt_tmp) (void)hipFree(d_bt_tmp);
+      d_bt_tmp = nullptr;
+      for (void* p : {(void*)d_det_tasks, (void*)d_gbuf, (void*)d_blk_group, (void*)d_gvec, (void*)d_tvec})
+         if (p) (void)hipFree(p);
+      d_det_tasks = nullptr; d_gbuf = nullptr; d_blk_group = nullptr; d_gvec = d_tvec = nullptr;
+      g_btm_grp.release(); g_sc_grp.release();
       if (d_slot_val) (void)hipFree(d_slot_val);
       if (d_vslot_val) (void)hipFree(d_vslot_val);
       d_slot_val = d_vslot_val = nullptr;
@@ -487,11 +512,85 @@ struct Engine {
          n_targets = n_slots = 0;
       }
    };
+   struct SlotEntry { long long target, slot; };
    bool deterministic = false;
+   // The slot / gather scheme of the head can be had without the rest of deterministic mode (PIPS_HIP_HEAD_SLOTS=1): on config 2
+   // the head phase then takes 5.0 ms against 5.5 ms with FP64 atomics (145 M per factorisation) - not worth 16 bytes of device
+   // memory per contribution and the longer analysis as a default.  Beyond HEAD_SLOTS_MAX contributions deterministic mode refuses.
+   bool head_slots = false;
+   bool slot_solves = false;    // single-RHS forward substitution through slots outside deterministic mode too (measured: no gain)
+   static constexpr long long HEAD_SLOTS_MAX = 400LL * 1000 * 1000;
    long long slots_total = 0, vslots_total = 0;
    double *d_slot_val = nullptr, *d_vslot_val = nullptr;
    std::vector<GatherList> g_levels, gv_levels;   // targets inside the head, per level (factorisation / forward substitution)
    GatherList g_tail, g_sc, gv_tail;
+   std::vector<SlotEntry> sc_e_keep;
+   std::vector<int> sc_blk_keep;
+   GatherList g_sc_grp;            // Schur targets of the head inside the group buffers
+   std::vector<int> h_bt_rowsc_keep, h_bt_rownnz_keep, h_bt_rowblk_keep;
+   GatherList g_btm_grp;           // border rows per (group, Schur column): Br^T z summed group-wise, then in the fixed tree
+   double *d_gvec = nullptr, *d_tvec = nullptr;
+   std::vector<TaskList> det_rounds;
+   TileTask* d_det_tasks = nullptr;
+   double* d_gbuf = nullptr;
+   int* d_blk_group = nullptr;
+   int det_n_groups = 0, det_first_slot = 0;
+   // groups for the deterministic Schur accumulation: the global problem has eight group slots; this rank (rank of n_ranks, blocks
+   // sharded contiguously and evenly) fills 8 / n_ranks of them (all eight when n_ranks does not divide 8: then only run-to-run
+   // reproducibility holds, not equality with other rank counts)
+   int set_det_groups(int rank, int n_ranks) {
+      if (!analyzed || !deterministic) return PIPS_OK;
+      const int slots = (n_ranks >= 1 && n_ranks <= 8 && 8 % n_ranks == 0) ? 8 / n_ranks : 8;
+      det_first_slot = slots == 8 ? 0 : rank * slots;
+      const int gs = std::max(1, (nblk + slots - 1) / slots);     // blocks per group
+      det_n_groups = (nblk + gs - 1) / gs;
+      std::vector<int> grp(std::max(nblk, 1), 0);
+      for (int b = 0; b < nblk; ++b) grp[b] = b / gs;
+      std::vector<std::vector<TileTask>> rounds(gs);
+      for (int b = 0; b < nblk; ++b) {
+         if (h_blks[b].ntc <= 0 || h_blks[b].nb <= 0) continue;
+         const int nt = h_blks[b].nb_pad / TILE;
+         for (int ti = 0; ti < nt; ++ti)
+            for (int tj = 0; tj <= ti; ++tj) rounds[b % gs].push_back({b, ti, tj, 0});
+      }
+      det_rounds.clear();
+      std::vector<TileTask> all;
+      for (int k = 0; k < gs; ++k) {
+         TaskList l;
+         l.off = (long long)all.size(); l.cnt = (int)rounds[k].size();
+         all.insert(all.end(), rounds[k].begin(), rounds[k].end());
+         det_rounds.push_back(l);
+      }
+      if (all.empty()) all.push_back({-1, 0, 0, 0});
+      for (void* p : {(void*)d_det_tasks, (void*)d_gbuf, (void*)d_blk_group})
+         if (p) (void)hipFree(p);
+      d_det_tasks = nullptr; d_gbuf = nullptr; d_blk_group = nullptr;
+      int rc;
+      if ((rc = dev_upload(&d_det_tasks, all, stream)) || (rc = dev_upload(&d_blk_group, grp, stream))) return rc;
+      if (S > 0) HIP_TRY(hipMalloc((void**)&d_gbuf, (size_t)det_n_groups * S * S * sizeof(double)));
+      {  // the head's own Schur contributions join their block's group buffer
+         g_sc_grp.release();
+         std::vector<SlotEntry> ent(sc_e_keep.size());
+         for (size_t i = 0; i < sc_e_keep.size(); ++i) ent[i] = {(long long)grp[sc_blk_keep[i]] * S * S + sc_e_keep[i].target, sc_e_keep[i].slot};
+         if ((rc = upload_gather(ent, g_sc_grp))) return rc;
+      }
+      // Br^T z in the same group order: rows of group g go to slot g of an 8 x S scratch matrix
+      g_btm_grp.release();
+      if (d_gvec) (void)hipFree(d_gvec);
+      if (d_tvec) (void)hipFree(d_tvec);
+      d_gvec = d_tvec = nullptr;
+      if (S > 0) {
+         std::vector<SlotEntry> ent;
+         for (long long i = 0; i < bt_rows_total; ++i)
+            if (h_bt_rownnz_keep[(size_t)i] > 0) ent.push_back({(long long)grp[h_bt_rowblk_keep[(size_t)i]] * S + h_bt_rowsc_keep[(size_t)i], i});
+         if ((rc = upload_gather(ent, g_btm_grp))) return rc;
+         HIP_TRY(hipMalloc((void**)&d_gvec, (size_t)8 * S * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_tvec, (size_t)S * sizeof(double)));
+      }
+      return PIPS_OK;
+   }
+   GatherList g_btm, g_bm;        // border products: rows per Schur column, entries per leaf row
+   double* d_bt_tmp = nullptr;
    int* d_gemm_ctr = nullptr;     // counter slots of the persistent update kernel
    int gemm_ctr_cursor = 0;
    bool persistent_gemm = false;   // measured: no gain, and it starves the side stream (see k_tile_gemm_persist); PIPS_HIP_PERSISTENT_GEMM=1
@@ -539,6 +638,10 @@ struct Engine {
                 timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
       if (!sc_groups.empty()) { c.sc_groups = &sc_groups; c.d_sc_tasks = d_sc_tasks; c.ev_sc = &ev_sc; }
       if (persistent_gemm) { c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor; }
+      if (deterministic && d_gbuf) {
+         c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = (long long)S * S; c.d_blk_group = d_blk_group;
+         c.n_groups = det_n_groups; c.first_slot = det_first_slot;
+      }
       return c;
    }
 
@@ -796,6 +899,23 @@ struct Engine {
          std::copy(in[b].btval.begin(), in[b].btval.end(), h_bval.begin() + bptr[b]);
       }
       bt_rows_total = (long long)h_bt_rowsc.size();
+      h_bt_rowsc_keep = h_bt_rowsc;
+      h_bt_rownnz_keep.assign((size_t)bt_rows_total, 0);
+      for (long long i = 0; i < bt_rows_total; ++i) h_bt_rownnz_keep[(size_t)i] = h_bt_rowptr[i + 1] - h_bt_rowptr[i];
+      h_bt_rowblk_keep.clear();
+      for (int b = 0; b < nblk; ++b)
+         if (!in[b].btrow.empty()) h_bt_rowblk_keep.insert(h_bt_rowblk_keep.end(), (size_t)S, b);
+      if (deterministic && bt_rows_total > 0) {   // gather lists of the border products (see k_border_rowdot)
+         std::vector<SlotEntry> by_sc, by_entry;
+         for (long long i = 0; i < bt_rows_total; ++i) {
+            if (h_bt_rowptr[i + 1] > h_bt_rowptr[i]) by_sc.push_back({(long long)h_bt_rowsc[i], i});
+            for (int q = h_bt_rowptr[i]; q < h_bt_rowptr[i + 1]; ++q) by_entry.push_back({h_bt_xoff[i] + h_bt_colidx[q], (long long)q});
+         }
+         g_btm.release(); g_bm.release();
+         if ((rc = upload_gather(by_sc, g_btm)) || (rc = upload_gather(by_entry, g_bm))) return rc;
+         if (d_bt_tmp) (void)hipFree(d_bt_tmp);
+         HIP_TRY(hipMalloc((void**)&d_bt_tmp, (size_t)std::max<long long>(std::max(bt_rows_total, nnzB_total), 1) * sizeof(double)));
+      }
       {  // non-empty Schur columns over all blocks (the reference skips empty border columns, :870-874)
          std::vector<char> used(std::max(S, 1), 0);
          for (int b = 0; b < nblk; ++b)
@@ -872,7 +992,15 @@ struct Engine {
       h_sns_keep = h_sns;
       analyzed = true;
       factored = false;
-      if (deterministic && (rc = build_deterministic(n_threads))) return rc;
+      head_slots = false;
+      const char* hs_env = getenv("PIPS_HIP_HEAD_SLOTS");
+      const bool want_slots = deterministic || (hs_env && atoi(hs_env) != 0 && schur_mode_eff == 1 && spine_total == 0);
+      if (want_slots && slots_total + vslots_total <= HEAD_SLOTS_MAX) {
+         if ((rc = build_deterministic(n_threads))) return rc;
+         head_slots = true;
+      } else if (deterministic)
+         PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: %lld head contributions exceed the slot budget of %lld", slots_total + vslots_total, HEAD_SLOTS_MAX);
+      if (deterministic && (rc = set_det_groups(0, 1))) return rc;
       return PIPS_OK;
    }
 
@@ -895,8 +1023,7 @@ struct Engine {
          hipLaunchKernelGGL(k_gather_slots, dim3(grid_for(g.n_targets, 256)), dim3(256), 0, stream, g.n_targets, g.d_tgt, g.d_off, g.d_slots, vals, target);
    }
 
-   // One entry per recorded contribution: (target, slot), sorted; then the CSR "target -> its slots"
-   struct SlotEntry { long long target, slot; };
+   // the recorded contributions (target, slot) are sorted, then turned into the CSR "target -> its slots"
    int upload_gather(std::vector<SlotEntry>& e, GatherList& g) {
       std::sort(e.begin(), e.end(), [](const SlotEntry& a, const SlotEntry& b) { return a.target != b.target ? a.target < b.target : a.slot < b.slot; });
       std::vector<long long> tgt, off, sl(e.size());
@@ -912,8 +1039,8 @@ struct Engine {
       return PIPS_OK;
    }
    int build_deterministic(int n_threads) {
-      if (d_sctab) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: not available with the sparse Schur complement");
       if (schur_mode_eff != 1) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode needs Schur mode 1 (augmented factorisation)");
+      if (spine_total > 0) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: spine kernels must be off");
       const int nlev = (int)levels.size();
       g_levels.assign(nlev, GatherList());
       gv_levels.assign(nlev, GatherList());
@@ -936,6 +1063,7 @@ struct Engine {
       // classify: Schur complement / tail of block b / head panel of a supernode at level l (targets of different blocks are disjoint)
       std::vector<std::vector<SlotEntry>> per_level(nlev);
       std::vector<SlotEntry> tail_e, sc_e;
+      sc_blk_keep.clear();
       std::vector<std::vector<std::pair<long long, int>>> panel_level(nblk);   // (panel offset inside the block arena, level), ascending
       for (int b = 0; b < nblk; ++b) {
          for (const HeadSupernode& hs : sym[b].sn) panel_level[b].push_back({hs.panel, hs.level});
@@ -948,7 +1076,7 @@ struct Engine {
          for (long long q = 0; q < cnt; ++q) {
             const long long t = rec[(size_t)(sn.slot + q)];
             if (t < 0) continue;
-            if (t & SCATTER_SC_FLAG) { sc_e.push_back({t & ~SCATTER_SC_FLAG, sn.slot + q}); continue; }
+            if (t & SCATTER_SC_FLAG) { sc_e.push_back({t & ~SCATTER_SC_FLAG, sn.slot + q}); sc_blk_keep.push_back(sn.blk); continue; }
             if (t >= bd.T) { tail_e.push_back({t, sn.slot + q}); continue; }
             const long long rel = t - bd.arena_off;
             auto& pl = panel_level[sn.blk];
@@ -960,6 +1088,7 @@ struct Engine {
       std::vector<long long>().swap(rec);
       for (int l = 0; l < nlev; ++l)
          if ((rc = upload_gather(per_level[l], g_levels[l]))) return rc;
+      sc_e_keep = sc_e;   // (unsorted, parallel to sc_blk_keep) for the group-wise variant of deterministic mode
       if ((rc = upload_gather(tail_e, g_tail)) || (rc = upload_gather(sc_e, g_sc))) return rc;
       // ---- forward-substitution scatter: same recording, targets are entries of the permuted work vector
       if (vslots_total > 0) {
@@ -1014,6 +1143,16 @@ struct Engine {
       if (rc) return rc;
       for (int b = 0; b < nblk; ++b) h_blks[b].sctab_off = off[b];
       HIP_TRY(hipMemcpy(d_blks, h_blks.data(), (size_t)nblk * sizeof(BlkDesc), hipMemcpyHostToDevice));
+      if (deterministic) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: not available with the sparse Schur complement");
+      if (head_slots) {   // the Schur targets of the head moved into the CSR value array: record again
+         for (auto& g : g_levels) g.release();
+         for (auto& g : gv_levels) g.release();
+         g_tail.release(); g_sc.release(); gv_tail.release();
+         if (d_slot_val) (void)hipFree(d_slot_val);
+         if (d_vslot_val) (void)hipFree(d_vslot_val);
+         d_slot_val = d_vslot_val = nullptr;
+         if ((rc = build_deterministic(1))) return rc;
+      }
       return PIPS_OK;
    }
 
@@ -1044,16 +1183,21 @@ struct Engine {
       if (timer.on) timer.end(stream);
       // the whole-factor record (phase 6) was pushed first; close it at the end
       const size_t total_rec = 0;
-      const ScatterCtx sx = deterministic ? ScatterCtx{2, nullptr, d_slot_val, d_arena, SC} : sx_atomic();
+      const ScatterCtx sx = head_slots ? ScatterCtx{2, nullptr, d_slot_val, d_arena, SC} : sx_atomic();
       for (size_t li = 0; li < levels.size(); ++li) {
          if (timer.on) timer.begin(stream, 1);
-         if (deterministic) gather(g_levels[li], d_slot_val, d_arena);   // contributions of the lower levels, in fixed order
+         if (head_slots) gather(g_levels[li], d_slot_val, d_arena);   // contributions of the lower levels, in fixed order
          launch_head_level(levels[li], SC, ldSC, sx);
          if (timer.on) timer.end(stream);
       }
-      if (deterministic) {
+      if (head_slots) {
+         if (timer.on) timer.begin(stream, 1);
          gather(g_tail, d_slot_val, d_arena);
-         if (SC) gather(g_sc, d_slot_val, SC);
+         if (SC && deterministic && d_gbuf) {
+            HIP_TRY(hipMemsetAsync(d_gbuf, 0, (size_t)det_n_groups * S * S * sizeof(double), stream));
+            gather(g_sc_grp, d_slot_val, d_gbuf);
+         } else if (SC) gather(g_sc, d_slot_val, SC);
+         if (timer.on) timer.end(stream);
       }
       if (spine_total > 0) {
          if (timer.on) timer.begin(stream, 1);
@@ -1103,10 +1247,10 @@ struct Engine {
       const long long xws = nrhs > 1 ? xw_total : 0;
       const dim3 pg(64, nblk, nrhs);
       hipLaunchKernelGGL(k_permute_in, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
-      if (deterministic) {
+      if (deterministic && nrhs != 1) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode solves one right-hand side at a time");
+      if (head_slots && nrhs == 1 && (deterministic || slot_solves)) {
          // forward substitution without atomics: the contributions go to their slots, every level first gathers what the lower
          // levels left for its own columns, the tail rows are gathered before the dense sweep
-         if (nrhs != 1) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode solves one right-hand side at a time");
          const ScatterCtx sxv{2, nullptr, d_vslot_val, xw, nullptr};
          for (size_t li = 0; li < levels.size(); ++li) {
             const LevelRange& L = levels[li];
@@ -1151,7 +1295,8 @@ struct Engine {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX)
+         // (deterministic mode: always the same kernel, whatever the batch size - the two variants add in different orders)
+         if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX && !deterministic)
             hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
@@ -1593,6 +1738,7 @@ int pips_hip_batch_create(void** handle, int n_blocks, int S, int device, void* 
    e->device = device;   // resolved at analyze time so that set_block / symbolic work without a GPU
    e->stream = (hipStream_t)stream;
    e->in.assign(n_blocks, BlockInput());
+   if (const char* d = getenv("PIPS_HIP_DETERMINISTIC")) e->deterministic = atoi(d) != 0;   // default of pips_hip_batch_set_deterministic
    *handle = e.release();
    return PIPS_OK;
 }
@@ -1759,7 +1905,11 @@ int pips_hip_batch_border_tmult_dev(void* handle, const double* z_dev, double* b
    Engine* e = (Engine*)handle;
    if (!e || !e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "border_tmult: analyze first");
    HIP_TRY(hipSetDevice(e->device));
-   if (e->bt_rows_total > 0)
+   if (e->bt_rows_total > 0 && e->deterministic) {
+      hipLaunchKernelGGL(k_border_rowdot, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr, e->d_bt_colidx, e->d_bval,
+                         e->d_bt_xoff, z_dev, e->d_bt_tmp, e->bt_rows_total, alpha);
+      e->gather(e->g_btm, e->d_bt_tmp, b0_dev);
+   } else if (e->bt_rows_total > 0)
       hipLaunchKernelGGL(k_border_tmult, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr,
                          e->d_bt_colidx, e->d_bval, e->d_bt_rowsc, e->d_bt_xoff, z_dev, b0_dev, e->bt_rows_total, alpha);
    HIP_TRY(hipGetLastError());
@@ -1770,7 +1920,11 @@ int pips_hip_batch_border_mult_dev(void* handle, const double* x0_dev, double* t
    Engine* e = (Engine*)handle;
    if (!e || !e->analyzed) PIPS_FAIL(PIPS_ERR_STATE, "border_mult: analyze first");
    HIP_TRY(hipSetDevice(e->device));
-   if (e->bt_rows_total > 0)
+   if (e->bt_rows_total > 0 && e->deterministic) {
+      hipLaunchKernelGGL(k_border_entry_products, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr, e->d_bval,
+                         e->d_bt_rowsc, x0_dev, e->d_bt_tmp, e->bt_rows_total, alpha);
+      e->gather(e->g_bm, e->d_bt_tmp, t_dev);
+   } else if (e->bt_rows_total > 0)
       hipLaunchKernelGGL(k_border_mult, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr,
                          e->d_bt_colidx, e->d_bval, e->d_bt_rowsc, e->d_bt_xoff, x0_dev, t_dev, e->bt_rows_total, alpha);
    HIP_TRY(hipGetLastError());
@@ -2121,7 +2275,8 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    if ((rc = dev_upload(&k->d_fin_val, val, nullptr))) return rc;
    // several ranks: Schur SYRK in row panels, each reduced as soon as it is final (PIPS_HIP_SC_PANELS, default 4 for S >= 1024; 1 =
    // one reduction after all leaf work); PIPS_HIP_SC_REDUCE=rsag: reduce-scatter + all-gather instead of the all-reduce
-   if (comm && (n_ranks > 1 || k->force_reduce)) {
+   if (e->deterministic && (rc = e->set_det_groups(rank, n_ranks))) return rc;
+   if (comm && (n_ranks > 1 || k->force_reduce) && !e->deterministic) {
       // default: panels only where the reduction is worth hiding (S >= 4096: >= 64 MB packed; splitting the SYRK costs ~1 ms)
       int panels = S >= 4096 ? 4 : 1;
       if (const char* pp = getenv("PIPS_HIP_SC_PANELS")) panels = atoi(pp);
@@ -2367,8 +2522,9 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
                          k->d_fin_val, k->n_fin);
    if (k->mz0 > 0) {
       if (!k->d_zdiag0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: mz0 > 0 needs pips_hip_kkt_set_root_inequalities + a zdiag0 vector");
-      hipLaunchKernelGGL(k_ctdc, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val, k->d_zdiag0,
-                         k->d_SC, k->S, (const int*)nullptr);
+      // deterministic mode: one thread walks the rows of C0 (the kernel's atomics then arrive in row order)
+      hipLaunchKernelGGL(k_ctdc, e->deterministic ? dim3(1) : dim3(grid_for(k->mz0, 128)), e->deterministic ? dim3(1) : dim3(128), 0, e->stream, k->mz0,
+                         k->d_c0_rp, k->d_c0_ci, k->d_c0_val, k->d_zdiag0, k->d_SC, k->S, (const int*)nullptr);
    }
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, k->d_SC, k->S,
@@ -2406,15 +2562,33 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
       HIP_TRY(hipMemcpyAsync(red, b0_dev, (size_t)head * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(red + head, b0_dev + head + k->mz0, (size_t)tailn * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
    }
+   if (e->deterministic && e->d_gvec && !k->sparse) {
+      // deterministic Lsolve: t = -sum_i Br_i^T K_i^-1 b_i is formed on its own - group-wise in block order, the (at most eight)
+      // groups in the fixed tree of k_reduce_groups, the ranks' parts by the all-reduce - and added to b0 on every rank: the
+      // association no longer depends on how the blocks are spread over 1, 2, 4 or 8 ranks
+      if ((rc = e->solve(b_leaf_dev))) return rc;
+      HIP_TRY(hipMemsetAsync(e->d_gvec, 0, (size_t)8 * k->S * sizeof(double), e->stream));
+      HIP_TRY(hipMemsetAsync(e->d_tvec, 0, (size_t)k->S * sizeof(double), e->stream));
+      if (e->bt_rows_total > 0) {
+         hipLaunchKernelGGL(k_border_rowdot, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr, e->d_bt_colidx, e->d_bval,
+                            e->d_bt_xoff, b_leaf_dev, e->d_bt_tmp, e->bt_rows_total, -1.0);
+         e->gather(e->g_btm_grp, e->d_bt_tmp, e->d_gvec);
+      }
+      hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (k->S + 255) / 256)), 1), dim3(256), 0, e->stream, e->d_tvec, k->S, k->S, e->d_gvec,
+                         (long long)k->S, e->det_n_groups, e->det_first_slot);
+      if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, e->d_tvec, (size_t)k->S, e->stream))) return rc;
+      hipLaunchKernelGGL(k_axpy, dim3(grid_for(k->S, 256)), dim3(256), 0, e->stream, red, e->d_tvec, 1.0, (long long)k->S);
+   } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
    if ((rc = e->solve(b_leaf_dev))) return rc;
    if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
    if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream)))
       return rc;
+   }
    // Dsolve: eliminate z0 through C0, solve with the Schur complement, recover z0 (solveReducedLinkCons :384-466)
    if (k->mz0 > 0)
-      hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
+      hipLaunchKernelGGL(k_z0_elim, e->deterministic ? dim3(1) : dim3(grid_for(k->mz0, 128)), e->deterministic ? dim3(1) : dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
    if (k->sparse) {
       if ((rc = k->root_sp->solve(red))) return rc;

@@ -605,7 +605,9 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
                                                const BlkDesc* __restrict__ blks, double* __restrict__ arena,
                                                const double* __restrict__ dtail, const double* __restrict__ winv,
                                                const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
-                                               const int* __restrict__ sctab, double* __restrict__ uarena) {
+                                               const int* __restrict__ sctab, double* __restrict__ uarena,
+                                               double* __restrict__ gbuf = nullptr, long long gstride = 0,
+                                               const int* __restrict__ blk_group = nullptr) {
    constexpr bool SCALE = (MODE == 2);   // in-loop diagonal scaling: only the Schur SYRK (border rows have no U copy)
    auto& As = sh.As;
    auto& Bs = sh.Bs;
@@ -784,7 +786,10 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
             const int gi = task.ti * TILE + row, gj = task.tj * TILE + col;
             if (gi < bd.nb && gj < bd.nb && gi >= gj) {
                const int* bm = bmap + bd.bmap_off;
-               atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, gi, gj), -v);
+               if (gbuf)   // deterministic mode: the block's group buffer, which no other workgroup of this launch touches
+                  *sc_entry(gbuf + blk_group[task.blk] * gstride, ldSC, bm, sctab, bd.sctab_off, bd.nb, gi, gj) -= v;
+               else
+                  atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, gi, gj), -v);
             }
          }
       }
@@ -798,7 +803,9 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
                                                      const BlkDesc* __restrict__ blks, double* __restrict__ arena,
                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
                                                      const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
-                                                     const int* __restrict__ sctab = nullptr, double* __restrict__ uarena = nullptr) {
+                                                     const int* __restrict__ sctab = nullptr, double* __restrict__ uarena = nullptr,
+                                                     double* __restrict__ gbuf = nullptr, long long gstride = 0,
+                                                     const int* __restrict__ blk_group = nullptr) {
    __shared__ GemmShared sh;
 #if defined(PIPS_EXPERIMENT_NO_XCD)
    const int tix = (int)blockIdx.x;
@@ -806,7 +813,25 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    const int per = (n_tasks + 7) >> 3;
    const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 #endif
-   tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena);
+   tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena, gbuf, gstride, blk_group);
+}
+
+// deterministic mode: SC += ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)) over the (at most eight) group buffers, lower triangle.
+// The order is a function of the global block partition only, so one rank with eight groups and two ranks with four groups each
+// followed by the two-operand sum of the all-reduce give the same bits.
+__global__ void k_reduce_groups(double* __restrict__ SC, int ld, int S, const double* __restrict__ gbuf, long long gstride, int n_groups,
+                                int first_slot) {
+   const int c = blockIdx.y;
+   for (int r = c + blockIdx.x * blockDim.x + threadIdx.x; r < S; r += gridDim.x * blockDim.x) {
+      const long long off = r + (long long)c * ld;
+      double p[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+         const int lg = g - first_slot;   // this rank's groups occupy the slots first_slot .. first_slot + n_groups - 1 of the global eight
+         p[g] = (lg >= 0 && lg < n_groups) ? gbuf[lg * gstride + off] : 0.0;
+      }
+      SC[off] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+   }
 }
 
 // Persistent variant for the deep-K updates: as many workgroups as the chip holds (two per CU), each pulls tiles from the slice
@@ -1618,6 +1643,26 @@ __global__ void k_border_tmult(const int* __restrict__ rowptr, const int* __rest
       const long long xo = row_xoff[i];
       for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * z[xo + colidx[p]];
       if (s != 0.0) atomic_add_f64(b0 + row_sc[i], alpha * s);
+   }
+}
+
+// deterministic mode: the same two products without atomics - per-row dot products / per-entry products into a scratch vector,
+// then k_gather_slots adds them up per Schur column / per leaf entry in a fixed order
+__global__ void k_border_rowdot(const int* __restrict__ rowptr, const int* __restrict__ colidx, const double* __restrict__ val,
+                                const long long* __restrict__ row_xoff, const double* __restrict__ z, double* __restrict__ out,
+                                long long nrows, double alpha) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      double s = 0.0;
+      const long long xo = row_xoff[i];
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * z[xo + colidx[p]];
+      out[i] = alpha * s;
+   }
+}
+__global__ void k_border_entry_products(const int* __restrict__ rowptr, const double* __restrict__ val, const int* __restrict__ row_sc,
+                                        const double* __restrict__ x0, double* __restrict__ out, long long nrows, double alpha) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      const double xs = alpha * x0[row_sc[i]];
+      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) out[p] = val[p] * xs;
    }
 }
 
