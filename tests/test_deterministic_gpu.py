@@ -108,3 +108,22 @@ def test_bit_identical_between_one_and_two_ranks(tmp_path, kind):
             assert np.array_equal(g["xl"][i], one["xl"][b])
             assert tuple(g["inertia"][i]) == one["inertia"][b]
         assert tuple(g["inertia"][-1]) == one["inertia"][-1]
+
+
+def test_ipm_is_bit_reproducible(monkeypatch):
+    """With PIPS_HIP_DETERMINISTIC=1 (the default of pips_hip_batch_set_deterministic for batches the harness creates) the whole
+    interior-point run - every iterate's mu, residual, objectives, step lengths, and the final point - repeats to the bit; the
+    harness' own reductions are two-stage with a fixed order.  Instance: one of the reference's GAMSsmall LPs whose default-mode
+    runs take 6 or 7 iterations depending on the order in which the atomics arrive."""
+    import json
+    monkeypatch.setenv("PIPS_HIP_DETERMINISTIC", "1")
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gamssmall.json")))["instances"]
+    inst = [d for d in data if d["name"] == "singletonInequalityColumn_B0Bl0"][0]
+    runs = []
+    for _ in range(3):
+        ipm = pa.GeneralIpmSolver(inst["blocks"], dual_reg=1e-9)
+        res = ipm.solve(max_iter=200, mutol=1e-8, artol=1e-8)
+        assert res["status"] == 0 and abs(res["objective"] - inst["expected_objective"]) < 1e-4
+        runs.append((res["iterations"], ipm.trace().tobytes(), ipm.iterate()["x"].tobytes(), ipm.iterate()["z"].tobytes()))
+        ipm.close()
+    assert all(r == runs[0] for r in runs)
