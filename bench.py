@@ -27,16 +27,19 @@ R_SOLVES = 4
 
 
 def update_kernel_algorithmic_flops(m, nb):
-    """Algorithmic flops of the tail update GEMM for one block with dense tail m and nb border rows: for tile column j
-    (K = j*TILE already factored columns) every lower-triangle entry of the tile column, plus its nb border entries,
-    receives one length-K dot product (2K flops).  Summed: ~ m^3/3 + nb*m^2."""
+    """Algorithmic flops of the tail update kernel k_tile_gemm<0> for one block with dense tail m and nb border rows.  The
+    launch of tile column j (K = j*TILE already factored columns) gives every entry of the column below its diagonal tile and
+    its nb border entries one length-K dot product (2K flops), and the lower triangle of the NEXT diagonal tile its dot
+    products with the same K columns (engine.hip TailPlan::build, diag_ahead; the last step of a diagonal tile, with the
+    column just finished, is the side stream's k_tile_gemm<4> and is not counted here).  Summed: ~ m^3/3 + nb*m^2."""
     fl = 0.0
     j = 0
     while j * TILE < m:
         K = j * TILE
         tc = min(TILE, m - K)
         below = m - K - tc
-        entries = tc * below + tc * (tc + 1) / 2.0 + nb * tc
+        tc_next = max(0, min(TILE, below))
+        entries = tc * below + nb * tc + tc_next * (tc_next + 1) / 2.0
         fl += 2.0 * K * entries
         j += 1
     return fl

@@ -68,7 +68,7 @@ struct TailPlan {
    // first: per block the tile-row envelope of its tail (BlockSym::tile_first); tiles left of it hold structural zeros and
    // get no task, update depths start at the envelope (a banded tail costs band^2 per column instead of column^2)
    int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false, bool split_diag = false,
-             const std::vector<const std::vector<int>*>* first = nullptr) {
+             const std::vector<const std::vector<int>*>* first = nullptr, bool diag_ahead = false) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -86,15 +86,25 @@ struct TailPlan {
       for (int j = 0; j < ntc_max; ++j) {
          const int p0 = panel > 0 ? j / panel * panel : 0;   // first tile column of j's panel
          auto fst = [&](int b, int t) { return first ? (*(*first)[b])[t] : 0; };
+         // diag_ahead: the diagonal tile of column j+1 takes its update with the columns < j inside the launch of column j
+         // (same depth as the other tiles of that launch); the list of its own only holds the last step, with column j-1.
+         // The side stream then has a K = TILE product and the tile factorisation on the path to trsm(j), not a product as
+         // deep as the matrix done by one workgroup per block.
          begin(upd_diag[j]);
          if (j > p0 && split_diag)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j) {
                   const int k0 = std::max(p0, fst(b, j));
-                  if (k0 < j) all.push_back({b, j, j, k0 | (j << 16)});
+                  if (k0 < j) all.push_back({b, j, j, (diag_ahead ? std::max(k0, j - 1) : k0) | (j << 16)});
                }
          end(upd_diag[j]);
          begin(upd[j]);
+         if (j > p0 && split_diag && diag_ahead)
+            for (int b = 0; b < nblk; ++b)
+               if (blks[b].ntc > j + 1) {
+                  const int k0 = std::max(p0, fst(b, j + 1));
+                  if (k0 < j) all.push_back({b, j + 1, j + 1, k0 | (j << 16)});
+               }
          if (j > p0)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j)
@@ -978,7 +988,9 @@ struct Engine {
       const bool diag_ahead = !getenv("PIPS_HIP_NO_DIAG_AHEAD");
       std::vector<const std::vector<int>*> firsts(nblk);
       for (int b = 0; b < nblk; ++b) firsts[b] = &sym[b].tile_first;
-      if ((rc = plan.build(h_blks, 0, false, diag_ahead, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts))) return rc;
+      if ((rc = plan.build(h_blks, 0, false, diag_ahead, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts,
+                           diag_ahead && !getenv("PIPS_HIP_DIAG_UPDATE_LATE"))))
+         return rc;
       if (diag_ahead && !side) {
          // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
          int prio_lo = 0, prio_hi = 0;
