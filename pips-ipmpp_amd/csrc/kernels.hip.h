@@ -1277,12 +1277,17 @@ __global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__
 }
 
 // tail forward step j: tiles i >= j of block b:  b_i -= L(i,j-1) (d z)_{j-1}  (j >= 1) ; tile i == j: z_j = Winv_j b_j
-// 256 threads: thread (row, half) accumulates 64 of the 128 columns with all its loads issued up front (the launch is
-// latency-bound for the late, small tile columns: one HBM round trip instead of sixteen), halves combined through LDS.
-__device__ __forceinline__ double tile_gemv_half(const double* __restrict__ M, long long ldm, const double* v, int row, int half) {
-   double m[64];
+// 256 threads: thread (row, half) accumulates 64 of the 128 columns, halves combined through LDS.  A launch is a chain of
+// dependent global-memory round trips (the late tile columns have 64 workgroups: pure latency), so everything that does not
+// depend on the step before is requested first: the L tile - and in the workgroup of the diagonal tile the Winv tile as well -
+// is requested before the vector of the previous step is looked at (-1 % fwd, -4 % bwd per sweep).  Tried and dropped
+// (profiles/r2_gemm_experiments.txt, sweeps): Winv tile of the diagonal workgroup prefetched into registers (256 VGPRs, one wave
+// per SIMD: +10 %) or into the L2 by touching its lines (+7 %: the extra requests queue in front of the tiles everybody waits for).
+__device__ __forceinline__ void tile_load_half(double (&m)[64], const double* __restrict__ M, long long ldm, int row, int half) {
 #pragma unroll
    for (int c = 0; c < 64; ++c) m[c] = M[row + (long long)(half * 64 + c) * ldm];
+}
+__device__ __forceinline__ double tile_dot_half(const double (&m)[64], const double* v, int half) {
    double s = 0.0;
 #pragma unroll
    for (int c = 0; c < 64; ++c) s += m[c] * v[half * 64 + c];
@@ -1301,11 +1306,22 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ t
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, row = tid & 127, half = tid >> 7, ti = task.ti, ld = bd.ldT;
    double* xt = xw + bd.xw_off + bd.n_head;
+   // requests in the order they are needed (loads return in order): vector of the previous step, own entry, L tile, Winv tile
+   double vprev = 0.0;
+   if (j >= 1 && tid < TILE) vprev = xt[(j - 1) * TILE + tid] * dtail[bd.dt_off + (j - 1) * TILE + tid];
    double acc = xt[ti * TILE + row];
+   double m[64];
+#if !defined(PIPS_SWEEP_LATE_LOADS)
+   if (j >= 1) tile_load_half(m, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, row, half);
+#endif
+   const double* Wj = winv + bd.winv_off + (long long)j * TILE * TILE;
    if (j >= 1) {
-      if (tid < TILE) v[tid] = xt[(j - 1) * TILE + tid] * dtail[bd.dt_off + (j - 1) * TILE + tid];
+      if (tid < TILE) v[tid] = vprev;
       __syncthreads();
-      const double s = tile_gemv_half(arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, v, row, half);
+#if defined(PIPS_SWEEP_LATE_LOADS)
+      tile_load_half(m, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, row, half);
+#endif
+      const double s = tile_dot_half(m, v, half);
       if (half == 1) part[row] = s;
       __syncthreads();
       if (half == 0) acc -= s + part[row];
@@ -1314,7 +1330,8 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ t
    if (ti == j) {
       if (half == 0) v[row] = acc;
       __syncthreads();
-      const double s = tile_gemv_half(winv + bd.winv_off + (long long)j * TILE * TILE, TILE, v, row, half);
+      tile_load_half(m, Wj, TILE, row, half);
+      const double s = tile_dot_half(m, v, half);
       if (half == 1) part[row] = s;
       __syncthreads();
       if (half == 0) acc = s + part[row];
@@ -1322,43 +1339,50 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ t
    if (half == 0) xt[ti * TILE + row] = acc;
 }
 
-// out[c] = sum_r M[r + c*ldm] v[r] for a 128 x 128 column-major tile: the tile is staged through LDS in chunks of 32
-// columns with coalesced row-contiguous loads, then 8 threads reduce each column (rows part + 8k: bank-conflict-free at
-// the 136-double stride).  256 threads; v and out are LDS arrays of 128 doubles.
-constexpr int TG_LD = 136;
-__device__ __forceinline__ void tile_tgemv(const double* __restrict__ M, long long ldm, const double* v, double* out,
-                                           double* Ls, int tid) {
-   const int row = tid & 127, cg = tid >> 7;
-   const int col = tid >> 3, part = tid & 7;
-   // issue the loads of all four 32-column chunks first (64 per thread in flight): one HBM round trip per tile
-   double m[4][16];
+// out[c] = sum_r M[r + c*ldm] v[r] for a 128 x 128 column-major tile.  A column is 1 KiB contiguous: one 16-byte-per-lane load
+// instruction of a wave fetches it whole (lane l holds rows 2l, 2l+1), each of the four waves takes 32 columns and has all its
+// 32 loads in flight at once (one HBM round trip per tile).  The 32 per-lane partial sums are then reduced over the 64 lanes
+// with a transposing butterfly: in the step with distance 32, 16, 8, 4, 2 every lane hands half of its values to its partner
+// and adds the partner's contribution to the half it keeps (31 exchanges instead of 32 x 6), after which lane l holds column
+// l >> 1 summed over the lanes of equal parity; one more exchange with distance 1 finishes it.  No LDS staging, no barrier
+// inside (round 1 staged 32-column chunks through LDS with two barriers each and ran 20 % behind the forward sweep).
+// 256 threads; v and out are LDS arrays of 128 doubles; the caller synchronises before v is read and after out is written.
+// Load and arithmetic are separate calls so that a kernel can have several tiles in flight before it needs the first.
+typedef double tg_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tile_tload(tg_d2 (&m)[32], const double* __restrict__ M, long long ldm, int tid) {
+   const int lane = tid & 63, w = tid >> 6;
+   const double* col0 = M + 2 * lane + (long long)(w * 32) * ldm;
 #pragma unroll
-   for (int chunk = 0; chunk < 4; ++chunk)
+   for (int e = 0; e < 32; ++e) m[e] = *(const tg_d2*)(col0 + (long long)e * ldm);
+}
+__device__ __forceinline__ void tile_tdot(const tg_d2 (&m)[32], const double* v, double* out, int tid) {
+   const int lane = tid & 63, w = tid >> 6;
+   const double x0 = v[2 * lane], x1 = v[2 * lane + 1];
+   double s[32];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) m[chunk][e] = M[row + (long long)(chunk * 32 + cg * 16 + e) * ldm];
+   for (int e = 0; e < 32; ++e) s[e] = m[e].x * x0 + m[e].y * x1;
 #pragma unroll
-   for (int chunk = 0; chunk < 4; ++chunk) {
+   for (int half = 16; half >= 1; half >>= 1) {
+      const int mask = 2 * half;   // lane distance 32, 16, 8, 4, 2
+      const bool up = (lane & mask) != 0;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) Ls[(cg * 16 + e) * TG_LD + row] = m[chunk][e];
-      __syncthreads();
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) s += Ls[col * TG_LD + part + 8 * k] * v[part + 8 * k];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      if (part == 0) out[chunk * 32 + col] = s;
-      __syncthreads();
+      for (int e = 0; e < half; ++e) {
+         const double send = up ? s[e] : s[e + half];
+         const double keep = up ? s[e + half] : s[e];
+         s[e] = keep + __shfl_xor(send, mask);
+      }
    }
+   const double r = s[0] + __shfl_xor(s[0], 1);
+   if ((lane & 1) == 0) out[w * 32 + (lane >> 1)] = r;
 }
 
 // tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} (if i+1 < ntc) ; tile j == i: x_i = Winv_i^T (d_i z_i)
+// Same ordering of the requests as in k_tail_fwd: the L tile is in flight before the vector of the step before is looked at.
 __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                  const double* __restrict__ arena, const double* __restrict__ dtail,
                                                  const double* __restrict__ winv, double* __restrict__ xw, int i,
                                                  long long xw_stride) {
    xw += xw_stride * blockIdx.y;
-   __shared__ double Ls[32 * TG_LD];
    __shared__ double v[TILE];
    __shared__ double outp[TILE];
    const TileTask task = tasks[blockIdx.x];
@@ -1366,19 +1390,33 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ t
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, tj = task.ti, ld = bd.ldT;
    double* xt = xw + bd.xw_off + bd.n_head;
+   const bool upd = i + 1 < bd.ntc;
+   double vnext = 0.0, dsc = 0.0;
+   if (upd && tid < TILE) vnext = xt[(i + 1) * TILE + tid];
    double acc = tid < TILE ? xt[tj * TILE + tid] : 0.0;
-   if (i + 1 < bd.ntc) {
-      if (tid < TILE) v[tid] = xt[(i + 1) * TILE + tid];
+   if (tj == i && tid < TILE) dsc = dtail[bd.dt_off + i * TILE + tid];
+   tg_d2 m[32];
+#if !defined(PIPS_SWEEP_LATE_LOADS)
+   if (upd) tile_tload(m, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, tid);
+#endif
+   const double* Wi = winv + bd.winv_off + (long long)i * TILE * TILE;
+   if (upd) {
+      if (tid < TILE) v[tid] = vnext;
       __syncthreads();
-      tile_tgemv(arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, v, outp, Ls, tid);
+#if defined(PIPS_SWEEP_LATE_LOADS)
+      tile_tload(m, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, tid);
+#endif
+      tile_tdot(m, v, outp, tid);
+      __syncthreads();
       if (tid < TILE) acc -= outp[tid];
    }
    if (tj == i) {
       __syncthreads();
-      if (tid < TILE) v[tid] = acc * dtail[bd.dt_off + i * TILE + tid];
+      if (tid < TILE) v[tid] = acc * dsc;
       __syncthreads();
-      // x[c] = sum_n Winv[n][c] v[n]
-      tile_tgemv(winv + bd.winv_off + (long long)i * TILE * TILE, TILE, v, outp, Ls, tid);
+      tile_tload(m, Wi, TILE, tid);
+      tile_tdot(m, v, outp, tid);   // x[c] = sum_n Winv[n][c] v[n]
+      __syncthreads();
       if (tid < TILE) acc = outp[tid];
    }
    if (tid < TILE) xt[tj * TILE + tid] = acc;

@@ -101,3 +101,133 @@ def test_hip_path_reproduces_third_party_golden_vectors():
     sol = bl.cpu().numpy().reshape(N, -1)
     for b in range(N):
         assert np.linalg.norm(sol[b] - g[f"sol{b}"]) / np.linalg.norm(g[f"sol{b}"]) < 1e-8
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0] at full size against ONE MKL-PARDISO factorisation of the global arrowhead matrix
+# (tests/golden/make_config0_pardiso.py: assembled from the generator's raw blocks, no Schur / solveCompressed code of the
+# restatement involved).  north_star: residual / solution parity 1e-8 against the CPU PARDISO path.
+# ----------------------------------------------------------------------------------------------------------------------
+def _config0():
+    from tests.util import Problem
+    g = np.load(os.path.join(HERE, "config0_global_pardiso.npz"))
+    prob = Problem(int(g["seed"]), int(g["N"]), int(g["n_i"]), int(g["my_i"]), int(g["n0"]), int(g["myl"]), float(g["rho"]),
+                   dual_reg=float(g["dual_reg"]))
+    return g, prob
+
+
+def test_oracle_matches_global_pardiso_solution_config0():
+    g, prob = _config0()
+    N, S, nl = prob.N, prob.S, prob.n_leaf
+    leaf = [prob.oracle_leaf(b) for b in range(N)]
+    SC = prob.oracle_finalize(prob.oracle_schur())
+    root = orc.DenseRootSolver(S)
+    root.matrixChanged(np.tril(SC))
+    pos = sum(s.get_inertia()[0] for s in leaf) + root.get_inertia()[0]
+    neg = sum(s.get_inertia()[1] for s in leaf) + root.get_inertia()[1]
+    assert (pos, neg) == tuple(int(v) for v in g["inertia"][:2])          # Sylvester: inertia adds up over the Schur complement
+    Bts = [prob.Bt_scipy(b) for b in range(N)]
+    for k in range(g["rhs"].shape[0]):
+        rhs, want = g["rhs"][k], g["sol"][k]
+        x0 = rhs[N * nl:].copy()
+        xs = [rhs[b * nl:(b + 1) * nl].copy() for b in range(N)]
+        orc.solve_compressed(x0, xs, leaf, Bts, root, prob.n0, 0, 0, prob.myl, 0)
+        got = np.concatenate(xs + [x0])
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-8
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_global_pardiso_solution_config0():
+    import torch
+    g, prob = _config0()
+    N, S, nl = prob.N, prob.S, prob.n_leaf
+    bt = pa.LeafBatch(N, S)
+    for b in range(N):
+        bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    bt.analyze(2)
+    for b in range(N):
+        bt.set_values(b, prob.blocks[b]["K"].val)
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0)
+    kkt.factorize(None, torch.tensor(prob.x_diag0, device="cuda"))
+    pos = sum(bt.inertia(b)[0] for b in range(N)) + kkt.root_inertia()[0]
+    neg = sum(bt.inertia(b)[1] for b in range(N)) + kkt.root_inertia()[1]
+    assert (pos, neg) == tuple(int(v) for v in g["inertia"][:2])
+    for k in range(g["rhs"].shape[0]):
+        rhs, want = g["rhs"][k], g["sol"][k]
+        b0 = torch.tensor(rhs[N * nl:].copy(), device="cuda")
+        bl = torch.tensor(rhs[:N * nl].copy(), device="cuda")
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        got = np.concatenate([bl.cpu().numpy(), b0.cpu().numpy()])
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-8
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-8
+
+
+# the general block structure (leaf inequality rows, root equality / inequality rows, both kinds of linking rows) against one
+# MKL-PARDISO factorisation of the global matrix (make_config0_pardiso.py: general_global_matrix)
+def _general():
+    from tests.test_general_gpu import GeneralProblem
+    g = np.load(os.path.join(HERE, "general_global_pardiso.npz"))
+    gp = GeneralProblem(int(g["seed"]), *[int(v) for v in g["dims"]], float(g["rho"]))
+    return g, gp
+
+
+def test_oracle_matches_global_pardiso_solution_general_structure():
+    g, gp = _general()
+    N, nx, my, mz, n0, my0, mz0, myl, mzl = gp.dims
+    S, nleaf = gp.S, nx + my + mz
+    leaf, Bts = [], []
+    SC = np.zeros((S, S))
+    for b in range(N):
+        s = orc.OracleLdl(gp.K_scipy(b), n_primal=nx)
+        s.matrixChanged()
+        Bt = gp.blocks[b]["Bt"].to_scipy()
+        orc.add_term_to_schur_compl_blocked(SC, s, Bt)
+        leaf.append(s)
+        Bts.append(Bt)
+    SCf = orc.finalize_kkt_dense(SC, n0, my0, myl, mzl, gp.x_diag0, A0=gp.A0.to_scipy(), F0=gp.F0.to_scipy(), G0=gp.G0.to_scipy(),
+                                 C0=gp.C0.to_scipy(), z_diag=gp.z_diag0, z_diag_link=gp.z_diag_link)
+    root = orc.DenseRootSolver(S)
+    root.matrixChanged(np.tril(SCf))
+    pos = sum(s.get_inertia()[0] for s in leaf) + root.get_inertia()[0]
+    neg = sum(s.get_inertia()[1] for s in leaf) + root.get_inertia()[1] + mz0      # the eliminated z0 rows: negative diagonal
+    assert (pos, neg) == tuple(int(v) for v in g["inertia"][:2])
+    for k in range(g["rhs"].shape[0]):
+        rhs, want = g["rhs"][k], g["sol"][k]
+        b0 = rhs[N * nleaf:].copy()
+        bs = [rhs[b * nleaf:(b + 1) * nleaf].copy() for b in range(N)]
+        orc.solve_compressed(b0, bs, leaf, Bts, root, n0, my0, mz0, myl, mzl, C0=gp.C0.to_scipy(), z_diag_reg=gp.z_diag0)
+        got = np.concatenate(bs + [b0])
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schur_mode", [1, 2])
+def test_hip_path_matches_global_pardiso_solution_general_structure(schur_mode):
+    import torch
+    g, gp = _general()
+    N, nx, my, mz, n0, my0, mz0, myl, mzl = gp.dims
+    S, nleaf = gp.S, nx + my + mz
+    bt = pa.LeafBatch(N, S)
+    bt.set_schur_mode(schur_mode)
+    for b in range(N):
+        bt.set_block(b, gp.blocks[b]["K"], nx, gp.blocks[b]["Bt"])
+    bt.analyze(4)
+    for b in range(N):
+        bt.set_values(b, gp.blocks[b]["K"].val)
+    kkt = pa.KktSystem(bt, n0, my0, myl, mzl, A0=gp.A0, F0=gp.F0, G0=gp.G0)
+    kkt.set_root_inequalities(gp.C0)
+    kkt.set_zdiag0(torch.tensor(gp.z_diag0, device="cuda"))
+    kkt.factorize(torch.tensor(np.concatenate([b["diag"] for b in gp.blocks]), device="cuda"),
+                  torch.tensor(gp.x_diag0, device="cuda"), torch.tensor(gp.z_diag_link, device="cuda"))
+    pos = sum(bt.inertia(b)[0] for b in range(N)) + kkt.root_inertia()[0]
+    neg = sum(bt.inertia(b)[1] for b in range(N)) + kkt.root_inertia()[1] + mz0
+    assert (pos, neg) == tuple(int(v) for v in g["inertia"][:2])
+    for k in range(g["rhs"].shape[0]):
+        rhs, want = g["rhs"][k], g["sol"][k]
+        b0 = torch.tensor(rhs[N * nleaf:].copy(), device="cuda")
+        bl = torch.tensor(rhs[:N * nleaf].copy(), device="cuda")
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        got = np.concatenate([bl.cpu().numpy(), b0.cpu().numpy()])
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-8
