@@ -168,6 +168,62 @@ struct TailPlan {
    }
 };
 
+// Single-launch tail sweeps (kernels.hip.h k_tail_rows_fwd / _bwd): task list (block, tile row) sorted by row, ticket and flag
+// storage.  PIPS_HIP_SWEEP_LAUNCHES=1 keeps the launch-per-tile-column kernels.
+struct SweepRt {
+   TileTask* d_tasks = nullptr;
+   int n_tasks = 0;
+   int* d_ints = nullptr;          // [0..1] ticket / finished, [2] error word, [4..] flags
+   long long* d_flag_off = nullptr;
+   int* d_tfirst = nullptr;
+   long long* d_tfirst_off = nullptr;
+   int epoch = 0;
+   bool enabled = false;
+   int build(const std::vector<BlkDesc>& blks, const std::vector<const std::vector<int>*>* first) {
+      release();
+      const int nblk = (int)blks.size();
+      int ntc_max = 0;
+      for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
+      std::vector<TileTask> tasks;
+      for (int i = 0; i < ntc_max; ++i)
+         for (int b = 0; b < nblk; ++b)
+            if (i < blks[b].ntc) tasks.push_back({b, i, 0, 0});
+      n_tasks = (int)tasks.size();
+      std::vector<long long> foff(nblk), tfoff(nblk);
+      std::vector<int> tf;
+      long long nf = 0;
+      for (int b = 0; b < nblk; ++b) {
+         foff[b] = nf;
+         nf += blks[b].ntc;
+         tfoff[b] = (long long)tf.size();
+         if (first)
+            for (int i = 0; i < blks[b].ntc; ++i) tf.push_back(std::min(i, (*(*first)[b])[i]));
+      }
+      int rc;
+      if ((rc = dev_upload(&d_tasks, tasks, nullptr))) return rc;
+      if ((rc = dev_upload(&d_flag_off, foff, nullptr))) return rc;
+      if (first) {
+         if ((rc = dev_upload(&d_tfirst, tf, nullptr))) return rc;
+         if ((rc = dev_upload(&d_tfirst_off, tfoff, nullptr))) return rc;
+      }
+      HIP_TRY(hipMalloc((void**)&d_ints, (size_t)(4 + std::max<long long>(nf, 1)) * sizeof(int)));
+      HIP_TRY(hipMemset(d_ints, 0, (size_t)(4 + std::max<long long>(nf, 1)) * sizeof(int)));
+      epoch = 0;
+      enabled = n_tasks > 0 && !getenv("PIPS_HIP_SWEEP_LAUNCHES");
+      return PIPS_OK;
+   }
+   SweepArgs args() {
+      return SweepArgs{d_tasks, n_tasks, d_ints, d_ints + 4, d_flag_off, d_tfirst, d_tfirst_off, ++epoch, d_ints + 2};
+   }
+   void release() {
+      for (void* p : {(void*)d_tasks, (void*)d_ints, (void*)d_flag_off, (void*)d_tfirst, (void*)d_tfirst_off})
+         if (p) (void)hipFree(p);
+      d_tasks = nullptr; d_ints = nullptr; d_flag_off = nullptr; d_tfirst = nullptr; d_tfirst_off = nullptr;
+      n_tasks = 0;
+      enabled = false;
+   }
+};
+
 struct PhaseTimer {
    bool on = false;
    struct Rec { hipEvent_t a, b; int phase; };
@@ -242,6 +298,7 @@ struct TailCtx {
    long long gstride = 0;
    const int* d_blk_group = nullptr;
    int n_groups = 0, first_slot = 0;
+   SweepRt* sweep = nullptr;            // single-launch solve sweeps
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
 constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
@@ -370,6 +427,12 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
 
 static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
+   if (c.sweep && c.sweep->enabled && nrhs == 1) {
+      hipLaunchKernelGGL(k_tail_rows_fwd, dim3(c.sweep->n_tasks), dim3(256), 0, c.stream, c.sweep->args(), c.d_blks, c.d_arena, c.d_dtail,
+                         c.d_winv, xw);
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
    for (int j = 0; j < p.ntc_max; ++j)
       if (p.fwd[j].cnt > 0)
          hipLaunchKernelGGL(k_tail_fwd, dim3(p.fwd[j].cnt, nrhs), dim3(256), 0, c.stream, p.d_tasks + p.fwd[j].off, c.d_blks,
@@ -380,6 +443,12 @@ static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_str
 
 static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
+   if (c.sweep && c.sweep->enabled && nrhs == 1) {
+      hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks), dim3(256), 0, c.stream, c.sweep->args(), c.d_blks, c.d_arena, c.d_dtail,
+                         c.d_winv, xw);
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
    for (int i = p.ntc_max - 1; i >= 0; --i)
       if (p.bwd[i].cnt > 0)
          hipLaunchKernelGGL(k_tail_bwd, dim3(p.bwd[i].cnt, nrhs), dim3(256), 0, c.stream, p.d_tasks + p.bwd[i].off, c.d_blks,
@@ -505,8 +574,10 @@ struct Engine {
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
       plan.release();
+      sweep.release();
    }
 
+   SweepRt sweep;
    hipStream_t side = nullptr;                       // diagonal tiles of the tail are factorised here, beside the column update
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
    // ---- deterministic mode (pips_hip_batch_set_deterministic): no FP64 atomics on the path.  Every scattered contribution of
@@ -652,6 +723,7 @@ struct Engine {
          c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = (long long)S * S; c.d_blk_group = d_blk_group;
          c.n_groups = det_n_groups; c.first_slot = det_first_slot;
       }
+      c.sweep = &sweep;
       return c;
    }
 
@@ -991,6 +1063,7 @@ struct Engine {
       if ((rc = plan.build(h_blks, 0, false, diag_ahead, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts,
                            diag_ahead && !getenv("PIPS_HIP_DIAG_UPDATE_LATE"))))
          return rc;
+      if ((rc = sweep.build(h_blks, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts))) return rc;
       if (diag_ahead && !side) {
          // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
          int prio_lo = 0, prio_hi = 0;
@@ -1512,7 +1585,9 @@ struct DenseLdl {
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
+      sweep.release();
    }
+   SweepRt sweep;
    int init() {
       HIP_TRY(hipSetDevice(device));
       int rc = PIPS_OK;
@@ -1530,6 +1605,7 @@ struct DenseLdl {
       // lookahead (second stream) pays once the trailing update of a panel outlasts a diagonal tile: S >= 6000 measured
       const bool lookahead = panel > 0 && d.ntc >= 48 && !getenv("PIPS_HIP_ROOT_NO_LOOKAHEAD");
       if ((rc = plan.build(h_blks, panel, lookahead))) return rc;
+      if ((rc = sweep.build(h_blks, nullptr))) return rc;
       if (lookahead) {
          int prio_lo = 0, prio_hi = 0;
          HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -1553,7 +1629,9 @@ struct DenseLdl {
       return PIPS_OK;
    }
    TailCtx ctx() {
-      return TailCtx{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
+      TailCtx c{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
+      c.sweep = &sweep;
+      return c;
    }
 
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)

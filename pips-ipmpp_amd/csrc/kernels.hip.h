@@ -1284,8 +1284,12 @@ __global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__
 // (profiles/r2_gemm_experiments.txt, sweeps): Winv tile of the diagonal workgroup prefetched into registers (256 VGPRs, one wave
 // per SIMD: +10 %) or into the L2 by touching its lines (+7 %: the extra requests queue in front of the tiles everybody waits for).
 __device__ __forceinline__ void tile_load_half(double (&m)[64], const double* __restrict__ M, long long ldm, int row, int half) {
+   const double* pc = M + row + (long long)(half * 64) * ldm;   // one running address, not 64 precomputed ones (128 VGPRs)
 #pragma unroll
-   for (int c = 0; c < 64; ++c) m[c] = M[row + (long long)(half * 64 + c) * ldm];
+   for (int c = 0; c < 64; ++c) {
+      m[c] = *pc;
+      pc += ldm;
+   }
 }
 __device__ __forceinline__ double tile_dot_half(const double (&m)[64], const double* v, int half) {
    double s = 0.0;
@@ -1351,9 +1355,12 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ t
 typedef double tg_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void tile_tload(tg_d2 (&m)[32], const double* __restrict__ M, long long ldm, int tid) {
    const int lane = tid & 63, w = tid >> 6;
-   const double* col0 = M + 2 * lane + (long long)(w * 32) * ldm;
+   const double* pc = M + 2 * lane + (long long)(w * 32) * ldm;
 #pragma unroll
-   for (int e = 0; e < 32; ++e) m[e] = *(const tg_d2*)(col0 + (long long)e * ldm);
+   for (int e = 0; e < 32; ++e) {
+      m[e] = *(const tg_d2*)pc;
+      pc += ldm;
+   }
 }
 __device__ __forceinline__ void tile_tdot(const tg_d2 (&m)[32], const double* v, double* out, int tid) {
    const int lane = tid & 63, w = tid >> 6;
@@ -1420,6 +1427,188 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ t
       if (tid < TILE) acc = outp[tid];
    }
    if (tid < TILE) xt[tj * TILE + tid] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail sweeps as ONE launch (k_tail_rows_fwd / k_tail_rows_bwd).  The column-at-a-time kernels above cost a launch per tile
+// column: 7.5 us of fixed cost each (35 per sweep at config 2, a quarter of the sweep; 125 for a root of 16 000) on top of the
+// bytes.  Here a workgroup owns one tile ROW (forward) or tile COLUMN (backward) of one block for the whole sweep: it walks
+// along its tiles, waits for the piece of the solution each one needs (a flag per tile column of the block, set by the workgroup
+// that owns that piece), and finally computes and publishes its own piece.  The next tile is requested before the wait, so the
+// stream of L overlaps the dependency chain instead of alternating with it.
+// Progress without co-residency: workgroups take a ticket when they start and the ticket, not blockIdx, picks the task; the
+// task list is sorted so that a task only ever waits for tasks with smaller tickets - whoever holds the smallest unfinished
+// ticket is running and waits for nobody, so the sweep completes whatever share of the chip the launch gets (other
+// processes on the device included).  A wait that exceeds ~10^7 polls gives up, raises *err and poisons its output with NaN.
+// Arithmetic and summation order are those of k_tail_fwd / k_tail_bwd: the results are bit-identical to the launch-per-column path.
+// ------------------------------------------------------------------------------------------------
+struct SweepArgs {
+   const TileTask* tasks;        // (blk, ti = row): sorted by row, then block
+   int n_tasks;
+   int* ticket;                  // [0] next ticket, [1] finished workgroups (the last one resets both)
+   int* flags;                   // one per (block, tile column): == epoch when that piece of the solution is final
+   const long long* flag_off;    // per block
+   const int* tfirst;            // per (block, tile row): first tile column inside the envelope; nullptr = 0
+   const long long* tfirst_off;
+   int epoch;
+   int* err;
+};
+constexpr long long SWEEP_POLL_LIMIT = 20000000;
+
+__device__ __forceinline__ bool sweep_wait(const int* f, int epoch) {
+   // No agent-scope fence anywhere in the sweeps: an acquire invalidates and a release writes back the whole L2 of the XCD,
+   // thousands of times per sweep (measured: 1.45 ms per sweep with the fences against 1.1 ms for the launch-per-column
+   // kernels).  Flags and solution pieces are written and read with agent-scope atomics, which go past the caches; everything
+   // else a workgroup reads during the sweep was written before the launch.
+   long long spins = 0;
+   while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > SWEEP_POLL_LIMIT) return false;
+   }
+   return true;
+}
+// ticket -> task; every thread of the workgroup gets the same answer
+__device__ __forceinline__ int sweep_ticket(const SweepArgs& a, int* sh) {
+   if (threadIdx.x == 0) *sh = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   __syncthreads();
+   return *sh;
+}
+__device__ __forceinline__ void sweep_done(const SweepArgs& a) {
+   if (threadIdx.x == 0) {
+      const int d = __hip_atomic_fetch_add(a.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == a.n_tasks - 1) {   // everybody has taken a ticket and finished: ready for the next launch
+         __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(a.ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+   }
+}
+__device__ __forceinline__ double sweep_load(const double* p) {   // a value another workgroup of this launch has written
+   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sweep_store(double* p, double x) {   // ... and one this workgroup publishes
+   __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every wave waits until its stores have been acknowledged (the agent-scope ones are written through), then the flag goes up.
+// The wait is explicit: a workgroup-scope release does not emit one, and without it the flag overtakes the data.
+__device__ __forceinline__ void sweep_publish(int* flag, int epoch) {
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   __syncthreads();
+   if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double sweep_nan() { return __builtin_nan(""); }
+
+__global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
+                                                      double* __restrict__ xw) {
+   __shared__ double v[TILE];
+   __shared__ double part[TILE];
+   __shared__ int sh_t, sh_ok;
+   const int t = sweep_ticket(a, &sh_t);
+   const TileTask task = a.tasks[t];
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, row = tid & 127, half = tid >> 7, i = task.ti, ld = bd.ldT;
+   double* xt = xw + bd.xw_off + bd.n_head;
+   int* fl = a.flags + a.flag_off[task.blk];
+   const int j0 = a.tfirst ? min(i, a.tfirst[a.tfirst_off[task.blk] + i]) : 0;
+   const double* Lrow = arena + bd.T + (long long)i * TILE;
+   double acc = half == 0 ? xt[i * TILE + row] : 0.0;
+   double m[64];
+   bool ok = true;
+   if (j0 < i) {
+      tile_load_half(m, Lrow + (long long)j0 * TILE * ld, ld, row, half);
+      for (int j = j0;; ++j) {
+         if (tid == 0) sh_ok = sweep_wait(fl + j, a.epoch) ? 1 : 0;
+         __syncthreads();
+         if (!sh_ok) { ok = false; break; }
+         if (tid < TILE) v[tid] = sweep_load(xt + j * TILE + tid) * dtail[bd.dt_off + j * TILE + tid];
+         __syncthreads();
+         const double s = tile_dot_half(m, v, half);
+         if (half == 1) part[row] = s;
+         __syncthreads();
+         if (half == 0) acc -= s + part[row];
+         if (j + 1 >= i) break;
+         // the same registers take the next tile, which is then on its way while this workgroup waits for the next piece
+         __builtin_amdgcn_sched_barrier(0);
+         tile_load_half(m, Lrow + (long long)(j + 1) * TILE * ld, ld, row, half);
+      }
+   }
+   if (ok) {
+      __syncthreads();
+      if (half == 0) v[row] = acc;
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      tile_load_half(m, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, row, half);
+      const double s = tile_dot_half(m, v, half);
+      if (half == 1) part[row] = s;
+      __syncthreads();
+      if (half == 0) acc = s + part[row];
+   } else {
+      acc = sweep_nan();
+      if (tid == 0) *a.err = 1;
+   }
+   if (half == 0) sweep_store(xt + i * TILE + row, acc);
+   sweep_publish(fl + i, a.epoch);
+   sweep_done(a);
+}
+
+// backward: the workgroup owns tile column i:  x_i = Winv_i^T ( d_i ( z_i - sum_{k > i} L(k,i)^T x_k ) ), k descending
+__global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+                                                      const double* __restrict__ dtail, const double* __restrict__ winv,
+                                                      double* __restrict__ xw) {
+   __shared__ double v[TILE];
+   __shared__ double outp[TILE];
+   __shared__ int sh_t, sh_ok;
+   const int t = sweep_ticket(a, &sh_t);
+   const TileTask task = a.tasks[a.n_tasks - 1 - t];   // last tile column first
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, i = task.ti, ld = bd.ldT;
+   double* xt = xw + bd.xw_off + bd.n_head;
+   int* fl = a.flags + a.flag_off[task.blk];
+   const int* tf = a.tfirst ? a.tfirst + a.tfirst_off[task.blk] : nullptr;
+   const double* Lcol = arena + bd.T + (long long)i * TILE * ld;
+   // tile rows k > i whose envelope reaches column i, from the last one down
+   auto next_k = [&](int k) {
+      while (k > i && tf && tf[k] > i) --k;
+      return k;
+   };
+   double acc = tid < TILE ? xt[i * TILE + tid] : 0.0;
+   const double dsc = tid < TILE ? dtail[bd.dt_off + i * TILE + tid] : 0.0;
+   tg_d2 m[32];
+   int k = next_k(bd.ntc - 1);
+   bool ok = true;
+   if (k > i) {
+      tile_tload(m, Lcol + (long long)k * TILE, ld, tid);
+      for (;;) {
+         if (tid == 0) sh_ok = sweep_wait(fl + k, a.epoch) ? 1 : 0;
+         __syncthreads();
+         if (!sh_ok) { ok = false; break; }
+         if (tid < TILE) v[tid] = sweep_load(xt + k * TILE + tid);
+         __syncthreads();
+         tile_tdot(m, v, outp, tid);
+         __syncthreads();
+         if (tid < TILE) acc -= outp[tid];
+         k = next_k(k - 1);
+         if (k <= i) break;
+         __builtin_amdgcn_sched_barrier(0);
+         tile_tload(m, Lcol + (long long)k * TILE, ld, tid);
+      }
+   }
+   if (ok) {
+      __syncthreads();
+      if (tid < TILE) v[tid] = acc * dsc;
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      tile_tload(m, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, tid);
+      tile_tdot(m, v, outp, tid);   // x[c] = sum_n Winv[n][c] v[n]
+      __syncthreads();
+      if (tid < TILE) acc = outp[tid];
+   } else {
+      acc = sweep_nan();
+      if (tid == 0) *a.err = 1;
+   }
+   if (tid < TILE) sweep_store(xt + i * TILE + tid, acc);
+   sweep_publish(fl + i, a.epoch);
+   sweep_done(a);
 }
 
 // ------------------------------------------------------------------------------------------------
