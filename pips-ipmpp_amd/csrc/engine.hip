@@ -289,6 +289,7 @@ struct TailCtx {
    // update launch takes the next slot
    int* d_ctr_pool = nullptr;
    int* ctr_cursor = nullptr;
+   bool balanced = false;               // k_tile_gemm_bal: tasks drawn from per-XCD counters, an eighth more workgroups than tasks
    // deterministic Schur accumulation (Engine::set_det_groups): the blocks are cut into at most eight contiguous groups with a
    // buffer each; round k of the SYRK handles the k-th block of every group, so a launch never has two workgroups on the same
    // entry of a buffer and the blocks of a group arrive in their order; k_reduce_groups then adds the buffers in a fixed tree
@@ -312,6 +313,12 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    auto gemm0 = [&](const TaskList& l, hipStream_t st) {
       const bool persist = c.d_ctr_pool && l.cnt >= GEMM_PERSIST_MIN_TASKS && *c.ctr_cursor < GEMM_CTR_SLOTS;
       int* ctr = persist ? c.d_ctr_pool + 8 * (*c.ctr_cursor)++ : nullptr;
+      if (persist && c.balanced && !c.is_root) {
+         const int wgs = ((l.cnt + 7) / 8 * 8) / 8 * 9;
+         hipLaunchKernelGGL(k_tile_gemm_bal<0>, dim3((wgs + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail,
+                            c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
+         return;
+      }
       if (c.is_root) {
          if (persist)
             hipLaunchKernelGGL(k_tile_gemm_persist<3>, dim3(512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
@@ -414,6 +421,12 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
                                c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena);
          HIP_TRY(hipEventRecord((*c.ev_sc)[g], c.stream));
       }
+      if (c.timer) c.timer->end(c.stream);
+   } else if (SC && p.schur.cnt > 0 && c.balanced && c.d_ctr_pool && !c.d_sctab && *c.ctr_cursor < GEMM_CTR_SLOTS) {
+      if (c.timer) c.timer->begin(c.stream, 5);
+      const int wgs = ((p.schur.cnt + 7) / 8 * 8) / 8 * 9;
+      hipLaunchKernelGGL(k_tile_gemm_bal<2>, dim3((wgs + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
+                         c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena, c.d_ctr_pool + 8 * (*c.ctr_cursor)++);
       if (c.timer) c.timer->end(c.stream);
    } else if (SC && p.schur.cnt > 0) {
       if (c.timer) c.timer->begin(c.stream, 5);
@@ -674,6 +687,7 @@ struct Engine {
    double* d_bt_tmp = nullptr;
    int* d_gemm_ctr = nullptr;     // counter slots of the persistent update kernel
    int gemm_ctr_cursor = 0;
+   bool balanced_gemm = true;      // k_tile_gemm_bal for launches of >= 1024 tiles (PIPS_HIP_BALANCED_GEMM=0: static shares)
    bool persistent_gemm = false;   // measured: no gain, and it starves the side stream (see k_tile_gemm_persist); PIPS_HIP_PERSISTENT_GEMM=1
    // ---- Schur SYRK in row-panel groups, so that a multi-rank root can reduce panel p while the leaves still compute p + 1 ..
    std::vector<TaskList> sc_groups;
@@ -718,7 +732,7 @@ struct Engine {
       TailCtx c{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
                 timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
       if (!sc_groups.empty()) { c.sc_groups = &sc_groups; c.d_sc_tasks = d_sc_tasks; c.ev_sc = &ev_sc; }
-      if (persistent_gemm) { c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor; }
+      if (persistent_gemm || balanced_gemm) { c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor; c.balanced = balanced_gemm; }
       if (deterministic && d_gbuf) {
          c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = (long long)S * S; c.d_blk_group = d_blk_group;
          c.n_groups = det_n_groups; c.first_slot = det_first_slot;
@@ -787,6 +801,7 @@ struct Engine {
       apply_tuning(opt);
       if (const char* sm = getenv("PIPS_HIP_SCHUR_MODE")) schur_mode = atoi(sm);
       if (const char* pg = getenv("PIPS_HIP_PERSISTENT_GEMM")) persistent_gemm = atoi(pg) != 0;
+      if (const char* bg = getenv("PIPS_HIP_BALANCED_GEMM")) balanced_gemm = atoi(bg) != 0;
       bool any_border = false;
       for (int b = 0; b < nblk; ++b) any_border = any_border || !in[b].btrow.empty();
       int rc = analyze_host(n_threads, schur_mode != 2);
@@ -1253,7 +1268,7 @@ struct Engine {
       hipLaunchKernelGGL(k_block_absmax_finish, dim3((nblk + 255) / 256), dim3(256), 0, stream, d_blks, nblk, thr_rel, repl_rel);
       hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
-      if (persistent_gemm) {
+      if (persistent_gemm || balanced_gemm) {
          if (!d_gemm_ctr) HIP_TRY(hipMalloc((void**)&d_gemm_ctr, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int)));
          HIP_TRY(hipMemsetAsync(d_gemm_ctr, 0, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int), stream));
          gemm_ctr_cursor = 0;

@@ -256,6 +256,18 @@ __global__ void k_leaf_diag(long long nleaf, const long long* __restrict__ code,
    }
 }
 
+// diagonals of the REGULARISED system the factors belong to: x rows ddp + reg, equality rows -(dual_reg + reg), inequality rows
+// nOmegaInv - reg (k_leaf_diag / pips_hip_kkt_set_root_regularization put the same terms into the factorised matrix)
+__global__ void k_reg_operator(long long nx, long long my, long long mz, const double* __restrict__ ddp, const double* __restrict__ dyz,
+                               double reg, double dual_reg, double* __restrict__ dop_r, double* __restrict__ dyz_r) {
+   const long long n = nx > my + mz ? nx : my + mz;
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+      if (i < nx) dop_r[i] = ddp[i] + reg;
+      if (i < my) dyz_r[i] = -(dual_reg + reg);
+      else if (i < my + mz) dyz_r[i] = dyz[i] - reg;
+   }
+}
+
 // LinearSystem::solve, reduction of the right-hand side (LinearSystem.C:327-395) for one residual set:
 //   rx = rQ + G/V rv + rgamma/V + Phi/W rw - rphi/W ; rs = rz + L/T rt + rlambda/T + Pi/U ru - rpi/U ; rhs = [rx | rA | rC - nOmegaInv rs]
 // zero_lin: the linear residuals (rQ, rA, rC, rz, rt, ru, rv, rw) are zero (corrector / Gondzio right-hand sides:
@@ -549,6 +561,7 @@ struct Ipm {
    Vars it, st, co, best;
    double *rQ = nullptr, *rAC = nullptr, *rz = nullptr, *rG = nullptr, *rL = nullptr, *rs = nullptr;
    double *dd = nullptr, *ddp = nullptr, *dyz = nullptr, *leaf_diag = nullptr, *b0 = nullptr, *bl = nullptr;
+   double *dop_r = nullptr, *dyz_r = nullptr;   // diagonals of the regularised system (k_reg_operator)
    double *rhs = nullptr, *sol = nullptr, *w_r = nullptr, *w_r0 = nullptr, *w_best = nullptr, *w_v = nullptr, *w_t = nullptr, *w_p = nullptr,
           *w_dx = nullptr, *w_tmp = nullptr;
    double *d_partial = nullptr, *d_out = nullptr, *h_out = nullptr, *d_bst = nullptr, *h_bst = nullptr;
@@ -737,6 +750,8 @@ struct Ipm {
          ++n_regularised;
       }
       last_reg = reg;
+      hipLaunchKernelGGL(k_reg_operator, dim3(egrid(std::max<long long>(nx, (long long)my + mz))), dim3(256), 0, stream, (long long)nx, (long long)my,
+                         (long long)mz, ddp, dyz, reg, dual_reg, dop_r, dyz_r);
       return PIPS_OK;
    }
 
@@ -753,16 +768,24 @@ struct Ipm {
    // outer solve runs on the primal-regularised system (the reference's choice when OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM is off,
    // LinearSystem.C:505-512 use_regularized_system) - a proximal-point step centred at the current iterate.  Off by default:
    // it made no difference to the 2 % of seeded LPs with free variables that end with status 3 (tools/native_sweep.py).
-   const double* dop() const { return free_in_operator ? ddp : dd; }
+   // reg_operator: the outer solve runs on the system the factors belong to (primal and dual regularisation included), i.e. the
+   // step is a regularised Newton step.  Switched on for the rest of an IPM iteration once an outer solve on the original system
+   // has failed: with dependent equality rows the original K is singular, its null-space component of y is whatever rounding
+   // makes of it and the preconditioner (eigenvalue 1 / dual_reg there) blows it up to 1e12 - the GAMSsmall instance
+   // hier_approach_4blocks_2by3 went wrong that way in 3 % of its runs.
+   const double* dop() const { return reg_operator ? dop_r : (free_in_operator ? ddp : dd); }
+   const double* dyzop() const { return reg_operator ? dyz_r : dyz; }
    bool free_in_operator = false;
+   bool reg_operator = false, reg_operator_always = false;
+   int n_reg_operator = 0;
    int kmult(const double* z_, double* out, const int* pred = nullptr) {
       TRY((spmv<SP_KX>(true, z_ + nx, out, dop(), z_, nullptr, nullptr, pred)));
-      TRY((spmv<SP_KYZ>(false, z_, out + nx, dyz, z_ + nx, nullptr, nullptr, pred)));
+      TRY((spmv<SP_KYZ>(false, z_, out + nx, dyzop(), z_ + nx, nullptr, nullptr, pred)));
       return PIPS_OK;
    }
    int kresidual(const double* rhs_, const double* z_, double* r, const int* pred = nullptr) {   // r = rhs - K z
       TRY((spmv<SP_RES_X>(true, z_ + nx, r, dop(), z_, rhs_, nullptr, pred)));
-      TRY((spmv<SP_RES_YZ>(false, z_, r + nx, dyz, z_ + nx, rhs_ + nx, nullptr, pred)));
+      TRY((spmv<SP_RES_YZ>(false, z_, r + nx, dyzop(), z_ + nx, rhs_ + nx, nullptr, pred)));
       return PIPS_OK;
    }
    // device-side reduction for BiCGStab: results to st[B_RED0 ..], summed over the ranks
@@ -931,8 +954,10 @@ struct Ipm {
          else TRY(iter_refine(rhs, sol));
          const bool reached = last_outer_res <= std::max(1e3 * outer_tol, 1e-7) || last_outer_abs <= 1e-12;
          if (!regularize || retry == 5 || reached || last_reg >= 0.5 * reg_max) break;   // more regularisation than reg_max only ruins the preconditioner
-         if (verbose_run) printf("   outer solve stopped at rel.res %.1e: factorising again with regularisation\n", last_outer_res);
+         if (verbose_run) printf("   outer solve stopped at rel.res %.1e: factorising again with regularisation%s\n", last_outer_res,
+                                 reg_operator ? "" : ", outer solve on the regularised system from here");
          ++n_refactor_outer;
+         if (!reg_operator) { reg_operator = true; ++n_reg_operator; }
          TRY(factorize(last_reg > 0.0 ? std::min(last_reg * 100.0, reg_max) : 1e-8));
       }
       hipLaunchKernelGGL(k_recover, dim3(egrid(std::max(std::max(nx, mz), my))), dim3(256), 0, stream, lay, zero_lin ? 1 : 0, sol, rs, rG, rL, it.G, it.L,
@@ -1068,6 +1093,8 @@ struct Ipm {
       double rnorm, pobj, dobj, m;
       TRY(residuals(&rnorm, &pobj, &dobj, &m));
       compl_rhs(0, 0, 0, 0, 0, 0);
+      reg_operator = reg_operator_always;
+      n_reg_operator = 0;
       TRY(factorize());
       TRY(solve(false, st));
       TRY(pips_hip_vec_axpy(NP + ND, 1.0, st.base, it.base, stream));
@@ -1132,6 +1159,7 @@ struct Ipm {
          outer_tol = iter <= 3 ? 1e-8 : (iter <= 7 ? 1e-9 : 1e-10);   // InteriorPointMethod.cpp:655-669
          // ---- predictor (affine scaling): complementarity residual = products of the pairs
          compl_rhs(0, 0, 0, 0, 0, 0);
+         reg_operator = reg_operator_always;   // every iteration starts on the original system
          TRY(factorize());
          TRY(solve(false, st));
          double ap, ad, maff;
@@ -1391,7 +1419,7 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    p->it.bind(bases[0], nx, my, mz, p->ncp); p->st.bind(bases[1], nx, my, mz, p->ncp);
    p->co.bind(bases[2], nx, my, mz, p->ncp); p->best.bind(bases[3], nx, my, mz, p->ncp);
    if ((rc = p->alloc(&p->rQ, nx)) || (rc = p->alloc(&p->rAC, (long long)my + mz)) || (rc = p->alloc(&p->rz, mz)) || (rc = p->alloc(&p->rG, p->ncp)) ||
-       (rc = p->alloc(&p->rL, p->ncp)) || (rc = p->alloc(&p->rs, mz)) || (rc = p->alloc(&p->dd, nx)) || (rc = p->alloc(&p->ddp, nx)) ||
+       (rc = p->alloc(&p->rL, p->ncp)) || (rc = p->alloc(&p->rs, mz)) || (rc = p->alloc(&p->dd, nx)) || (rc = p->alloc(&p->ddp, nx)) || (rc = p->alloc(&p->dop_r, nx)) || (rc = p->alloc(&p->dyz_r, (long long)my + mz)) ||
        (rc = p->alloc(&p->dyz, (long long)my + mz)) || (rc = p->alloc(&p->leaf_diag, p->nleaf)))
       return rc;
    double** zs[] = {&p->rhs, &p->sol, &p->w_r, &p->w_r0, &p->w_best, &p->w_v, &p->w_t, &p->w_p, &p->w_dx, &p->w_tmp};
@@ -1562,7 +1590,7 @@ int pips_ipm_set_option(void* handle, const char* name, double value) {
       if (!(value > 0.0)) PIPS_FAIL(PIPS_ERR_ARG, "FREE_VARIABLE_PROXIMAL_TERM must be > 0");
       p->free_reg = value;
    }
-   else if (key == "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM") p->free_in_operator = value == 0.0;   // reference identifier (PIPSIPMppOptions.C)
+   else if (key == "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM") p->free_in_operator = p->reg_operator_always = value == 0.0;   // reference identifier (PIPSIPMppOptions.C)
    else if (key == "FREE_VARIABLE_PROXIMAL_FOLLOWS_MU") p->free_reg_follows_mu = value != 0.0;
    else if (key == "FREE_VARIABLE_PROXIMAL_MIN") p->free_reg_min = value;
    else if (key == "REGULARIZATION_MAX") p->reg_max = value;

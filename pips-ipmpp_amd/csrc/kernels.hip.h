@@ -816,6 +816,40 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
    tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena, gbuf, gstride, blk_group);
 }
 
+// One task per workgroup as above, but the task is drawn from the XCD's counter when the workgroup starts, and a workgroup whose
+// XCD has run dry takes from the others.  The launch has an eighth more workgroups than tasks: the XCDs run at different
+// clocks under this load (1827 .. 1920 MHz on one box: profiles/r2_gemm_experiments.txt) and with equal static shares the
+// slow ones finish 5 % after the fast ones; here the fast XCD's surplus workgroups finish the slow XCDs' slices and the slow
+// XCDs' surplus workgroups find nothing and leave.  Unlike the persistent variant no workgroup outlives its tile, so the
+// diagonal-tile chain on the side stream still gets its slots as tiles retire.
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_tile_gemm_bal(const TileTask* __restrict__ tasks, int n_tasks,
+                                                         const BlkDesc* __restrict__ blks, double* __restrict__ arena,
+                                                         const double* __restrict__ dtail, const double* __restrict__ winv,
+                                                         const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
+                                                         const int* __restrict__ sctab, double* __restrict__ uarena,
+                                                         int* __restrict__ ctr) {
+   __shared__ GemmShared sh;
+   __shared__ int s_tix;
+   if (threadIdx.x == 0) {
+      const int per = (n_tasks + 7) >> 3;
+      const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID[3:0] */) & 7);
+      int got = -1;
+      for (int d = 0; d < 8 && got < 0; ++d) {
+         const int x = (xcc + d) & 7;
+         if (__hip_atomic_load(ctr + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per) continue;   // slice known to be empty
+         const int t = __hip_atomic_fetch_add(ctr + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         const int tix = x * per + t;
+         if (t < per && tix < n_tasks) got = tix;
+      }
+      s_tix = got;
+   }
+   __syncthreads();
+   const int tix = s_tix;
+   if (tix < 0) return;
+   tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena);
+}
+
 // deterministic mode: SC += ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)) over the (at most eight) group buffers, lower triangle.
 // The order is a function of the global block partition only, so one rank with eight groups and two ranks with four groups each
 // followed by the two-operand sum of the all-reduce give the same bits.
