@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -256,7 +257,7 @@ __global__ void k_leaf_diag(long long nleaf, const long long* __restrict__ code,
    }
 }
 
-// diagonals of the REGULARISED system the factors belong to: x rows ddp + reg, equality rows -(dual_reg + reg), inequality rows
+// diagonals of the REGULARISED system the factors belong to: x rows dd (or ddp) + reg, equality rows -(dual_reg + reg), inequality rows
 // nOmegaInv - reg (k_leaf_diag / pips_hip_kkt_set_root_regularization put the same terms into the factorised matrix)
 __global__ void k_reg_operator(long long nx, long long my, long long mz, const double* __restrict__ ddp, const double* __restrict__ dyz,
                                double reg, double dual_reg, double* __restrict__ dop_r, double* __restrict__ dyz_r) {
@@ -735,23 +736,38 @@ struct Ipm {
       const double freg = free_reg_follows_mu ? std::min(free_reg, std::max(cur_mu, free_reg_min)) : free_reg;
       hipLaunchKernelGGL(k_diagonals, dim3(egrid(std::max(nx, mz))), dim3(256), 0, stream, lay, it.G, it.L, M, freg, dd, ddp, dyz);
       double reg = reg_start;
-      for (int attempt = 0;; ++attempt) {
+      // Escalation that does not lower the number of perturbed pivots only ruins the preconditioner (a pivot can be perturbed for
+      // reasons regularisation does not touch): remember the smallest regularisation with the lowest count, stop after two
+      // escalations without progress and go back to it.
+      int best_pert = INT_MAX, stalled = 0;
+      double best_reg = reg;
+      auto factor_with = [&](double r, int* pert) -> int {
          if (nleaf > 0)
-            hipLaunchKernelGGL(k_leaf_diag, dim3(egrid(nleaf)), dim3(256), 0, stream, nleaf, d_code, ddp, dyz + my, reg, dual_reg + reg, reg, leaf_diag);
-         TRY(pips_hip_kkt_set_root_regularization(kkt, reg, dual_reg + reg));
+            hipLaunchKernelGGL(k_leaf_diag, dim3(egrid(nleaf)), dim3(256), 0, stream, nleaf, d_code, ddp, dyz + my, r, dual_reg + r, r, leaf_diag);
+         TRY(pips_hip_kkt_set_root_regularization(kkt, r, dual_reg + r));
          TRY(pips_hip_kkt_factorize(kkt, leaf_diag, ddp, mzl > 0 ? dyz + my + mz0 : nullptr));
          ++n_factorize;
-         int pert;
-         TRY(perturbed_pivots(&pert));
-         if (verbose_run && (pert || reg > 0.0)) printf("   factorize: regularisation %.1e, %d perturbed pivots\n", reg, pert);
-         last_pert = pert;
-         if (pert == 0 || attempt == 4 || !regularize || !eager_inertia_loop || reg >= 0.5 * std::max(reg_eager_max, reg_start)) break;
+         TRY(perturbed_pivots(pert));
+         if (verbose_run && (*pert || r > 0.0)) printf("   factorize: regularisation %.1e, %d perturbed pivots\n", r, *pert);
+         return PIPS_OK;
+      };
+      int pert = 0;
+      for (int attempt = 0;; ++attempt) {
+         TRY(factor_with(reg, &pert));
+         if (pert < best_pert) { best_pert = pert; best_reg = reg; stalled = 0; }
+         else ++stalled;
+         if (pert == 0 || attempt == 4 || stalled >= 2 || !regularize || !eager_inertia_loop || reg >= 0.5 * std::max(reg_eager_max, reg_start)) break;
          reg = reg == 0.0 ? 1e-8 : std::min(reg * 100.0, reg_max);
          ++n_regularised;
       }
+      if (pert > best_pert || (pert == best_pert && best_reg < reg && pert > 0)) {
+         reg = best_reg;
+         TRY(factor_with(reg, &pert));
+      }
+      last_pert = pert;
       last_reg = reg;
       hipLaunchKernelGGL(k_reg_operator, dim3(egrid(std::max<long long>(nx, (long long)my + mz))), dim3(256), 0, stream, (long long)nx, (long long)my,
-                         (long long)mz, ddp, dyz, reg, dual_reg, dop_r, dyz_r);
+                         (long long)mz, free_in_operator ? ddp : dd, dyz, reg, dual_reg, dop_r, dyz_r);
       return PIPS_OK;
    }
 
@@ -768,11 +784,19 @@ struct Ipm {
    // outer solve runs on the primal-regularised system (the reference's choice when OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM is off,
    // LinearSystem.C:505-512 use_regularized_system) - a proximal-point step centred at the current iterate.  Off by default:
    // it made no difference to the 2 % of seeded LPs with free variables that end with status 3 (tools/native_sweep.py).
-   // reg_operator: the outer solve runs on the system the factors belong to (primal and dual regularisation included), i.e. the
-   // step is a regularised Newton step.  Switched on for the rest of an IPM iteration once an outer solve on the original system
-   // has failed: with dependent equality rows the original K is singular, its null-space component of y is whatever rounding
-   // makes of it and the preconditioner (eigenvalue 1 / dual_reg there) blows it up to 1e12 - the GAMSsmall instance
-   // hier_approach_4blocks_2by3 went wrong that way in 3 % of its runs.
+   // reg_operator: the outer solve runs on the REGULARISED system - primal regularisation on x, dual regularisation on the equality
+   // and inequality rows, the terms the factorised matrix carries - i.e. the step is a regularised Newton step.  PIPS-IPM++'s own
+   // default (PIPSIPMppOptions.C:293 OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM false; LinearSystem.C:505 use_regularized_system,
+   // compute_regularized_system_residuals :806-845); option OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM 0 selects it here for every solve.
+   // Default here: the original system first (the reference's known-answer iteration counts are reproduced that way: with
+   // dependent equality rows the regularised step of an instance like parallelEqualityRows_B0A2 needs 6 iterations instead
+   // of 4), and the regularised system for the rest of an IPM iteration as soon as an outer solve on the original one has been long
+   // (> 12 BiCGStab iterations) or inexact: with dependent rows the original K is singular, the null-space component of y is
+   // whatever rounding makes of it, and a long Krylov run with a preconditioner whose eigenvalue there is 1 / dual_reg blows it
+   // up to 1e12 - hier_approach_4blocks_2by3 ended with status 3 / 4 in 3 % of its runs that way.  The switch costs no
+   // factorisation: the factors already belong to the regularised system.
+   // The proximal term of free variables is a device of this preconditioner, not one of the reference's regularisation
+   // diagonals: it enters the operator only with FREE_VARIABLE_PROXIMAL_IN_OPERATOR.
    const double* dop() const { return reg_operator ? dop_r : (free_in_operator ? ddp : dd); }
    const double* dyzop() const { return reg_operator ? dyz_r : dyz; }
    bool free_in_operator = false;
@@ -953,11 +977,17 @@ struct Ipm {
          if (outer_mode == 2) TRY(bicgstab(rhs, sol));
          else TRY(iter_refine(rhs, sol));
          const bool reached = last_outer_res <= std::max(1e3 * outer_tol, 1e-7) || last_outer_abs <= 1e-12;
-         if (!regularize || retry == 5 || reached || last_reg >= 0.5 * reg_max) break;   // more regularisation than reg_max only ruins the preconditioner
-         if (verbose_run) printf("   outer solve stopped at rel.res %.1e: factorising again with regularisation%s\n", last_outer_res,
-                                 reg_operator ? "" : ", outer solve on the regularised system from here");
+         if (regularize && !reg_operator && (last_outer_steps > 12 || !(last_outer_res <= std::max(10.0 * outer_tol, 1e-9) || last_outer_abs <= 1e-12))) {
+            // long or inexact on the original system: same factors, regularised system (see reg_operator)
+            if (verbose_run) printf("   outer solve on the original system: %d iterations, rel.res %.1e - repeating it on the regularised system\n",
+                                    last_outer_steps, last_outer_res);
+            reg_operator = true;
+            ++n_reg_operator;
+            continue;
+         }
+         if (!regularize || retry >= 5 || reached || last_reg >= 0.5 * reg_max) break;   // more regularisation than reg_max only ruins the preconditioner
+         if (verbose_run) printf("   outer solve stopped at rel.res %.1e: factorising again with regularisation\n", last_outer_res);
          ++n_refactor_outer;
-         if (!reg_operator) { reg_operator = true; ++n_reg_operator; }
          TRY(factorize(last_reg > 0.0 ? std::min(last_reg * 100.0, reg_max) : 1e-8));
       }
       hipLaunchKernelGGL(k_recover, dim3(egrid(std::max(std::max(nx, mz), my))), dim3(256), 0, stream, lay, zero_lin ? 1 : 0, sol, rs, rG, rL, it.G, it.L,
@@ -1590,7 +1620,8 @@ int pips_ipm_set_option(void* handle, const char* name, double value) {
       if (!(value > 0.0)) PIPS_FAIL(PIPS_ERR_ARG, "FREE_VARIABLE_PROXIMAL_TERM must be > 0");
       p->free_reg = value;
    }
-   else if (key == "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM") p->free_in_operator = p->reg_operator_always = value == 0.0;   // reference identifier (PIPSIPMppOptions.C)
+   else if (key == "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM") p->reg_operator_always = p->reg_operator = value == 0.0;   // reference identifier (PIPSIPMppOptions.C:293: false)
+   else if (key == "FREE_VARIABLE_PROXIMAL_IN_OPERATOR") p->free_in_operator = value != 0.0;
    else if (key == "FREE_VARIABLE_PROXIMAL_FOLLOWS_MU") p->free_reg_follows_mu = value != 0.0;
    else if (key == "FREE_VARIABLE_PROXIMAL_MIN") p->free_reg_min = value;
    else if (key == "REGULARIZATION_MAX") p->reg_max = value;
