@@ -542,6 +542,7 @@ struct Ipm {
    hipStream_t stream = nullptr;
    // dimensions
    int N = 0, n0 = 0, my0 = 0, mz0 = 0, myl = 0, mzl = 0;
+   int e_mz0 = 0, e_mzl = 0;   // what the KKT engine is told: root inequality rows either eliminated (e_mz0 = mz0) or kept as rows among the linking inequalities
    int nx = 0, my = 0, mz = 0;
    long long ncp = 0, nxyz = 0, NP = 0, ND = 0, nleaf = 0;
    int S = 0;
@@ -745,7 +746,7 @@ struct Ipm {
          if (nleaf > 0)
             hipLaunchKernelGGL(k_leaf_diag, dim3(egrid(nleaf)), dim3(256), 0, stream, nleaf, d_code, ddp, dyz + my, r, dual_reg + r, r, leaf_diag);
          TRY(pips_hip_kkt_set_root_regularization(kkt, r, dual_reg + r));
-         TRY(pips_hip_kkt_factorize(kkt, leaf_diag, ddp, mzl > 0 ? dyz + my + mz0 : nullptr));
+         TRY(pips_hip_kkt_factorize(kkt, leaf_diag, ddp, e_mzl > 0 ? dyz + my + e_mz0 : nullptr));
          ++n_factorize;
          TRY(perturbed_pivots(pert));
          if (verbose_run && (*pert || r > 0.0)) printf("   factorize: regularisation %.1e, %d perturbed pivots\n", r, *pert);
@@ -1251,7 +1252,18 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    p->ncp = 2LL * mz + 2LL * nx; p->nxyz = (long long)nx + my + mz;
    p->NP = nx + mz + p->ncp; p->ND = my + mz + p->ncp;
    p->lay = Lay{nx, my, mz, p->ncp};
-   const int S = n0 + my0 + myl + mzl;
+   // Root inequality rows C0 x0 - s = ...: the reference eliminates them from the root system (-C0^T Omega^-1 C0 on the x0 block,
+   // sLinsysRootAug.C:1276-1294) and leaves the rest to Bunch-Kaufman.  With static pivots that is a trap: an active row has
+   // Omega^-1 ~ 1e14, the x0 block becomes a huge rank-one matrix plus the O(1) rest, the second pivot of that block is the
+   // difference of two 1e14 numbers and is (rightly) reported as perturbed at every regularisation - the preconditioner is gone
+   // (seeded general LPs: 2 % ended with status 3).  So the harness keeps these rows in the root system, as rows of the
+   // linking-inequality kind with no leaf part: diagonal nOmegaInv, pivots -(|nOmegaInv| + reg + C0 D0^-1 C0^T), no cancellation.
+   // PIPS_IPM_ROOT_INEQ_ELIMINATE=1 restores the elimination (pips_hip_kkt_set_root_inequalities).
+   const bool eliminate_z0 = getenv("PIPS_IPM_ROOT_INEQ_ELIMINATE") && atoi(getenv("PIPS_IPM_ROOT_INEQ_ELIMINATE")) != 0;
+   p->e_mz0 = eliminate_z0 ? mz0 : 0;
+   p->e_mzl = eliminate_z0 ? mzl : mz0 + mzl;
+   const int e_mz0 = p->e_mz0, e_mzl = p->e_mzl;
+   const int S = n0 + my0 + myl + e_mzl;
    p->S = S;
    int rc = pips_hip_batch_create(&p->batch, N, S, device, nullptr);
    if (rc) return rc;
@@ -1302,14 +1314,23 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
       if (rc) return rc;
       std::vector<int> Brd(S + 1);
       auto P3 = [](const View& m) { return m; };
-      const View a_ = P3(A), c_ = P3(Cm), f_ = P3(BL), g_ = P3(DL);
-      rc = pips_border_assemble(nxi, myi, mzi, n0, my0, myl, mzl, nullptr, nullptr, nullptr, present(a_) ? a_.rp : nullptr, a_.ci, a_.v,
+      const View a_ = P3(A), c_ = P3(Cm), f_ = P3(BL);
+      View g_ = P3(DL);
+      std::vector<int> g_rp;
+      if (e_mzl != mzl && present(g_)) {   // root inequality rows ride among the linking inequalities: no leaf part
+         g_rp.assign((size_t)e_mzl + 1, 0);
+         for (int r = 0; r <= mzl; ++r) g_rp[(size_t)(e_mzl - mzl) + r] = g_.rp[r] - g_.rp[0];
+         g_.ci += g_.rp[0]; g_.v += g_.rp[0];
+         g_.rp = g_rp.data();
+         g_.rows = e_mzl;
+      }
+      rc = pips_border_assemble(nxi, myi, mzi, n0, my0, myl, e_mzl, nullptr, nullptr, nullptr, present(a_) ? a_.rp : nullptr, a_.ci, a_.v,
                                 present(c_) ? c_.rp : nullptr, c_.ci, c_.v, present(f_) ? f_.rp : nullptr, f_.ci, f_.v,
                                 present(g_) ? g_.rp : nullptr, g_.ci, g_.v, Brd.data(), nullptr, nullptr);
       if (rc) return rc;
       std::vector<int> Bci(Brd[S]);
       std::vector<double> Bv(Brd[S]);
-      rc = pips_border_assemble(nxi, myi, mzi, n0, my0, myl, mzl, nullptr, nullptr, nullptr, present(a_) ? a_.rp : nullptr, a_.ci, a_.v,
+      rc = pips_border_assemble(nxi, myi, mzi, n0, my0, myl, e_mzl, nullptr, nullptr, nullptr, present(a_) ? a_.rp : nullptr, a_.ci, a_.v,
                                 present(c_) ? c_.rp : nullptr, c_.ci, c_.v, present(f_) ? f_.rp : nullptr, f_.ci, f_.v,
                                 present(g_) ? g_.rp : nullptr, g_.ci, g_.v, Brd.data(), Bci.data(), Bv.data());
       if (rc) return rc;
@@ -1385,13 +1406,30 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    for (int i = 0; i < N; ++i)
       if ((rc = pips_hip_batch_set_values(p->batch, i, kvals[i].data()))) return rc;
    if ((rc = pips_hip_batch_set_refinement_backward_error(p->batch, 2, 1e-15))) return rc;   // PARDISO iparm[7]=2 semantics
-   const View A0 = view(root.A), F0 = view(root.BL), G0 = view(root.DL), C0 = view(root.C);
+   const View A0 = view(root.A), F0 = view(root.BL), C0 = view(root.C);
+   View G0 = view(root.DL);
+   std::vector<int> g0_rp, g0_ci;
+   std::vector<double> g0_v;
+   if (e_mzl != mzl) {   // G0' = [C0; G0]
+      g0_rp.assign(1, 0);
+      const View G0in = G0;
+      for (const View* m : {&C0, &G0in}) {
+         const int nr = m == &C0 ? mz0 : mzl;
+         for (int r = 0; r < nr; ++r) {
+            if (present(*m))
+               for (int q = m->rp[r]; q < m->rp[r + 1]; ++q) { g0_ci.push_back(m->ci[q]); g0_v.push_back(m->v[q]); }
+            g0_rp.push_back((int)g0_ci.size());
+         }
+      }
+      g0_ci.push_back(0); g0_v.push_back(0.0);   // never empty arrays
+      G0.rows = e_mzl; G0.cols = n0; G0.rp = g0_rp.data(); G0.ci = g0_ci.data(); G0.v = g0_v.data();
+   }
    auto rp = [](const View& m) { return present(m) ? m.rp : nullptr; };
    if (sparse_root)
-      rc = pips_hip_kkt_create_sparse(&p->kkt, p->batch, n0, my0, myl, mzl, rp(A0), A0.ci, A0.v, rp(F0), F0.ci, F0.v, rp(G0), G0.ci, G0.v, 0, nullptr,
+      rc = pips_hip_kkt_create_sparse(&p->kkt, p->batch, n0, my0, myl, e_mzl, rp(A0), A0.ci, A0.v, rp(F0), F0.ci, F0.v, rp(G0), G0.ci, G0.v, 0, nullptr,
                                       nullptr, p->comm, p->rank, p->n_ranks);
    else
-      rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, my0, myl, mzl, rp(A0), A0.ci, A0.v, rp(F0), F0.ci, F0.v, rp(G0), G0.ci, G0.v, p->comm, p->rank,
+      rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, my0, myl, e_mzl, rp(A0), A0.ci, A0.v, rp(F0), F0.ci, F0.v, rp(G0), G0.ci, G0.v, p->comm, p->rank,
                                p->n_ranks);
    if (rc) return rc;
    HIP_TRYH(hipGetDevice(&p->device));
@@ -1407,12 +1445,12 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    // ---- maps: KKT right-hand sides <- [x|y|z], leaf diagonal codes
    {
       std::vector<long long> pack;
-      pack.reserve((size_t)S + mz0 + p->nleaf);
+      pack.reserve((size_t)S + e_mz0 + p->nleaf);
       for (int k = 0; k < n0; ++k) pack.push_back(k);
       for (int k = 0; k < my0; ++k) pack.push_back((long long)nx + k);
-      for (int k = 0; k < mz0; ++k) pack.push_back((long long)nx + my + k);
+      for (int k = 0; k < e_mz0; ++k) pack.push_back((long long)nx + my + k);
       for (int k = 0; k < myl; ++k) pack.push_back((long long)nx + my0 + k);
-      for (int k = 0; k < mzl; ++k) pack.push_back((long long)nx + my + mz0 + k);
+      for (int k = 0; k < e_mzl; ++k) pack.push_back((long long)nx + my + e_mz0 + k);   // [z0 | zlink] is contiguous in the harness' z order
       std::vector<long long> code;
       code.reserve(p->nleaf);
       for (int i = 1; i <= N; ++i) {
@@ -1423,8 +1461,8 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
       p->npack = (long long)pack.size();
       if ((rc = p->up(&p->d_pack, pack)) || (rc = p->up(&p->d_code, code))) return rc;
    }
-   if (mz0 > 0) {
-      if ((rc = pips_hip_kkt_set_root_inequalities(p->kkt, mz0, C0.rp, C0.ci, C0.v))) return rc;
+   if (e_mz0 > 0) {
+      if ((rc = pips_hip_kkt_set_root_inequalities(p->kkt, e_mz0, C0.rp, C0.ci, C0.v))) return rc;
    }
    {
       std::vector<int> la, lat;
@@ -1455,8 +1493,8 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    double** zs[] = {&p->rhs, &p->sol, &p->w_r, &p->w_r0, &p->w_best, &p->w_v, &p->w_t, &p->w_p, &p->w_dx, &p->w_tmp};
    for (auto d : zs)
       if ((rc = p->alloc(d, p->nxyz))) return rc;
-   if ((rc = p->alloc(&p->b0, (long long)S + mz0 + p->nleaf))) return rc;   // [b0 | leaves] in one array (one gather / scatter)
-   p->bl = p->b0 + S + mz0;
+   if ((rc = p->alloc(&p->b0, (long long)S + e_mz0 + p->nleaf))) return rc;   // [b0 | leaves] in one array (one gather / scatter)
+   p->bl = p->b0 + S + e_mz0;
    if ((rc = p->alloc(&p->d_partial, (long long)RED_MAX * RED_GRID)) || (rc = p->alloc(&p->d_out, 2 * RED_MAX)) || (rc = p->alloc(&p->d_bst, B_SLOTS)))
       return rc;
    HIP_TRYH(hipHostMalloc((void**)&p->h_out, 2 * RED_MAX * sizeof(double), hipHostMallocDefault));
@@ -1464,7 +1502,7 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    HIP_TRYH(hipMalloc((void**)&p->d_pred, P_COUNT * sizeof(int)));
    p->owned.push_back(p->d_pred);
    HIP_TRYH(hipMemset(p->d_pred, 0, P_COUNT * sizeof(int)));
-   if (mz0 > 0 && (rc = pips_hip_kkt_set_zdiag0_dev(p->kkt, p->dyz + my))) return rc;   // nOmegaInv of the root rows: head of the z part
+   if (e_mz0 > 0 && (rc = pips_hip_kkt_set_zdiag0_dev(p->kkt, p->dyz + my))) return rc;   // nOmegaInv of the root rows: head of the z part
    return PIPS_OK;
 }
 

@@ -177,7 +177,8 @@ def test_block_angular_spmv_against_scipy(seed):
 
 def _kkt_matrices(d, G, L, dual_reg, n0, root_rows):
     """K = [dd J^T; J diag(0, nOmegaInv)] and the preconditioner the device factorises: dual regularisation on every equality row
-    and on the linking inequality rows (sLinsysRootAug.C:1545-1600), proximal term on free variables."""
+    and on the inequality rows of the root system - linking rows (sLinsysRootAug.C:1545-1600) and the root's own, which the
+    harness keeps as rows of the root system instead of eliminating them -, proximal term on free variables."""
     mz, nx, my = d["C"].shape[0], d["A"].shape[1], d["A"].shape[0]
     M = np.concatenate([d["iclow"], d["icupp"], d["ixlow"], d["ixupp"]])
     ratio = np.where(M != 0, L / np.where(M != 0, G, 1.0), 0.0)
@@ -189,7 +190,7 @@ def _kkt_matrices(d, G, L, dual_reg, n0, root_rows):
     free = (d["ixlow"] == 0) & (d["ixupp"] == 0)
     mz0, mzl = root_rows
     zreg = np.zeros(mz)
-    zreg[mz0:mz0 + mzl] = dual_reg
+    zreg[:mz0 + mzl] = dual_reg
     P = sp.bmat([[sp.diags(dd + 1e-6 * free), J.T], [J, sp.diags(np.concatenate([-dual_reg * np.ones(my), nom - zreg]))]], format="csc")
     return K, P
 
