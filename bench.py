@@ -27,7 +27,7 @@ R_SOLVES = 4
 
 
 def update_kernel_algorithmic_flops(m, nb):
-    """Algorithmic flops of the tail update kernel k_tile_gemm<0> for one block with dense tail m and nb border rows.  The
+    """Algorithmic flops of the tail update kernel (k_tile_gemm_bal<0>, or k_tile_gemm<0> with static shares) for one block with dense tail m and nb border rows.  The
     launch of tile column j (K = j*TILE already factored columns) gives every entry of the column below its diagonal tile and
     its nb border entries one length-K dot product (2K flops), and the lower triangle of the NEXT diagonal tile its dot
     products with the same K columns (engine.hip TailPlan::build, diag_ahead; the last step of a diagonal tile, with the
@@ -311,7 +311,8 @@ def main():
     achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
     traffic = update_kernel_traffic(n_blocks_total, n_i, S, world)
     roofline = {
-        "kernel": "k_tile_gemm<0> (tail update, v_mfma_f64_4x4x4_4b_f64)", "bound": "mfma", "achieved": round(achieved, 2),
+        "kernel": ("k_tile_gemm<0>" if os.environ.get("PIPS_HIP_BALANCED_GEMM") == "0" else "k_tile_gemm_bal<0>")
+                  + " (tail update, v_mfma_f64_4x4x4_4b_f64)", "bound": "mfma", "achieved": round(achieved, 2),
         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
         # per launch, like `achieved`: 34 launches of growing depth K = 128 j make up one factorisation, so the figures are
         # the per-factorize totals divided by the launch count (the rocprofv3 average duration of this kernel is the same

@@ -55,28 +55,29 @@ wa = calib.get("calib_atomic8", {}).get("bytes_per_counter_KiB", 1024.0)
 fetch, write, st = counter_by_kernel("fetch", "FETCH_SIZE"), counter_by_kernel("write", "WRITE_SIZE"), stats("stats")
 # which width a kernel's global traffic has: the tile kernels stream 16 B / lane (LDS-DMA), everything else 8-byte accesses
 WIDE = ("k_tile_gemm", "k_arena_clear")
+UPDATE = ("k_tile_gemm_bal<0>", "k_tile_gemm<0>")   # the tail update kernel: balanced variant (default) or static shares
 rows = []
 for k in sorted(set(fetch) | set(write)):
     if k.startswith("calib_"):
         continue
     wide = k.startswith(WIDE)
     fb = fetch.get(k, (0, 0))[0] * (f16 if wide else f8)
-    atom = k in ("k_tile_gemm<2>",) or k.startswith("k_head_factor")
-    wb = write.get(k, (0, 0))[0] * (wa if atom else (w16 if wide and k != "k_tile_gemm<0>" else w8))
+    atom = k in ("k_tile_gemm<2>", "k_tile_gemm_bal<2>") or k.startswith("k_head_factor")
+    wb = write.get(k, (0, 0))[0] * (wa if atom else (w16 if wide and k not in UPDATE else w8))
     n_pmc = max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1], 1)
     calls, avg_ns = st.get(k, (0, 0.0))
     per_launch = (fb + wb) / n_pmc
     rows.append({"kernel": k, "launches_in_pmc_run": n_pmc, "hbm_read_bytes_per_launch": fb / n_pmc, "hbm_write_bytes_per_launch": wb / n_pmc,
                  "avg_launch_us": avg_ns / 1e3, "achieved_TBps": (per_launch / (avg_ns * 1e-9) / 1e12) if avg_ns > 0 else None})
 n_fact = 2   # bench.py --steps 1 --warmup 0 runs 2 factorizations (the timed step + the instrumented one for the roofline object)
-upd = next((r for r in rows if r["kernel"] == "k_tile_gemm<0>"), None)
+upd = next((r for r in rows if r["kernel"] in UPDATE), None)
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) on `python3 bench.py --steps 1 "
                  "--warmup 0 --no-cpu-baseline --no-ipm`, durations from the --kernel-trace --stats pass, MI355X (tools/profile_bench.sh)",
        "calibration": calib, "factorizations_in_pmc_run": n_fact, "kernels": rows}
 json.dump(res, open(os.path.join(out, f"{tag}_bench_hbm_by_kernel.json"), "w"), indent=1)
 if upd:
     tot = (upd["hbm_read_bytes_per_launch"] + upd["hbm_write_bytes_per_launch"]) * upd["launches_in_pmc_run"]
-    json.dump({"kernel": "k_tile_gemm<0>", "source": res["source"], "correction": f"FETCH_SIZE KiB x {f16:.0f}, WRITE_SIZE KiB x {w8:.0f} (tools/pmc_calib on the same box)",
+    json.dump({"kernel": upd["kernel"], "source": res["source"], "correction": f"FETCH_SIZE KiB x {f16:.0f}, WRITE_SIZE KiB x {w8:.0f} (tools/pmc_calib on the same box)",
                "factorizations_in_run": n_fact, "launches_in_run": upd["launches_in_pmc_run"],
                "hbm_read_bytes_per_factorize": upd["hbm_read_bytes_per_launch"] * upd["launches_in_pmc_run"] / n_fact,
                "hbm_write_bytes_per_factorize": upd["hbm_write_bytes_per_launch"] * upd["launches_in_pmc_run"] / n_fact,
