@@ -1008,6 +1008,11 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
                                                   const long long* __restrict__ psign_off, int* __restrict__ inertia,
                                                   const double* __restrict__ pref) {
    __shared__ DiagShared sh;
+#if !defined(PIPS_DIAG_NO_SETPRIO)
+   // The 128 pivots are one dependent chain, and this workgroup shares its SIMDs with waves of the update kernel that always have
+   // an MFMA ready: highest issue priority for the chain (the update loses nothing measurable, the chain no longer queues).
+   __builtin_amdgcn_s_setprio(3);
+#endif
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
