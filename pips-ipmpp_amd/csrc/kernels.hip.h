@@ -938,18 +938,22 @@ __device__ __forceinline__ double pivot_rcp(double d) {
 // branch-free: every LDS operand is fetched unconditionally and up front, masks are applied with selects (the first
 // version let the compiler turn `i > k ? lds[i] : 0` into serialized conditional loads: 92 us per tile instead of 77;
 // what remains is the instruction stream of one wave per SIMD, ~150 VALU/LDS instructions per pivot).
+// block (a, b), b <= a, of the lower block triangle
+__device__ __forceinline__ constexpr int LI(int a, int b) { return a * (a + 1) / 2 + b; }
+
 template <int KB>
-__device__ __forceinline__ void diag_block(double (&A)[8][8], double (&X)[8][8], DiagShared& sh, const BlkDesc& bd,
+__device__ __forceinline__ void diag_block(double (&A)[36], double (&X)[36], DiagShared& sh, const BlkDesc& bd,
                                            int tx, int ty, int tid, int gk0, int3& cnt) {
+#pragma unroll 1
    for (int kt = 0; kt < 16; ++kt) {
       const int k = KB * 16 + kt, buf = kt & 1;
       if (ty == kt) {
 #pragma unroll
-         for (int a = KB; a < 8; ++a) sh.colk[buf][tx + 16 * a] = A[a][KB];   // A(i, k), i >= 16 KB
+         for (int a = KB; a < 8; ++a) sh.colk[buf][tx + 16 * a] = A[LI(a, KB)];   // A(i, k), i >= 16 KB
       }
       if (tx == kt) {
 #pragma unroll
-         for (int b = 0; b <= KB; ++b) sh.xrow[buf][ty + 16 * b] = X[KB][b];  // X(k, c), c < 16 (KB+1)
+         for (int b = 0; b <= KB; ++b) sh.xrow[buf][ty + 16 * b] = X[LI(KB, b)];  // X(k, c), c < 16 (KB+1)
       }
       __syncthreads();
       const double piv = sh.colk[buf][k], pr = sh.prs[k];
@@ -976,23 +980,23 @@ __device__ __forceinline__ void diag_block(double (&A)[8][8], double (&X)[8][8],
       {
          const double ajk = ty > kt ? cj[KB] : 0.0;
 #pragma unroll
-         for (int a = KB; a < 8; ++a) A[a][KB] -= li[a] * ajk;
+         for (int a = KB; a < 8; ++a) A[LI(a, KB)] -= li[a] * ajk;
       }
 #pragma unroll
       for (int b = KB + 1; b < 8; ++b) {
 #pragma unroll
-         for (int a = b; a < 8; ++a) A[a][b] -= li[a] * cj[b];
+         for (int a = b; a < 8; ++a) A[LI(a, b)] -= li[a] * cj[b];
       }
       // X(i,c) -= l_ik X(k,c) for c < k ;  X(i,k) = -l_ik     (c = ty + 16 b < k for every b < KB)
 #pragma unroll
       for (int b = 0; b < KB; ++b) {
 #pragma unroll
-         for (int a = KB; a < 8; ++a) X[a][b] -= li[a] * xr[b];
+         for (int a = KB; a < 8; ++a) X[LI(a, b)] -= li[a] * xr[b];
       }
       {
          const double xkc = ty < kt ? xr[KB] : (ty == kt ? 1.0 : 0.0);
 #pragma unroll
-         for (int a = KB; a < 8; ++a) X[a][KB] -= li[a] * xkc;
+         for (int a = KB; a < 8; ++a) X[LI(a, KB)] -= li[a] * xkc;
       }
    }
 }
@@ -1002,7 +1006,7 @@ __device__ __forceinline__ void diag_block(double (&A)[8][8], double (&X)[8][8],
 // pivot k the owners publish column k of A and row k of X through a double-buffered LDS line, everybody applies the
 // rank-1 update to its registers: one barrier per column, no LDS read-modify-write chains.  X is accumulated by
 // applying each elimination to an identity:  X <- (I - l_k e_k^T) X.
-__global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+__global__ __launch_bounds__(256, 2) void k_tile_diag(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                   double* __restrict__ arena, double* __restrict__ dtail,
                                                   double* __restrict__ winv, const signed char* __restrict__ psign,
                                                   const long long* __restrict__ psign_off, int* __restrict__ inertia,
@@ -1023,14 +1027,16 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
       sh.prs[tid] = pref[bd.xw_off + bd.n_head + tj * TILE + tid];
       sh.sgn[tid] = tj * TILE + tid < bd.m ? (int)psign[psign_off[task.blk] + bd.n_head + tj * TILE + tid] : 1;
    }
-   double A[8][8], X[8][8];
+   // only the 36 blocks on and below the block diagonal exist (LI): 72 doubles per thread; the full 8 x 8 arrays made the
+   // kernel a 496-register one that needs a completely empty CU, i.e. it could only start once the update launch beside it drained
+   double A[36], X[36];
 #pragma unroll
    for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
+      for (int b = 0; b <= a; ++b) {
          const int i = tx + 16 * a, j = ty + 16 * b;
-         A[a][b] = (b <= a && i >= j) ? C[i + (long long)j * ld] : 0.0;   // blocks above the diagonal are never touched
-         X[a][b] = 0.0;
+         A[LI(a, b)] = i >= j ? C[i + (long long)j * ld] : 0.0;
+         X[LI(a, b)] = 0.0;
       }
    __syncthreads();
    const int gk0 = tj * TILE;
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
    diag_block<7>(A, X, sh, bd, tx, ty, tid, gk0, cnt);
    double* dk = sh.dk;
    __syncthreads();
-   // store L (unit lower, scaled), D, and Winv[n][k] = X[n][k] / d_n
+   // store L (unit lower, scaled), D, and Winv[n][k] = X[LI(n, k)] / d_n
    double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
 #pragma unroll
    for (int a = 0; a < 8; ++a)
@@ -1053,9 +1059,10 @@ __global__ __launch_bounds__(256) void k_tile_diag(const TileTask* __restrict__ 
       for (int b = 0; b < 8; ++b) {
          const int i = tx + 16 * a, j = ty + 16 * b;
          if (b > a) { W[i + (long long)j * TILE] = 0.0; continue; }
-         if (i > j) C[i + (long long)j * ld] = A[a][b] / dk[j];
+         const double av = A[LI(a < b ? b : a, b)], xv = X[LI(a < b ? b : a, b)];   // (the index is only evaluated for b <= a)
+         if (i > j) C[i + (long long)j * ld] = av / dk[j];
          else if (i == j) C[i + (long long)j * ld] = dk[j];
-         const double x = i == j ? 1.0 : (i > j ? X[a][b] : 0.0);
+         const double x = i == j ? 1.0 : (i > j ? xv : 0.0);
          W[i + (long long)j * TILE] = x / dk[i];
       }
    if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = dk[tid];
