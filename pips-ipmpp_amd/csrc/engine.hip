@@ -173,7 +173,8 @@ struct TailPlan {
 struct SweepRt {
    TileTask* d_tasks = nullptr;
    int n_tasks = 0;
-   int* d_ints = nullptr;          // [0..1] ticket / finished, [2] error word, [4..] flags
+   int* d_ints = nullptr;          // [0 .. 2 NRHS) ticket / finished per right-hand side, then the error word, then the flags
+   long long n_flags = 0;
    long long* d_flag_off = nullptr;
    int* d_tfirst = nullptr;
    long long* d_tfirst_off = nullptr;
@@ -206,14 +207,17 @@ struct SweepRt {
          if ((rc = dev_upload(&d_tfirst, tf, nullptr))) return rc;
          if ((rc = dev_upload(&d_tfirst_off, tfoff, nullptr))) return rc;
       }
-      HIP_TRY(hipMalloc((void**)&d_ints, (size_t)(4 + std::max<long long>(nf, 1)) * sizeof(int)));
-      HIP_TRY(hipMemset(d_ints, 0, (size_t)(4 + std::max<long long>(nf, 1)) * sizeof(int)));
+      n_flags = std::max<long long>(nf, 1);
+      const size_t ints = (size_t)(2 * SWEEP_NRHS_MAX + 2 + n_flags * SWEEP_NRHS_MAX);
+      HIP_TRY(hipMalloc((void**)&d_ints, ints * sizeof(int)));
+      HIP_TRY(hipMemset(d_ints, 0, ints * sizeof(int)));
       epoch = 0;
       enabled = n_tasks > 0 && !getenv("PIPS_HIP_SWEEP_LAUNCHES");
       return PIPS_OK;
    }
-   SweepArgs args() {
-      return SweepArgs{d_tasks, n_tasks, d_ints, d_ints + 4, d_flag_off, d_tfirst, d_tfirst_off, ++epoch, d_ints + 2};
+   SweepArgs args(long long xw_stride) {
+      return SweepArgs{d_tasks, n_tasks, d_ints, d_ints + 2 * SWEEP_NRHS_MAX + 2, d_flag_off, d_tfirst, d_tfirst_off, ++epoch,
+                       d_ints + 2 * SWEEP_NRHS_MAX, n_flags, xw_stride};
    }
    void release() {
       for (void* p : {(void*)d_tasks, (void*)d_ints, (void*)d_flag_off, (void*)d_tfirst, (void*)d_tfirst_off})
@@ -458,8 +462,8 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
 
 static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
-   if (c.sweep && c.sweep->enabled && nrhs == 1) {
-      hipLaunchKernelGGL(k_tail_rows_fwd, dim3(c.sweep->n_tasks), dim3(256), 0, c.stream, c.sweep->args(), c.d_blks, c.d_arena, c.d_dtail,
+   if (c.sweep && c.sweep->enabled && nrhs <= SWEEP_NRHS_MAX) {
+      hipLaunchKernelGGL(k_tail_rows_fwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride), c.d_blks, c.d_arena, c.d_dtail,
                          c.d_winv, xw);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
@@ -474,8 +478,8 @@ static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_str
 
 static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
-   if (c.sweep && c.sweep->enabled && nrhs == 1) {
-      hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks), dim3(256), 0, c.stream, c.sweep->args(), c.d_blks, c.d_arena, c.d_dtail,
+   if (c.sweep && c.sweep->enabled && nrhs <= SWEEP_NRHS_MAX) {
+      hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride), c.d_blks, c.d_arena, c.d_dtail,
                          c.d_winv, xw);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;

@@ -1498,8 +1498,11 @@ struct SweepArgs {
    const long long* tfirst_off;
    int epoch;
    int* err;
+   // several right-hand sides: blockIdx.y = right-hand side, each with its own tickets (2 ints), flags and work vector
+   long long flag_stride, xw_stride;
 };
 constexpr long long SWEEP_POLL_LIMIT = 20000000;
+constexpr int SWEEP_NRHS_MAX = 32;
 
 __device__ __forceinline__ bool sweep_wait(const int* f, int epoch) {
    // No agent-scope fence anywhere in the sweeps: an acquire invalidates and a release writes back the whole L2 of the XCD,
@@ -1515,16 +1518,17 @@ __device__ __forceinline__ bool sweep_wait(const int* f, int epoch) {
 }
 // ticket -> task; every thread of the workgroup gets the same answer
 __device__ __forceinline__ int sweep_ticket(const SweepArgs& a, int* sh) {
-   if (threadIdx.x == 0) *sh = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   if (threadIdx.x == 0) *sh = __hip_atomic_fetch_add(a.ticket + 2 * blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    __syncthreads();
    return *sh;
 }
 __device__ __forceinline__ void sweep_done(const SweepArgs& a) {
    if (threadIdx.x == 0) {
-      const int d = __hip_atomic_fetch_add(a.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int* t = a.ticket + 2 * blockIdx.y;
+      const int d = __hip_atomic_fetch_add(t + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d == a.n_tasks - 1) {   // everybody has taken a ticket and finished: ready for the next launch
-         __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         __hip_atomic_store(a.ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(t + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
    }
 }
@@ -1553,8 +1557,8 @@ __global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDes
    const TileTask task = a.tasks[t];
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, row = tid & 127, half = tid >> 7, i = task.ti, ld = bd.ldT;
-   double* xt = xw + bd.xw_off + bd.n_head;
-   int* fl = a.flags + a.flag_off[task.blk];
+   double* xt = xw + a.xw_stride * blockIdx.y + bd.xw_off + bd.n_head;
+   int* fl = a.flags + a.flag_stride * blockIdx.y + a.flag_off[task.blk];
    const int j0 = a.tfirst ? min(i, a.tfirst[a.tfirst_off[task.blk] + i]) : 0;
    const double* Lrow = arena + bd.T + (long long)i * TILE;
    double acc = half == 0 ? xt[i * TILE + row] : 0.0;
@@ -1608,8 +1612,8 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
    const TileTask task = a.tasks[a.n_tasks - 1 - t];   // last tile column first
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, i = task.ti, ld = bd.ldT;
-   double* xt = xw + bd.xw_off + bd.n_head;
-   int* fl = a.flags + a.flag_off[task.blk];
+   double* xt = xw + a.xw_stride * blockIdx.y + bd.xw_off + bd.n_head;
+   int* fl = a.flags + a.flag_stride * blockIdx.y + a.flag_off[task.blk];
    const int* tf = a.tfirst ? a.tfirst + a.tfirst_off[task.blk] : nullptr;
    const double* Lcol = arena + bd.T + (long long)i * TILE * ld;
    // tile rows k > i whose envelope reaches column i, from the last one down

@@ -126,3 +126,34 @@ def test_row_sweeps_dense_root(n, monkeypatch):
     for k in range(2):
         assert np.array_equal(got[0][k], got[1][k])
     assert np.linalg.norm(A @ got[1][0] - rhs) / np.linalg.norm(rhs) < 1e-10
+
+
+@pytest.mark.parametrize("nrhs", [2, 7])
+def test_row_sweeps_several_right_hand_sides(nrhs, monkeypatch):
+    """DoubleLinearSolver::solve(nrhs, ...) with the per-right-hand-side scheme (grid.y = right-hand side): every right-hand side has
+    its own tickets and flags; agrees with the launch-per-column kernels, and right-hand side r with the single solve of r."""
+    monkeypatch.setenv("PIPS_HIP_MULTI", "0")        # the scheme that runs the single-vector kernels with a grid over the right-hand sides
+    prob = Problem(31, 1, 3000, 1500, 0, 0, 0.004)
+    K = prob.blocks[0]["K"]
+    rng = np.random.default_rng(2)
+    rhs = rng.standard_normal((nrhs, prob.n_leaf))
+    got = []
+    for launches in (True, False):
+        if launches:
+            monkeypatch.setenv("PIPS_HIP_SWEEP_LAUNCHES", "1")
+        else:
+            monkeypatch.delenv("PIPS_HIP_SWEEP_LAUNCHES", raising=False)
+        s = pa.HipLdlSolver(K, prob.n_i)
+        s.analyze()
+        s.matrixChanged()
+        x = s.solve(rhs.copy())
+        one = s.solve(rhs[nrhs - 1].copy())
+        got.append((x, one))
+        s.close()
+    # (the sparse head adds with atomics and the deterministic mode takes one right-hand side at a time: agreement to rounding)
+    scale = np.abs(got[0][0]).max()
+    assert np.abs(got[0][0] - got[1][0]).max() <= 1e-11 * scale
+    assert np.abs(got[1][0][nrhs - 1] - got[1][1]).max() <= 1e-11 * scale
+    Kf = prob.K_full(0)
+    for r in range(nrhs):
+        assert np.abs(Kf @ got[1][0][r] - rhs[r]).max() / np.abs(rhs[r]).max() < 1e-9
