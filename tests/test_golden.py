@@ -231,3 +231,58 @@ def test_hip_path_matches_global_pardiso_solution_general_structure(schur_mode):
         bt.sync()
         got = np.concatenate([bl.cpu().numpy(), b0.cpu().numpy()])
         assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-8
+
+
+# one leaf block of BASELINE configs[1] at full size (10 000 variables, border to S = 2000) against MKL PARDISO
+# (tests/golden/make_config1_block_pardiso.py): K^-1 b, inertia and the action of the block's Schur contribution
+def _config1_block():
+    from tests.util import Problem
+    from tests.golden.make_config1_block_pardiso import vectors
+    g = np.load(os.path.join(HERE, "config1_block_pardiso.npz"))
+    prob = Problem(int(g["seed"]), 1, int(g["n_i"]), int(g["my_i"]), int(g["n0"]), int(g["myl"]), float(g["rho"]), dual_reg=float(g["dual_reg"]))
+    rhs, v = vectors(int(g["seed"]), prob.n_leaf, prob.S)
+    return g, prob, rhs, v
+
+
+def test_oracle_matches_pardiso_on_a_full_size_config1_block():
+    g, prob, rhs, v = _config1_block()
+    s = prob.oracle_leaf(0)
+    assert s.get_inertia()[:2] == tuple(int(x) for x in g["inertia"][:2])
+    for k in range(2):
+        x = rhs[k].copy()
+        s.solve(x)
+        assert np.linalg.norm(x - g["sol"][k]) / np.linalg.norm(g["sol"][k]) < 1e-8
+    Bt = prob.Bt_scipy(0)
+    t = Bt.T @ v[0]
+    s.solve(t)
+    w = Bt @ t
+    assert np.linalg.norm(w - g["schur_action"][0]) / np.linalg.norm(g["schur_action"][0]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_pardiso_on_a_full_size_config1_block():
+    import torch
+    from tests.util import hip_lower_as_rowmajor
+    g, prob, rhs, v = _config1_block()
+    S = prob.S
+    bt = pa.LeafBatch(1, S)
+    bt.set_block(0, prob.blocks[0]["K"], prob.n_i, prob.blocks[0]["Bt"])
+    bt.analyze(4)
+    bt.set_values(0, prob.blocks[0]["K"].val)
+    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
+    bt.factor(SC, S)
+    bt.sync()
+    assert bt.inertia(0)[:2] == tuple(int(x) for x in g["inertia"][:2])
+    for k in range(2):
+        x = torch.tensor(rhs[k].copy(), device="cuda")
+        bt.solve(x)
+        bt.sync()
+        got = x.cpu().numpy()
+        assert np.linalg.norm(got - g["sol"][k]) / np.linalg.norm(g["sol"][k]) < 1e-8
+        assert np.abs(got - g["sol"][k]).max() / np.abs(g["sol"][k]).max() < 1e-8
+    # the leaf's contribution to the Schur complement is -Br^T K^-1 Br (lower triangle authoritative): its action on v
+    L = hip_lower_as_rowmajor(SC.cpu().numpy(), S)
+    full = L + np.tril(L, -1).T
+    for k in range(2):
+        w = -(full @ v[k])
+        assert np.linalg.norm(w - g["schur_action"][k]) / np.linalg.norm(g["schur_action"][k]) < 1e-8
