@@ -197,8 +197,8 @@ struct SweepRt {
          foff[b] = nf;
          nf += blks[b].ntc;
          tfoff[b] = (long long)tf.size();
-         if (first)
-            for (int i = 0; i < blks[b].ntc; ++i) tf.push_back(std::min(i, (*(*first)[b])[i]));
+         if (first)   // tail rows and, behind them, the border tile rows (border-backward sweep)
+            for (int i = 0; i < blks[b].ntr; ++i) tf.push_back(i < blks[b].ntc ? std::min(i, (*(*first)[b])[i]) : (*(*first)[b])[i]);
       }
       int rc;
       if ((rc = dev_upload(&d_tasks, tasks, nullptr))) return rc;
@@ -476,11 +476,12 @@ static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_str
    return PIPS_OK;
 }
 
-static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
+static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0, int border = 0) {
    const TailPlan& p = *c.plan;
+   if (border && !(c.sweep && c.sweep->enabled)) PIPS_FAIL(PIPS_ERR_STATE, "border-backward sweep needs the single-launch tail sweeps");
    if (c.sweep && c.sweep->enabled && nrhs <= SWEEP_NRHS_MAX) {
       hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride), c.d_blks, c.d_arena, c.d_dtail,
-                         c.d_winv, xw);
+                         c.d_winv, xw, border);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
@@ -862,7 +863,7 @@ struct Engine {
          uar += (long long)s.m_pad * s.m_pad;
          d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
          arena += s.arena;
-         xw += s.n_head + s.m_pad;
+         xw += s.n_head + s.m_pad + s.nb_pad;   // [head | padded tail | border rows (border-backward sweep only)]
          winv += (long long)d.ntc * TILE * TILE;
          dt += s.m_pad;
          sncol += s.n_head;
@@ -1101,6 +1102,24 @@ struct Engine {
                            diag_ahead && !getenv("PIPS_HIP_DIAG_UPDATE_LATE"))))
          return rc;
       if ((rc = sweep.build(h_blks, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts))) return rc;
+      {
+         // border-backward sweep: worth it where the border rows of the factor (what it reads on top of a backward sweep) are no
+         // more than what the forward sweep it saves would read, with a margin for the chain and the launches it also saves
+         double fwd_entries = 0.0, border_entries = 0.0;
+         for (int b = 0; b < nblk; ++b) {
+            const BlockSym& sb = sym[b];
+            fwd_entries += 0.5 * (double)sb.m_pad * sb.m_pad;
+            border_entries += (double)sb.nb_pad * sb.m_pad;
+            for (const HeadSupernode& sn : sb.sn) {
+               const int nbord = sn.r - sn.rb;
+               fwd_entries += (double)sn.w * (sn.r - nbord) + 0.5 * sn.w * sn.w;
+               border_entries += (double)sn.w * nbord;
+            }
+         }
+         border_backward_ok = schur_mode_eff == 1 && nnzB_total > 0 && sweep.enabled && !deterministic && border_entries <= 1.25 * fwd_entries;
+         if (const char* bb = getenv("PIPS_HIP_BORDER_BACKWARD"))
+            border_backward_ok = atoi(bb) != 0 && schur_mode_eff == 1 && nnzB_total > 0 && sweep.enabled && !deterministic;
+      }
       if (diag_ahead && !side) {
          // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
          int prio_lo = 0, prio_hi = 0;
@@ -1333,6 +1352,7 @@ struct Engine {
       int rc = tail_factor(c, SC, ldSC);
       if (rc) return rc;
       factored = true;
+      perturbed_cache = -1;
       if (SC && schur_mode_eff == 2 && !schur_cols.empty()) {
          if (timer.on) timer.begin(stream, 5);
          rc = schur_by_solves(SC, ldSC);
@@ -1585,6 +1605,53 @@ struct Engine {
    int fetch_inertia() {
       HIP_TRY(hipMemcpyAsync(h_inertia.data(), d_inertia, h_inertia.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
+      return PIPS_OK;
+   }
+
+   // ---- border-backward sweep ----------------------------------------------------------------------
+   // u_i = K_i^-1 Br_i x0 for every block from the augmented factor alone:  Br_i = L D L21^T, so  u = L^-T (L21^T x0)  - the
+   // backward sweep of the augmented factor [L 0; L21 I] with a zero right-hand side and the border unknowns fixed to -x0.  No
+   // border product, no forward sweep, no diagonal scaling.  Pays where the border rows of the factor are no larger than what a
+   // forward sweep reads (decided at analyze time, border_backward_ok); needs Schur mode 1 and the single-launch tail sweeps.
+   // There is no refinement in it: the caller uses it only while the factorisation has no perturbed pivot (perturbed_leaf_pivots).
+   bool border_backward_ok = false;
+   int perturbed_cache = -1;   // perturbed pivots of the current factorisation over all blocks; -1 = not fetched yet
+   int perturbed_leaf_pivots(int* out) {
+      if (perturbed_cache < 0) {
+         int rc = fetch_inertia();
+         if (rc) return rc;
+         int z = 0;
+         for (int b = 0; b < nblk; ++b) z += h_inertia[3 * b + 2];
+         perturbed_cache = z;
+      }
+      *out = perturbed_cache;
+      return PIPS_OK;
+   }
+   int solve_border_backward(const double* x0_dev, double* out_dev) {
+      if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
+      HIP_TRY(hipSetDevice(device));
+      HIP_TRY(hipMemsetAsync(d_xw, 0, (size_t)xw_total * sizeof(double), stream));
+      hipLaunchKernelGGL(k_border_fill, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_bmap, x0_dev, d_xw);
+      TailCtx c = ctx();
+      int rc = tail_bwd(c, d_xw, 1, 0, 1);
+      if (rc) return rc;
+      const ScatterCtx none{0, nullptr, nullptr, nullptr, nullptr};
+      if (spine_total > 0)
+         hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, 1), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, 1);
+      for (int l = (int)levels.size() - 1; l >= 0; --l) {
+         const LevelRange& L = levels[l];
+         const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+         const int cnt = L.small_cnt + L.large_cnt;
+         if (cnt > 0 && (long long)cnt < CHAIN_LAUNCH_MAX)
+            hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1);
+         else if (cnt > 0)
+            hipLaunchKernelGGL(k_head_bwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1);
+         if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt,
+                               d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, none, 1);
+      }
+      hipLaunchKernelGGL(k_permute_out, dim3(64, nblk, 1), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, out_dev, 0LL, d_xw, 0LL);
+      HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
 };
@@ -2726,10 +2793,18 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
       HIP_TRY(hipMemcpyAsync(b0_dev, red, (size_t)head * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(b0_dev + head + k->mz0, red + head, (size_t)tailn * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
    }
-   // Ltsolve: b_i -= K_i^-1 Br_i x0 (LniTransMult, DistributedLinearSystem.C:430-483)
-   HIP_TRY(hipMemsetAsync(k->d_t, 0, (size_t)e->n_total * sizeof(double), e->stream));
-   if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, 1.0))) return rc;
-   if ((rc = e->solve(k->d_t))) return rc;
+   // Ltsolve: b_i -= K_i^-1 Br_i x0 (LniTransMult, DistributedLinearSystem.C:430-483).  Where the stored border rows are thin
+   // enough and no pivot of the factorisation was perturbed: from the augmented factor with one backward sweep
+   // (Engine::solve_border_backward); else border product + full solve with refinement.
+   int pert = 1;
+   if (e->border_backward_ok && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
+   if (e->border_backward_ok && !k->sparse && pert == 0) {
+      if ((rc = e->solve_border_backward(red, k->d_t))) return rc;
+   } else {
+      HIP_TRY(hipMemsetAsync(k->d_t, 0, (size_t)e->n_total * sizeof(double), e->stream));
+      if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, 1.0))) return rc;
+      if ((rc = e->solve(k->d_t))) return rc;
+   }
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;

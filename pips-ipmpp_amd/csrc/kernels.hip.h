@@ -519,12 +519,16 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
    if (threadIdx.x < 3 && cnt_s[threadIdx.x]) atomicAdd(&inertia[3 * blk_s + threadIdx.x], cnt_s[threadIdx.x]);
 }
 
+// Position of row `ra` of a supernode's row list in the block's work vector: rows of K_i at ra, border rows (ra >= n, only
+// touched by the border-backward sweep, Engine::solve_border_backward) behind the padded tail.
+__device__ __forceinline__ int xw_row(const BlkDesc& bd, int ra) { return ra < bd.n ? ra : bd.n_head + bd.m_pad + (ra - bd.n); }
+
 // forward / backward substitution for the simple leaves: y = b_c (unit pivot block); b[rows] -= l y   /   x_c = z_c - l^T x[rows]
 __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                                           const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                           const double* __restrict__ arena, double* __restrict__ xw,
                                                           long long xw_stride, int backward,
-                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
+                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int border = 0) {
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= cnt) return;
    const SnDesc sn = sns[sn_begin + t];
@@ -543,8 +547,8 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
       double s = 0.0;
       for (int a = 0; a < sn.r; ++a) {
          const int ra = rows[a];
-         if (ra >= bd.n) break;
-         s += P[1 + a] * xb[ra];
+         if (ra >= bd.n && !border) break;
+         s += P[1 + a] * xb[xw_row(bd, ra)];
       }
       xb[sn.c0] -= s;
    }
@@ -1136,7 +1140,8 @@ __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns,
 // head backward: x_J = L11^-T (z_J - L21^T x_below); throughput variant
 __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
+                                                int border = 0) {
    __shared__ double y[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
@@ -1148,7 +1153,7 @@ __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns,
       double s = 0.0;
       for (int a = tid; a < r; a += 64) {
          const int ra = rows[a];
-         if (ra < bd.n) s += P[w + a + (long long)k * ld] * xb[ra];
+         if (ra < bd.n || border) s += P[w + a + (long long)k * ld] * xb[xw_row(bd, ra)];
       }
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
       if (tid == 0) y[k] = xb[sn.c0 + k] - s;
@@ -1236,7 +1241,7 @@ constexpr int RED_ROWS = 16;   // dot products finished per pass through the wav
 
 template <int WB>
 __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65]) {
+                                              const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0) {
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
@@ -1249,8 +1254,8 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
    for (int k = 0; k < WB; ++k) part[k] = 0.0;
    for (int a = tid; a < r; a += 64) {
       const int ra = rows[a];
-      if (ra >= bd.n) break;
-      const double xa = xb[ra];
+      if (ra >= bd.n && !border) break;
+      const double xa = xb[xw_row(bd, ra)];
 #pragma unroll
       for (int k = 0; k < WB; ++k)
          if (k < w) part[k] += P[w + a + (long long)k * ld] * xa;
@@ -1286,19 +1291,20 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
 
 template <int DUMMY = 0>
 __device__ __forceinline__ void head_bwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                             const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65]) {
-   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xb, red);
-   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xb, red);
-   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, red);
+                                             const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0) {
+   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xb, red, border);
+   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xb, red, border);
+   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, red, border);
 }
 
 __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
+                                                int border = 0) {
    __shared__ double red[RED_ROWS][65];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_bwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red);
+   head_bwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red, border);
 }
 
 // spine sweeps of the solve: one wave per (block, right-hand side) walks the block's spine supernodes inside one launch
@@ -1306,7 +1312,7 @@ __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict_
 __global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__ spine, const int* __restrict__ spine_off,
                                                         const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
                                                         const int* __restrict__ rowidx, const double* __restrict__ arena,
-                                                        double* __restrict__ xw, long long xw_stride, int backward) {
+                                                        double* __restrict__ xw, long long xw_stride, int backward, int border = 0) {
    __shared__ double ys[HEAD_WMAX];
    __shared__ double red[RED_ROWS][65];
    const int p0 = spine_off[blockIdx.x], p1 = spine_off[blockIdx.x + 1];
@@ -1316,7 +1322,7 @@ __global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__
    for (int q = 0; q < p1 - p0; ++q) {
       const SnDesc sn = sns[spine[backward ? p1 - 1 - q : p0 + q]];
       if (!backward) head_fwd_any(sn, bd, rowidx, arena, xb, ys);
-      else head_bwd_any(sn, bd, rowidx, arena, xb, red);
+      else head_bwd_any(sn, bd, rowidx, arena, xb, red, border);
       __threadfence();
       __syncthreads();
    }
@@ -1602,9 +1608,11 @@ __global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDes
 }
 
 // backward: the workgroup owns tile column i:  x_i = Winv_i^T ( d_i ( z_i - sum_{k > i} L(k,i)^T x_k ) ), k descending
+// border != 0 (Engine::solve_border_backward): the border tile rows of the augmented factor take part - L21(k, i) for the tile rows
+// k >= ntc below the tail, whose "solution" is given (minus the root's x0, at xt[k * TILE ..]) and needs no flag.
 __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
                                                       const double* __restrict__ dtail, const double* __restrict__ winv,
-                                                      double* __restrict__ xw) {
+                                                      double* __restrict__ xw, int border = 0) {
    __shared__ double v[TILE];
    __shared__ double outp[TILE];
    __shared__ int sh_t, sh_ok;
@@ -1624,15 +1632,20 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
    double acc = tid < TILE ? xt[i * TILE + tid] : 0.0;
    const double dsc = tid < TILE ? dtail[bd.dt_off + i * TILE + tid] : 0.0;
    tg_d2 m[32];
-   int k = next_k(bd.ntc - 1);
+   int k = next_k((border ? bd.ntr : bd.ntc) - 1);
    bool ok = true;
    if (k > i) {
       tile_tload(m, Lcol + (long long)k * TILE, ld, tid);
       for (;;) {
-         if (tid == 0) sh_ok = sweep_wait(fl + k, a.epoch) ? 1 : 0;
-         __syncthreads();
-         if (!sh_ok) { ok = false; break; }
-         if (tid < TILE) v[tid] = sweep_load(xt + k * TILE + tid);
+         if (k < bd.ntc) {
+            if (tid == 0) sh_ok = sweep_wait(fl + k, a.epoch) ? 1 : 0;
+            __syncthreads();
+            if (!sh_ok) { ok = false; break; }
+            if (tid < TILE) v[tid] = sweep_load(xt + k * TILE + tid);
+         } else {
+            __syncthreads();
+            if (tid < TILE) v[tid] = xt[k * TILE + tid];   // border rows: written before the launch
+         }
          __syncthreads();
          tile_tdot(m, v, outp, tid);
          __syncthreads();
@@ -1659,6 +1672,15 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
    if (tid < TILE) sweep_store(xt + i * TILE + tid, acc);
    sweep_publish(fl + i, a.epoch);
    sweep_done(a);
+}
+
+// border part of the work vectors for the border-backward sweep: minus the root solution at the block's border rows, zero padding
+__global__ void k_border_fill(const BlkDesc* __restrict__ blks, const int* __restrict__ bmap, const double* __restrict__ x0,
+                              double* __restrict__ xw) {
+   const BlkDesc bd = blks[blockIdx.y];
+   double* xbd = xw + bd.xw_off + bd.n_head + bd.m_pad;
+   const int* bm = bmap + bd.bmap_off;
+   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < bd.nb_pad; r += gridDim.x * blockDim.x) xbd[r] = r < bd.nb ? -x0[bm[r]] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
