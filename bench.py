@@ -335,8 +335,8 @@ def main():
             "config": {"workload": f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""),
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
-                       "ltsolve": ("border product + refined leaf solve" if os.environ.get("PIPS_HIP_BORDER_BACKWARD") == "0" else
-                                   "one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed (DESIGN.md 4.5)"),
+                       "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed (DESIGN.md 4.5)"
+                                   if info.get("ltsolve_from_augmented_factor") else "border product + refined leaf solve"),
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},

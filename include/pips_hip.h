@@ -130,7 +130,8 @@ int pips_hip_batch_border_mult_dev(void* handle, const double* x0_dev, double* t
 int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero);
 /* what[0]=sum nnz(L) what[1]=sum n what[2]=sum n_head what[3]=sum tail m what[4]=#head supernodes what[5]=max levels
  * what[6]=factor flops what[7]=border (TRSM+SYRK) flops what[8]=arena bytes what[9]=max tail tile columns
- * what[10]=bytes of the head-to-head update position tables what[11]=sum of non-empty border columns what[12]=sum nnz(K lower) */
+ * what[10]=bytes of the head-to-head update position tables what[11]=sum of non-empty border columns what[12]=sum nnz(K lower)
+ * what[13]=1 if solveCompressed takes its Ltsolve from the augmented factor (one backward sweep) while no pivot is perturbed */
 int pips_hip_batch_info(void* handle, int64_t* what, int n_what);
 int pips_hip_batch_sync(void* handle);
 /* per-phase device time of the last pips_hip_batch_factor in ms (HIP events on the handle's stream):

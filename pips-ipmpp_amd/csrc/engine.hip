@@ -2154,6 +2154,7 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
    Engine* e = (Engine*)handle;
    if (!e || e->sym.empty()) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_info: analyze first");
    sym_info(e->sym, what, n_what);
+   if (n_what > 13) what[13] = e->border_backward_ok ? 1 : 0;
    return PIPS_OK;
 }
 

@@ -422,9 +422,10 @@ class LeafBatch:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(13, np.int64)
-        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(13)), "pips_hip_batch_info")
-        keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK"]
+        what = np.zeros(14, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(14)), "pips_hip_batch_info")
+        keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK",
+                "ltsolve_from_augmented_factor"]
         return {k: int(v) for k, v in zip(keys, what)}
 
     def sync(self):
