@@ -1790,6 +1790,19 @@ struct KktSystem {
    double root_reg_primal = 0.0, root_reg_dual = 0.0;   // pips_hip_kkt_set_root_regularization
    hipStream_t comm_stream = nullptr;   // panel-wise Schur reduction beside the leaf work
    hipEvent_t ev_reduced = nullptr;
+   // The dense root is factorised on a stream of its own: it is a latency chain (S = 2000: 16 diagonal tiles, 1.9 ms with the chip
+   // nearly idle) and nothing needs its factors before the Dsolve of the next solveCompressed - the leaf solves of that call's
+   // Lsolve run beside it.  root_wait() joins the main stream with it (before Dsolve, the next factorisation, an inertia query).
+   hipStream_t root_stream = nullptr;
+   hipEvent_t ev_sc_final = nullptr, ev_root_done = nullptr;
+   bool root_pending = false;
+   int root_wait() {
+      if (root_pending) {
+         HIP_TRY(hipStreamWaitEvent(leaves->stream, ev_root_done, 0));
+         root_pending = false;
+      }
+      return PIPS_OK;
+   }
    size_t packed_cap = 0;
    bool use_rsag = false, force_reduce = false;
    // sparse root: SC lives as the value array of a lower-triangular CSR pattern inside a one-block sparse
@@ -1800,6 +1813,9 @@ struct KktSystem {
    long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
    int* d_sc_rowptr = nullptr;
    ~KktSystem() {
+      if (root_stream) { (void)hipStreamSynchronize(root_stream); (void)hipStreamDestroy(root_stream); }
+      if (ev_sc_final) (void)hipEventDestroy(ev_sc_final);
+      if (ev_root_done) (void)hipEventDestroy(ev_root_done);
       if (comm_stream) (void)hipStreamDestroy(comm_stream);
       if (ev_reduced) (void)hipEventDestroy(ev_reduced);
       void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr};
@@ -2659,6 +2675,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    int rc;
    if (leaf_diag_dev && (rc = pips_hip_batch_set_diagonals_dev(e, leaf_diag_dev))) return rc;
    const size_t n = (size_t)k->S * k->S;
+   if ((rc = k->root_wait())) return rc;                                         // the previous root factorisation still reads d_SC
    HIP_TRY(hipMemsetAsync(k->d_SC, 0, n * sizeof(double), e->stream));            // initializeKKT (:840-847)
    if ((rc = e->factor(k->d_SC, k->S))) return rc;                               // children factor2 + assembleLocalKKT
    // reduceKKT (:860-881).  PIPS_HIP_FORCE_REDUCE exercises the reduction path with a one-rank communicator (tests).
@@ -2731,7 +2748,24 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
       hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->S - k->n0, 256)), dim3(256), 0, e->stream, k->d_SC, k->S, (const int*)nullptr, k->n0,
                          k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
-   return k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)
+   static const bool root_async = !getenv("PIPS_HIP_ROOT_SYNC");
+   if (!root_async) return k->root->factor_dev(k->d_SC, k->S, 0);                  // factorizeKKT (:1436-1464)
+   if (!k->root_stream) {
+      int prio_lo = 0, prio_hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      HIP_TRY(hipStreamCreateWithPriority(&k->root_stream, hipStreamNonBlocking, prio_hi));
+      HIP_TRY(hipEventCreateWithFlags(&k->ev_sc_final, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&k->ev_root_done, hipEventDisableTiming));
+   }
+   HIP_TRY(hipEventRecord(k->ev_sc_final, e->stream));
+   HIP_TRY(hipStreamWaitEvent(k->root_stream, k->ev_sc_final, 0));
+   k->root->stream = k->root_stream;
+   rc = k->root->factor_dev(k->d_SC, k->S, 0);
+   k->root->stream = e->stream;                                                   // solves and queries run on the main stream
+   if (rc) return rc;
+   HIP_TRY(hipEventRecord(k->ev_root_done, k->root_stream));
+   k->root_pending = true;
+   return PIPS_OK;
 }
 
 int pips_hip_kkt_set_root_regularization(void* handle, double primal, double dual) {
@@ -2787,7 +2821,10 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
                          k->d_zdiag0, b0_dev + head, red);
    if (k->sparse) {
       if ((rc = k->root_sp->solve(red))) return rc;
-   } else if ((rc = k->root->solve_dev(red))) return rc;
+   } else {
+      if ((rc = k->root_wait())) return rc;
+      if ((rc = k->root->solve_dev(red))) return rc;
+   }
    if (k->mz0 > 0) {
       hipLaunchKernelGGL(k_z0_elim, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, 1, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
@@ -2845,6 +2882,8 @@ int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero) {
    KktSystem* k = (KktSystem*)handle;
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    if (k->sparse) return pips_hip_batch_inertia(k->root_sp.get(), 0, pos, neg, zero);
+   int rcw = k->root_wait();
+   if (rcw) return rcw;
    return pips_hip_dense_ldl_inertia(k->root.get(), pos, neg, zero);
 }
 
