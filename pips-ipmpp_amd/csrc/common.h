@@ -49,7 +49,7 @@ void constrained_amd(int n, const std::vector<int>& ap, const std::vector<int>& 
 // the leaves, exact column counts.  Returns false (perm untouched or unusable) when the block has no small separators -
 // random sparsity - or is too small; the caller then uses constrained_amd on the whole block.
 bool dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& ai, int n_primal, int max_depth,
-                     std::vector<int>& perm, std::vector<int>& colcount);
+                     std::vector<int>& perm, std::vector<int>& colcount, int min_size = 512);
 
 // ---- symbolic analysis of one leaf block (symbolic.cpp) --------------------------------------
 struct HeadSupernode {
@@ -103,7 +103,12 @@ struct CsrPattern {
 struct AnalyzeOptions {
    int tile = 128;            // dense tile size
    int max_sn_width = 32;     // head supernode width cap
-   int nd_depth = 4;          // levels of dual-row nested dissection tried before minimum degree (0 = off)
+   // dual-row nested dissection tried before minimum degree (0 levels = off).  Time-coupled blocks are chains: every level halves
+   // them.  Measured on the energy-like family (tools/config3_probe.py, 32 blocks x 50 000): depth 4 / segments >= 512 rows
+   // (round 1's setting) 119 levels, factorize 50 ms, solveCompressed 20 ms, nnz(L) 112 M; depth 12 / >= 128 rows 14 levels, 20.7 ms,
+   // 9.0 ms, 82 M; deeper brings nothing more.  Blocks without thin separators (config 2) fall through to minimum degree unchanged.
+   int nd_depth = 12;
+   int nd_min_size = 128;     // a segment with fewer dual rows is not dissected further
    const int* user_perm = nullptr;   // given elimination order (perm[new] = old) instead of minimum degree / dissection
    bool constrain_order = true;   // dual rows only after their primal neighbours (leaf KKT blocks); false: plain minimum degree,
                                   // the inertia hint still supplies the expected pivot signs (sparse Schur complement)

@@ -514,6 +514,7 @@ static void apply_tuning(AnalyzeOptions& opt) {
    opt.max_sn_width = HEAD_WMAX;
    if (const char* rz = getenv("PIPS_HIP_RELAX_ZEROS")) opt.relax_zeros = atof(rz);   // share of explicit zeros per panel
    if (const char* ndd = getenv("PIPS_HIP_ND_DEPTH")) opt.nd_depth = atoi(ndd);        // dissection levels (0 = off)
+   if (const char* ndm = getenv("PIPS_HIP_ND_MIN")) opt.nd_min_size = atoi(ndm);      // smallest segment that is still dissected
    if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);       // seconds per scattered update
    if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
 }

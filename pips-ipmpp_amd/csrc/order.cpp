@@ -341,11 +341,11 @@ void exact_colcounts(int n, const std::vector<int>& ap, const std::vector<int>& 
 }  // namespace
 
 bool dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& ai, int n_primal, int max_depth,
-                     std::vector<int>& perm, std::vector<int>& colcount) {
+                     std::vector<int>& perm, std::vector<int>& colcount, int min_size) {
    if (max_depth <= 0 || n_primal <= 0 || n_primal >= n) return false;
    Dissector D(n, n_primal, ap, ai);
    D.max_depth = max_depth;
-   D.min_size = 512;
+   D.min_size = min_size > 0 ? min_size : 512;
    if (D.nd < 2 * D.min_size) return false;
    if (!D.build_dual_graph(64LL << 20)) return false;
    D.label.assign(D.nd, -1);

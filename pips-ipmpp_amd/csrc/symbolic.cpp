@@ -53,7 +53,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       out.colcount.assign(n, 0);
    } else if (!opt.constrain_order)
       constrained_amd(n, ap, ai, -1, out.perm, out.colcount);
-   else if (!dissected_order(n, ap, ai, n_primal, opt.nd_depth, out.perm, out.colcount))
+   else if (!dissected_order(n, ap, ai, n_primal, opt.nd_depth, out.perm, out.colcount, opt.nd_min_size))
       constrained_amd(n, ap, ai, n_primal, out.perm, out.colcount);
    out.iperm.assign(n, 0);
    for (int k = 0; k < n; ++k) out.iperm[out.perm[k]] = k;

@@ -346,10 +346,12 @@ class _TimeCoupledProblem(Problem):
 
 @pytest.mark.parametrize("cut", ["model", "all_head"])
 @pytest.mark.parametrize("n_i", [600, 3000], ids=["chain_and_spine", "dissected"])
-def test_time_coupled_blocks_match_oracle(cut, n_i):
-    """n_i = 600: too small for dissection, the head is one chain per block (level-scheduled bottom, spine kernels on top);
-    n_i = 3000: the dual-row separators of the partial nested dissection cut each block into independent segments."""
+def test_time_coupled_blocks_match_oracle(cut, n_i, monkeypatch):
+    """n_i = 600, dissection switched off: the head is one chain per block (level-scheduled bottom, spine kernels on top);
+    n_i = 3000: the dual-row separators of the nested dissection cut each block into independent segments."""
     import torch
+    if n_i == 600:
+        monkeypatch.setenv("PIPS_HIP_ND_DEPTH", "0")     # keeps the chain / spine kernels under test
     prob = _TimeCoupledProblem(5, 3, n_i, n_i // 2, 10, 8, 6)
     S, N = prob.S, prob.N
     bt = pa.LeafBatch(N, S)
