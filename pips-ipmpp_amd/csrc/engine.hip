@@ -891,10 +891,10 @@ struct Engine {
       for (int b = 0; b < nblk; ++b)
          for (int l = 0; l < (int)sym[b].sn.size(); ++l) {
             const HeadSupernode& s = sym[b].sn[l];
-            // class 0: "simple leaf" (w = 1, r <= 16, level 0, every row in the tail/border) -> one thread each;
+            // class 0: "simple leaf" (w = 1, r <= 16, level 0) -> one thread each;
             // class 1: small (one wave); class 2: large (256 threads)
             int cls = (s.w <= 8 && s.r <= 64) ? 1 : 2;
-            if (s.w == 1 && s.r <= SIMPLE_RMAX && s.level == 0 && (s.r == 0 || sym[b].rowidx[s.rows] >= sym[b].n_head)) cls = 0;
+            if (s.w == 1 && s.r <= SIMPLE_RMAX && s.level == 0) cls = 0;
             keys.push_back({s.level, cls, b, l});
             nlev = std::max(nlev, s.level + 1);
          }
@@ -1151,7 +1151,7 @@ struct Engine {
    void launch_head_level(const LevelRange& L, double* SC, int ldSC, const ScatterCtx& sx) {
       if (L.simple_cnt > 0)
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
-                            L.simple_cnt, d_blks, d_rowidx, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
+                            L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
       if (L.small_cnt > 0)
          hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
                             d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);

@@ -455,15 +455,16 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor_spine(const int* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// "simple leaf" head supernodes: width 1, at most 16 rows below, elimination-tree leaves whose rows all lie in the dense
-// tail or the border (every primal column of an LP block looks like this: ~10^4 per block).  One THREAD per supernode:
+// "simple leaf" head supernodes: width 1, at most 16 rows below, elimination-tree leaves (every primal column of an LP block
+// looks like this: ~10^4 per block; their rows lie in the dense tail / border, or - time-coupled blocks - in the head, where
+// the positions come from the segment tables).  One THREAD per supernode:
 // the launch is throughput-bound instead of paying a workgroup's dependent-load latency chain per 21-flop supernode.
 // ------------------------------------------------------------------------------------------------
 constexpr int SIMPLE_RMAX = 16;
 
 __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                                            const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                           const signed char* __restrict__ psign,
+                                                           const int* __restrict__ upd, const signed char* __restrict__ psign,
                                                            const long long* __restrict__ psign_off, const int* __restrict__ bmap,
                                                            double* __restrict__ arena, double* __restrict__ SC, int ldSC,
                                                            int* __restrict__ inertia, const double* __restrict__ pref,
@@ -494,9 +495,32 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
       double* T = arena + bd.T;
       const int* bm = bmap + bd.bmap_off;
       const int n = bd.n, n_head = bd.n_head;
+      // target columns inside the head (time-coupled blocks: the rows of a primal column are dual rows the dissection keeps in the
+      // head): positions from the precomputed segment tables, as in head_factor_body; l is re-read from the panel (L1 hits)
+      // because the segment bounds are run-time values and a dynamically indexed register array would go to scratch
+      int b_head = 0;
+      {
+         const int* U = upd + sn.upd;
+         const int nseg = sn.n_useg < r ? sn.n_useg : r;   // every segment holds at least one of the r rows
+         for (int sg = 0; sg < nseg; ++sg) {
+            const int sb0 = U[0], sb1 = U[1], tld = U[3];
+            if (sb0 != b_head || sb1 <= sb0 || sb1 > r) break;   // segments tile the head rows in order; anything else is not a table of this supernode
+            const long long tpanel = (long long)(((unsigned long long)(unsigned)U[5] << 32) | (unsigned long long)(unsigned)U[4]);
+            const int* pp = U + USEG_HDR;
+            double* TP = arena + bd.arena_off + tpanel;
+            for (int b = sb0; b < sb1; ++b) {
+               const double lbd = P[1 + b] * d;
+               const long long colo = (long long)pp[b - sb0] * tld;
+               for (int a = b; a < r; ++a)
+                  scatter_add(sx, TP + pp[a - sb0] + colo, false, pair_slot(sn.slot, a, b, r), -P[1 + a] * lbd);
+            }
+            U += USEG_HDR + (r - sb0);
+            b_head = sb1;
+         }
+      }
 #pragma unroll
       for (int b = 0; b < SIMPLE_RMAX; ++b) {
-         if (b < r) {
+         if (b < r && b >= b_head) {
             const int cb = ro[b];
             const double lbd = l[b] * d;
 #pragma unroll
@@ -1507,7 +1531,7 @@ struct SweepArgs {
    // several right-hand sides: blockIdx.y = right-hand side, each with its own tickets (2 ints), flags and work vector
    long long flag_stride, xw_stride;
 };
-constexpr long long SWEEP_POLL_LIMIT = 20000000;
+constexpr long long SWEEP_POLL_LIMIT = 4000000;   // ~5 s of polling: three orders of magnitude above the longest legitimate wait
 constexpr int SWEEP_NRHS_MAX = 32;
 
 __device__ __forceinline__ bool sweep_wait(const int* f, int epoch) {

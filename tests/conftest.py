@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # No test of this suite needs more than a few minutes (the longest generates 256 x 50 000-variable blocks).  If the
+    # pytest-timeout plugin is there, a test that hangs - a wedged device, a kernel that never returns - ends the session with a
+    # stack dump after 15 minutes instead of holding the GPU box until somebody else's limit kills it.
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900
+        config.option.timeout_method = "thread"
 
 
 def pytest_sessionstart(session):
