@@ -506,7 +506,10 @@ struct BlockInput {
 
 constexpr long long CHAIN_LAUNCH_MAX = 1024;   // waves per launch below which the head solve kernels are latency-bound
 
-struct LevelRange { int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt; };
+struct LevelRange {
+   int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt;
+   int small_lds = 0, large_lds = 0;   // doubles of LDS the widest L21 panel of the class needs (r * (w | 1)), capped at the kernel's capacity
+};
 
 // Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
 static void apply_tuning(AnalyzeOptions& opt) {
@@ -901,6 +904,19 @@ struct Engine {
       std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
          return a.level != b.level ? a.level < b.level : a.cls < b.cls;
       });
+      if (getenv("PIPS_HIP_DUMP_LEVELS")) {   // development aid: shape of the head, level by level
+         std::vector<long long> cnt(nlev * 3, 0), rmax(nlev, 0), wsum(nlev, 0), pairs(nlev, 0);
+         for (const Key& k : keys) {
+            const HeadSupernode& s = sym[k.blk].sn[k.loc];
+            ++cnt[k.level * 3 + k.cls];
+            rmax[k.level] = std::max<long long>(rmax[k.level], s.r);
+            wsum[k.level] += s.w;
+            pairs[k.level] += (long long)s.r * (s.r + 1) / 2;
+         }
+         for (int l = 0; l < nlev; ++l)
+            fprintf(stderr, "level %3d: simple %lld small %lld large %lld  columns %lld  max r %lld  update pairs %lld\n", l, cnt[3 * l], cnt[3 * l + 1],
+                    cnt[3 * l + 2], wsum[l], rmax[l], pairs[l]);
+      }
       // ---- spine: the top levels that hold at most two supernodes of every block (chain-like trees of time-coupled
       //      blocks).  One launch per level would be pure latency there; they go to the per-block spine kernels instead.
       n_levels_all = nlev;
@@ -921,8 +937,8 @@ struct Engine {
       long long slots_acc = 0, vslots_acc = 0;
       std::vector<std::vector<int>> sorted_id(nblk);
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
-      levels.assign(lstar, LevelRange{0, 0, 0, 0, 0, 0});
-      levels_top.assign(nlev - lstar, LevelRange{0, 0, 0, 0, 0, 0});
+      levels.assign(lstar, LevelRange{0, 0, 0, 0, 0, 0, 0, 0});
+      levels_top.assign(nlev - lstar, LevelRange{0, 0, 0, 0, 0, 0, 0, 0});
       for (int i = 0; i < nsn_total; ++i) {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
@@ -935,6 +951,9 @@ struct Engine {
          if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
          else if (k.cls == 1) { if (L.small_cnt++ == 0) L.small_begin = i; }
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
+         const long long need = (long long)s.r * (s.w | 1);
+         if (k.cls == 1) L.small_lds = (int)std::max<long long>(L.small_lds, std::min<long long>(need, 640));
+         else if (k.cls == 2) L.large_lds = (int)std::max<long long>(L.large_lds, std::min<long long>(need, 6144));
       }
       // spine lists: per block, ascending local index = postorder (children before parents)
       std::vector<int> h_spine, h_spine_off(nblk + 1, 0);
@@ -1153,12 +1172,13 @@ struct Engine {
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
                             L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
       if (L.small_cnt > 0)
-         hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), 0, stream, d_sns, L.small_begin,
-                            d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
-      if (L.large_cnt > 0)
-         hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), 0, stream, d_sns,
+         hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), (size_t)std::max(L.small_lds, 1) * sizeof(double), stream, d_sns,
+                            L.small_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
+                            L.small_lds);
+      if (L.large_cnt > 0)   // the L21 cache is sized to the widest panel of this launch: small panels, many workgroups per compute unit
+         hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), (size_t)std::max(L.large_lds, 1) * sizeof(double), stream, d_sns,
                             L.large_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
-                            d_inertia, d_pref, d_sctab, sx);
+                            d_inertia, d_pref, d_sctab, sx, L.large_lds);
    }
    void gather(const GatherList& g, const double* vals, double* target) {
       if (g.n_targets > 0)

@@ -270,12 +270,14 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
                                                  const long long* __restrict__ psign_off, const int* __restrict__ bmap,
                                                  double* __restrict__ arena, double* __restrict__ SC, int ldSC,
                                                  int* __restrict__ inertia, const double* __restrict__ pref,
-                                                 const int* __restrict__ sctab, const ScatterCtx& sx) {
+                                                 const int* __restrict__ sctab, const ScatterCtx& sx, double* Ls, int lcap) {
+   // Ls / lcap: LDS cache for L21 and its capacity in doubles (at most LCAP).  The level kernels size it per launch to what the
+   // supernodes of that launch need (dynamic LDS): a fixed 48 KB held a launch of tens of thousands of small supernodes
+   // (time-coupled blocks: w ~ 20, r ~ 60) to two workgroups per compute unit.
    __shared__ double Ld[WMAX * WMAX];  // pivot block, column-major ld = w; column k keeps l_ik * d_k (unscaled)
    __shared__ double dk[WMAX];
    __shared__ double prf[WMAX];
    __shared__ int sgn[WMAX];
-   __shared__ double Ls[LCAP];
 
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
    double* P = arena + sn.panel;
@@ -333,7 +335,7 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
    // ---- L21 := A21 L11^-T D^-1, one row per thread (coalesced along the rows of each column).  With the unscaled
    //      pivot block the recurrence reads  l_k = (a_k - sum_{l<k} l_l * Ld[k,l]) / d_k.
    const int lw = w | 1;   // odd LDS row stride: conflict-free when lanes walk over rows
-   const bool cacheL = (long long)r * lw <= LCAP;
+   const bool cacheL = (long long)r * lw <= lcap;
    for (int a = tid; a < r; a += BLOCK) {
       double y[WMAX];
       double* row = P + w + a;
@@ -422,10 +424,11 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor(const SnDesc* __restrict_
                                                       const int* __restrict__ bmap, double* __restrict__ arena,
                                                       double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
                                                       const double* __restrict__ pref, const int* __restrict__ sctab,
-                                                      ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
+                                                      ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int lcap = LCAP) {
+   extern __shared__ double head_Ls[];   // lcap doubles (launch parameter)
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab, sx);
+   head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab, sx, head_Ls, lcap);
 }
 
 // "Spine" of a chain-like elimination tree: the top levels that hold at most two supernodes per block.  Level scheduling
@@ -442,13 +445,14 @@ __global__ __launch_bounds__(BLOCK) void k_head_factor_spine(const int* __restri
                                                             const int* __restrict__ bmap, double* __restrict__ arena,
                                                             double* __restrict__ SC, int ldSC, int* __restrict__ inertia,
                                                             const double* __restrict__ pref, const int* __restrict__ sctab) {
+   __shared__ double Ls[LCAP];
    const int p0 = spine_off[blockIdx.x], p1 = spine_off[blockIdx.x + 1];
    if (p0 == p1) return;
    const BlkDesc bd = blks[blockIdx.x];
    for (int p = p0; p < p1; ++p) {
       const SnDesc sn = sns[spine[p]];
       head_factor_body<BLOCK, WMAX, LCAP>(sn, bd, rowidx, upd, psign, psign_off, bmap, arena, SC, ldSC, inertia, pref, sctab,
-                                          ScatterCtx{0, nullptr, nullptr, nullptr, nullptr});
+                                          ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, Ls, LCAP);
       __threadfence();
       __syncthreads();
    }
