@@ -310,10 +310,6 @@ constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the c
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
-   // experiment: unused dynamic LDS for the diagonal-tile kernel, so that fewer update workgroups fit beside it on its CU
-   static const int pad_root = getenv("PIPS_HIP_DIAG_LDS_PAD_ROOT") ? atoi(getenv("PIPS_HIP_DIAG_LDS_PAD_ROOT")) : 0;
-   static const int pad_leaf = getenv("PIPS_HIP_DIAG_LDS_PAD_LEAF") ? atoi(getenv("PIPS_HIP_DIAG_LDS_PAD_LEAF")) : 0;
-   const int diag_lds_pad = c.is_root ? pad_root : pad_leaf;
    static const int root_chunk = getenv("PIPS_HIP_ROOT_CHUNK") ? atoi(getenv("PIPS_HIP_ROOT_CHUNK")) : 0;
    auto gemm_diag_tiles = [&](const TaskList& l, hipStream_t st) {
       hipLaunchKernelGGL(k_tile_gemm<4>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
@@ -378,7 +374,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipEventRecord(c.ev_panel, c.stream));
          HIP_TRY(hipStreamWaitEvent(c.side, c.ev_panel, 0));
          gemm_diag_tiles(p.upd_diag[j], c.side);
-         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds_pad, c.side, p.d_tasks + p.diag[j].off,
+         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.side, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
          HIP_TRY(hipEventRecord(c.ev_rest, c.side));
       } else if (p.upd_diag[j].cnt > 0) {
@@ -393,7 +389,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_rest, 0));   // trsm needs Winv_j and d_j
       } else {
          if (c.timer) c.timer->begin(c.stream, 3);
-         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), diag_lds_pad, c.stream, p.d_tasks + p.diag[j].off,
+         hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
          if (c.timer) c.timer->end(c.stream);
       }
