@@ -128,3 +128,19 @@ def test_partial_nested_dissection_on_time_coupled_block():
     finally:
         del os.environ["PIPS_HIP_ND_DEPTH"]
     assert np.array_equal(a["perm"], b["perm"])
+
+
+def test_deep_dissection_beats_the_round_one_setting():
+    """Time-coupled block of 20 000 variables: dissecting the dual rows down to 128-row segments (the default) gives a far
+    shallower elimination tree than 4 levels / 512-row segments (round 1's cap) at about the same fill."""
+    n_i, my_i = 20000, 10000
+    K, W = _banded_kkt(n_i, my_i, 12, seed=3)
+    os.environ["PIPS_HIP_ND_DEPTH"], os.environ["PIPS_HIP_ND_MIN"] = "4", "512"
+    try:
+        old = pa.symbolic_probe(K, n_i, force_n_head=K.nrows)
+    finally:
+        del os.environ["PIPS_HIP_ND_DEPTH"], os.environ["PIPS_HIP_ND_MIN"]
+    new = pa.symbolic_probe(K, n_i, force_n_head=K.nrows, want_perm=True)
+    assert new["n_levels"] * 3 < old["n_levels"], (new["n_levels"], old["n_levels"])
+    assert new["nnzL"] <= 1.10 * old["nnzL"], (new["nnzL"], old["nnzL"])
+    assert sorted(new["perm"].tolist()) == list(range(K.nrows))
