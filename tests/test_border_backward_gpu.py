@@ -123,3 +123,21 @@ def test_border_backward_general_structure(monkeypatch):
     for (b0, bl, x0n, xln), (_, _, x0o, xlo) in zip(new, old):
         assert np.abs(x0n - x0o).max() <= 1e-9 * np.abs(x0o).max()
         assert np.abs(xln - xlo).max() <= 1e-9 * np.abs(xlo).max()
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_border_backward_forced_on_the_general_structure_sweep(case, monkeypatch):
+    """the seeded general-structure cases of test_general_gpu.py (root equality / inequality rows, linking rows of both kinds,
+    empty parts) with the augmented-factor Ltsolve forced on, against the restatement"""
+    from tests.test_general_gpu import _check_general
+    monkeypatch.setenv("PIPS_HIP_BORDER_BACKWARD", "1")
+    rng = np.random.default_rng(8100 + case)
+    N = int(rng.integers(1, 4))
+    nx = int(rng.choice([40, 120, 260, 500]))
+    my = int(nx * rng.choice([0.2, 0.4]))
+    mz = int(nx * rng.choice([0.0, 0.1, 0.3]))
+    n0 = int(rng.integers(2, 16))
+    my0, mz0 = int(rng.integers(0, min(5, n0 // 2 + 1))), int(rng.integers(0, 6))
+    myl, mzl = int(rng.integers(0, 8)), int(rng.integers(0, 6))
+    rho = max(float(rng.choice([0.03, 0.08])), 4.0 / nx)
+    _check_general(700 + case, (N, nx, my, mz, n0, my0, mz0, myl, mzl), rho, 1, False)
