@@ -38,7 +38,9 @@ def apply_options(opts, batch=None, ipm=None):
                                   (partial factorisation of the augmented block - what PardisoSchurSolver does in the reference)
       PARDISO_NITERATIVE_REFINS   >= 0 -> at most that many refinement steps per leaf solve (iparm[7])
       PARDISO_PIVOT_PERTURBATION  k > 0 -> pivots replaced at 1e-k relative (iparm[9])
-    ipm (IpmSolver): GONDZIO_MAX_CORRECTORS, OUTER_SOLVE, OUTER_BICG_MAX_ITER, REGULARIZATION"""
+    ipm (IpmSolver / GeneralIpmSolver): GONDZIO_MAX_CORRECTORS, OUTER_SOLVE, OUTER_BICG_MAX_ITER, OUTER_BICG_MAX_NORMR_DIVERGENCES,
+      OUTER_BICG_MAX_STAGNATIONS, OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM (false = every outer solve on the regularised system, what
+      PIPSIPMppOptions.C:293 sets), REGULARIZATION"""
     applied, ignored = [], []
     for ident, value in opts.items():
         done = False
@@ -52,7 +54,8 @@ def apply_options(opts, batch=None, ipm=None):
             elif ident == "PARDISO_PIVOT_PERTURBATION" and value > 0:
                 batch.set_options(repl_rel=10.0 ** (-int(value)))
                 done = True
-        if ipm is not None and ident in ("GONDZIO_MAX_CORRECTORS", "OUTER_SOLVE", "OUTER_BICG_MAX_ITER", "REGULARIZATION"):
+        if ipm is not None and ident in ("GONDZIO_MAX_CORRECTORS", "OUTER_SOLVE", "OUTER_BICG_MAX_ITER", "OUTER_BICG_MAX_NORMR_DIVERGENCES",
+                                         "OUTER_BICG_MAX_STAGNATIONS", "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM", "REGULARIZATION"):
             if ident == "OUTER_SOLVE" and value == 0:
                 ignored.append(ident)   # the harness always refines against the original system
                 continue

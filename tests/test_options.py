@@ -44,6 +44,14 @@ def test_options_reach_the_batch_and_the_harness(tmp_path):
     r1 = ipm.solve(max_iter=100, mutol=1e-8, artol=1e-8)
     assert r0["status"] == 0 and r1["status"] == 0 and abs(r0["objective"] - r1["objective"]) < 1e-6 * abs(r0["objective"])
     assert base.stats()["gondzio_correctors"] > 0 and ipm.stats()["gondzio_correctors"] == 0
+    # the reference's own default for the system the outer solve runs on (PIPSIPMppOptions.C:293) reaches the harness
+    q = tmp_path / "reg.opt"
+    q.write_text("OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM false bool\nOUTER_BICG_MAX_STAGNATIONS 4 int\n")
+    ipm2 = pa.IpmSolver(6, 5, blocks, F0, c, b)
+    applied, ignored = apply_options(load_options(str(q)), ipm=ipm2)
+    assert applied == ["OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM", "OUTER_BICG_MAX_STAGNATIONS"] and ignored == []
+    r2 = ipm2.solve(max_iter=100, mutol=1e-8, artol=1e-8)
+    assert r2["status"] == 0 and abs(r0["objective"] - r2["objective"]) < 1e-6 * abs(r0["objective"])
     with pytest.raises(RuntimeError):
         ipm.set_option("NOT_AN_OPTION", 1)
     with pytest.raises(RuntimeError):
