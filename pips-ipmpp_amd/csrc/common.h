@@ -92,7 +92,37 @@ struct BlockSym {
    std::vector<int> colcount;           // AMD column counts (diagnostics)
    std::vector<int> tile_first;         // per tile row of the tail panel (m_pad + nb_pad rows): first tile column inside the
                                         // row envelope of the tail's Schur complement (0 = dense row); fill stays inside it
+   // ---- multifrontal head (symbolic.cpp "multifrontal metadata"): every head supernode that is not a simple leaf is a front
+   //      (w + r) x (w + r) whose update matrix (r x r, packed lower) goes to its parent front instead of being scattered
+   bool mf_ok = false;                  // every front fits the LDS budget (AnalyzeOptions::mf_lds_doubles)
+   int mf_max_front = 0;                // largest w + r among the fronts
+   int64_t mf_U_total = 0;              // doubles of update-matrix storage of this block
+   std::vector<int> sn_parent;          // per head supernode: the head supernode that holds its first below-row, else -1
+   std::vector<int64_t> mf_U;           // per head supernode: offset of its packed update matrix, -1 if it has none
+   std::vector<int64_t> mf_meta;        // per head supernode: offset of its front record inside mf_int, -1 for simple leaves
+   std::vector<int> mf_int;             // front records
+   std::vector<int64_t> mf_fix;         // positions inside mf_int that hold LOCAL supernode ids (the engine renumbers them)
 };
+
+// Front record of supernode J inside BlockSym::mf_int (offsets relative to the record's start):
+//   [0]                    number of child fronts
+//   [1]                    number of simple leaves hanging below this front
+//   [2]                    1 if the front has a parent front (its update matrix stays in the update arena), 0 if it is scattered
+//   [3]                    length of the leaf part
+//   [4]                    number of leaf items
+//   [5]                    doubles of leaf values, sum of (1 + r_c)
+//   [6]                    sum of the children's r_c
+//   [7]                    0
+//   [8 ..)                 child table, 2 ints per child front, children ascending: { offset of its update matrix minus this front's, r_c }
+//   then                   per child, in the same order, the position of each of its r_c below-rows inside THIS front (0 .. w + r)
+//   then                   the leaf part
+//   leaf part              colptr[w + r + 1] | items (2 ints each) | leaf table (3 ints per leaf) | position lists
+//   leaf item              { offset of the leaf's 1 + r_c values << 9 | r_c << 4 | b,  offset of its position list inside the leaf part }
+//                          - the leaf's b-th row is this front column; items are sorted by front column, inside a column by leaf
+//   leaf table entry       { panel offset inside the block arena, r_c, offset of its values }
+//   position list          position of each of the leaf's r_c rows inside the front
+constexpr int MF_HDR = 8;
+constexpr int MF_MAX_FRONT = 512;    // a thread per front row
 
 struct CsrPattern {
    int nrows = 0, ncols = 0;
@@ -112,6 +142,10 @@ struct AnalyzeOptions {
    const int* user_perm = nullptr;   // given elimination order (perm[new] = old) instead of minimum degree / dissection
    bool constrain_order = true;   // dual rows only after their primal neighbours (leaf KKT blocks); false: plain minimum degree,
                                   // the inertia hint still supplies the expected pivot signs (sparse Schur complement)
+   int simple_rmax = 16;      // width-1 tree leaves with at most this many rows are "simple leaves" (one thread each on the device)
+   int64_t mf_lds_doubles = 19200;   // LDS budget of one front (150 KB of the 160 KB): the packed front if it fits, else its w panel
+                                     // columns (the update matrix then stays in device memory); neither, or more than
+                                     // MF_MAX_FRONT rows: the block is not multifrontal
    double relax_zeros = 0.4;  // supernode amalgamation: admissible share of explicit zeros in a panel (0 = fundamental)
    int min_tail = 256;        // do not open a dense tail smaller than this
    int force_n_head = -1;     // >=0: override the cost model (tests)

@@ -507,6 +507,14 @@ struct LevelRange {
    int small_lds = 0, large_lds = 0;   // doubles of LDS the widest L21 panel of the class needs (r * (w | 1)), capped at the kernel's capacity
 };
 
+// Multifrontal head: one launch per (level, front class); class = (workgroup size, width bound) of k_front.
+struct MfLaunch { int level, cls, begin, cnt, lds_doubles; };
+static inline int mf_class(int w, long long nf, long long lds_budget) {
+   const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
+   if (pw + r * (r + 1) / 2 + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
+   return (nf <= 64 ? 0 : nf <= 128 ? 1 : 2) + 3 * (w <= 16 ? 0 : 1);
+}
+
 // Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
 static void apply_tuning(AnalyzeOptions& opt) {
    opt.tile = TILE;
@@ -516,6 +524,7 @@ static void apply_tuning(AnalyzeOptions& opt) {
    if (const char* ndm = getenv("PIPS_HIP_ND_MIN")) opt.nd_min_size = atoi(ndm);      // smallest segment that is still dissected
    if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);       // seconds per scattered update
    if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
+   if (const char* ml = getenv("PIPS_HIP_MF_LDS")) opt.mf_lds_doubles = atoll(ml);   // LDS budget of a front in doubles (tests: small values force the device-memory variant)
 }
 
 struct Engine {
@@ -547,6 +556,11 @@ struct Engine {
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
    int *d_schur_cols = nullptr, *d_schur_slot = nullptr;
+   bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
+   std::vector<MfLaunch> mf_launches;
+   double* d_mfU = nullptr;    // update matrices of the fronts
+   int* d_mfint = nullptr;     // front records (common.h)
+   long long mfU_total = 0;
    int spine_total = 0, n_levels_all = 0;   // supernodes handled by the per-block spine kernels; tree height before the cut
    int *d_spine = nullptr, *d_spine_off = nullptr;
    long long n_total = 0, nnzK_total = 0, nnzB_total = 0, arena_total = 0, xw_total = 0, bt_rows_total = 0;
@@ -577,6 +591,10 @@ struct Engine {
    void release() {
       if (d_uarena) (void)hipFree(d_uarena);
       d_uarena = nullptr;
+      if (d_mfU) (void)hipFree(d_mfU);
+      if (d_mfint) (void)hipFree(d_mfint);
+      d_mfU = nullptr; d_mfint = nullptr;
+      mf_launches.clear();
       if (d_gemm_ctr) (void)hipFree(d_gemm_ctr);
       d_gemm_ctr = nullptr;
       for (auto& g : g_levels) g.release();
@@ -836,13 +854,31 @@ struct Engine {
       }
       HIP_TRY(hipSetDevice(device));
       release();
+      {  // multifrontal head: every block's fronts must fit the LDS; the slot machinery of deterministic mode records scatters
+         const char* env = getenv("PIPS_HIP_MF");
+         const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
+         mf = !(env && atoi(env) == 0) && !deterministic && !(hs && atoi(hs) != 0);
+         for (int b = 0; b < nblk && mf; ++b) {
+            mf = sym[b].mf_ok;
+            // fronts with very many leaves below them: the staged leaf data must fit beside the front
+            for (size_t l = 0; l < sym[b].sn.size() && mf; ++l) {
+               if (sym[b].mf_meta[l] < 0) continue;
+               const HeadSupernode& s = sym[b].sn[l];
+               const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
+               const long long nf = s.w + s.r, pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));
+               const long long packed = pw + (long long)s.r * (s.r + 1) / 2 + 8, panel = pw + 8;
+               const long long extra = H[5] + (H[6] + H[3] + 1) / 2 + 2;
+               if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) mf = false;   // 159 KB of the 160
+            }
+         }
+      }
 
       // ---- offsets
       h_blks.assign(nblk, BlkDesc());
       kptr.assign(nblk + 1, 0);
       x_off.assign(nblk + 1, 0);
       std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0),
-         upd_base(nblk + 1, 0);
+         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0);
       long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0, uar = 0;
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
@@ -872,6 +908,8 @@ struct Engine {
          x_off[b + 1] = x_off[b] + s.n;
          rows_base[b + 1] = rows_base[b] + (long long)s.rowidx.size();
          upd_base[b + 1] = upd_base[b] + (long long)s.upd.size();
+         mfU_base[b + 1] = mfU_base[b] + (mf ? s.mf_U_total : 0);
+         mfint_base[b + 1] = mfint_base[b] + (mf ? (long long)s.mf_int.size() : 0);
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
          bmap_off[b + 1] = bmap_off[b] + s.nb;
       }
@@ -882,29 +920,54 @@ struct Engine {
                                  "use more ranks or fewer blocks per batch", nnzK_total, nnzB_total, n_total);
       nsn_total = (int)sn_base[nblk];
 
-      // ---- supernodes sorted by (level, size class)
-      struct Key { int level, cls, blk, loc; };
+      // ---- supernodes sorted by (level, size class); multifrontal head: by (level, kernel variant, LDS need)
+      struct Key { int level, cls, lds, blk, loc; };
       std::vector<Key> keys;
       keys.reserve(nsn_total);
       int nlev = 0;
+      auto is_simple = [](const HeadSupernode& s) { return s.w == 1 && s.r <= SIMPLE_RMAX && s.level == 0; };
+      // multifrontal: a level with few fronts is latency, not throughput - all its (LDS-resident) fronts go into ONE launch of the
+      // largest variant any of them needs instead of one launch per variant
+      constexpr int MF_MERGE_MAX = 1024;
+      std::vector<int> lev_cnt, lev_b, lev_w;
+      if (mf)
+         for (int b = 0; b < nblk; ++b)
+            for (const HeadSupernode& s : sym[b].sn) {
+               if (is_simple(s)) continue;
+               if ((int)lev_cnt.size() <= s.level) { lev_cnt.resize(s.level + 1, 0); lev_b.resize(s.level + 1, 0); lev_w.resize(s.level + 1, 0); }
+               const int c = mf_class(s.w, s.w + s.r, opt.mf_lds_doubles);
+               ++lev_cnt[s.level];
+               if (c < 6) { lev_b[s.level] = std::max(lev_b[s.level], c % 3); lev_w[s.level] = std::max(lev_w[s.level], c / 3); }
+            }
       for (int b = 0; b < nblk; ++b)
          for (int l = 0; l < (int)sym[b].sn.size(); ++l) {
             const HeadSupernode& s = sym[b].sn[l];
             // class 0: "simple leaf" (w = 1, r <= 16, level 0) -> one thread each;
             // class 1: small (one wave); class 2: large (256 threads)
-            int cls = (s.w <= 8 && s.r <= 64) ? 1 : 2;
-            if (s.w == 1 && s.r <= SIMPLE_RMAX && s.level == 0) cls = 0;
-            keys.push_back({s.level, cls, b, l});
+            int cls = (s.w <= 8 && s.r <= 64) ? 1 : 2, lds = 0;
+            if (mf && !is_simple(s)) {
+               int c = mf_class(s.w, s.w + s.r, opt.mf_lds_doubles);
+               if (c < 6 && lev_cnt[s.level] <= MF_MERGE_MAX) c = lev_b[s.level] + 3 * lev_w[s.level];
+               cls = 1 + c;
+               // LDS of a front: the packed front (or its panel columns) + 8 doubles of slack, the leaves' values, and as ints the
+               // children's position lists and the leaf part of the record (common.h "Front record")
+               const long long nf = s.w + s.r;
+               const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
+               const long long pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));   // packed panel / aligned L21 copy
+               lds = (int)(pw + (c >= 6 ? 0 : (long long)s.r * (s.r + 1) / 2) + 8 + H[5] + (H[6] + H[3] + 1) / 2 + 2);
+            }
+            if (is_simple(s)) cls = 0;
+            keys.push_back({s.level, cls, lds, b, l});
             nlev = std::max(nlev, s.level + 1);
          }
       std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-         return a.level != b.level ? a.level < b.level : a.cls < b.cls;
+         return a.level != b.level ? a.level < b.level : (a.cls != b.cls ? a.cls < b.cls : a.lds < b.lds);
       });
       if (getenv("PIPS_HIP_DUMP_LEVELS")) {   // development aid: shape of the head, level by level
          std::vector<long long> cnt(nlev * 3, 0), rmax(nlev, 0), wsum(nlev, 0), pairs(nlev, 0);
          for (const Key& k : keys) {
             const HeadSupernode& s = sym[k.blk].sn[k.loc];
-            ++cnt[k.level * 3 + k.cls];
+            ++cnt[k.level * 3 + std::min(k.cls, 2)];
             rmax[k.level] = std::max<long long>(rmax[k.level], s.r);
             wsum[k.level] += s.w;
             pairs[k.level] += (long long)s.r * (s.r + 1) / 2;
@@ -927,7 +990,7 @@ struct Engine {
          }
          while (lstar > 0 && width[lstar - 1] <= 2) --lstar;
          const char* env = getenv("PIPS_HIP_SPINE");
-         if (nlev - lstar < 8 || (env && atoi(env) == 0) || deterministic) lstar = nlev;   // the spine kernels hand over through atomics
+         if (nlev - lstar < 8 || (env && atoi(env) == 0) || deterministic || mf) lstar = nlev;   // the spine kernels hand over through atomics
       }
       std::vector<SnDesc> h_sns(nsn_total);
       long long slots_acc = 0, vslots_acc = 0;
@@ -939,14 +1002,32 @@ struct Engine {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
-                           s.n_useg, s.rb, slots_acc, vslots_acc};
+                           s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1};
+         if (mf) {
+            const BlockSym& bs = sym[k.blk];
+            if (bs.mf_U[k.loc] >= 0) h_sns[i].U = mfU_base[k.blk] + bs.mf_U[k.loc];
+            if (bs.mf_meta[k.loc] >= 0) h_sns[i].mf = mfint_base[k.blk] + bs.mf_meta[k.loc];
+         }
          slots_acc += (long long)s.r * (s.r + 1) / 2;
          vslots_acc += s.r;
          sorted_id[k.blk][k.loc] = i;
          LevelRange& L = k.level >= lstar ? levels_top[k.level - lstar] : levels[k.level];
          if (k.cls == 0) { if (L.simple_cnt++ == 0) L.simple_begin = i; }
-         else if (k.cls == 1) { if (L.small_cnt++ == 0) L.small_begin = i; }
+         else if (k.cls == 1 || mf) { if (L.small_cnt++ == 0) L.small_begin = i; }   // multifrontal: one contiguous range of fronts per level
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
+         if (mf && k.cls > 0) {
+            // one launch per (level, variant, LDS bucket): the dynamic LDS of a launch is that of its largest front, and it decides how
+            // many fronts share a compute unit - a bucket spans at most a quarter more than its smallest member (small runs stay whole)
+            bool open = mf_launches.empty() || mf_launches.back().level != k.level || mf_launches.back().cls != k.cls - 1;
+            if (!open) {
+               const MfLaunch& m = mf_launches.back();
+               const int first_lds = keys[m.begin].lds;
+               if (m.cnt >= 2048 && k.lds > std::max(first_lds + first_lds / 4, first_lds + 256)) open = true;
+            }
+            if (open) mf_launches.push_back({k.level, k.cls - 1, i, 0, 0});
+            ++mf_launches.back().cnt;
+            mf_launches.back().lds_doubles = std::max(mf_launches.back().lds_doubles, k.lds);
+         }
          const long long need = (long long)s.r * (s.w | 1);
          if (k.cls == 1) L.small_lds = (int)std::max<long long>(L.small_lds, std::min<long long>(need, 640));
          else if (k.cls == 2) L.large_lds = (int)std::max<long long>(L.large_lds, std::min<long long>(need, 6144));
@@ -992,6 +1073,17 @@ struct Engine {
          std::copy(in[b].kcol.begin(), in[b].kcol.end(), h_kcolidx.begin() + kptr[b]);
       }
       h_krowptr[n_total] = (int)nnzK_total;
+      if (mf) {
+         std::vector<int> h_mfint((size_t)mfint_base[nblk]);
+         for (int b = 0; b < nblk; ++b) {
+            const BlockSym& s = sym[b];
+            std::copy(s.mf_int.begin(), s.mf_int.end(), h_mfint.begin() + mfint_base[b]);
+            for (int64_t pos : s.mf_fix) h_mfint[(size_t)(mfint_base[b] + pos)] = sorted_id[b][s.mf_int[(size_t)pos]];
+         }
+         mfU_total = mfU_base[nblk];
+         if ((rc = dev_upload(&d_mfint, h_mfint, stream))) return rc;
+         HIP_TRY(hipMalloc((void**)&d_mfU, (size_t)std::max<long long>(mfU_total, 1) * sizeof(double)));
+      }
       {  // both triangles, row by row: entry (i, j) of the lower CSR also appears in row j as (j, i)
          std::vector<int> frp(n_total + 1, 0);
          for (int b = 0; b < nblk; ++b)
@@ -1166,7 +1258,9 @@ struct Engine {
    void launch_head_level(const LevelRange& L, double* SC, int ldSC, const ScatterCtx& sx) {
       if (L.simple_cnt > 0)
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
-                            L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx);
+                            L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
+                            mf ? 1 : 0);
+      if (mf) return;
       if (L.small_cnt > 0)
          hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), (size_t)std::max(L.small_lds, 1) * sizeof(double), stream, d_sns,
                             L.small_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
@@ -1175,6 +1269,49 @@ struct Engine {
          hipLaunchKernelGGL((k_head_factor<256, 32, 6144>), dim3(L.large_cnt), dim3(256), (size_t)std::max(L.large_lds, 1) * sizeof(double), stream, d_sns,
                             L.large_begin, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC,
                             d_inertia, d_pref, d_sctab, sx, L.large_lds);
+   }
+   template <int BLOCK, int WMAX, bool UG = false>
+   int launch_front(const MfLaunch& m, double* SC, int ldSC) {
+      const size_t lds = (size_t)m.lds_doubles * sizeof(double);
+      if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front<BLOCK, WMAX, UG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_front<BLOCK, WMAX, UG>), dim3(m.cnt), dim3(BLOCK), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_psign,
+                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg);
+      return PIPS_OK;
+   }
+   long long* d_mfdbg = nullptr;   // PIPS_HIP_MF_CLOCKS: phase stamps of every front (8 per supernode), dumped after the factorisation
+   int dump_front_clocks() {
+      std::vector<long long> h((size_t)nsn_total * 8);
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpy(h.data(), d_mfdbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      static const char* names[7] = {"panel+zero", "stage ints", "leaf values + children", "leaf columns", "pivots", "update", "write-out"};
+      for (const MfLaunch& m : mf_launches) {
+         double ph[8] = {0}; long long nfs = 0, ws = 0;
+         for (int i = m.begin; i < m.begin + m.cnt; ++i) {
+            for (int q = 0; q < 7; ++q) ph[q] += (double)(h[(size_t)i * 8 + q + 1] - h[(size_t)i * 8 + q]);
+            nfs += h_sns_keep[i].w + h_sns_keep[i].r; ws += h_sns_keep[i].w;
+         }
+         fprintf(stderr, "[mf clocks] level %2d variant %d fronts %6d lds %6d  avg nf %5.1f w %4.1f | ", m.level, m.cls, m.cnt, m.lds_doubles * 8, (double)nfs / m.cnt, (double)ws / m.cnt);
+         for (int q = 0; q < 7; ++q) fprintf(stderr, "%s %.1f%s", names[q], ph[q] / m.cnt * 0.01, q == 6 ? " us\n" : ", ");
+      }
+      return PIPS_OK;
+   }
+   int launch_fronts(int level, double* SC, int ldSC) {
+      int rc = PIPS_OK;
+      for (const MfLaunch& m : mf_launches) {
+         if (m.level != level) continue;
+         switch (m.cls) {
+            case 0: rc = launch_front<64, 16>(m, SC, ldSC); break;
+            case 1: rc = launch_front<128, 16>(m, SC, ldSC); break;
+            case 2: rc = launch_front<256, 16>(m, SC, ldSC); break;
+            case 3: rc = launch_front<64, 32>(m, SC, ldSC); break;
+            case 4: rc = launch_front<128, 32>(m, SC, ldSC); break;
+            case 5: rc = launch_front<256, 32>(m, SC, ldSC); break;
+            case 6: rc = launch_front<256, 32, true>(m, SC, ldSC); break;
+            default: rc = launch_front<512, 32, true>(m, SC, ldSC); break;
+         }
+         if (rc) return rc;
+      }
+      return PIPS_OK;
    }
    void gather(const GatherList& g, const double* vals, double* target) {
       if (g.n_targets > 0)
@@ -1346,6 +1483,7 @@ struct Engine {
          if (timer.on) timer.begin(stream, 1);
          if (head_slots) gather(g_levels[li], d_slot_val, d_arena);   // contributions of the lower levels, in fixed order
          launch_head_level(levels[li], SC, ldSC, sx);
+         if (mf) { const int frc = launch_fronts((int)li, SC, ldSC); if (frc) return frc; }
          if (timer.on) timer.end(stream);
       }
       if (head_slots) {
@@ -1362,6 +1500,10 @@ struct Engine {
          hipLaunchKernelGGL((k_head_factor_spine<256, 32, 6144>), dim3(nblk), dim3(256), 0, stream, d_spine, d_spine_off, d_sns, d_blks,
                             d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab);
          if (timer.on) timer.end(stream);
+      }
+      if (mf && getenv("PIPS_HIP_MF_CLOCKS")) {
+         if (!d_mfdbg) HIP_TRY(hipMalloc((void**)&d_mfdbg, (size_t)std::max(nsn_total, 1) * 8 * sizeof(long long)));
+         else { int drc = dump_front_clocks(); if (drc) return drc; }
       }
       hipLaunchKernelGGL(k_pref_tail, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_arena, d_pref, 0);
       HIP_TRY(hipGetLastError());
@@ -2188,6 +2330,10 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
    if (!e || e->sym.empty()) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_info: analyze first");
    sym_info(e->sym, what, n_what);
    if (n_what > 13) what[13] = e->border_backward_ok ? 1 : 0;
+   if (n_what > 14) what[14] = e->mf ? 1 : 0;
+   if (n_what > 15) { what[15] = 0; for (const BlockSym& s : e->sym) what[15] = std::max<int64_t>(what[15], s.mf_max_front); }
+   if (n_what > 16) what[16] = e->mfU_total * 8;
+   if (n_what > 17) { what[17] = 0; for (const MfLaunch& m : e->mf_launches) if (m.cls >= 6) what[17] += m.cnt; }
    return PIPS_OK;
 }
 
@@ -2935,6 +3081,20 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
    int rc = analyze_block(K, B, n_primal, opt, sym[0]);
    if (rc) return rc;
    if (what) sym_info(sym, what, n_what);
+   if (const char* dump = getenv("PIPS_HIP_DUMP_SN")) {   // development aid: one line per head supernode
+      if (FILE* f = fopen(dump, "w")) {
+         const BlockSym& bs = sym[0];
+         for (const HeadSupernode& s : bs.sn) {
+            const int* rows = bs.rowidx.data() + s.rows;
+            int nh = 0, nt = 0;
+            for (int a = 0; a < s.r; ++a) { if (rows[a] < bs.n_head) ++nh; else if (rows[a] < bs.n) ++nt; }
+            fprintf(f, "%d %d %d %d %d %d %d %d\n", s.c0, s.w, s.r, s.level, nh, nt, s.r - nh - nt, s.n_useg);
+         }
+         fclose(f);
+         fprintf(stderr, "[pips_hip] multifrontal: ok %d, largest front %d, update matrices %lld doubles, records %zu ints\n", (int)bs.mf_ok, bs.mf_max_front,
+                 (long long)bs.mf_U_total, bs.mf_int.size());
+      }
+   }
    if (perm) std::copy(sym[0].perm.begin(), sym[0].perm.end(), perm);
    if (colcount) std::copy(sym[0].colcount.begin(), sym[0].colcount.end(), colcount);
    return PIPS_OK;

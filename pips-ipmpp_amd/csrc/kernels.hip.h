@@ -34,6 +34,8 @@ struct SnDesc {
    long long slot;   // deterministic mode: first contribution slot of the factorisation scatter (r (r + 1) / 2 slots: pair (a, b),
                      // a >= b, has slot + b r - b (b - 1) / 2 + a - b)
    long long vslot;  // ... and of the forward-substitution scatter (r slots)
+   long long U;      // multifrontal head: offset of the packed r x r update matrix inside the update arena, -1 if none
+   long long mf;     // multifrontal head: offset of the front record inside mfint (common.h "Front record"), -1 for simple leaves
 };
 
 
@@ -258,6 +260,7 @@ constexpr int HEAD_WMAX = 32;   // widest head supernode (solve kernels)
 
 // Head-to-head update segments (symbolic.cpp "update segments"): 8-int header + positions, read-only on the device.
 constexpr int USEG_HDR = 8;
+constexpr int MF_HDR_DEV = 4;
 
 // BLOCK threads; WMAX widest supernode handled; LCAP doubles of L21 cached in LDS.
 // Latency matters more than throughput here (a chain-like elimination tree runs one supernode per block per launch), so
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                                                            double* __restrict__ arena, double* __restrict__ SC, int ldSC,
                                                            int* __restrict__ inertia, const double* __restrict__ pref,
                                                            const int* __restrict__ sctab,
-                                                           ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}) {
+                                                           ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int mf = 0) {
    __shared__ int cnt_s[3];
    __shared__ int blk_s;
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -499,11 +502,14 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
       double* T = arena + bd.T;
       const int* bm = bmap + bd.bmap_off;
       const int n = bd.n, n_head = bd.n_head;
+      // multifrontal head: a leaf below a front leaves its rank-one update to that front (k_front reads d and l from the panel)
+      const bool to_parent = mf && sn.n_useg > 0;
       // target columns inside the head (time-coupled blocks: the rows of a primal column are dual rows the dissection keeps in the
       // head): positions from the precomputed segment tables, as in head_factor_body; l is re-read from the panel (L1 hits)
       // because the segment bounds are run-time values and a dynamically indexed register array would go to scratch
       int b_head = 0;
-      {
+      if (to_parent) b_head = r;
+      else {
          const int* U = upd + sn.upd;
          const int nseg = sn.n_useg < r ? sn.n_useg : r;   // every segment holds at least one of the r rows
          for (int sg = 0; sg < nseg; ++sg) {
@@ -545,6 +551,293 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
    }
    __syncthreads();
    if (threadIdx.x < 3 && cnt_s[threadIdx.x]) atomicAdd(&inertia[3 * blk_s + threadIdx.x], cnt_s[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multifrontal head: one workgroup per front, no FP64 atomics between fronts.
+//   front of supernode J = lower triangle on (its w columns, its r below-rows), packed by columns:
+//       F(i, j) = F[co(j) + i - j],  co(j) = j nf - j (j - 1) / 2,  nf = w + r
+//   the columns j >= w are the update matrix U_J - in the same packed layout a matrix of dimension r has, so it leaves
+//   (to the update arena) and arrives (from the children) as one contiguous piece.  The whole front lives in LDS (UG = false);
+//   fronts too large for that keep only their w panel columns there and work on U_J where it ends up anyway, in the update
+//   arena (UG = true: plain loads and stores of one workgroup, ordered by its barriers).
+//   A front is a latency chain, not a stream; the kernel is organised around that:
+//   0. thread i requests row i of the panel (K entries, scattered into the arena by k_scatter) straight into registers, and the
+//      first w lanes of EVERY wave the pivot rows - up to 64 loads in flight per thread while the LDS front is zeroed;
+//   1. assemble what the children left: child fronts' update matrices are added at the recorded positions, one child after
+//      the other (inside a child the positions are distinct: fire-and-forget LDS adds); the rank-one updates of the simple
+//      leaves below, a thread per front column walking its item list.  Fixed order everywhere: results do not depend on timing;
+//   2. factorise the w panel columns.  Every wave holds the pivot rows itself (lane j = row j) and eliminates them redundantly,
+//      applying each column to its own rows as it goes: pivot, reciprocal and the column's entries travel by v_readlane, there
+//      is no barrier and no LDS traffic in the w dependent steps;
+//   3. U -= L21 D L21^T in 4 x 4 register tiles from a 16-byte aligned copy of L21;
+//   4. U to the update arena - or, for a front whose parent column lies in the dense tail, into the tail / Schur complement (the
+//      only atomics left: these targets are shared between fronts).  The panel went to the arena from the registers in step 2.
+// BLOCK >= w + r threads; WMAX >= w.
+// ------------------------------------------------------------------------------------------------
+// packed lower-triangular index p (columns of a matrix of dimension n one after the other) -> column b; row a = b + p - cu(b)
+__device__ __forceinline__ int packed_col(int p, int n) {
+   const float t = 2.0f * n + 1.0f;
+   int b = (int)((t - sqrtf(t * t - 8.0f * (float)p)) * 0.5f);
+   b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
+   while (b > 0 && b * n - b * (b - 1) / 2 > p) --b;
+   while (b + 1 < n && (b + 1) * n - (b + 1) * b / 2 <= p) ++b;
+   return b;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane: wave-uniform
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+   return __hiloint2double(hi, lo);
+}
+
+// fire-and-forget LDS add (ds_add_f64): no read latency on the issuing wave; where several adds hit one address their order
+// is the program order of the one thread that issues them, or separated by a barrier
+__device__ __forceinline__ void lds_add(double* p, double v) {
+   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int BLOCK, int WMAX, bool UG>
+__global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns, int sn_begin, const BlkDesc* __restrict__ blks,
+                                                const int* __restrict__ rowidx, const int* __restrict__ mfint,
+                                                const signed char* __restrict__ psign, const long long* __restrict__ psign_off,
+                                                const int* __restrict__ bmap, double* __restrict__ arena,
+                                                double* __restrict__ uarena, double* __restrict__ SC, int ldSC,
+                                                int* __restrict__ inertia, const double* __restrict__ pref,
+                                                const int* __restrict__ sctab, long long* __restrict__ dbg) {
+   extern __shared__ __attribute__((aligned(16))) double mf_F[];
+   __shared__ double dk[WMAX];
+   // development aid (PIPS_HIP_MF_CLOCKS): thread 0 stamps the phase boundaries, 8 stamps per front
+#define MF_STAMP(q) do { if (dbg && threadIdx.x == 0) dbg[(long long)(sn_begin + blockIdx.x) * 8 + (q)] = (long long)wall_clock64(); } while (0)
+   MF_STAMP(0);
+   double* F = mf_F;
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   const int w = sn.w, r = sn.r, nf = w + r, tid = threadIdx.x, lane = tid & 63, i = tid;
+   const int* H = mfint + sn.mf;
+   const int n_child = H[0], n_leaf = H[1], has_parent = H[2], n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
+   const int np = r * (r + 1) / 2;
+   auto co = [nf](int j) { return j * nf - j * (j - 1) / 2; };
+   const int cw = co(w);                                       // packed size of the panel columns
+   const int rp = (r + 3) & ~3;                                // row stride of the aligned L21 copy (step 3)
+   const int pw = cw > w * rp ? cw : w * rp;   // the panel region holds the packed panel, later that copy
+   double* FU = UG ? uarena + sn.U : F + pw;                   // U(a, b) = FU[cu(b) + a - b]
+   auto cu = [r](int b) { return b * r - b * (b - 1) / 2; };
+   // F(i, j) += v
+   auto front_add = [&](int fi, int fj, double v) {
+      if (fj < w) lds_add(F + co(fj) + (fi - fj), v);
+      else if (UG) FU[cu(fj - w) + (fi - fj)] += v;
+      else lds_add(FU + cu(fj - w) + (fi - fj), v);
+   };
+   double* P = arena + sn.panel;
+   // LDS behind the front: the leaves' values, then ints: the children's position lists, the leaf part of the record
+   double* vals = F + pw + (UG ? 0 : np) + 8;
+   int* relbuf = (int*)(vals + n_vals);
+   int* leafpart = relbuf + sum_rc;
+
+   const double prf = lane < w ? pref[bd.xw_off + sn.c0 + lane] : 1.0;
+   const int sgn = lane < w ? (int)psign[psign_off[sn.blk] + sn.c0 + lane] : 0;
+
+   // ---- 1. assemble
+   {
+      typedef double double2_t __attribute__((ext_vector_type(2)));
+      const int nz = (pw + (UG ? 0 : np) + 8 + 1) >> 1;          // (the region behind is overwritten below: an odd tail is harmless)
+      double2_t* F2 = (double2_t*)F;
+      const double2_t z = {0.0, 0.0};
+      for (int idx = tid; idx < nz; idx += BLOCK) F2[idx] = z;
+      if (UG) for (int idx = tid; idx < np; idx += BLOCK) FU[idx] = 0.0;
+   }
+   __syncthreads();   // zeros before the staged data (the zeroing may reach one double into the values)
+   MF_STAMP(1);
+   {   // the children's position lists and the leaf part: one contiguous piece of the record
+      const int* src = H + MF_HDR + 2 * n_child;
+      for (int idx = tid; idx < sum_rc + n_leafpart; idx += BLOCK) relbuf[idx] = src[idx];
+   }
+   __syncthreads();
+   MF_STAMP(2);
+   if (n_leaf) {   // the leaves' d and l, a thread per leaf
+      const double* A = arena + bd.arena_off;
+      const int* tab = leafpart + (nf + 1) + 2 * n_items;
+      for (int t = tid; t < n_leaf; t += BLOCK) {
+         const double* Pc = A + tab[3 * t];
+         const int rc = tab[3 * t + 1];
+         double* out = vals + tab[3 * t + 2];
+         double v[SIMPLE_RMAX + 1];
+#pragma unroll
+         for (int a = 0; a <= SIMPLE_RMAX; ++a) v[a] = a <= rc ? Pc[a] : 0.0;
+#pragma unroll
+         for (int a = 0; a <= SIMPLE_RMAX; ++a) if (a <= rc) out[a] = v[a];
+      }
+   }
+   {
+      int off = 0;
+      for (int c = 0; c < n_child; ++c) {
+         const int rc = H[MF_HDR + 2 * c + 1];
+         const double* Uc = uarena + sn.U + H[MF_HDR + 2 * c];
+         const int* rel = relbuf + off;
+         const int npc = rc * (rc + 1) / 2;
+         int bb = packed_col(tid < npc ? tid : 0, rc), ao = tid - (bb * rc - bb * (bb - 1) / 2);   // this thread's entry: column bb, row bb + ao
+         constexpr int NB = 16;                                  // loads in flight per thread: the update matrix comes from another compute unit's launch
+         for (int base = 0; base < npc; base += NB * BLOCK) {
+            double v[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { const int p = base + u * BLOCK + tid; v[u] = p < npc ? Uc[p] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+               const int p = base + u * BLOCK + tid;
+               if (p < npc) {
+                  front_add(rel[bb + ao], rel[bb], v[u]);
+                  ao += BLOCK;                                   // BLOCK entries further down the packed triangle
+                  while (bb < rc - 1 && ao >= rc - bb) { ao -= rc - bb; ++bb; }
+               }
+            }
+         }
+         off += rc;
+         __syncthreads();
+      }
+   }
+   MF_STAMP(3);
+   if (n_leaf) {
+      if (n_child == 0) __syncthreads();   // the leaf values are in place
+      const int* colptr = leafpart;
+      const int* it2 = leafpart + (nf + 1);
+      for (int q = tid; q < nf; q += BLOCK) {
+         for (int it = colptr[q]; it < colptr[q + 1]; ++it) {
+            const int i0 = it2[2 * it], i1 = it2[2 * it + 1];
+            const int b = i0 & 15, rc = (i0 >> 4) & 31;
+            const double* lv = vals + (i0 >> 9);
+            const int* rel = leafpart + i1;
+            const double lbd = -lv[1 + b] * lv[0];
+            for (int a = b; a < rc; ++a) front_add(rel[a], q, lv[1 + a] * lbd);
+         }
+      }
+   }
+   __syncthreads();
+
+   // ---- 2. panel factorisation
+   MF_STAMP(4);
+   // thread i takes row i of the panel (K entries, scattered into the arena by k_scatter, + what was assembled in LDS); the first
+   // w lanes of EVERY wave also take the pivot rows
+   double y[WMAX], yp[WMAX];
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) y[k] = (i < nf && k < w && k <= i) ? P[i + (long long)k * nf] : 0.0;
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) yp[k] = (lane < w && k <= lane) ? P[lane + (long long)k * nf] : 0.0;
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) if (i < nf && k < w && k <= i) y[k] += F[co(k) + i - k];
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) if (lane < w && k <= lane) yp[k] += F[co(k) + lane - k];
+   int c_pos = 0, c_neg = 0, c_pert = 0;
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) {
+      if (k < w) {
+         bool pert;
+         const double d = fix_pivot(readlane_f64(yp[k], k), __builtin_amdgcn_readlane(sgn, k), readlane_f64(prf, k), bd.thr_rel, bd.repl_rel,
+                                    bd.repl_abs, pert);
+         if (pert) ++c_pert; else if (d > 0) ++c_pos; else ++c_neg;
+         const double rd = 1.0 / d;
+         const double uik = y[k], upk = yp[k];
+         const double tcol = upk * rd;                     // lane j: l_jk
+         // no branch per column: beyond column w - 1 tcol is 0 (yp is), and entries right of the diagonal of the pivot block
+         // collect garbage that nobody reads
+#pragma unroll
+         for (int j = k + 1; j < WMAX; ++j) {
+            const double t = readlane_f64(tcol, j);
+            y[j] -= uik * t;
+            yp[j] -= upk * t;
+         }
+         y[k] = i == k ? d : uik * rd;
+         if (tid == 0) dk[k] = d;
+      }
+   }
+   if (tid == 0) {
+      if (c_pos) atomicAdd(&inertia[3 * sn.blk + 0], c_pos);
+      if (c_neg) atomicAdd(&inertia[3 * sn.blk + 1], c_neg);
+      if (c_pert) atomicAdd(&inertia[3 * sn.blk + 2], c_pert);
+   }
+   if (i < nf) {
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k)
+         if (k < w && k <= i) P[i + (long long)k * nf] = y[k];    // l_ik, d_k on the diagonal: what the solves read
+   }
+   __syncthreads();   // every wave has taken its rows out of the packed panel: the region becomes the L21 copy Lt[k * rp + a]
+   if (i >= w && i < nf) {
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k)
+         if (k < w) F[k * rp + (i - w)] = y[k];
+   }
+   for (int idx = tid; idx < w * (rp - r); idx += BLOCK) { const int k = idx / (rp - r); F[k * rp + r + (idx - k * (rp - r))] = 0.0; }
+   __syncthreads();
+
+   // ---- 3. U -= L21 D L21^T, 4 x 4 tiles over the lower triangle (tile pairs ta >= tb, column-major)
+   MF_STAMP(5);
+   if (r > 0) {
+      typedef double double2_t __attribute__((ext_vector_type(2)));
+      const int nt = rp >> 2, ntiles = nt * (nt + 1) / 2;
+      for (int t = tid; t < ntiles; t += BLOCK) {
+         const int tb = packed_col(t, nt), ta = tb + (t - (tb * nt - tb * (tb - 1) / 2));
+         const int a0 = 4 * ta, b0 = 4 * tb;
+         double acc[4][4];
+#pragma unroll
+         for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int z = 0; z < 4; ++z) acc[x][z] = 0.0;
+#pragma unroll 4
+         for (int k = 0; k < w; ++k) {
+            const double2_t* ca = (const double2_t*)(F + k * rp + a0);
+            const double2_t* cb = (const double2_t*)(F + k * rp + b0);
+            const double2_t a01 = ca[0], a23 = ca[1], b01 = cb[0], b23 = cb[1];
+            const double d = dk[k];
+            const double la[4] = {a01.x, a01.y, a23.x, a23.y};
+            const double lb[4] = {b01.x * d, b01.y * d, b23.x * d, b23.y * d};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+               for (int z = 0; z < 4; ++z) acc[x][z] += la[x] * lb[z];
+         }
+#pragma unroll
+         for (int z = 0; z < 4; ++z) {
+            const int b = b0 + z;
+            if (b < r) {
+               double* ub = FU + cu(b) - b;
+#pragma unroll
+               for (int x = 0; x < 4; ++x) {
+                  const int a = a0 + x;
+                  if (a < r && a >= b) { if (UG) ub[a] -= acc[x][z]; else lds_add(ub + a, -acc[x][z]); }
+               }
+            }
+         }
+      }
+   }
+   __syncthreads();
+
+   // ---- 4. the update matrix leaves
+   MF_STAMP(6);
+   if (r == 0) { MF_STAMP(7); return; }
+   if (has_parent) {   // the parent front picks it up from the update arena
+      if (!UG) {
+         double* Ug = uarena + sn.U;
+         for (int idx = tid; idx < np; idx += BLOCK) Ug[idx] = FU[idx];
+      }
+      MF_STAMP(7);
+      return;
+   }
+   // no head parent: the below-rows are tail rows [0, rb) and border rows [rb, r)
+   const int* rows = rowidx + sn.rows;
+   const int n = bd.n, n_head = bd.n_head, rb = sn.rb;
+   double* T = arena + bd.T;
+   const int* bm = bmap + bd.bmap_off;
+   for (int idx = tid; idx < r * r; idx += BLOCK) {
+      const int b = idx / r, a = idx - b * r;
+      if (a < b) continue;
+      const double u = FU[cu(b) + a - b];
+      const int ra = rows[a], cb = rows[b];
+      if (b < rb) {
+         const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
+         atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, u);
+      } else if (SC)
+         atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n), u);
+   }
+   MF_STAMP(7);
 }
 
 // Position of row `ra` of a supernode's row list in the block's work vector: rows of K_i at ra, border rows (ra >= n, only

@@ -305,6 +305,128 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       }
    }
 
+   // ---- multifrontal metadata.  A head supernode that is not a simple leaf is a front: the (w + r) x (w + r) lower triangle on its
+   //      columns and below-rows.  Its update matrix (the r x r trailing part after the w pivots) is handed to the parent front -
+   //      the supernode that holds its first below-row - which adds it at the positions recorded here ("extend-add"); simple
+   //      leaves (width 1, no children, a handful of rows: every primal column of an LP block) are not fronts of their own, the
+   //      parent front forms their rank-one updates itself from the leaf's column.  Nothing is scattered with atomics, the order
+   //      of the additions is fixed by these lists.  Fronts without a head parent (parent column in the dense tail) scatter their
+   //      update matrix into the tail / Schur complement as before; so do simple leaves without a head parent.
+   {
+      const int nsn = (int)out.sn.size();
+      out.sn_parent.assign(nsn, -1);
+      out.mf_U.assign(nsn, -1);
+      out.mf_meta.assign(nsn, -1);
+      out.mf_U_total = 0;
+      out.mf_max_front = 0;
+      out.mf_ok = true;
+      auto is_simple = [&](const HeadSupernode& sn) { return sn.w == 1 && sn.r <= opt.simple_rmax && sn.level == 0; };
+      std::vector<std::vector<int>> kids(nsn), leaves(nsn);
+      for (int s = 0; s < nsn; ++s) {
+         const HeadSupernode& sn = out.sn[s];
+         if (sn.r > 0 && out.rowidx[sn.rows] < n_head) {
+            const int p = out.sn_of_col[out.rowidx[sn.rows]];
+            out.sn_parent[s] = p;
+            (is_simple(sn) ? leaves[p] : kids[p]).push_back(s);
+         }
+         if (!is_simple(sn)) {
+            const int64_t nf = sn.w + sn.r;
+            out.mf_max_front = std::max(out.mf_max_front, (int)nf);
+            const int64_t cw = (int64_t)sn.w * nf - (int64_t)sn.w * (sn.w - 1) / 2, lt = (int64_t)sn.w * ((sn.r + 3) / 4 * 4);
+            if (nf > MF_MAX_FRONT || std::max(cw, lt) + 8 > opt.mf_lds_doubles) out.mf_ok = false;
+         }
+      }
+      if (out.arena >= (int64_t)INT32_MAX) out.mf_ok = false;   // leaf records keep panel offsets as int
+      // position of the rows of supernode c inside the front of its parent p
+      auto positions = [&](const HeadSupernode& c, const HeadSupernode& p, std::vector<int>& pos) -> bool {
+         const int* rows = out.rowidx.data() + c.rows;
+         const int* prow = out.rowidx.data() + p.rows;
+         int q = 0;
+         for (int a = 0; a < c.r; ++a) {
+            const int ra = rows[a];
+            if (ra < p.c0 + p.w) { pos.push_back(ra - p.c0); continue; }
+            while (q < p.r && prow[q] < ra) ++q;
+            if (q == p.r || prow[q] != ra) return false;
+            pos.push_back(p.w + q);
+         }
+         return true;
+      };
+      // update-matrix offsets first (a parent's record refers to its children's and to its own)
+      for (int s = 0; s < nsn; ++s) {
+         const HeadSupernode& sn = out.sn[s];
+         if (is_simple(sn)) continue;
+         out.mf_U[s] = out.mf_U_total;
+         out.mf_U_total += (int64_t)sn.r * (sn.r + 1) / 2;
+      }
+      if (out.mf_U_total >= (int64_t)INT32_MAX) out.mf_ok = false;
+      std::vector<int> pos;
+      for (int s = 0; s < nsn && out.mf_ok; ++s) {
+         const HeadSupernode& sn = out.sn[s];
+         if (is_simple(sn)) continue;
+         const int64_t base = (int64_t)out.mf_int.size();
+         out.mf_meta[s] = base;
+         const int nf = sn.w + sn.r, n_leaf = (int)leaves[s].size();
+         int sum_rc = 0;
+         for (int c : kids[s]) sum_rc += out.sn[c].r;
+         int hdr[MF_HDR] = {(int)kids[s].size(), n_leaf, out.sn_parent[s] >= 0 ? 1 : 0, 0, 0, 0, sum_rc, 0};
+         const size_t hpos = out.mf_int.size();
+         out.mf_int.insert(out.mf_int.end(), hdr, hdr + MF_HDR);
+         for (int c : kids[s]) {
+            out.mf_int.push_back((int)(out.mf_U[c] - out.mf_U[s]));
+            out.mf_int.push_back(out.sn[c].r);
+         }
+         for (int c : kids[s]) {
+            pos.clear();
+            if (!positions(out.sn[c], sn, pos))
+               PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, rows of supernode %d missing in its parent front", out.sn[c].c0);
+            out.mf_int.insert(out.mf_int.end(), pos.begin(), pos.end());
+         }
+         if (n_leaf == 0) continue;
+         // leaf part: colptr | items | leaf table | position lists
+         std::vector<int> tab, lists, item_col, item_a, item_b;
+         int n_vals = 0, n_items = 0;
+         for (int c : leaves[s]) n_items += out.sn[c].r;
+         const int list_base = (nf + 1) + 2 * n_items + 3 * n_leaf;   // offset of the first position list inside the leaf part
+         for (int c : leaves[s]) {
+            const HeadSupernode& lf = out.sn[c];
+            pos.clear();
+            if (!positions(lf, sn, pos))
+               PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, rows of leaf column %d missing in its parent front", lf.c0);
+            const int loff = list_base + (int)lists.size();
+            tab.push_back((int)lf.panel);
+            tab.push_back(lf.r);
+            tab.push_back(n_vals);
+            lists.insert(lists.end(), pos.begin(), pos.end());
+            for (int b = 0; b < lf.r; ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (lf.r << 4) | b); item_b.push_back(loff); }
+            n_vals += 1 + lf.r;
+         }
+         if (n_vals >= (1 << 22)) { out.mf_ok = false; break; }
+         std::vector<int> colptr(nf + 1, 0);
+         for (int q : item_col) ++colptr[q + 1];
+         for (int q = 0; q < nf; ++q) colptr[q + 1] += colptr[q];
+         std::vector<int> items(2 * item_col.size()), fill(colptr.begin(), colptr.end() - 1);
+         for (size_t i = 0; i < item_col.size(); ++i) {   // stable: leaves stay in order
+            const int at = fill[item_col[i]]++;
+            items[2 * at] = item_a[i];
+            items[2 * at + 1] = item_b[i];
+         }
+         out.mf_int.insert(out.mf_int.end(), colptr.begin(), colptr.end());
+         out.mf_int.insert(out.mf_int.end(), items.begin(), items.end());
+         out.mf_int.insert(out.mf_int.end(), tab.begin(), tab.end());
+         out.mf_int.insert(out.mf_int.end(), lists.begin(), lists.end());
+         out.mf_int[hpos + 3] = list_base + (int)lists.size();
+         out.mf_int[hpos + 4] = n_items;
+         out.mf_int[hpos + 5] = n_vals;
+      }
+      if (!out.mf_ok) {
+         std::vector<int>().swap(out.mf_int);
+         std::vector<int64_t>().swap(out.mf_fix);
+         out.mf_U.assign(nsn, -1);
+         out.mf_meta.assign(nsn, -1);
+         out.mf_U_total = 0;
+      }
+   }
+
    // ---- scatter maps
    auto head_dst = [&](int c, int r) -> int64_t {
       const HeadSupernode& sn = out.sn[out.sn_of_col[c]];

@@ -422,10 +422,10 @@ class LeafBatch:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(14, np.int64)
-        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(14)), "pips_hip_batch_info")
+        what = np.zeros(18, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(18)), "pips_hip_batch_info")
         keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK",
-                "ltsolve_from_augmented_factor"]
+                "ltsolve_from_augmented_factor", "multifrontal_head", "max_front", "update_matrix_bytes", "fronts_in_device_memory"]
         return {k: int(v) for k, v in zip(keys, what)}
 
     def sync(self):

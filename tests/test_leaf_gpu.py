@@ -344,24 +344,43 @@ class _TimeCoupledProblem(Problem):
             blk.update(W=Wp, K=K, dpos=dpos)
 
 
+@pytest.mark.parametrize("head", ["multifrontal", "multifrontal_devmem", "scatter"])
 @pytest.mark.parametrize("cut", ["model", "all_head"])
 @pytest.mark.parametrize("n_i", [600, 3000], ids=["chain_and_spine", "dissected"])
-def test_time_coupled_blocks_match_oracle(cut, n_i, monkeypatch):
+def test_time_coupled_blocks_match_oracle(cut, n_i, head, monkeypatch):
     """n_i = 600, dissection switched off: the head is one chain per block (level-scheduled bottom, spine kernels on top);
-    n_i = 3000: the dual-row separators of the nested dissection cut each block into independent segments."""
+    n_i = 3000: the dual-row separators of the nested dissection cut each block into independent segments.
+    head: the multifrontal head kernels (fronts in LDS / update matrices in device memory) or the scattering ones."""
     import torch
     if n_i == 600:
         monkeypatch.setenv("PIPS_HIP_ND_DEPTH", "0")     # keeps the chain / spine kernels under test
+    if head == "scatter":
+        monkeypatch.setenv("PIPS_HIP_MF", "0")
+
     prob = _TimeCoupledProblem(5, 3, n_i, n_i // 2, 10, 8, 6)
     S, N = prob.S, prob.N
-    bt = pa.LeafBatch(N, S)
-    for b in range(N):
-        bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
-    if cut == "all_head":
-        bt.set_options(force_n_head=prob.n_leaf)
-    bt.analyze(2)
+
+    def analysed():
+        bt = pa.LeafBatch(N, S)
+        for b in range(N):
+            bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+        if cut == "all_head":
+            bt.set_options(force_n_head=prob.n_leaf)
+        bt.analyze(2)
+        return bt
+
+    bt = analysed()
     info = bt.info()
+    if head == "multifrontal_devmem":
+        # an LDS budget one double short of the largest packed front: its panel columns still fit, its update matrix is
+        # worked on in device memory (the variant fronts beyond ~200 rows take at the default budget)
+        bt.close()
+        monkeypatch.setenv("PIPS_HIP_MF_LDS", str(info["max_front"] * (info["max_front"] + 1) // 2 + 7))
+        bt = analysed()
+        info = bt.info()
+        assert info["fronts_in_device_memory"] > 0, info
     assert bt.schur_mode() in (1, 2)
+    assert info["multifrontal_head"] == (0 if head == "scatter" else 1), info
     if cut == "all_head" and n_i == 600:
         assert info["n_levels"] >= 10, info          # really chain-like
         assert info["n_sn"] < 0.9 * info["n_head"]    # amalgamation merged columns
@@ -381,7 +400,7 @@ def test_time_coupled_blocks_match_oracle(cut, n_i, monkeypatch):
         xo = rhs.reshape(N, -1)[b].copy()
         prob.oracle_leaf(b).solve(xo)
         assert np.linalg.norm(x.reshape(N, -1)[b] - xo) / np.linalg.norm(xo) < RTOL_SOLVE
-    if cut == "all_head" and n_i == 600:
+    if cut == "all_head" and n_i == 600 and head == "scatter":
         # the narrow top levels are handled by the per-block spine kernels: far fewer launches than tree levels
         bt.set_timing(True)
         SC.zero_()

@@ -1,0 +1,7 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/trace1; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/tools/config3_probe.py ${1:-64} 50000 > $OUT/log.txt 2>&1
+python3 $R/tools/trace_fronts.py $(find $OUT -name "*kernel_trace.csv" | head -1) 1 > $OUT/fronts.txt
+find $OUT -name "*kernel_trace.csv" -delete
+cat $OUT/fronts.txt
