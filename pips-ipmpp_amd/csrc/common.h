@@ -98,7 +98,9 @@ struct BlockSym {
    int mf_max_front = 0;                // largest w + r among the fronts
    int64_t mf_U_total = 0;              // doubles of update-matrix storage of this block
    std::vector<int> sn_parent;          // per head supernode: the head supernode that holds its first below-row, else -1
-   std::vector<int64_t> mf_U;           // per head supernode: offset of its packed update matrix, -1 if it has none
+   std::vector<int64_t> mf_U;           // per head supernode: offset of its packed update matrix; simple leaf below a front: offset of
+                                        // its 1 + r values inside the block's leaf-value region; -1: neither
+   int64_t mf_LV_total = 0;             // doubles of leaf values of this block
    std::vector<int64_t> mf_meta;        // per head supernode: offset of its front record inside mf_int, -1 for simple leaves
    std::vector<int> mf_int;             // front records
    std::vector<int64_t> mf_fix;         // positions inside mf_int that hold LOCAL supernode ids (the engine renumbers them)
@@ -112,14 +114,14 @@ struct BlockSym {
 //   [4]                    number of leaf items
 //   [5]                    doubles of leaf values, sum of (1 + r_c)
 //   [6]                    sum of the children's r_c
-//   [7]                    0
+//   [7]                    offset of the leaves' values (d_c, l_c: 1 + r_c doubles per leaf, leaves ascending) inside the block's
+//                          leaf-value region: the leaf kernel writes them there, the front reads them as one piece
 //   [8 ..)                 child table, 2 ints per child front, children ascending: { offset of its update matrix minus this front's, r_c }
 //   then                   per child, in the same order, the position of each of its r_c below-rows inside THIS front (0 .. w + r)
 //   then                   the leaf part
-//   leaf part              colptr[w + r + 1] | items (2 ints each) | leaf table (3 ints per leaf) | position lists
+//   leaf part              colptr[w + r + 1] | items (2 ints each) | position lists
 //   leaf item              { offset of the leaf's 1 + r_c values << 9 | r_c << 4 | b,  offset of its position list inside the leaf part }
 //                          - the leaf's b-th row is this front column; items are sorted by front column, inside a column by leaf
-//   leaf table entry       { panel offset inside the block arena, r_c, offset of its values }
 //   position list          position of each of the leaf's r_c rows inside the front
 constexpr int MF_HDR = 8;
 constexpr int MF_MAX_FRONT = 512;    // a thread per front row

@@ -512,13 +512,18 @@ struct MfLaunch { int level, cls, begin, cnt, lds_doubles; };
 static inline int mf_class(int w, long long nf, long long lds_budget) {
    const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
    if (pw + r * (r + 1) / 2 + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
-   return (nf <= 64 ? 0 : nf <= 128 ? 1 : 2) + 3 * (w <= 16 ? 0 : 1);
+   return (nf <= 64 ? 0 : 2) + 3 * (w <= 16 ? 0 : 1);   // more than one wave: 256 threads - the phases around the pivots are spread over them
 }
 
 // Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
 static void apply_tuning(AnalyzeOptions& opt) {
    opt.tile = TILE;
-   opt.max_sn_width = HEAD_WMAX;
+   // Supernode width cap.  16 instead of the kernels' limit of 32: on the time-coupled family (tools/config3_probe.py, 64 x 50 000)
+   // narrower supernodes carry fewer explicit zeros (nnz(L) 164 M -> 151 M), halve the dependent pivot chain of a front and the
+   // registers its rows take; factorisation 13.4 -> 12.5 ms, solveCompressed 9.3 -> 8.9 ms.  Random sparsity (config 2) has no
+   // supernodes wider than one column in the head.
+   opt.max_sn_width = 16;
+   if (const char* sw = getenv("PIPS_HIP_SN_WIDTH")) opt.max_sn_width = std::max(1, std::min(HEAD_WMAX, atoi(sw)));
    if (const char* rz = getenv("PIPS_HIP_RELAX_ZEROS")) opt.relax_zeros = atof(rz);   // share of explicit zeros per panel
    if (const char* ndd = getenv("PIPS_HIP_ND_DEPTH")) opt.nd_depth = atoi(ndd);        // dissection levels (0 = off)
    if (const char* ndm = getenv("PIPS_HIP_ND_MIN")) opt.nd_min_size = atoi(ndm);      // smallest segment that is still dissected
@@ -559,6 +564,7 @@ struct Engine {
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
    double* d_mfU = nullptr;    // update matrices of the fronts
+   double* d_mfLV = nullptr;   // d and l of the simple leaves below fronts, front by front
    int* d_mfint = nullptr;     // front records (common.h)
    long long mfU_total = 0;
    int spine_total = 0, n_levels_all = 0;   // supernodes handled by the per-block spine kernels; tree height before the cut
@@ -592,8 +598,9 @@ struct Engine {
       if (d_uarena) (void)hipFree(d_uarena);
       d_uarena = nullptr;
       if (d_mfU) (void)hipFree(d_mfU);
+      if (d_mfLV) (void)hipFree(d_mfLV);
       if (d_mfint) (void)hipFree(d_mfint);
-      d_mfU = nullptr; d_mfint = nullptr;
+      d_mfU = nullptr; d_mfLV = nullptr; d_mfint = nullptr;
       mf_launches.clear();
       if (d_gemm_ctr) (void)hipFree(d_gemm_ctr);
       d_gemm_ctr = nullptr;
@@ -878,7 +885,7 @@ struct Engine {
       kptr.assign(nblk + 1, 0);
       x_off.assign(nblk + 1, 0);
       std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0),
-         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0);
+         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0), mfLV_base(nblk + 1, 0);
       long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0, uar = 0;
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
@@ -910,6 +917,8 @@ struct Engine {
          upd_base[b + 1] = upd_base[b] + (long long)s.upd.size();
          mfU_base[b + 1] = mfU_base[b] + (mf ? s.mf_U_total : 0);
          mfint_base[b + 1] = mfint_base[b] + (mf ? (long long)s.mf_int.size() : 0);
+         mfLV_base[b + 1] = mfLV_base[b] + (mf ? s.mf_LV_total : 0);
+         d.lv_off = mfLV_base[b];
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
          bmap_off[b + 1] = bmap_off[b] + s.nb;
       }
@@ -1005,7 +1014,7 @@ struct Engine {
                            s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1};
          if (mf) {
             const BlockSym& bs = sym[k.blk];
-            if (bs.mf_U[k.loc] >= 0) h_sns[i].U = mfU_base[k.blk] + bs.mf_U[k.loc];
+            if (bs.mf_U[k.loc] >= 0) h_sns[i].U = (k.cls == 0 ? mfLV_base[k.blk] : mfU_base[k.blk]) + bs.mf_U[k.loc];
             if (bs.mf_meta[k.loc] >= 0) h_sns[i].mf = mfint_base[k.blk] + bs.mf_meta[k.loc];
          }
          slots_acc += (long long)s.r * (s.r + 1) / 2;
@@ -1083,6 +1092,7 @@ struct Engine {
          mfU_total = mfU_base[nblk];
          if ((rc = dev_upload(&d_mfint, h_mfint, stream))) return rc;
          HIP_TRY(hipMalloc((void**)&d_mfU, (size_t)std::max<long long>(mfU_total, 1) * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_mfLV, (size_t)std::max<long long>(mfLV_base[nblk], 1) * sizeof(double)));
       }
       {  // both triangles, row by row: entry (i, j) of the lower CSR also appears in row j as (j, i)
          std::vector<int> frp(n_total + 1, 0);
@@ -1259,7 +1269,7 @@ struct Engine {
       if (L.simple_cnt > 0)
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
                             L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
-                            mf ? 1 : 0);
+                            mf ? 1 : 0, d_mfLV);
       if (mf) return;
       if (L.small_cnt > 0)
          hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), (size_t)std::max(L.small_lds, 1) * sizeof(double), stream, d_sns,
@@ -1275,7 +1285,7 @@ struct Engine {
       const size_t lds = (size_t)m.lds_doubles * sizeof(double);
       if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front<BLOCK, WMAX, UG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_front<BLOCK, WMAX, UG>), dim3(m.cnt), dim3(BLOCK), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_psign,
-                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg);
+                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV);
       return PIPS_OK;
    }
    long long* d_mfdbg = nullptr;   // PIPS_HIP_MF_CLOCKS: phase stamps of every front (8 per supernode), dumped after the factorisation

@@ -54,6 +54,7 @@ struct BlkDesc {
    long long U;          // offset of the block's scaled tail copy U = L D (m_pad x m_pad, ld = m_pad) inside the U arena
    double thr_rel, repl_rel;  // pivot threshold / replacement relative to the pivot's reference magnitude pref[k]
    double repl_abs;           // replacement when no reference magnitude exists (structurally zero diagonal)
+   long long lv_off;          // multifrontal head: offset of the block's leaf values inside the leaf-value arena
 };
 
 struct TileTask { int blk, ti, tj, pad; };
@@ -476,7 +477,8 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                                                            double* __restrict__ arena, double* __restrict__ SC, int ldSC,
                                                            int* __restrict__ inertia, const double* __restrict__ pref,
                                                            const int* __restrict__ sctab,
-                                                           ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int mf = 0) {
+                                                           ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int mf = 0,
+                                                           double* __restrict__ lvals = nullptr) {
    __shared__ int cnt_s[3];
    __shared__ int blk_s;
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -504,6 +506,13 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
       const int n = bd.n, n_head = bd.n_head;
       // multifrontal head: a leaf below a front leaves its rank-one update to that front (k_front reads d and l from the panel)
       const bool to_parent = mf && sn.n_useg > 0;
+      if (to_parent) {   // ... as one contiguous piece per front: d, l_0 .. l_{r-1}
+         double* lv = lvals + sn.U;
+         lv[0] = d;
+#pragma unroll
+         for (int a = 0; a < SIMPLE_RMAX; ++a)
+            if (a < r) lv[1 + a] = l[a];
+      }
       // target columns inside the head (time-coupled blocks: the rows of a primal column are dual rows the dissection keeps in the
       // head): positions from the precomputed segment tables, as in head_factor_body; l is re-read from the panel (L1 hits)
       // because the segment bounds are run-time values and a dynamically indexed register array would go to scratch
@@ -603,7 +612,8 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
                                                 const int* __restrict__ bmap, double* __restrict__ arena,
                                                 double* __restrict__ uarena, double* __restrict__ SC, int ldSC,
                                                 int* __restrict__ inertia, const double* __restrict__ pref,
-                                                const int* __restrict__ sctab, long long* __restrict__ dbg) {
+                                                const int* __restrict__ sctab, long long* __restrict__ dbg,
+                                                const double* __restrict__ lvals) {
    extern __shared__ __attribute__((aligned(16))) double mf_F[];
    __shared__ double dk[WMAX];
    // development aid (PIPS_HIP_MF_CLOCKS): thread 0 stamps the phase boundaries, 8 stamps per front
@@ -654,42 +664,41 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    }
    __syncthreads();
    MF_STAMP(2);
-   if (n_leaf) {   // the leaves' d and l, a thread per leaf
-      const double* A = arena + bd.arena_off;
-      const int* tab = leafpart + (nf + 1) + 2 * n_items;
-      for (int t = tid; t < n_leaf; t += BLOCK) {
-         const double* Pc = A + tab[3 * t];
-         const int rc = tab[3 * t + 1];
-         double* out = vals + tab[3 * t + 2];
-         double v[SIMPLE_RMAX + 1];
-#pragma unroll
-         for (int a = 0; a <= SIMPLE_RMAX; ++a) v[a] = a <= rc ? Pc[a] : 0.0;
-#pragma unroll
-         for (int a = 0; a <= SIMPLE_RMAX; ++a) if (a <= rc) out[a] = v[a];
-      }
+   if (n_leaf) {   // the leaves' d and l: written as one piece by the leaf kernel
+      const double* lv = lvals + bd.lv_off + H[7];
+      for (int idx = tid; idx < n_vals; idx += BLOCK) vals[idx] = lv[idx];
    }
    {
+      // A wave takes a PAIR of columns (b, rc - 1 - b) of a child's packed update matrix - together rc + 1 entries whatever b is -
+      // and walks down it 64 rows at a time: coalesced reads, the target column is wave-uniform, one LDS read (the row's position)
+      // and one fire-and-forget add per entry.  (pair, 64-row piece) items go round-robin over the waves, NB loads in flight each.
+      constexpr int NW = BLOCK / 64, NB = 12;
+      const int wave = tid >> 6;
       int off = 0;
       for (int c = 0; c < n_child; ++c) {
          const int rc = H[MF_HDR + 2 * c + 1];
          const double* Uc = uarena + sn.U + H[MF_HDR + 2 * c];
          const int* rel = relbuf + off;
-         const int npc = rc * (rc + 1) / 2;
-         int bb = packed_col(tid < npc ? tid : 0, rc), ao = tid - (bb * rc - bb * (bb - 1) / 2);   // this thread's entry: column bb, row bb + ao
-         constexpr int NB = 16;                                  // loads in flight per thread: the update matrix comes from another compute unit's launch
-         for (int base = 0; base < npc; base += NB * BLOCK) {
+         const int npairs = (rc + 1) >> 1, pieces = (rc + 1 + 63) >> 6, nitems = npairs * pieces;
+         for (int s0 = wave; s0 < nitems; s0 += NW * NB) {
             double v[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) { const int p = base + u * BLOCK + tid; v[u] = p < npc ? Uc[p] : 0.0; }
+            int ea[NB], eb[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-               const int p = base + u * BLOCK + tid;
-               if (p < npc) {
-                  front_add(rel[bb + ao], rel[bb], v[u]);
-                  ao += BLOCK;                                   // BLOCK entries further down the packed triangle
-                  while (bb < rc - 1 && ao >= rc - bb) { ao -= rc - bb; ++bb; }
+               const int item = s0 + u * NW;
+               ea[u] = -1; eb[u] = 0; v[u] = 0.0;
+               if (item < nitems) {
+                  const int pr = item / pieces, e = (item - pr * pieces) * 64 + lane;   // pr, pieces: wave-uniform
+                  const int b1 = pr, b2 = rc - 1 - pr, n1 = rc - b1;
+                  int a = -1, b = b1;
+                  if (e < n1) a = b1 + e;
+                  else if (b2 != b1 && e - n1 <= pr) { b = b2; a = b2 + (e - n1); }
+                  if (a >= 0) { ea[u] = a; eb[u] = b; v[u] = Uc[b * rc - b * (b - 1) / 2 + (a - b)]; }
                }
             }
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+               if (ea[u] >= 0) front_add(rel[ea[u]], rel[eb[u]], v[u]);
          }
          off += rc;
          __syncthreads();
@@ -718,6 +727,8 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    // thread i takes row i of the panel (K entries, scattered into the arena by k_scatter, + what was assembled in LDS); the first
    // w lanes of EVERY wave also take the pivot rows
    double y[WMAX], yp[WMAX];
+   const bool wave_has_rows = (tid & ~63) < nf;               // wave-uniform: the waves beyond the last row only help in the other phases
+   if (wave_has_rows) {
 #pragma unroll
    for (int k = 0; k < WMAX; ++k) y[k] = (i < nf && k < w && k <= i) ? P[i + (long long)k * nf] : 0.0;
 #pragma unroll
@@ -727,26 +738,38 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 #pragma unroll
    for (int k = 0; k < WMAX; ++k) if (lane < w && k <= lane) yp[k] += F[co(k) + lane - k];
    int c_pos = 0, c_neg = 0, c_pert = 0;
+   // The pivot of column k + 1 is known as soon as column k has been applied to row k + 1: it is fixed and inverted right there, so
+   // that the reciprocal's dependent chain runs beside the other updates of column k instead of after them.
+   bool pert;
+   double d = fix_pivot(readlane_f64(yp[0], 0), __builtin_amdgcn_readlane(sgn, 0), readlane_f64(prf, 0), bd.thr_rel, bd.repl_rel, bd.repl_abs, pert);
+   double rd = 1.0 / d;
 #pragma unroll
    for (int k = 0; k < WMAX; ++k) {
       if (k < w) {
-         bool pert;
-         const double d = fix_pivot(readlane_f64(yp[k], k), __builtin_amdgcn_readlane(sgn, k), readlane_f64(prf, k), bd.thr_rel, bd.repl_rel,
-                                    bd.repl_abs, pert);
          if (pert) ++c_pert; else if (d > 0) ++c_pos; else ++c_neg;
-         const double rd = 1.0 / d;
          const double uik = y[k], upk = yp[k];
          const double tcol = upk * rd;                     // lane j: l_jk
          // no branch per column: beyond column w - 1 tcol is 0 (yp is), and entries right of the diagonal of the pivot block
          // collect garbage that nobody reads
+         double dn = 1.0, rdn = 1.0;
+         bool pertn = false;
+         if (k + 1 < WMAX) {
+            const double t = readlane_f64(tcol, k + 1);
+            y[k + 1] -= uik * t;
+            yp[k + 1] -= upk * t;
+            dn = fix_pivot(readlane_f64(yp[k + 1], k + 1), __builtin_amdgcn_readlane(sgn, k + 1), readlane_f64(prf, k + 1), bd.thr_rel,
+                           bd.repl_rel, bd.repl_abs, pertn);
+            rdn = 1.0 / dn;
+         }
 #pragma unroll
-         for (int j = k + 1; j < WMAX; ++j) {
+         for (int j = k + 2; j < WMAX; ++j) {
             const double t = readlane_f64(tcol, j);
             y[j] -= uik * t;
             yp[j] -= upk * t;
          }
          y[k] = i == k ? d : uik * rd;
          if (tid == 0) dk[k] = d;
+         d = dn; rd = rdn; pert = pertn;
       }
    }
    if (tid == 0) {
@@ -758,6 +781,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 #pragma unroll
       for (int k = 0; k < WMAX; ++k)
          if (k < w && k <= i) P[i + (long long)k * nf] = y[k];    // l_ik, d_k on the diagonal: what the solves read
+   }
    }
    __syncthreads();   // every wave has taken its rows out of the packed panel: the region becomes the L21 copy Lt[k * rp + a]
    if (i >= w && i < nf) {

@@ -318,6 +318,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       out.mf_U.assign(nsn, -1);
       out.mf_meta.assign(nsn, -1);
       out.mf_U_total = 0;
+      out.mf_LV_total = 0;
       out.mf_max_front = 0;
       out.mf_ok = true;
       auto is_simple = [&](const HeadSupernode& sn) { return sn.w == 1 && sn.r <= opt.simple_rmax && sn.level == 0; };
@@ -358,7 +359,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_U[s] = out.mf_U_total;
          out.mf_U_total += (int64_t)sn.r * (sn.r + 1) / 2;
       }
-      if (out.mf_U_total >= (int64_t)INT32_MAX) out.mf_ok = false;
+      if (out.mf_U_total >= (int64_t)INT32_MAX || 18 * (int64_t)nsn >= (int64_t)INT32_MAX) out.mf_ok = false;
       std::vector<int> pos;
       for (int s = 0; s < nsn && out.mf_ok; ++s) {
          const HeadSupernode& sn = out.sn[s];
@@ -382,24 +383,24 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             out.mf_int.insert(out.mf_int.end(), pos.begin(), pos.end());
          }
          if (n_leaf == 0) continue;
-         // leaf part: colptr | items | leaf table | position lists
-         std::vector<int> tab, lists, item_col, item_a, item_b;
+         // leaf part: colptr | items | position lists
+         std::vector<int> lists, item_col, item_a, item_b;
          int n_vals = 0, n_items = 0;
          for (int c : leaves[s]) n_items += out.sn[c].r;
-         const int list_base = (nf + 1) + 2 * n_items + 3 * n_leaf;   // offset of the first position list inside the leaf part
+         const int list_base = (nf + 1) + 2 * n_items;   // offset of the first position list inside the leaf part
+         out.mf_int[hpos + 7] = (int)out.mf_LV_total;
          for (int c : leaves[s]) {
             const HeadSupernode& lf = out.sn[c];
             pos.clear();
             if (!positions(lf, sn, pos))
                PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, rows of leaf column %d missing in its parent front", lf.c0);
             const int loff = list_base + (int)lists.size();
-            tab.push_back((int)lf.panel);
-            tab.push_back(lf.r);
-            tab.push_back(n_vals);
+            out.mf_U[c] = out.mf_LV_total + n_vals;
             lists.insert(lists.end(), pos.begin(), pos.end());
             for (int b = 0; b < lf.r; ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (lf.r << 4) | b); item_b.push_back(loff); }
             n_vals += 1 + lf.r;
          }
+         out.mf_LV_total += n_vals;
          if (n_vals >= (1 << 22)) { out.mf_ok = false; break; }
          std::vector<int> colptr(nf + 1, 0);
          for (int q : item_col) ++colptr[q + 1];
@@ -412,7 +413,6 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          }
          out.mf_int.insert(out.mf_int.end(), colptr.begin(), colptr.end());
          out.mf_int.insert(out.mf_int.end(), items.begin(), items.end());
-         out.mf_int.insert(out.mf_int.end(), tab.begin(), tab.end());
          out.mf_int.insert(out.mf_int.end(), lists.begin(), lists.end());
          out.mf_int[hpos + 3] = list_base + (int)lists.size();
          out.mf_int[hpos + 4] = n_items;
@@ -424,6 +424,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_U.assign(nsn, -1);
          out.mf_meta.assign(nsn, -1);
          out.mf_U_total = 0;
+         out.mf_LV_total = 0;
       }
    }
 
