@@ -7,6 +7,14 @@ N = 1 runs BASELINE.json configs[1]: 64 scenario blocks x 10k vars (my_i = 5k), 
 batched on one device.  N > 1 shards 64 blocks per GPU (weak scaling), one process per GPU, RCCL all-reduce of SC and b0.
 All inputs are resident in HBM before the timed region.  `value` counts 64-block scenario groups processed per second
 (= N x IPM-iteration linear-algebra units per second), so it is the whole-job aggregate.
+
+--family time-coupled --blocks-per-gpu 256 --n 50000 runs the per-GPU share of BASELINE.json configs[3] (2048 blocks x 50 000
+variables on 8 GPUs: banded W_i, 95 first-stage variables, 31 two-link rows between neighbouring blocks: S = 8000); there the
+sparse head of the leaf factorisation is the dominant kernel group and the roofline object prices it against HBM.
+
+The line accounts for itself: `phase_ms` lists every phase of the step (HIP events on the streams the work runs on, one
+instrumented step after the timed region), `roofline` is the kernel group with the largest share of the step for the
+configuration that was run, `roofline_all` the others; with N > 1 `collective` carries the reductions' time, bytes and overlap.
 """
 import argparse
 import json
@@ -22,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md)
 TILE = 128
 R_SOLVES = 4
 
@@ -57,12 +66,28 @@ def update_kernel_traffic(n_blocks, n_i, S, world):
         return None
 
 
-def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
+def head_traffic(family, n_blocks, n_i):
+    """HBM bytes of the sparse-head kernels per factorize from the committed PMC summary (tools/profile_cfg3.sh pmc); only valid for
+    the profiled workload."""
+    path = os.path.join(ROOT, "profiles", "r3_cfg3_head_traffic.json")
+    if family != "time-coupled" or n_blocks != 256 or n_i != 50000 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["hbm_bytes_per_factorize"]
+    except Exception:
+        return None
+
+
+def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device, block_data=None):
+    """block_data: b -> (W, T, F) for families other than the generator's"""
     S = n0 + myl
     bt = pa.LeafBatch(len(blocks), S, device=device)
     vals, diags = [], []
     for i, b in enumerate(blocks):
-        W, T, F, c, xs = pa.gen_block(seed, b + 1, n_i, my_i, n0, myl, rho)
+        if block_data is not None:
+            W, T, F = block_data(b)
+        else:
+            W, T, F, c, xs = pa.gen_block(seed, b + 1, n_i, my_i, n0, myl, rho)
         K, dpos = pa.kkt_leaf_assemble(n_i, W)
         Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F)
         diag = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
@@ -79,14 +104,22 @@ def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device):
     return bt, np.concatenate(diags)
 
 
-def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho):
+def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho, family_blocks=None, family_F0=None):
     """Full interior-point solve (Mehrotra + Gondzio harness, termination mu <= 1e-8 and ||r||inf <= 1e-8 dnorm) of the LP the
     generator defines for this shape: b = A x*, x* ~ U(0.5, 1.5)."""
-    F0, c0, x0s = pa.gen_root(seed, n0, myl)
+    rng = np.random.default_rng(seed)
+    if family_blocks is not None:
+        F0, c0, x0s = family_F0, rng.uniform(0.5, 1.5, n0), rng.uniform(0.5, 1.5, n0)
+    else:
+        F0, c0, x0s = pa.gen_root(seed, n0, myl)
     blocks, cs, bs = [], [c0], []
     blink = F0.to_scipy() @ x0s
     for b in range(1, N + 1):
-        W, T, F, c, xs = pa.gen_block(seed, b, n_i, my_i, n0, myl, rho)
+        if family_blocks is not None:
+            W, T, F = family_blocks[b - 1]
+            c, xs = rng.uniform(0.5, 1.5, n_i), rng.uniform(0.5, 1.5, n_i)
+        else:
+            W, T, F, c, xs = pa.gen_block(seed, b, n_i, my_i, n0, myl, rho)
         blocks.append((W, T, F))
         cs.append(c)
         bs.append(T.to_scipy() @ x0s + W.to_scipy() @ xs)
@@ -102,7 +135,7 @@ def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho):
             "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i)}
 
 
-def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
+def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, block0=None):
     """Reference-style CPU path timed on a bounded sample and extrapolated linearly (all blocks are statistically
     identical and independent): per block PARDISO phase 12 (or the oracle LDL^T) + multi-RHS solves for the border
     columns (K5) + the sparse accumulation (K6) + 2*R single solves; plus the dense root dsytrf."""
@@ -112,7 +145,10 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
     import psutil
     cores = min(16, os.cpu_count() or 1)         # bounded: the sample must not exhaust the host
     mem_ok = psutil.virtual_memory().available > 48 * 2**30
-    W, T, F, c, xs = pa.gen_block(seed, 1, n_i, my_i, n0, myl, rho)
+    if block0 is not None:
+        W, T, F = block0
+    else:
+        W, T, F, c, xs = pa.gen_block(seed, 1, n_i, my_i, n0, myl, rho)
     K, dpos = pa.kkt_leaf_assemble(n_i, W)
     K.val[dpos] = np.concatenate([pa.gen_diagonal(seed, 1, n_i), -1e-8 * np.ones(my_i)])
     Ks = sp.csr_matrix((K.val, K.colidx, K.rowptr), shape=(K.nrows, K.ncols))
@@ -131,7 +167,9 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
     t0 = time.perf_counter()
     solver.matrixChanged()
     t_factor = time.perf_counter() - t0
-    cols = np.nonzero(np.diff(Bt.indptr) > 0)[0][:n_rhs_sample]
+    nonempty = np.nonzero(np.diff(Bt.indptr) > 0)[0]
+    cols = nonempty[:n_rhs_sample]
+    n_border = len(nonempty)          # the reference skips empty border columns (DistributedLinearSystem.C:870-874)
     dense = np.ascontiguousarray(Bt[cols].toarray())
     # best of two / three repetitions: the first multi-RHS call pays thread start-up, and the host is shared
     t_schur = float("inf")
@@ -140,7 +178,7 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
         t0 = time.perf_counter()
         solver.solve(rhs)
         SCrows = (Bt @ rhs.T).T  # noqa: F841  (K6)
-        t_schur = min(t_schur, (time.perf_counter() - t0) * (S / max(1, len(cols))))
+        t_schur = min(t_schur, (time.perf_counter() - t0) * (n_border / max(1, len(cols))))
     t_solve = float("inf")
     for rep in range(3):
         x = np.random.default_rng(rep).standard_normal(K.nrows)
@@ -153,12 +191,12 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total):
     t0 = time.perf_counter()
     root.matrixChanged(M)
     t_root = time.perf_counter() - t0
-    per_group = 64 * (t_factor + t_schur + 2 * R_SOLVES * t_solve) + t_root
+    per_group = bpg * (t_factor + t_schur + 2 * R_SOLVES * t_solve) + t_root
     return {
-        "value": 1.0 / per_group, "unit": "64-block work units/s", "cores": used, "kind": "port",
-        "sample": (f"1 of {n_blocks_total} blocks: factor {t_factor:.1f}s, {len(cols)} of {S} border columns solved "
-                   f"(extrapolated {t_schur:.1f}s), 1 single solve {t_solve*1e3:.0f}ms, root dsytrf {t_root:.2f}s; "
-                   f"x64 blocks per unit, {2*R_SOLVES} leaf solves per block; {kind_detail}"),
+        "value": 1.0 / per_group, "unit": f"{bpg}-block work units/s", "cores": used, "kind": "port",
+        "sample": (f"1 of {n_blocks_total} blocks: factor {t_factor:.2f}s, {len(cols)} of {n_border} non-empty border columns solved "
+                   f"(extrapolated {t_schur:.2f}s), 1 single solve {t_solve*1e3:.0f}ms, root dsytrf {t_root:.2f}s; "
+                   f"x{bpg} blocks per unit, {2*R_SOLVES} leaf solves per block; {kind_detail}"),
     }
 
 
@@ -174,6 +212,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ipm", action="store_true", help="skip the end-to-end IPM run reported next to the metric (N = 1 only)")
+    ap.add_argument("--family", choices=["random", "time-coupled"], default="random",
+                    help="random: the generator of SURVEY 8d (BASELINE configs[1], [2], [4]); time-coupled: banded blocks with 2-link rows "
+                         "(configs[3]; --schur-dim and --rho are ignored: S = 95 + 31 (blocks - 1))")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,11 +243,18 @@ def main():
     import pips_ipmpp_amd as pa
 
     n_i, my_i = a.n, a.n // 2
-    n0 = myl = a.schur_dim // 2
-    S = n0 + myl
     bpg = a.blocks_per_gpu
     blocks = list(range(rank * bpg, (rank + 1) * bpg))
     n_blocks_total = bpg * world
+    fam_blocks = fam_F0 = None
+    if a.family == "time-coupled":
+        c3 = pa.CONFIG3_SHARE
+        # every rank draws the whole chain (the 2-link rows tie neighbouring blocks together) and keeps its contiguous share
+        fam_blocks, fam_F0, my_i, myl = pa.time_coupled_blocks(n_blocks_total, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
+        n0 = c3["n0"]
+    else:
+        n0 = myl = a.schur_dim // 2
+    S = n0 + myl
 
     comm = None
     comm_kind = "none"
@@ -257,8 +305,12 @@ def main():
                 comm = pa.ExternalComm.torch_distributed()
                 comm_kind = "rccl (torch.distributed callback)"
 
-    bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank)
-    F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
+    bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank,
+                                    block_data=(lambda b: fam_blocks[b]) if fam_blocks is not None else None)
+    if fam_blocks is not None:
+        F0 = fam_F0
+    else:
+        F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
     kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, comm=comm, rank=rank, n_ranks=world)
     dev = torch.device("cuda", local_rank)
     diag = torch.tensor(diag_h, device=dev)
@@ -295,45 +347,98 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- roofline of the dominant kernel (tile update GEMM), timed live with HIP events on the library's stream
+    # ---- phase table + rooflines: ONE instrumented step (1 factorize + 4 solveCompressed) after the timed region, HIP events on
+    #      the streams the work runs on (pips_hip_batch_get_timing / pips_hip_kkt_get_timing)
     bt.set_timing(True)
-    kkt.factorize(diag, xd0)
+    step()
     tm = bt.get_timing()
+    tk = kkt.get_timing()
     bt.set_timing(False)
     info = bt.info()
+    nb_blocks = len(blocks)
     upd_ms, upd_launches = tm["tail_update"]
     # per-block tail sizes are statistically equal; use the exact aggregate from the symbolic phase
-    m_avg = info["m"] / len(blocks)
+    m_avg = info["m"] / nb_blocks
     # border rows that ride along = the NON-EMPTY border columns of a block (info["nb"]), not S: on configurations whose blocks
     # touch only part of the linking columns the difference is large (configs[4] share: S = 16000, ~3700 non-empty per block)
-    nb_avg = info["nb"] / len(blocks)
-    alg_flops = len(blocks) * update_kernel_algorithmic_flops(int(round(m_avg)), int(round(nb_avg)))
-    achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-    traffic = update_kernel_traffic(n_blocks_total, n_i, S, world)
-    roofline = {
-        "kernel": ("k_tile_gemm<0>" if os.environ.get("PIPS_HIP_BALANCED_GEMM") == "0" else "k_tile_gemm_bal<0>")
-                  + " (tail update, v_mfma_f64_4x4x4_4b_f64)", "bound": "mfma", "achieved": round(achieved, 2),
-        "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
-        # per launch, like `achieved`: 34 launches of growing depth K = 128 j make up one factorisation, so the figures are
-        # the per-factorize totals divided by the launch count (the rocprofv3 average duration of this kernel is the same
-        # quotient); the totals are kept next to them
-        "traffic": (traffic / upd_launches if traffic and upd_launches else None),
-        "avg_launch_ms": round(upd_ms / max(upd_launches, 1), 4),
-        "algorithmic_flops_per_launch": alg_flops / max(upd_launches, 1),
-        "launches_per_factorize": upd_launches, "ms_per_factorize": round(upd_ms, 3),
-        "algorithmic_flops_per_factorize": alg_flops, "traffic_per_factorize": traffic,
-        "phase_ms": {k: round(v[0], 3) for k, v in tm.items()},
-    }
+    nb_avg = info["nb"] / nb_blocks
+    n_solve_once = max(tm["solve_tail"][1], 1)
+
+    def group(name, kernel, bound, ms_, launches, work, note=None):
+        """work: algorithmic flops (mfma) or bytes (hbm) of the group per step"""
+        peak, unit, scale = (PEAK_FP64_MFMA_TFLOPS, "TFLOP/s", 1e12) if bound == "mfma" else (PEAK_HBM_GBS, "GB/s", 1e9)
+        ach = work / (ms_ * 1e-3) / scale if ms_ > 0 else 0.0
+        g = {"group": name, "kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+             "frac": round(ach / peak, 4), "ms_per_step": round(ms_, 3), "launches_per_step": int(launches),
+             "avg_launch_ms": round(ms_ / max(launches, 1), 4),
+             ("algorithmic_flops_per_step" if bound == "mfma" else "algorithmic_bytes_per_step"): work,
+             ("algorithmic_flops_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): work / max(launches, 1)}
+        if note:
+            g["note"] = note
+        return g
+
+    upd_flops = nb_blocks * update_kernel_algorithmic_flops(int(round(m_avg)), int(round(nb_avg)))
+    groups = [
+        group("tail update", ("k_tile_gemm<0>" if os.environ.get("PIPS_HIP_BALANCED_GEMM") == "0" else "k_tile_gemm_bal<0>")
+              + " (v_mfma_f64_4x4x4_4b_f64)", "mfma", upd_ms, upd_launches, upd_flops,
+              "sum_j 2 (128 j) [tc below + tc (tc + 1) / 2 + nb tc] per block (DESIGN.md 4)"),
+        group("Schur SYRK", "k_tile_gemm_bal<2>", "mfma", tm["schur"][0], tm["schur"][1], nb_blocks * nb_avg * (nb_avg + 1) * m_avg,
+              "nb (nb + 1) m per block"),
+        # SURVEY 8d: bytes_F = 8 (nnz K + nnz L) + 4 (nnz K + nnz_idx L), here for the part of L the sparse head produces
+        group("sparse head", "k_front<*> + k_head_factor_simple" if info.get("multifrontal_head") else "k_head_factor*", "hbm", tm["head"][0], tm["head"][1],
+              8.0 * (info["nnzK"] + info["nnzL_head"]) + 4.0 * (info["nnzK"] + info["head_row_indices"]),
+              "8 (nnz K + nnz L_head) + 4 (nnz K + row indices of the head supernodes): read K once, write L once"),
+        group("dense root", "k_tile_gemm<3> + k_tile_diag + k_tile_gemm<1>", "mfma", tk["root_factor"][0], 1, S ** 3 / 3.0, "S^3 / 3"),
+        group("leaf solve sweeps", "k_head_fwd / k_head_bwd / k_head_solve_simple / k_tail_rows_fwd / _bwd", "hbm",
+              tm["solve_head_fwd"][0] + tm["solve_tail"][0] + tm["solve_head_bwd"][0], n_solve_once, n_solve_once * 16.0 * info["nnzL"],
+              "every entry of L read once per sweep, forward and backward: 16 nnz(L) bytes per leaf solve pass"),
+    ]
+    dominant = max(groups, key=lambda g: g["ms_per_step"])
+    roofline = dict(dominant)
+    traffic = update_kernel_traffic(n_blocks_total, n_i, S, world) if dominant["group"] == "tail update" else head_traffic(a.family, n_blocks_total, n_i)
+    if dominant["group"] not in ("tail update", "sparse head"):
+        traffic = None
+    # per launch, like `achieved` (the rocprofv3 average duration of the kernel is ms_per_step / launches_per_step)
+    roofline["traffic"] = (traffic / dominant["launches_per_step"] if traffic and dominant["launches_per_step"] else None)
+    roofline["traffic_per_step"] = traffic
+    # every phase of the step.  Top level: the partition of pips_hip_kkt_factorize / pips_hip_kkt_solve_compressed (4 solves);
+    # below it what the leaf engine reports for its own part.  The root factorisation runs on a stream of its own beside the first
+    # Lsolve's leaf solve; only what exceeds that solve is on the critical path.
+    top = {k: round(v[0], 3) for k, v in tk.items()}
+    lsolve_first = tk["lsolve_leaf"][0] / max(tk["lsolve_leaf"][1], 1)
+    root_exposed = max(0.0, tk["root_factor"][0] - lsolve_first) if not os.environ.get("PIPS_HIP_ROOT_SYNC") else tk["root_factor"][0]
+    accounted = sum(tk[k][0] for k in ("diag_zero", "leaf_factor", "reduce", "finalize", "lsolve_leaf", "lsolve_border_reduce", "dsolve",
+                                       "ltsolve", "combine")) + root_exposed
+    phase_ms = {"step": top, "root_factor_exposed": round(root_exposed, 3), "accounted": round(accounted, 3),
+                "leaf_factor": {k: round(tm[k][0], 3) for k in ("scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur")},
+                "leaf_solves": {k: round(tm[k][0], 3) for k in ("solve_permute", "solve_head_fwd", "solve_tail", "solve_head_bwd", "solve_refine")},
+                "leaf_solve_passes": n_solve_once}
+    collective = None
+    if use_dist:
+        payload = 8.0 * S * (S + 1) / 2
+        P = max(world, 1)
+        tot = tk["reduce_panels"][0] if tk["reduce_panels"][1] > 0 else tk["reduce"][0]
+        collective = {"schur_reduce_exposed_ms": round(tk["reduce"][0], 3), "schur_reduce_total_ms": round(tot, 3),
+                      "schur_panels": tk["reduce_panels"][1] or 1,
+                      "overlapped_fraction": (round(1.0 - tk["reduce"][0] / tot, 3) if tk["reduce_panels"][1] > 0 and tot > 0 else 0.0),
+                      "b0_reduce_ms_in": "phase_ms.step.lsolve_border_reduce (border product + all-reduce of S doubles, x4)",
+                      "payload_bytes_per_step": payload + R_SOLVES * 8.0 * S,
+                      "wire_bytes_per_gpu_per_step": 2.0 * (P - 1) / P * (payload + R_SOLVES * 8.0 * S)}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
         out = {
             "metric": "KKT factor+solve per IPM iter/sec, N-block arrowhead LP",
-            "value": round(world * a.steps / dt, 4), "unit": "64-block work units/s (1 factorize + 4 solveCompressed)",
+            "value": round(world * a.steps / dt, 4), "unit": f"{bpg}-block work units/s (1 factorize + 4 solveCompressed)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
-                                   f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""),
+            "config": {"workload": (f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
+                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""))
+                       if a.family == "random" else
+                       (f"time-coupled family: {n_blocks_total} blocks x {n_i} vars ({my_i} banded eq rows, 10 nnz/row), 95 first-stage variables, "
+                        f"31 two-link rows per neighbouring pair, Schur dim {S}, {bpg} blocks/GPU"
+                        + (" [per-GPU share of BASELINE configs[3]]" if bpg == 256 and n_i == 50000 else "")),
+                       "family": a.family, "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed (DESIGN.md 4.5)"
                                    if info.get("ltsolve_from_augmented_factor") else "border product + refined leaf solve"),
@@ -341,18 +446,23 @@ def main():
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},
             "roofline": roofline,
+            "roofline_all": [{k: g[k] for k in ("group", "bound", "achieved", "peak", "unit", "frac", "ms_per_step", "launches_per_step")} for g in groups],
+            "phase_ms": phase_ms,
         }
+        if collective:
+            out["collective"] = collective
         if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(pa, a.seed, n_i, my_i, n0, myl, a.rho, n_blocks_total)
+                out["cpu_baseline"] = cpu_baseline(pa, a.seed, n_i, my_i, n0, myl, a.rho, n_blocks_total, bpg,
+                                                   fam_blocks[0] if fam_blocks is not None else None)
             except Exception as e:  # the baseline must never break the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "64-block work units/s", "cores": 0, "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": f"{bpg}-block work units/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
         if not a.no_ipm and world == 1:
             # "report units/s, and separately end-to-end IPM iterations/s of a full solve with the host driver" - the
             # device-resident harness on the LP of the same generator and shape, outside the timed region of the metric
             try:
-                out["ipm_end_to_end"] = ipm_end_to_end(pa, a.seed, n_blocks_total, n_i, my_i, n0, myl, a.rho)
+                out["ipm_end_to_end"] = ipm_end_to_end(pa, a.seed, n_blocks_total, n_i, my_i, n0, myl, a.rho, fam_blocks, fam_F0)
             except Exception as e:
                 out["ipm_end_to_end"] = {"error": str(e)}
         # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a pipe: push it out

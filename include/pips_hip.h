@@ -134,9 +134,11 @@ int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero);
  * what[13]=1 if solveCompressed takes its Ltsolve from the augmented factor (one backward sweep) while no pivot is perturbed */
 int pips_hip_batch_info(void* handle, int64_t* what, int n_what);
 int pips_hip_batch_sync(void* handle);
-/* per-phase device time of the last pips_hip_batch_factor in ms (HIP events on the handle's stream):
- * ms[0]=scatter ms[1]=head ms[2]=tail update GEMM ms[3]=tail diag ms[4]=tail trsm ms[5]=Schur SYRK ms[6]=total
- * cnt[i] = number of kernel launches of phase i.  Enable with pips_hip_batch_set_timing(handle, 1). */
+/* per-phase device time in ms (HIP events on the handle's stream) of the last pips_hip_batch_factor
+ *   ms[0]=scatter ms[1]=head ms[2]=tail update GEMM ms[3]=tail diag ms[4]=tail trsm ms[5]=Schur SYRK ms[6]=total
+ * and, summed over the solves since that factorisation,
+ *   ms[7]=permute in/out ms[8]=head forward ms[9]=tail sweeps + D ms[10]=head backward ms[11]=refinement residual + norms
+ * cnt[i] = number of records of phase i (n <= 16).  Enable with pips_hip_batch_set_timing(handle, 1). */
 int pips_hip_batch_set_timing(void* handle, int on);
 int pips_hip_batch_get_timing(void* handle, double* ms, int64_t* cnt, int n);
 void pips_hip_batch_destroy(void* handle);
@@ -185,6 +187,12 @@ int pips_hip_kkt_set_zdiag0_dev(void* handle, const double* zdiag0_dev);
 int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev);
 int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld);
 int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero);
+/* phase times (ms, HIP events on the streams the work runs on) of the last pips_hip_kkt_factorize and of the solveCompressed calls
+ * since; on while the batch's timing switch is on:  ms[0]=diagonals + zero SC  ms[1]=leaf factorisation  ms[2]=Schur reduction
+ * ms[3]=finalize  ms[4]=root factorisation  ms[5]=Lsolve leaf solves  ms[6]=Lsolve border product + b0 reduction  ms[7]=Dsolve
+ * ms[8]=Ltsolve  ms[9]=x_i = z_i - u_i  ms[10]=panel-wise Schur reduction on its own stream, summed over the panels (ms[2] is
+ * then what the main stream waited for it: the exposed part).  What bench.py's phase table is made of. */
+int pips_hip_kkt_get_timing(void* handle, double* ms, int64_t* cnt, int n);
 void pips_hip_kkt_destroy(void* handle);
 
 /* plain device buffers for hosts that do not bring their own allocator */

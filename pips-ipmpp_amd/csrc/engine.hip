@@ -234,8 +234,9 @@ struct PhaseTimer {
    std::vector<Rec> recs;
    std::vector<hipEvent_t> pool;
    size_t used = 0;
-   double ms[8] = {0};
-   long long cnt[8] = {0};
+   static constexpr int NPHASE = 16;
+   double ms[NPHASE] = {0};
+   long long cnt[NPHASE] = {0};
    hipEvent_t get() {
       if (used == pool.size()) {
          hipEvent_t e;
@@ -255,8 +256,17 @@ struct PhaseTimer {
       if (!on) return;
       (void)hipEventRecord(recs.back().b, s);
    }
+   // a record that stays open across others: begin_i returns its index (-1 when off)
+   int begin_i(hipStream_t s, int phase) {
+      if (!on) return -1;
+      begin(s, phase);
+      return (int)recs.size() - 1;
+   }
+   void end_i(int idx, hipStream_t s) {
+      if (on && idx >= 0) (void)hipEventRecord(recs[idx].b, s);
+   }
    void collect() {
-      for (int i = 0; i < 8; ++i) { ms[i] = 0; cnt[i] = 0; }
+      for (int i = 0; i < NPHASE; ++i) { ms[i] = 0; cnt[i] = 0; }
       for (auto& r : recs) {
          float t = 0;
          if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.phase] += t; ++cnt[r.phase]; }
@@ -1557,7 +1567,10 @@ struct Engine {
       if (!xw) xw = d_xw;
       const long long xws = nrhs > 1 ? xw_total : 0;
       const dim3 pg(64, nblk, nrhs);
+      timer.begin(stream, 7);
       hipLaunchKernelGGL(k_permute_in, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
+      timer.end(stream);
+      timer.begin(stream, 8);
       if (deterministic && nrhs != 1) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode solves one right-hand side at a time");
       if (head_slots && nrhs == 1 && (deterministic || slot_solves)) {
          // forward substitution without atomics: the contributions go to their slots, every level first gathers what the lower
@@ -1591,7 +1604,10 @@ struct Engine {
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
                             d_arena, xw, xws, 0);
+      timer.end(stream);
+      timer.begin(stream, 9);
       TailCtx c = ctx();
+      c.timer = nullptr;   // (the tail's own phase records belong to the factorisation)
       int rc = tail_fwd(c, xw, nrhs, xws);
       if (rc) return rc;
       if (nsn_total > 0)
@@ -1599,6 +1615,8 @@ struct Engine {
                             d_arena, xw, xws);
       rc = tail_bwd(c, xw, nrhs, xws);
       if (rc) return rc;
+      timer.end(stream);
+      timer.begin(stream, 10);
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
                             d_arena, xw, xws, 1);
@@ -1615,7 +1633,10 @@ struct Engine {
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
                                L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 1);
       }
+      timer.end(stream);
+      timer.begin(stream, 7);
       hipLaunchKernelGGL(k_permute_out, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, x_dev, x_stride, xw, xws);
+      timer.end(stream);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
@@ -1735,6 +1756,7 @@ struct Engine {
       int rc = solve_once(x_dev);
       if (rc) return rc;
       for (int it = 0; it < refine_steps; ++it) {
+         timer.begin(stream, 11);
          HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
          hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                             x_dev, d_res, n_total, d_rowbase, 0LL);
@@ -1746,6 +1768,7 @@ struct Engine {
             if (refine_mode == 1)
                hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, x_dev, d_blks, d_norms + 2 * nblk);
             HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)3 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
+            timer.end(stream);
             if (refine_mode == 1 && h_amax.empty()) {
                h_amax.resize(nblk);
                std::vector<BlkDesc> tmp(nblk);
@@ -1761,7 +1784,8 @@ struct Engine {
             }
             last_refine_measure = worst;
             if (worst <= refine_tol) break;
-         }
+         } else
+            timer.end(stream);
          rc = solve_once(d_res);
          if (rc) return rc;
          hipLaunchKernelGGL(k_axpy, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, x_dev, d_res, 1.0, n_total);
@@ -1974,6 +1998,11 @@ struct KktSystem {
    }
    size_t packed_cap = 0;
    bool use_rsag = false, force_reduce = false;
+   // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
+   // 0 diagonals + zero SC, 1 leaf factorisation, 2 Schur reduction, 3 finalize, 4 root factorisation (its own stream),
+   // 5 Lsolve leaf solves, 6 Lsolve border product + b0 reduction, 7 Dsolve, 8 Ltsolve, 9 x_i = z_i - u_i,
+   // 10 panel-wise Schur reduction on its own stream (sum over the panels; phase 2 is then only what the main stream waited for it)
+   PhaseTimer timer;
    // sparse root: SC lives as the value array of a lower-triangular CSR pattern inside a one-block sparse
    // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
    bool sparse = false;
@@ -2344,6 +2373,13 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
    if (n_what > 15) { what[15] = 0; for (const BlockSym& s : e->sym) what[15] = std::max<int64_t>(what[15], s.mf_max_front); }
    if (n_what > 16) what[16] = e->mfU_total * 8;
    if (n_what > 17) { what[17] = 0; for (const MfLaunch& m : e->mf_launches) if (m.cls >= 6) what[17] += m.cnt; }
+   if (n_what > 19) {   // the sparse head alone: stored entries of L and row indices (algorithmic bytes of its factorisation)
+      what[18] = what[19] = 0;
+      for (const BlockSym& s : e->sym) {
+         what[18] += s.nnzL - (int64_t)s.m * (s.m + 1) / 2;
+         what[19] += (int64_t)s.rowidx.size();
+      }
+   }
    return PIPS_OK;
 }
 
@@ -2368,7 +2404,7 @@ int pips_hip_batch_get_timing(void* handle, double* ms, int64_t* cnt, int n) {
    HIP_TRY(hipSetDevice(e->device));
    HIP_TRY(hipStreamSynchronize(e->stream));
    e->timer.collect();
-   for (int i = 0; i < n && i < 8; ++i) {
+   for (int i = 0; i < n && i < PhaseTimer::NPHASE; ++i) {
       if (ms) ms[i] = e->timer.ms[i];
       if (cnt) cnt[i] = e->timer.cnt[i];
    }
@@ -2811,13 +2847,20 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    int rc;
    if (leaf_diag_dev && (rc = pips_hip_batch_set_diagonals_dev(e, leaf_diag_dev))) return rc;
    const size_t nnz = (size_t)k->sc_rowptr[k->S];
+   PhaseTimer& tm = k->timer;
+   tm.on = e->timer.on;
+   tm.reset();
    HIP_TRY(hipMemsetAsync(r->d_kval, 0, nnz * sizeof(double), e->stream));
+   tm.begin(e->stream, 1);
    if ((rc = e->factor(r->d_kval, 0))) return rc;
+   tm.end(e->stream);
    const bool reduce = k->n_ranks > 1 || k->force_reduce;
+   tm.begin(e->stream, 2);
    if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       if ((rc = pips_hip_allreduce_sum(k->comm, r->d_kval, nnz, e->stream))) return rc;
    }
+   tm.end(e->stream);
    if (xdiag0_dev && k->n0 > 0)
       hipLaunchKernelGGL(k_add_at, dim3(grid_for(k->n0, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_xdiag_pos, xdiag0_dev, k->n0);
    if (k->n_fin > 0)
@@ -2836,7 +2879,10 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
       hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->S - k->n0, 256)), dim3(256), 0, e->stream, r->d_kval, 0, k->d_sc_rowptr, k->n0,
                          k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
-   return r->factor(nullptr, 0);
+   tm.begin(e->stream, 4);
+   rc = r->factor(nullptr, 0);
+   tm.end(e->stream);
+   return rc;
 }
 
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev) {
@@ -2846,13 +2892,21 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    HIP_TRY(hipSetDevice(e->device));
    if (k->sparse) return kkt_factorize_sparse(k, leaf_diag_dev, xdiag0_dev, zdiag_link_dev);
    int rc;
+   PhaseTimer& tm = k->timer;
+   tm.on = e->timer.on;
+   tm.reset();
+   tm.begin(e->stream, 0);
    if (leaf_diag_dev && (rc = pips_hip_batch_set_diagonals_dev(e, leaf_diag_dev))) return rc;
    const size_t n = (size_t)k->S * k->S;
    if ((rc = k->root_wait())) return rc;                                         // the previous root factorisation still reads d_SC
    HIP_TRY(hipMemsetAsync(k->d_SC, 0, n * sizeof(double), e->stream));            // initializeKKT (:840-847)
+   tm.end(e->stream);
+   tm.begin(e->stream, 1);
    if ((rc = e->factor(k->d_SC, k->S))) return rc;                               // children factor2 + assembleLocalKKT
+   tm.end(e->stream);
    // reduceKKT (:860-881).  PIPS_HIP_FORCE_REDUCE exercises the reduction path with a one-rank communicator (tests).
    const bool reduce = k->n_ranks > 1 || k->force_reduce;
+   const int rec_reduce = tm.begin_i(e->stream, 2);   // what the main stream waits for the reduction: its exposed part
    if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       // only the lower triangle is authoritative: reduce S(S+1)/2 packed doubles instead of S^2
@@ -2885,9 +2939,11 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
             const size_t cnt = (size_t)R0 * h + h * (h + 1) / 2;
             HIP_TRY(hipStreamWaitEvent(k->comm_stream, e->ev_sc[q], 0));
             const dim3 pg(std::max(1, std::min(64, (R1 - R0 + 255) / 256)), R1);
+            const int rec_panel = tm.begin_i(k->comm_stream, 10);   // pack + collective + unpack of this panel, beside the leaf work
             hipLaunchKernelGGL(k_pack_rows, pg, dim3(256), 0, k->comm_stream, k->d_SC, k->S, R0, R1, k->d_packed + off, 0);
             if ((rc = reduce_piece(k->d_packed + off, cnt, k->comm_stream))) return rc;
             hipLaunchKernelGGL(k_pack_rows, pg, dim3(256), 0, k->comm_stream, k->d_SC, k->S, R0, R1, k->d_packed + off, 1);
+            tm.end_i(rec_panel, k->comm_stream);
             off += (cnt + P - 1) / P * P;
          }
          HIP_TRY(hipEventRecord(k->ev_reduced, k->comm_stream));
@@ -2899,7 +2955,9 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
          hipLaunchKernelGGL(k_pack_lower, pg, dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_packed, 1);
       }
    }
+   tm.end_i(rec_reduce, e->stream);
    // finalizeKKTdense
+   tm.begin(e->stream, 3);
    if (xdiag0_dev && k->n0 > 0)
       hipLaunchKernelGGL(k_add_diag, dim3(grid_for(k->n0, 256)), dim3(256), 0, e->stream, k->d_SC, k->S, 0, xdiag0_dev, k->n0);
    if (k->n_fin > 0)
@@ -2921,8 +2979,14 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
       hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->S - k->n0, 256)), dim3(256), 0, e->stream, k->d_SC, k->S, (const int*)nullptr, k->n0,
                          k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
+   tm.end(e->stream);
    static const bool root_async = !getenv("PIPS_HIP_ROOT_SYNC");
-   if (!root_async) return k->root->factor_dev(k->d_SC, k->S, 0);                  // factorizeKKT (:1436-1464)
+   if (!root_async) {
+      tm.begin(e->stream, 4);
+      rc = k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)
+      tm.end(e->stream);
+      return rc;
+   }
    if (!k->root_stream) {
       int prio_lo = 0, prio_hi = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -2933,7 +2997,9 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    HIP_TRY(hipEventRecord(k->ev_sc_final, e->stream));
    HIP_TRY(hipStreamWaitEvent(k->root_stream, k->ev_sc_final, 0));
    k->root->stream = k->root_stream;
+   tm.begin(k->root_stream, 4);
    rc = k->root->factor_dev(k->d_SC, k->S, 0);
+   tm.end(k->root_stream);
    k->root->stream = e->stream;                                                   // solves and queries run on the main stream
    if (rc) return rc;
    HIP_TRY(hipEventRecord(k->ev_root_done, k->root_stream));
@@ -2983,12 +3049,17 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
+   k->timer.begin(e->stream, 5);
    if ((rc = e->solve(b_leaf_dev))) return rc;
+   k->timer.end(e->stream);
+   k->timer.begin(e->stream, 6);
    if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
    if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream)))
       return rc;
+   k->timer.end(e->stream);
    }
    // Dsolve: eliminate z0 through C0, solve with the Schur complement, recover z0 (solveReducedLinkCons :384-466)
+   k->timer.begin(e->stream, 7);
    if (k->mz0 > 0)
       hipLaunchKernelGGL(k_z0_elim, e->deterministic ? dim3(1) : dim3(grid_for(k->mz0, 128)), e->deterministic ? dim3(1) : dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
@@ -3007,6 +3078,8 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    // Ltsolve: b_i -= K_i^-1 Br_i x0 (LniTransMult, DistributedLinearSystem.C:430-483).  Where the stored border rows are thin
    // enough and no pivot of the factorisation was perturbed: from the augmented factor with one backward sweep
    // (Engine::solve_border_backward); else border product + full solve with refinement.
+   k->timer.end(e->stream);
+   k->timer.begin(e->stream, 8);
    int pert = 1;
    if (e->border_backward_ok && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
    if (e->border_backward_ok && !k->sparse && pert == 0) {
@@ -3016,8 +3089,25 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
       if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, 1.0))) return rc;
       if ((rc = e->solve(k->d_t))) return rc;
    }
+   k->timer.end(e->stream);
+   k->timer.begin(e->stream, 9);
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
+   k->timer.end(e->stream);
    HIP_TRY(hipGetLastError());
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_get_timing(void* handle, double* ms, int64_t* cnt, int n) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   HIP_TRY(hipSetDevice(k->leaves->device));
+   HIP_TRY(hipStreamSynchronize(k->leaves->stream));
+   if (k->root_stream) HIP_TRY(hipStreamSynchronize(k->root_stream));
+   k->timer.collect();
+   for (int i = 0; i < n && i < PhaseTimer::NPHASE; ++i) {
+      if (ms) ms[i] = k->timer.ms[i];
+      if (cnt) cnt[i] = k->timer.cnt[i];
+   }
    return PIPS_OK;
 }
 

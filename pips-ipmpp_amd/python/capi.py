@@ -59,7 +59,7 @@ SYMBOLS = [
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
     "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
-    "pips_hip_kkt_root_inertia", "pips_hip_kkt_destroy",
+    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
@@ -422,10 +422,10 @@ class LeafBatch:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(18, np.int64)
-        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(18)), "pips_hip_batch_info")
+        what = np.zeros(20, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(20)), "pips_hip_batch_info")
         keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK",
-                "ltsolve_from_augmented_factor", "multifrontal_head", "max_front", "update_matrix_bytes", "fronts_in_device_memory"]
+                "ltsolve_from_augmented_factor", "multifrontal_head", "max_front", "update_matrix_bytes", "fronts_in_device_memory", "nnzL_head", "head_row_indices"]
         return {k: int(v) for k, v in zip(keys, what)}
 
     def sync(self):
@@ -435,10 +435,11 @@ class LeafBatch:
         _check(lib.pips_hip_batch_set_timing(self._h, C.c_int(1 if on else 0)), "set_timing")
 
     def get_timing(self):
-        ms = np.zeros(8)
-        cnt = np.zeros(8, np.int64)
-        _check(lib.pips_hip_batch_get_timing(self._h, _ptr(ms), _ptr(cnt), C.c_int(8)), "get_timing")
-        names = ["scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur", "total"]
+        ms = np.zeros(16)
+        cnt = np.zeros(16, np.int64)
+        _check(lib.pips_hip_batch_get_timing(self._h, _ptr(ms), _ptr(cnt), C.c_int(16)), "get_timing")
+        names = ["scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur", "total", "solve_permute", "solve_head_fwd", "solve_tail",
+                 "solve_head_bwd", "solve_refine"]
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(names)}
 
     def close(self):
@@ -605,6 +606,15 @@ class KktSystem:
         self.batch.sync()
         _check(lib.pips_hip_memcpy_d2h(_ptr(out), C.c_void_p(p), C.c_size_t(out.nbytes)), "memcpy_d2h")
         return out
+
+    def get_timing(self):
+        """Phase times (ms, launches) of the last factorize and the solveCompressed calls since (batch timing switch on)."""
+        ms = np.zeros(16)
+        cnt = np.zeros(16, np.int64)
+        _check(lib.pips_hip_kkt_get_timing(self._h, _ptr(ms), _ptr(cnt), C.c_int(16)), "kkt get_timing")
+        names = ["diag_zero", "leaf_factor", "reduce", "finalize", "root_factor", "lsolve_leaf", "lsolve_border_reduce", "dsolve", "ltsolve", "combine",
+                 "reduce_panels"]
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(names)}
 
     def root_inertia(self):
         p, n, z = C.c_int(), C.c_int(), C.c_int()
