@@ -55,7 +55,12 @@ void pips_hip_ldl_destroy(void* handle);
 /* ---------------------------------------------------------------------------------------------------------------
  * 2. Dense root solver: drop-in for DeSymIndefSolver (DeSymIndefSolver.C:56-168; dsytrf_/dsytrs_).
  * ------------------------------------------------------------------------------------------------------------- */
+/* n_primal >= 0: inertia hint (rows [0, n_primal) are expected to give positive pivots, the rest negative ones) - the caller vouches
+ * for a quasi-definite order and the factorisation keeps it (static pivots); n_primal < 0: no hint, the matrix is pivoted like
+ * dsytrf does: Bunch-Kaufman 1 x 1 / 2 x 2 pivots, the search bounded to the 128 x 128 diagonal tiles.
+ * pips_hip_dense_ldl_set_pivoting overrides: 0 static order, 1 Bunch-Kaufman. */
 int pips_hip_dense_ldl_create(void** handle, int n, int n_primal, int device);
+int pips_hip_dense_ldl_set_pivoting(void* handle, int mode);
 /* = DeSymIndefSolver::matrixChanged(): A is the n x n row-major DenseSymmetricMatrix storage (DenseStorage.C:64-83,
  * lower triangle authoritative, lda = n); it is copied to the device and factorised */
 int pips_hip_dense_ldl_factor(void* handle, const double* A_host, int lda);
@@ -187,6 +192,9 @@ int pips_hip_kkt_set_zdiag0_dev(void* handle, const double* zdiag0_dev);
 int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev);
 int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld);
 int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero);
+/* dense root: 0 static pivot order (default: the Schur complement the leaves build is quasi-definite in the order x0, duals),
+ * 1 Bunch-Kaufman inside the diagonal tiles (default once pips_hip_kkt_set_root_inequalities folds -C0^T Omega^-1 C0 into the x0 block) */
+int pips_hip_kkt_set_root_pivoting(void* handle, int mode);
 /* phase times (ms, HIP events on the streams the work runs on) of the last pips_hip_kkt_factorize and of the solveCompressed calls
  * since; on while the batch's timing switch is on:  ms[0]=diagonals + zero SC  ms[1]=leaf factorisation  ms[2]=Schur reduction
  * ms[3]=finalize  ms[4]=root factorisation  ms[5]=Lsolve leaf solves  ms[6]=Lsolve border product + b0 reduction  ms[7]=Dsolve

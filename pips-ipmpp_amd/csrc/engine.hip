@@ -314,6 +314,7 @@ struct TailCtx {
    const int* d_blk_group = nullptr;
    int n_groups = 0, first_slot = 0;
    SweepRt* sweep = nullptr;            // single-launch solve sweeps
+   bool bunch_kaufman = false;          // diagonal tiles with 1 x 1 / 2 x 2 pivoting (k_tile_diag_bk) instead of the static pivot order
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
 constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
@@ -384,6 +385,10 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipEventRecord(c.ev_panel, c.stream));
          HIP_TRY(hipStreamWaitEvent(c.side, c.ev_panel, 0));
          gemm_diag_tiles(p.upd_diag[j], c.side);
+         if (c.bunch_kaufman)
+            hipLaunchKernelGGL(k_tile_diag_bk, dim3(p.diag[j].cnt), dim3(256), 0, c.side, p.d_tasks + p.diag[j].off, c.d_blks, c.d_arena, c.d_dtail,
+                               c.d_winv, c.d_inertia);
+         else
          hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.side, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
          HIP_TRY(hipEventRecord(c.ev_rest, c.side));
@@ -399,6 +404,10 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_rest, 0));   // trsm needs Winv_j and d_j
       } else {
          if (c.timer) c.timer->begin(c.stream, 3);
+         if (c.bunch_kaufman)
+            hipLaunchKernelGGL(k_tile_diag_bk, dim3(p.diag[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.diag[j].off, c.d_blks, c.d_arena, c.d_dtail,
+                               c.d_winv, c.d_inertia);
+         else
          hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
          if (c.timer) c.timer->end(c.stream);
@@ -1854,6 +1863,11 @@ struct Engine {
 // ---------------------------------------------------------------------------------------------------------------
 struct DenseLdl {
    int device = 0, n = 0, npad = 0, n_primal = -1;
+   // 0: static pivot order with the expected signs of the inertia hint (right for the quasi-definite Schur complement the fused
+   //    path builds itself: no search on the critical path of the 128 dependent pivots of a tile);
+   // 1: Bunch-Kaufman 1 x 1 / 2 x 2 pivoting bounded to the diagonal tile (k_tile_diag_bk): what a drop-in for DeSymIndefSolver
+   //    needs - dsytrf takes any symmetric matrix (DeSymIndefSolver.C:78)
+   int pivoting = 0;
    hipStream_t stream = nullptr;
    double thr_rel = 1e-13, repl_rel = 1e-8;
    bool factored = false;
@@ -1928,6 +1942,7 @@ struct DenseLdl {
    TailCtx ctx() {
       TailCtx c{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
       c.sweep = &sweep;
+      c.bunch_kaufman = pivoting == 1;
       return c;
    }
 
@@ -1998,6 +2013,7 @@ struct KktSystem {
    }
    size_t packed_cap = 0;
    bool use_rsag = false, force_reduce = false;
+   bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
    // 0 diagonals + zero SC, 1 leaf factorisation, 2 Schur reduction, 3 finalize, 4 root factorisation (its own stream),
    // 5 Lsolve leaf solves, 6 Lsolve border product + b0 reduction, 7 Dsolve, 8 Ltsolve, 9 x_i = z_i - u_i,
@@ -2564,9 +2580,20 @@ int pips_hip_dense_ldl_create(void** handle, int n, int n_primal, int device) {
    d->n = n;
    d->n_primal = n_primal;
    d->device = dev;
+   // no inertia hint = a plain DeSymIndefSolver replacement: pivot like dsytrf; with a hint the caller vouches for the quasi-definite order
+   d->pivoting = n_primal < 0 ? 1 : 0;
+   if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) d->pivoting = atoi(pv) != 0;
    rc = d->init();
    if (rc) return rc;
    *handle = d.release();
+   return PIPS_OK;
+}
+
+int pips_hip_dense_ldl_set_pivoting(void* handle, int mode) {
+   DenseLdl* d = (DenseLdl*)handle;
+   if (!d || mode < 0 || mode > 1) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_dense_ldl_set_pivoting: mode 0 (static order) or 1 (Bunch-Kaufman inside the diagonal tiles)");
+   d->pivoting = mode;
+   d->factored = false;
    return PIPS_OK;
 }
 
@@ -2674,6 +2701,7 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    k->root->stream = e->stream;
    k->root->thr_rel = e->thr_rel;
    k->root->repl_rel = e->repl_rel;
+   if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) { k->root->pivoting = atoi(pv) != 0; k->root_pivoting_set = true; }
    int rc = k->root->init();
    if (rc) return rc;
    HIP_TRY(hipMalloc((void**)&k->d_SC, (size_t)S * S * sizeof(double)));
@@ -3116,12 +3144,24 @@ int pips_hip_kkt_set_root_inequalities(void* handle, int mz0, const int* C0_rowp
    if (!k || mz0 < 0 || (mz0 > 0 && (!C0_rowptr || !C0_colidx || !C0_val))) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_root_inequalities: bad arguments");
    HIP_TRY(hipSetDevice(k->leaves->device));
    k->mz0 = mz0;
+   // -C0^T Omega^-1 C0 in the x0 block (sLinsysRootAug.C:1276-1294): an active row makes it a huge low-rank matrix plus an O(1) rest,
+   // the static pivot rule then takes the cancelled pivots for zeros - the reference leaves that to dsytrf, so does the root here
+   if (k->root && !k->root_pivoting_set) k->root->pivoting = mz0 > 0 ? 1 : 0;
    if (mz0 == 0) return PIPS_OK;
    std::vector<int> rp(C0_rowptr, C0_rowptr + mz0 + 1), ci(C0_colidx, C0_colidx + C0_rowptr[mz0]);
    std::vector<double> v(C0_val, C0_val + C0_rowptr[mz0]);
    int rc;
    if ((rc = dev_upload(&k->d_c0_rp, rp, nullptr)) || (rc = dev_upload(&k->d_c0_ci, ci, nullptr)) || (rc = dev_upload(&k->d_c0_val, v, nullptr))) return rc;
    HIP_TRY(hipMalloc((void**)&k->d_red, (size_t)std::max(k->S, 1) * sizeof(double)));
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_set_root_pivoting(void* handle, int mode) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || mode < 0 || mode > 1) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_root_pivoting: mode 0 (static order) or 1 (Bunch-Kaufman inside the diagonal tiles)");
+   if (k->sparse) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_set_root_pivoting: the sparse root is factorised by the leaf engine (static pivot order)");
+   k->root->pivoting = mode;
+   k->root_pivoting_set = true;
    return PIPS_OK;
 }
 

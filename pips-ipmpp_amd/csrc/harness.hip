@@ -246,6 +246,12 @@ __global__ void k_diagonals(Lay d, const double* __restrict__ G, const double* _
    }
 }
 
+// out[k] = in[k] - reg: the regularised dual diagonal of the eliminated root inequality rows (sLinsysRootAug.C:384-466 eliminates z0 with
+// dual_inequality_diagonal_regularized)
+__global__ void k_shift_diag(const double* __restrict__ in, double reg, double* __restrict__ out, int n) {
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = in[k] - reg;
+}
+
 // K_i diagonals of every leaf from the primal diagonal, the dual regularisation and nOmegaInv: code[p] >= 0 an x index,
 // -1 an equality row, <= -2 the inequality row -2 - code[p]
 __global__ void k_leaf_diag(long long nleaf, const long long* __restrict__ code, const double* __restrict__ ddp,
@@ -564,6 +570,7 @@ struct Ipm {
    double *rQ = nullptr, *rAC = nullptr, *rz = nullptr, *rG = nullptr, *rL = nullptr, *rs = nullptr;
    double *dd = nullptr, *ddp = nullptr, *dyz = nullptr, *leaf_diag = nullptr, *b0 = nullptr, *bl = nullptr;
    double *dop_r = nullptr, *dyz_r = nullptr;   // diagonals of the regularised system (k_reg_operator)
+   double* zd0 = nullptr;                       // eliminated root inequality rows: nOmegaInv - dual regularisation (dual_inequality_diagonal_regularized)
    double *rhs = nullptr, *sol = nullptr, *w_r = nullptr, *w_r0 = nullptr, *w_best = nullptr, *w_v = nullptr, *w_t = nullptr, *w_p = nullptr,
           *w_dx = nullptr, *w_tmp = nullptr;
    double *d_partial = nullptr, *d_out = nullptr, *h_out = nullptr, *d_bst = nullptr, *h_bst = nullptr;
@@ -746,6 +753,7 @@ struct Ipm {
          if (nleaf > 0)
             hipLaunchKernelGGL(k_leaf_diag, dim3(egrid(nleaf)), dim3(256), 0, stream, nleaf, d_code, ddp, dyz + my, r, dual_reg + r, r, leaf_diag);
          TRY(pips_hip_kkt_set_root_regularization(kkt, r, dual_reg + r));
+         if (e_mz0 > 0) hipLaunchKernelGGL(k_shift_diag, dim3(egrid(e_mz0)), dim3(256), 0, stream, dyz + my, dual_reg + r, zd0, e_mz0);
          TRY(pips_hip_kkt_factorize(kkt, leaf_diag, ddp, e_mzl > 0 ? dyz + my + e_mz0 : nullptr));
          ++n_factorize;
          TRY(perturbed_pivots(pert));
@@ -1253,13 +1261,14 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    p->NP = nx + mz + p->ncp; p->ND = my + mz + p->ncp;
    p->lay = Lay{nx, my, mz, p->ncp};
    // Root inequality rows C0 x0 - s = ...: the reference eliminates them from the root system (-C0^T Omega^-1 C0 on the x0 block,
-   // sLinsysRootAug.C:1276-1294) and leaves the rest to Bunch-Kaufman.  With static pivots that is a trap: an active row has
-   // Omega^-1 ~ 1e14, the x0 block becomes a huge rank-one matrix plus the O(1) rest, the second pivot of that block is the
-   // difference of two 1e14 numbers and is (rightly) reported as perturbed at every regularisation - the preconditioner is gone
-   // (seeded general LPs: 2 % ended with status 3).  So the harness keeps these rows in the root system, as rows of the
-   // linking-inequality kind with no leaf part: diagonal nOmegaInv, pivots -(|nOmegaInv| + reg + C0 D0^-1 C0^T), no cancellation.
-   // PIPS_IPM_ROOT_INEQ_ELIMINATE=1 restores the elimination (pips_hip_kkt_set_root_inequalities).
-   const bool eliminate_z0 = getenv("PIPS_IPM_ROOT_INEQ_ELIMINATE") && atoi(getenv("PIPS_IPM_ROOT_INEQ_ELIMINATE")) != 0;
+   // sLinsysRootAug.C:1276-1294) and leaves the rest to dsytrf's Bunch-Kaufman pivoting.  So does the harness now that the dense root
+   // pivots (k_tile_diag_bk; pips_hip_kkt_set_root_inequalities switches it on): an active row has Omega^-1 ~ 1e14, the x0 block is
+   // then a huge low-rank matrix plus an O(1) rest and a static pivot order reports the cancelled pivots as perturbed at every
+   // regularisation (round 2: 2 % of the seeded general LPs ended with status 3 that way, which is why the rows were then kept in
+   // the root system as rows of the linking-inequality kind - diagonal nOmegaInv, no cancellation).  That formulation remains for the
+   // sparse root, whose factorisation is the leaf engine's (static order), and under PIPS_IPM_ROOT_INEQ_ELIMINATE=0.
+   const bool sparse_root_req = getenv("PIPS_IPM_SPARSE_ROOT") && atoi(getenv("PIPS_IPM_SPARSE_ROOT")) != 0;
+   const bool eliminate_z0 = getenv("PIPS_IPM_ROOT_INEQ_ELIMINATE") ? atoi(getenv("PIPS_IPM_ROOT_INEQ_ELIMINATE")) != 0 : !sparse_root_req;
    p->e_mz0 = eliminate_z0 ? mz0 : 0;
    p->e_mzl = eliminate_z0 ? mzl : mz0 + mzl;
    const int e_mz0 = p->e_mz0, e_mzl = p->e_mzl;
@@ -1502,7 +1511,7 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
    HIP_TRYH(hipMalloc((void**)&p->d_pred, P_COUNT * sizeof(int)));
    p->owned.push_back(p->d_pred);
    HIP_TRYH(hipMemset(p->d_pred, 0, P_COUNT * sizeof(int)));
-   if (e_mz0 > 0 && (rc = pips_hip_kkt_set_zdiag0_dev(p->kkt, p->dyz + my))) return rc;   // nOmegaInv of the root rows: head of the z part
+   if (e_mz0 > 0 && ((rc = p->alloc(&p->zd0, e_mz0)) || (rc = pips_hip_kkt_set_zdiag0_dev(p->kkt, p->zd0)))) return rc;   // nOmegaInv of the root rows, regularised
    return PIPS_OK;
 }
 

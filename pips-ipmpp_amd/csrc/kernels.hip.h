@@ -1423,6 +1423,238 @@ __global__ __launch_bounds__(256, 2) void k_tile_diag(const TileTask* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Diagonal tile with Bunch-Kaufman pivoting (1 x 1 and 2 x 2 pivots, search bounded to the tile): the dense root as a drop-in
+// for DeSymIndefSolver (LAPACK dsytrf, DeSymIndefSolver.C:56-97), which takes whatever the host hands it - e.g. the x0 block with
+// -C0^T Omega^-1 C0 folded in (sLinsysRootAug.C:1276-1294), where a static pivot order loses pivots to cancellation.
+//   No interchange is ever performed.  The pivot of a step is an INDEX p (or a pair p, q) among the tile's not yet eliminated
+//   ones; eliminating it from the remaining rows and columns is  A <- E A E^T  with  E = I - l e_p^T.  With G the product of all
+//   E in pivot order,  G A G^T = Lambda  is diagonal in the tile's ORIGINAL index space, i.e.  A = M Lambda M^T,  M = G^-1: the
+//   permutation of the textbook P L D L^T P^T is absorbed by M, which nobody needs to be triangular - the trsm multiplies with
+//   Winv = Lambda^-1 G, the sweeps of the solves apply Winv and Winv^T as dense 128 x 128 tiles, exactly as with static pivots.
+//   A 2 x 2 pivot block [a b; b c] is diagonalised by a plane rotation that goes into rows p, q of G, so Lambda stays diagonal
+//   everywhere outside this kernel; its two eigenvalues carry the inertia the way DeSymIndefSolver::get_inertia counts a 2 x 2
+//   block (:135-160: one positive, one negative).
+//   Pivot choice per step (Bunch-Kaufman, alpha = (1 + sqrt 17) / 8; k = first remaining index, lambda = largest |A(i, k)| among
+//   the remaining i != k, attained at r; sigma = the same for column r):  |a_kk| >= alpha lambda -> k;  |a_kk| sigma >= alpha lambda^2
+//   -> k;  |a_rr| >= alpha sigma -> r;  else the pair (k, r).  A column that is zero on and below... everywhere counts as perturbed.
+//   The search sees the tile only: entries of the panel below it are not consulted (growth there is not bounded by alpha).
+// Thread (tx, ty) owns A(tx + 16 a, ty + 16 b) for the 36 blocks on and below the block diagonal (diagonal blocks are kept
+// symmetric in full) and G(tx + 16 a, ty + 16 b) for all 64.  The column maxima are DPP reductions over the 16 lanes of a row
+// (the 16 values of tx cover every row of the tile), so the common case - the first test passes - costs no extra barrier.
+// ------------------------------------------------------------------------------------------------
+struct DiagBkShared {
+   double col[4][TILE];    // published columns: [step & 1] the candidate k, [2 + (step & 1)] the partner r
+   double xrow[4][TILE];   // rows of G of the same indices
+   double dk[TILE];
+};
+
+template <int N>
+__device__ __forceinline__ double row16_ror(double v) {   // value of the lane N places to the right inside the 16-lane row (cyclic)
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+   hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_max(double v) {
+   v = fmax(v, row16_ror<8>(v)); v = fmax(v, row16_ror<4>(v)); v = fmax(v, row16_ror<2>(v)); v = fmax(v, row16_ror<1>(v));
+   return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+   v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false)); v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false));
+   v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false)); v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false));
+   return v;
+}
+
+// column p = 16 PA + pm of the symmetric matrix and row p of G into LDS lines; eliminated indices are published as zeros
+template <int PA>
+__device__ __forceinline__ void bk_publish(const double (&A)[36], const double (&X)[64], double* line, double* xline, int pm, int tx, int ty,
+                                           unsigned long long e0, unsigned long long e1) {
+   auto gone = [&](int i) { return ((i < 64 ? e0 >> i : e1 >> (i - 64)) & 1ull) != 0; };
+   if (ty == pm) {
+#pragma unroll
+      for (int a = PA; a < 8; ++a) { const int i = tx + 16 * a; line[i] = gone(i) ? 0.0 : A[LI(a, PA)]; }
+   }
+   if (tx == pm) {
+#pragma unroll
+      for (int b = 0; b < PA; ++b) { const int j = ty + 16 * b; line[j] = gone(j) ? 0.0 : A[LI(PA, b)]; }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) xline[ty + 16 * b] = X[PA * 8 + b];
+   }
+}
+__device__ __forceinline__ void bk_publish_any(const double (&A)[36], const double (&X)[64], double* line, double* xline, int p, int tx, int ty,
+                                               unsigned long long e0, unsigned long long e1) {
+   const int pm = p & 15;
+   switch (p >> 4) {   // wave-uniform
+      case 0: bk_publish<0>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      case 1: bk_publish<1>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      case 2: bk_publish<2>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      case 3: bk_publish<3>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      case 4: bk_publish<4>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      case 5: bk_publish<5>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      case 6: bk_publish<6>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+      default: bk_publish<7>(A, X, line, xline, pm, tx, ty, e0, e1); break;
+   }
+}
+
+__global__ __launch_bounds__(256) void k_tile_diag_bk(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
+                                                     double* __restrict__ arena, double* __restrict__ dtail,
+                                                     double* __restrict__ winv, int* __restrict__ inertia) {
+   __shared__ DiagBkShared sh;
+   __builtin_amdgcn_s_setprio(3);
+   const TileTask task = tasks[blockIdx.x];
+   if (task.blk < 0) return;
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, tj = task.tj, ld = bd.ldT;
+   const int tx = tid & 15, ty = tid >> 4;
+   double* C = arena + bd.T + (long long)tj * TILE + (long long)tj * TILE * ld;
+   double A[36], X[64];
+#pragma unroll
+   for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+         const int i = tx + 16 * a, j = ty + 16 * b;
+         if (b <= a) A[LI(a, b)] = i >= j ? C[i + (long long)j * ld] : C[j + (long long)i * ld];   // diagonal blocks: mirrored
+         X[a * 8 + b] = i == j ? 1.0 : 0.0;
+      }
+   const int gk0 = tj * TILE;
+   const double alpha = 0.6403882032022076;   // (1 + sqrt(17)) / 8
+   unsigned long long e0 = 0ull, e1 = 0ull;     // eliminated indices (identical in every thread)
+   int c_pos = 0, c_neg = 0, c_pert = 0;
+   auto count = [&](int p, double d, bool pert) {
+      if (gk0 + p < bd.m) { c_pert += pert; c_pos += (!pert && d > 0); c_neg += (!pert && !(d > 0)); }
+   };
+   int step = 0;
+   for (int n_done = 0; n_done < TILE; ++step) {
+      const int buf = step & 1;
+      const int k = e0 != ~0ull ? __ffsll((long long)~e0) - 1 : 64 + __ffsll((long long)~e1) - 1;
+      bk_publish_any(A, X, sh.col[buf], sh.xrow[buf], k, tx, ty, e0, e1);
+      __syncthreads();
+      double ci[8], cj[8], xr[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) { ci[a] = sh.col[buf][tx + 16 * a]; cj[a] = sh.col[buf][ty + 16 * a]; xr[a] = sh.xrow[buf][ty + 16 * a]; }
+      const double akk = sh.col[buf][k];
+      double part = 0.0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) part = fmax(part, tx + 16 * a == k ? 0.0 : fabs(ci[a]));
+      const double lam = row16_max(part);
+      int p = k, q = -1;          // pivot index / partner of a 2 x 2 pivot
+      double cri[8], crj[8], xq[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) { cri[a] = 0.0; crj[a] = 0.0; xq[a] = 0.0; }
+      double arr = 0.0, akr = 0.0;
+      if (!(fabs(akk) >= alpha * lam) && lam > 0.0) {     // (wave-uniform: every thread holds the same akk, lam)
+         int cand = 1 << 20;
+#pragma unroll
+         for (int a = 0; a < 8; ++a) if (tx + 16 * a != k && fabs(ci[a]) == lam) cand = min(cand, tx + 16 * a);
+         const int r = row16_min(cand);
+         bk_publish_any(A, X, sh.col[2 + buf], sh.xrow[2 + buf], r, tx, ty, e0, e1);
+         __syncthreads();
+#pragma unroll
+         for (int a = 0; a < 8; ++a) { cri[a] = sh.col[2 + buf][tx + 16 * a]; crj[a] = sh.col[2 + buf][ty + 16 * a]; xq[a] = sh.xrow[2 + buf][ty + 16 * a]; }
+         arr = sh.col[2 + buf][r];
+         akr = sh.col[buf][r];
+         double ps = 0.0;
+#pragma unroll
+         for (int a = 0; a < 8; ++a) ps = fmax(ps, tx + 16 * a == r ? 0.0 : fabs(cri[a]));
+         const double sig = row16_max(ps);
+         if (fabs(akk) * sig >= alpha * lam * lam) {
+            // k after all
+         } else if (fabs(arr) >= alpha * sig) {
+            p = r;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { ci[a] = cri[a]; cj[a] = crj[a]; xr[a] = xq[a]; }
+         } else
+            q = r;
+      }
+      if (q < 0) {
+         // ---- 1 x 1 pivot at index p
+         double d = p == k ? akk : arr;
+         const bool pert = !(fmax(fabs(d), p == k ? lam : 0.0) > 1e-290) || !(fabs(d) > 0.0);
+         if (pert) d = bd.repl_abs > 0.0 ? bd.repl_abs : 1.0;
+         count(p, d, pert);
+         if (tid == 0) sh.dk[p] = d;
+         const double dinv = 1.0 / d;
+         double li[8];
+#pragma unroll
+         for (int a = 0; a < 8; ++a) li[a] = tx + 16 * a == p ? 0.0 : ci[a] * dinv;
+#pragma unroll
+         for (int b = 0; b < 8; ++b) if (ty + 16 * b == p) cj[b] = 0.0;
+#pragma unroll
+         for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) A[LI(a, b)] -= li[a] * cj[b];
+#pragma unroll
+         for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) X[a * 8 + b] -= li[a] * xr[b];
+         if (p < 64) e0 |= 1ull << p; else e1 |= 1ull << (p - 64);
+         n_done += 1;
+      } else {
+         // ---- 2 x 2 pivot on (k, q): [a_ b_; b_ c_]
+         const double a_ = akk, b_ = akr, c_ = arr;
+         const double det = a_ * c_ - b_ * b_, idet = 1.0 / det;
+         double wk[8], wq[8];
+#pragma unroll
+         for (int a = 0; a < 8; ++a) {
+            const int i = tx + 16 * a;
+            const bool out = i == k || i == q;
+            wk[a] = out ? 0.0 : (ci[a] * c_ - cri[a] * b_) * idet;
+            wq[a] = out ? 0.0 : (cri[a] * a_ - ci[a] * b_) * idet;
+         }
+#pragma unroll
+         for (int b = 0; b < 8; ++b) { const int j = ty + 16 * b; if (j == k || j == q) { cj[b] = 0.0; crj[b] = 0.0; } }
+#pragma unroll
+         for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) A[LI(a, b)] -= wk[a] * cj[b] + wq[a] * crj[b];
+#pragma unroll
+         for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) X[a * 8 + b] -= wk[a] * xr[b] + wq[a] * xq[b];
+         // [a_ b_; b_ c_] = R diag(l1, l2) R^T with R = [cs -sn; sn cs]; rows k, q of G become R^T (G_k; G_q)
+         const double hd = 0.5 * (a_ - c_), rad = sqrt(hd * hd + b_ * b_), mid = 0.5 * (a_ + c_);
+         const double l1 = mid + rad, l2 = mid - rad;
+         // eigenvector of l1: (b_, l1 - a_) or (l1 - c_, b_), the better conditioned of the two
+         double vx = fabs(l1 - c_) >= fabs(l1 - a_) ? l1 - c_ : b_, vy = fabs(l1 - c_) >= fabs(l1 - a_) ? b_ : l1 - a_;
+         const double nv = 1.0 / sqrt(vx * vx + vy * vy);
+         const double cs = vx * nv, sn = vy * nv;
+#pragma unroll
+         for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+               const int i = tx + 16 * a;
+               if (i == k) X[a * 8 + b] = cs * xr[b] + sn * xq[b];
+               else if (i == q) X[a * 8 + b] = -sn * xr[b] + cs * xq[b];
+            }
+         if (tid == 0) { sh.dk[k] = l1; sh.dk[q] = l2; }
+         count(k, l1, false);
+         count(q, l2, false);
+         if (k < 64) e0 |= 1ull << k; else e1 |= 1ull << (k - 64);
+         if (q < 64) e0 |= 1ull << q; else e1 |= 1ull << (q - 64);
+         n_done += 2;
+      }
+   }
+   __syncthreads();
+   // Winv[n][c] = G(n, c) / lambda_n ; the tile itself keeps Lambda on its diagonal (nothing reads the rest: every consumer goes
+   // through Winv and dtail)
+   double* W = winv + bd.winv_off + (long long)tj * TILE * TILE;
+#pragma unroll
+   for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+         const int i = tx + 16 * a, j = ty + 16 * b;
+         W[i + (long long)j * TILE] = X[a * 8 + b] / sh.dk[i];
+         if (i >= j) C[i + (long long)j * ld] = i == j ? sh.dk[i] : 0.0;
+      }
+   if (tid < TILE) dtail[bd.dt_off + tj * TILE + tid] = sh.dk[tid];
+   if (tid == 0) {
+      if (c_pos) atomicAdd(&inertia[3 * task.blk + 0], c_pos);
+      if (c_neg) atomicAdd(&inertia[3 * task.blk + 1], c_neg);
+      if (c_pert) atomicAdd(&inertia[3 * task.blk + 2], c_pert);
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
 // solves
 // ------------------------------------------------------------------------------------------------
 // gather/scatter between original-order flat vectors and the permuted work vectors

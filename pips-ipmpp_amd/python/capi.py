@@ -49,7 +49,7 @@ SYMBOLS = [
     "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
     "pips_hip_ldl_get_perm", "pips_hip_ldl_destroy",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
-    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_destroy",
+    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_destroy",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
     "pips_hip_batch_last_refinement_steps", "pips_hip_batch_set_refinement_backward_error",
     "pips_hip_batch_last_refinement_measure", "pips_hip_batch_analyze",
@@ -59,7 +59,7 @@ SYMBOLS = [
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
     "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
-    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_destroy",
+    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
@@ -298,6 +298,10 @@ class HipDenseLdlSolver:
         self._h = C.c_void_p()
         _check(lib.pips_hip_dense_ldl_create(C.byref(self._h), C.c_int(n), C.c_int(n_primal), C.c_int(device)),
                "pips_hip_dense_ldl_create")
+
+    def set_pivoting(self, mode):
+        """0: static pivot order (needs the inertia hint), 1: Bunch-Kaufman 1 x 1 / 2 x 2 pivots inside the diagonal tiles."""
+        _check(lib.pips_hip_dense_ldl_set_pivoting(self._h, C.c_int(mode)), "pips_hip_dense_ldl_set_pivoting")
 
     def matrixChanged(self, A_rowmajor_lower):
         A = _f64(A_rowmajor_lower)
@@ -615,6 +619,9 @@ class KktSystem:
         names = ["diag_zero", "leaf_factor", "reduce", "finalize", "root_factor", "lsolve_leaf", "lsolve_border_reduce", "dsolve", "ltsolve", "combine",
                  "reduce_panels"]
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(names)}
+
+    def set_root_pivoting(self, mode):
+        _check(lib.pips_hip_kkt_set_root_pivoting(self._h, C.c_int(mode)), "pips_hip_kkt_set_root_pivoting")
 
     def root_inertia(self):
         p, n, z = C.c_int(), C.c_int(), C.c_int()
