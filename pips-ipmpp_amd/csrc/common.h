@@ -101,6 +101,8 @@ struct BlockSym {
    std::vector<int64_t> mf_U;           // per head supernode: offset of its packed update matrix; simple leaf below a front: offset of
                                         // its 1 + r values inside the block's leaf-value region; -1: neither
    int64_t mf_LV_total = 0;             // doubles of leaf values of this block
+   std::vector<int64_t> mf_V;           // per front: offset of its update vector (r doubles; the multifrontal solves), -1 for simple leaves
+   int64_t mf_V_total = 0;
    std::vector<int64_t> mf_meta;        // per head supernode: offset of its front record inside mf_int, -1 for simple leaves
    std::vector<int> mf_int;             // front records
    std::vector<int64_t> mf_fix;         // positions inside mf_int that hold LOCAL supernode ids (the engine renumbers them)
@@ -116,10 +118,12 @@ struct BlockSym {
 //   [6]                    sum of the children's r_c
 //   [7]                    offset of the leaves' values (d_c, l_c: 1 + r_c doubles per leaf, leaves ascending) inside the block's
 //                          leaf-value region: the leaf kernel writes them there, the front reads them as one piece
-//   [8 ..)                 child table, 2 ints per child front, children ascending: { offset of its update matrix minus this front's, r_c }
+//   [8 ..)                 child table, 3 ints per child front, children ascending:
+//                             { offset of its update matrix minus this front's, r_c, offset of its update VECTOR (solves) minus this front's }
 //   then                   per child, in the same order, the position of each of its r_c below-rows inside THIS front (0 .. w + r)
 //   then                   the leaf part
-//   leaf part              colptr[w + r + 1] | items (2 ints each) | position lists
+//   leaf part              colptr[w + r + 1] | items (2 ints each) | leaf table (4 ints per leaf) | position lists
+//   leaf table entry       { the leaf's column (permuted index), offset of its values, r_c, offset of its position list inside the leaf part }
 //   leaf item              { offset of the leaf's 1 + r_c values << 9 | r_c << 4 | b,  offset of its position list inside the leaf part }
 //                          - the leaf's b-th row is this front column; items are sorted by front column, inside a column by leaf
 //   position list          position of each of the leaf's r_c rows inside the front

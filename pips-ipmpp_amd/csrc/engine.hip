@@ -180,8 +180,22 @@ struct SweepRt {
    long long* d_tfirst_off = nullptr;
    int epoch = 0;
    bool enabled = false;
+   long long poll_limit = SWEEP_POLL_LIMIT;
+   // A wait that gave up poisoned its output with NaN and raised the error word; the host learns of it at its next synchronisation
+   // point (batch sync, inertia queries, host-side solves): the word is read, cleared and turned into an error return.
+   int take_error(const char* who) {
+      if (!d_ints) return PIPS_OK;
+      int w = 0;
+      HIP_TRY(hipMemcpy(&w, d_ints + 2 * SWEEP_NRHS_MAX, sizeof(int), hipMemcpyDeviceToHost));
+      if (!w) return PIPS_OK;
+      HIP_TRY(hipMemset(d_ints + 2 * SWEEP_NRHS_MAX, 0, sizeof(int)));
+      PIPS_FAIL(PIPS_ERR_HIP, "%s: a single-launch solve sweep gave up waiting for a piece of the solution after %lld polls (its output is NaN); "
+                              "another process holding the device for seconds can cause that - PIPS_HIP_SWEEP_LAUNCHES=1 selects the launch-per-column sweeps",
+                who, poll_limit);
+   }
    int build(const std::vector<BlkDesc>& blks, const std::vector<const std::vector<int>*>* first) {
       release();
+      if (const char* pl = getenv("PIPS_HIP_SWEEP_POLL_LIMIT")) poll_limit = atoll(pl);
       const int nblk = (int)blks.size();
       int ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -217,7 +231,7 @@ struct SweepRt {
    }
    SweepArgs args(long long xw_stride) {
       return SweepArgs{d_tasks, n_tasks, d_ints, d_ints + 2 * SWEEP_NRHS_MAX + 2, d_flag_off, d_tfirst, d_tfirst_off, ++epoch,
-                       d_ints + 2 * SWEEP_NRHS_MAX, n_flags, xw_stride};
+                       d_ints + 2 * SWEEP_NRHS_MAX, n_flags, xw_stride, poll_limit};
    }
    void release() {
       for (void* p : {(void*)d_tasks, (void*)d_ints, (void*)d_flag_off, (void*)d_tfirst, (void*)d_tfirst_off})
@@ -527,7 +541,7 @@ struct LevelRange {
 };
 
 // Multifrontal head: one launch per (level, front class); class = (workgroup size, width bound) of k_front.
-struct MfLaunch { int level, cls, begin, cnt, lds_doubles; };
+struct MfLaunch { int level, cls, begin, cnt, lds_doubles, lds_fwd = 0, lds_bwd = 0; };
 static inline int mf_class(int w, long long nf, long long lds_budget) {
    const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
    if (pw + r * (r + 1) / 2 + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
@@ -580,10 +594,18 @@ struct Engine {
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
    int *d_schur_cols = nullptr, *d_schur_slot = nullptr;
+   // ... and front-wise solves (k_front_fwd / k_front_bwd, one wave per front, update vectors child -> parent, leaves through the item
+   // lists: no atomics outside the tail rows).  OFF by default - measured on the configs[3] share (256 x 50 000): a pass takes 3.1 ms
+   // forward + 5.4 ms backward against 2.4 + 2.7 ms of the level kernels it replaces (k_head_fwd / k_head_bwd / k_head_solve_simple):
+   // a front's share of a sweep is a few hundred multiply-adds behind four or five dependent memory round trips (descriptor ->
+   // record -> lists / values -> gathered solution entries), and the thread-per-leaf kernels hide that latency behind 12.6 M
+   // threads where a wave per front cannot.  PIPS_HIP_MF_SOLVES=1 selects them (tests do).
+   bool mf_solves = false;
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
    double* d_mfU = nullptr;    // update matrices of the fronts
    double* d_mfLV = nullptr;   // d and l of the simple leaves below fronts, front by front
+   double* d_mfV = nullptr;    // update vectors of the fronts (multifrontal solves)
    int* d_mfint = nullptr;     // front records (common.h)
    long long mfU_total = 0;
    int spine_total = 0, n_levels_all = 0;   // supernodes handled by the per-block spine kernels; tree height before the cut
@@ -618,6 +640,8 @@ struct Engine {
       d_uarena = nullptr;
       if (d_mfU) (void)hipFree(d_mfU);
       if (d_mfLV) (void)hipFree(d_mfLV);
+      if (d_mfV) (void)hipFree(d_mfV);
+      d_mfV = nullptr;
       if (d_mfint) (void)hipFree(d_mfint);
       d_mfU = nullptr; d_mfLV = nullptr; d_mfint = nullptr;
       mf_launches.clear();
@@ -644,6 +668,11 @@ struct Engine {
       d_arena = d_kval = d_bval = d_winv = d_dtail = d_xw = d_rhs = d_res = d_stage = d_pref = d_norms = nullptr;
       if (h_norms) (void)hipHostFree(h_norms);
       h_norms = nullptr;
+      if (h_inertia_pin) (void)hipHostFree(h_inertia_pin);
+      h_inertia_pin = nullptr;
+      if (ev_inertia) (void)hipEventDestroy(ev_inertia);
+      ev_inertia = nullptr;
+      inertia_in_flight = false;
       for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res}) { if (*q) (void)hipFree(*q); *q = nullptr; }
       mx_cap = 0;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
@@ -884,6 +913,7 @@ struct Engine {
          const char* env = getenv("PIPS_HIP_MF");
          const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
          mf = !(env && atoi(env) == 0) && !deterministic && !(hs && atoi(hs) != 0);
+         mf_solves = getenv("PIPS_HIP_MF_SOLVES") && atoi(getenv("PIPS_HIP_MF_SOLVES")) != 0;
          for (int b = 0; b < nblk && mf; ++b) {
             mf = sym[b].mf_ok;
             // fronts with very many leaves below them: the staged leaf data must fit beside the front
@@ -897,6 +927,7 @@ struct Engine {
                if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) mf = false;   // 159 KB of the 160
             }
          }
+         mf_solves = mf_solves && mf;
       }
 
       // ---- offsets
@@ -904,7 +935,7 @@ struct Engine {
       kptr.assign(nblk + 1, 0);
       x_off.assign(nblk + 1, 0);
       std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0),
-         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0), mfLV_base(nblk + 1, 0);
+         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0), mfLV_base(nblk + 1, 0), mfV_base(nblk + 1, 0);
       long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0, uar = 0;
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
@@ -937,6 +968,7 @@ struct Engine {
          mfU_base[b + 1] = mfU_base[b] + (mf ? s.mf_U_total : 0);
          mfint_base[b + 1] = mfint_base[b] + (mf ? (long long)s.mf_int.size() : 0);
          mfLV_base[b + 1] = mfLV_base[b] + (mf ? s.mf_LV_total : 0);
+         mfV_base[b + 1] = mfV_base[b] + (mf ? s.mf_V_total : 0);
          d.lv_off = mfLV_base[b];
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
          bmap_off[b + 1] = bmap_off[b] + s.nb;
@@ -1035,6 +1067,7 @@ struct Engine {
             const BlockSym& bs = sym[k.blk];
             if (bs.mf_U[k.loc] >= 0) h_sns[i].U = (k.cls == 0 ? mfLV_base[k.blk] : mfU_base[k.blk]) + bs.mf_U[k.loc];
             if (bs.mf_meta[k.loc] >= 0) h_sns[i].mf = mfint_base[k.blk] + bs.mf_meta[k.loc];
+            if (bs.mf_V[k.loc] >= 0) h_sns[i].vslot = mfV_base[k.blk] + bs.mf_V[k.loc];   // (the slot machinery of deterministic mode is off)
          }
          slots_acc += (long long)s.r * (s.r + 1) / 2;
          vslots_acc += s.r;
@@ -1055,6 +1088,12 @@ struct Engine {
             if (open) mf_launches.push_back({k.level, k.cls - 1, i, 0, 0});
             ++mf_launches.back().cnt;
             mf_launches.back().lds_doubles = std::max(mf_launches.back().lds_doubles, k.lds);
+            {  // LDS of the solve kernels (k_front_fwd / k_front_bwd)
+               const int* H = sym[k.blk].mf_int.data() + sym[k.blk].mf_meta[k.loc];
+               const int wmax = (k.cls - 1) % 6 < 3 && k.cls - 1 < 6 ? 16 : 32, nf = s.w + s.r;
+               mf_launches.back().lds_fwd = std::max(mf_launches.back().lds_fwd, nf + H[5] + (H[6] + H[3] + 1) / 2 + 2);
+               mf_launches.back().lds_bwd = std::max(mf_launches.back().lds_bwd, nf + H[5] + 64 * wmax + wmax * wmax + (H[3] + 1) / 2 + 2);
+            }
          }
          const long long need = (long long)s.r * (s.w | 1);
          if (k.cls == 1) L.small_lds = (int)std::max<long long>(L.small_lds, std::min<long long>(need, 640));
@@ -1112,6 +1151,7 @@ struct Engine {
          if ((rc = dev_upload(&d_mfint, h_mfint, stream))) return rc;
          HIP_TRY(hipMalloc((void**)&d_mfU, (size_t)std::max<long long>(mfU_total, 1) * sizeof(double)));
          HIP_TRY(hipMalloc((void**)&d_mfLV, (size_t)std::max<long long>(mfLV_base[nblk], 1) * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_mfV, (size_t)std::max<long long>(mfV_base[nblk], 1) * sizeof(double)));
       }
       {  // both triangles, row by row: entry (i, j) of the lower CSR also appears in row j as (j, i)
          std::vector<int> frp(n_total + 1, 0);
@@ -1342,6 +1382,32 @@ struct Engine {
       }
       return PIPS_OK;
    }
+   // multifrontal solves: the fronts of one level, forward (ascending levels) or backward
+   int launch_front_solves(int level, bool backward, double* xw, int border) {
+      for (const MfLaunch& m : mf_launches) {
+         if (m.level != level) continue;
+         const bool wide = !(m.cls < 3);   // classes 0-2: w <= 16
+         const size_t lds = (size_t)(backward ? m.lds_bwd : m.lds_fwd) * sizeof(double);
+         if (!backward) {
+            if (wide) {
+               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_fwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+               hipLaunchKernelGGL(k_front_fwd<32>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, d_mfV, xw);
+            } else {
+               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+               hipLaunchKernelGGL(k_front_fwd<16>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, d_mfV, xw);
+            }
+         } else {
+            if (wide) {
+               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+               hipLaunchKernelGGL(k_front_bwd<32>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, xw, border);
+            } else {
+               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_bwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+               hipLaunchKernelGGL(k_front_bwd<16>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, xw, border);
+            }
+         }
+      }
+      return PIPS_OK;
+   }
    void gather(const GatherList& g, const double* vals, double* target) {
       if (g.n_targets > 0)
          hipLaunchKernelGGL(k_gather_slots, dim3(grid_for(g.n_targets, 256)), dim3(256), 0, stream, g.n_targets, g.d_tgt, g.d_off, g.d_slots, vals, target);
@@ -1549,6 +1615,13 @@ struct Engine {
       }
       if (timer.on) (void)hipEventRecord(timer.recs[total_rec].b, stream);
       h_amax.clear();
+      if (!h_inertia_pin) {
+         HIP_TRY(hipHostMalloc((void**)&h_inertia_pin, (size_t)std::max(3 * nblk, 1) * sizeof(int), hipHostMallocDefault));
+         HIP_TRY(hipEventCreateWithFlags(&ev_inertia, hipEventDisableTiming));
+      }
+      HIP_TRY(hipMemcpyAsync(h_inertia_pin, d_inertia, (size_t)3 * nblk * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipEventRecord(ev_inertia, stream));
+      inertia_in_flight = true;
       return PIPS_OK;
    }
 
@@ -1596,6 +1669,15 @@ struct Engine {
             if (cnt > 0) hipLaunchKernelGGL(k_head_fwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, 0LL, sxv);
          }
          gather(gv_tail, d_vslot_val, xw);
+      } else if (mf_solves && nrhs == 1) {
+         for (size_t li = 0; li < levels.size(); ++li) {
+            const LevelRange& L = levels[li];
+            if (L.simple_cnt > 0)   // only the leaves without a front above them
+               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
+                                  L.simple_cnt, d_blks, d_rowidx, d_arena, xw, 0LL, 0, sx_atomic(), 0, 1);
+            int frc = launch_front_solves((int)li, false, xw, 0);
+            if (frc) return frc;
+         }
       } else
       for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0)
@@ -1619,9 +1701,10 @@ struct Engine {
       c.timer = nullptr;   // (the tail's own phase records belong to the factorisation)
       int rc = tail_fwd(c, xw, nrhs, xws);
       if (rc) return rc;
+      const bool mfs = mf_solves && nrhs == 1;
       if (nsn_total > 0)
          hipLaunchKernelGGL(k_head_dscale, dim3(grid_for(nsn_total, 256), nrhs), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
-                            d_arena, xw, xws);
+                            d_arena, xw, xws, mfs ? 1 : 0);
       rc = tail_bwd(c, xw, nrhs, xws);
       if (rc) return rc;
       timer.end(stream);
@@ -1629,6 +1712,16 @@ struct Engine {
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
                             d_arena, xw, xws, 1);
+      if (mfs) {
+         for (int l = (int)levels.size() - 1; l >= 0; --l) {
+            const LevelRange& L = levels[l];
+            int frc = launch_front_solves(l, true, xw, 0);
+            if (frc) return frc;
+            if (L.simple_cnt > 0)
+               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
+                                  L.simple_cnt, d_blks, d_rowidx, d_arena, xw, 0LL, 1, sx_atomic(), 0, 1);
+         }
+      } else
       for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
@@ -1804,7 +1897,17 @@ struct Engine {
       return PIPS_OK;
    }
 
+   // The inertia counters travel to pinned host memory at the end of every factorisation (factor()); a query only waits for that
+   // copy - not for whatever was queued behind the factorisation (the leaf solves of an Lsolve, say).
+   int* h_inertia_pin = nullptr;
+   hipEvent_t ev_inertia = nullptr;
+   bool inertia_in_flight = false;
    int fetch_inertia() {
+      if (inertia_in_flight && h_inertia_pin) {
+         HIP_TRY(hipEventSynchronize(ev_inertia));
+         std::copy(h_inertia_pin, h_inertia_pin + h_inertia.size(), h_inertia.begin());
+         return PIPS_OK;
+      }
       HIP_TRY(hipMemcpyAsync(h_inertia.data(), d_inertia, h_inertia.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       return PIPS_OK;
@@ -1840,6 +1943,15 @@ struct Engine {
       const ScatterCtx none{0, nullptr, nullptr, nullptr, nullptr};
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, 1), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, 1);
+      if (mf_solves) {   // (zero right-hand side: the diagonal scaling fused into k_front_bwd divides zeros)
+         for (int l = (int)levels.size() - 1; l >= 0; --l) {
+            const LevelRange& L = levels[l];
+            if ((rc = launch_front_solves(l, true, d_xw, 1))) return rc;
+            if (L.simple_cnt > 0)
+               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt,
+                                  d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, none, 1, 1);
+         }
+      } else
       for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
@@ -2322,7 +2434,7 @@ int pips_hip_batch_solve(void* handle, double* x_host) {
    if (rc) return rc;
    HIP_TRY(hipMemcpyAsync(x_host, e->d_stage, bytes, hipMemcpyDeviceToHost, e->stream));
    HIP_TRY(hipStreamSynchronize(e->stream));
-   return PIPS_OK;
+   return e->sweep.take_error("pips_hip_batch_solve");
 }
 
 int pips_hip_batch_border_tmult_dev(void* handle, const double* z_dev, double* b0_dev, double alpha) {
@@ -2404,7 +2516,7 @@ int pips_hip_batch_sync(void* handle) {
    if (!e) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    HIP_TRY(hipSetDevice(e->device));
    HIP_TRY(hipStreamSynchronize(e->stream));
-   return PIPS_OK;
+   return e->sweep.take_error("pips_hip_batch_sync");
 }
 
 int pips_hip_batch_set_timing(void* handle, int on) {
@@ -2637,7 +2749,7 @@ int pips_hip_dense_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
       HIP_TRY(hipMemcpyAsync(x, d->d_in, (size_t)d->n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
       HIP_TRY(hipStreamSynchronize(d->stream));
    }
-   return PIPS_OK;
+   return d->sweep.take_error("pips_hip_dense_ldl_solve");
 }
 
 int pips_hip_dense_ldl_inertia(void* handle, int* pos, int* neg, int* zero) {
@@ -2646,6 +2758,7 @@ int pips_hip_dense_ldl_inertia(void* handle, int* pos, int* neg, int* zero) {
    HIP_TRY(hipSetDevice(d->device));
    HIP_TRY(hipMemcpyAsync(d->h_inertia, d->d_inertia, 3 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
    HIP_TRY(hipStreamSynchronize(d->stream));
+   { const int rce = d->sweep.take_error("pips_hip_dense_ldl_inertia"); if (rce) return rce; }
    if (pos) *pos = d->h_inertia[0];
    if (neg) *neg = d->h_inertia[1];
    if (zero) *zero = d->h_inertia[2];

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    __syncthreads();   // zeros before the staged data (the zeroing may reach one double into the values)
    MF_STAMP(1);
    {   // the children's position lists and the leaf part: one contiguous piece of the record
-      const int* src = H + MF_HDR + 2 * n_child;
+      const int* src = H + MF_HDR + 3 * n_child;
       for (int idx = tid; idx < sum_rc + n_leafpart; idx += BLOCK) relbuf[idx] = src[idx];
    }
    __syncthreads();
@@ -676,8 +676,8 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
       const int wave = tid >> 6;
       int off = 0;
       for (int c = 0; c < n_child; ++c) {
-         const int rc = H[MF_HDR + 2 * c + 1];
-         const double* Uc = uarena + sn.U + H[MF_HDR + 2 * c];
+         const int rc = H[MF_HDR + 3 * c + 1];
+         const double* Uc = uarena + sn.U + H[MF_HDR + 3 * c];
          const int* rel = relbuf + off;
          const int npairs = (rc + 1) >> 1, pieces = (rc + 1 + 63) >> 6, nitems = npairs * pieces;
          for (int s0 = wave; s0 < nitems; s0 += NW * NB) {
@@ -868,15 +868,195 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 // touched by the border-backward sweep, Engine::solve_border_backward) behind the padded tail.
 __device__ __forceinline__ int xw_row(const BlkDesc& bd, int ra) { return ra < bd.n ? ra : bd.n_head + bd.m_pad + (ra - bd.n); }
 
+// ------------------------------------------------------------------------------------------------
+// multifrontal head, the solves: ONE WAVE per front (a front's share of a sweep is w (w + r) multiply-adds: what counts is how
+// many fronts are in flight), no FP64 atomics between fronts, the panel is read once per sweep with coalesced loads.
+//   forward  (levels ascending):  t = [b_J ; 0] + the children's update vectors at the recorded positions - the simple leaves'
+//            l_c y_c (their items, a lane per front row);  y_J = L11^-1 t_J;  u_J = t_rows - L21 y_J goes to the parent through
+//            the update-vector arena (a front without a head parent adds it to the tail rows of the work vector).
+//   backward (levels descending):  x_rows gathered from the work vector,  x_J = L11^-T (D^-1 y_J - L21^T x_rows);  then the
+//            leaves below the front:  x_c = y_c / d_c - l_c^T x_front.  The diagonal scaling is fused (k_head_dscale only sees the
+//            leaves without a front above them).
+// LDS: [ t / x of the front (nf) | leaf values (n_vals) | partial sums 64 x WMAX, Ld WMAX x WMAX (backward) | ints ].
+// ------------------------------------------------------------------------------------------------
+template <int WMAX>
+__global__ __launch_bounds__(64) void k_front_fwd(const SnDesc* __restrict__ sns, int sn_begin, const BlkDesc* __restrict__ blks,
+                                                 const int* __restrict__ rowidx, const int* __restrict__ mfint,
+                                                 const double* __restrict__ arena, const double* __restrict__ lvals,
+                                                 double* __restrict__ varena, double* __restrict__ xw) {
+   extern __shared__ __attribute__((aligned(16))) double mf_S[];
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   const int w = sn.w, r = sn.r, nf = w + r, lane = threadIdx.x;
+   const int* H = mfint + sn.mf;
+   const int n_child = H[0], n_leaf = H[1], has_parent = H[2], n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
+   double* t = mf_S;
+   double* vals = t + nf;
+   int* relbuf = (int*)(vals + n_vals);
+   int* leafpart = relbuf + sum_rc;
+   double* xb = xw + bd.xw_off;
+   const double* P = arena + sn.panel;
+   {
+      const int* src = H + MF_HDR + 3 * n_child;
+      for (int idx = lane; idx < sum_rc + n_leafpart; idx += 64) relbuf[idx] = src[idx];
+      const double* lv = lvals + bd.lv_off + H[7];
+      for (int idx = lane; idx < n_vals; idx += 64) vals[idx] = lv[idx];
+      for (int i = lane; i < nf; i += 64) t[i] = i < w ? xb[sn.c0 + i] : 0.0;
+   }
+   // row `lane` of the pivot block, on its way while the front is assembled
+   double row[WMAX];
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k < lane) ? P[lane + (long long)k * nf] : 0.0;
+   __syncthreads();
+   if (n_leaf) {   // y_c of the leaves goes where their d sits (the forward sweep has no use for d)
+      const int* tab = leafpart + (nf + 1) + 2 * n_items;
+      for (int c = lane; c < n_leaf; c += 64) vals[tab[4 * c + 1]] = xb[tab[4 * c]];
+   }
+   {
+      int off = 0;
+      for (int c = 0; c < n_child; ++c) {
+         const int rc = H[MF_HDR + 3 * c + 1];
+         const double* Vc = varena + sn.vslot + H[MF_HDR + 3 * c + 2];
+         for (int a = lane; a < rc; a += 64) t[relbuf[off + a]] += Vc[a];   // distinct positions inside a child
+         off += rc;
+         __syncthreads();
+      }
+   }
+   if (n_leaf) {
+      if (n_child == 0) __syncthreads();
+      const int* colptr = leafpart;
+      const int* it2 = leafpart + (nf + 1);
+      for (int q = lane; q < nf; q += 64) {
+         double acc = 0.0;
+         for (int it = colptr[q]; it < colptr[q + 1]; ++it) {
+            const int i0 = it2[2 * it];
+            const double* lv = vals + (i0 >> 9);
+            acc += lv[1 + (i0 & 15)] * lv[0];
+         }
+         t[q] -= acc;
+      }
+      __syncthreads();
+   }
+   // y_J = L11^-1 t_J: lane i < w owns t_i; column k travels by shuffle
+   double tv = lane < w ? t[lane] : 0.0;
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) {
+      if (k < w) {
+         const double yk = __shfl(tv, k);
+         tv -= row[k] * yk;                      // row[k] is 0 for k >= lane
+      }
+   }
+   if (lane < w) { t[lane] = tv; xb[sn.c0 + lane] = tv; }
+   __syncthreads();
+   // u_J = t_rows - L21 y_J
+   const int* rows = rowidx + sn.rows;
+   for (int i = w + lane; i < nf; i += 64) {
+      double acc = t[i];
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) if (k < w) acc -= P[i + (long long)k * nf] * t[k];
+      if (has_parent) varena[sn.vslot + (i - w)] = acc;
+      else {
+         const int ra = rows[i - w];
+         if (ra < bd.n) atomic_add_f64(xb + ra, acc);   // tail rows: shared between the fronts that end there
+      }
+   }
+}
+
+template <int WMAX>
+__global__ __launch_bounds__(64) void k_front_bwd(const SnDesc* __restrict__ sns, int sn_begin, const BlkDesc* __restrict__ blks,
+                                                 const int* __restrict__ rowidx, const int* __restrict__ mfint,
+                                                 const double* __restrict__ arena, const double* __restrict__ lvals,
+                                                 double* __restrict__ xw, int border) {
+   extern __shared__ __attribute__((aligned(16))) double mf_S[];
+   const SnDesc sn = sns[sn_begin + blockIdx.x];
+   const BlkDesc bd = blks[sn.blk];
+   const int w = sn.w, r = sn.r, nf = w + r, lane = threadIdx.x;
+   const int* H = mfint + sn.mf;
+   const int n_child = H[0], n_leaf = H[1], n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
+   double* xf = mf_S;
+   double* vals = xf + nf;
+   double* part = vals + n_vals;               // [k][lane]
+   double* Ld = part + 64 * WMAX;              // [i][k]
+   int* leafpart = (int*)(Ld + WMAX * WMAX);
+   double* xb = xw + bd.xw_off;
+   const double* P = arena + sn.panel;
+   const int* rows = rowidx + sn.rows;
+   {
+      const int* src = H + MF_HDR + 3 * n_child + sum_rc;
+      for (int idx = lane; idx < n_leafpart; idx += 64) leafpart[idx] = src[idx];
+      const double* lv = lvals + bd.lv_off + H[7];
+      for (int idx = lane; idx < n_vals; idx += 64) vals[idx] = lv[idx];
+      for (int i = w + lane; i < nf; i += 64) {
+         const int ra = rows[i - w];
+         xf[i] = (ra < bd.n || border) ? xb[xw_row(bd, ra)] : 0.0;
+      }
+   }
+   double row[WMAX];
+#pragma unroll
+   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k <= lane) ? P[lane + (long long)k * nf] : 0.0;
+   double v;
+   {
+      // d_i sits at row[i]: pick it without a dynamic register index
+      double di = 1.0;
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) if (k == lane) di = row[k];
+      v = lane < w ? xb[sn.c0 + lane] / di : 0.0;
+   }
+   __syncthreads();
+   // s_k = sum over the rows of L21(a, k) x_a: every lane sums its rows, the 64 partial sums of a column are added by lane k
+   {
+      double p[WMAX];
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) p[k] = 0.0;
+      for (int i = w + lane; i < nf; i += 64) {
+         const double xi = xf[i];
+#pragma unroll
+         for (int k = 0; k < WMAX; ++k) if (k < w) p[k] += P[i + (long long)k * nf] * xi;
+      }
+#pragma unroll
+      for (int k = 0; k < WMAX; ++k) if (k < w) part[k * 64 + lane] = p[k];
+      if (lane < w) {
+#pragma unroll
+         for (int k = 0; k < WMAX; ++k) if (k < lane) Ld[lane * WMAX + k] = row[k];
+      }
+      __syncthreads();
+      if (lane < w) {
+         double sk = 0.0;
+         for (int j = 0; j < 64; ++j) sk += part[lane * 64 + j];
+         v -= sk;
+      }
+   }
+   // x_J = L11^-T v: column i of L11^T is row i of L11; once x_i is final it leaves every v_k, k < i
+   for (int i = w - 1; i >= 0; --i) {
+      const double xi = __shfl(v, i);
+      if (lane < i) v -= Ld[i * WMAX + lane] * xi;
+   }
+   if (lane < w) { xb[sn.c0 + lane] = v; xf[lane] = v; }
+   __syncthreads();
+   if (n_leaf) {
+      const int* tab = leafpart + (nf + 1) + 2 * n_items;
+      for (int c = lane; c < n_leaf; c += 64) {
+         const int c0 = tab[4 * c], rc = tab[4 * c + 2];
+         const double* lv = vals + tab[4 * c + 1];
+         const int* rel = leafpart + tab[4 * c + 3];
+         double x = xb[c0] / lv[0];
+         for (int a = 0; a < rc; ++a) x -= lv[1 + a] * xf[rel[a]];
+         xb[c0] = x;
+      }
+   }
+}
+
+
 // forward / backward substitution for the simple leaves: y = b_c (unit pivot block); b[rows] -= l y   /   x_c = z_c - l^T x[rows]
 __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                                           const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                           const double* __restrict__ arena, double* __restrict__ xw,
                                                           long long xw_stride, int backward,
-                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int border = 0) {
+                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int border = 0, int mf = 0) {
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= cnt) return;
    const SnDesc sn = sns[sn_begin + t];
+   if (mf && sn.n_useg > 0) return;   // multifrontal solves: the front above this leaf does its part (k_front_fwd / k_front_bwd)
    const BlkDesc bd = blks[sn.blk];
    const double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
@@ -1801,10 +1981,11 @@ __global__ __launch_bounds__(64) void k_head_fwd_chain(const SnDesc* __restrict_
 
 // head diagonal scaling: z = D^-1 y for the head columns
 __global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
-                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+                              const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride, int mf = 0) {
    xw += xw_stride * blockIdx.y;
    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsn; s += gridDim.x * blockDim.x) {
       const SnDesc sn = sns[s];
+      if (mf && (sn.mf >= 0 || sn.n_useg > 0)) continue;   // fused into k_front_bwd
       const BlkDesc bd = blks[sn.blk];
       const int ld = sn.w + sn.r;
       for (int k = 0; k < sn.w; ++k) xw[bd.xw_off + sn.c0 + k] /= arena[sn.panel + k + (long long)k * ld];
@@ -2083,11 +2264,12 @@ struct SweepArgs {
    int* err;
    // several right-hand sides: blockIdx.y = right-hand side, each with its own tickets (2 ints), flags and work vector
    long long flag_stride, xw_stride;
+   long long poll_limit;         // polls after which a wait gives up (SWEEP_POLL_LIMIT; PIPS_HIP_SWEEP_POLL_LIMIT for tests)
 };
-constexpr long long SWEEP_POLL_LIMIT = 4000000;   // ~5 s of polling: three orders of magnitude above the longest legitimate wait
+constexpr long long SWEEP_POLL_LIMIT = 4000000;   // ~5 s of polling (4e6 polls): three orders of magnitude above the longest legitimate wait
 constexpr int SWEEP_NRHS_MAX = 32;
 
-__device__ __forceinline__ bool sweep_wait(const int* f, int epoch) {
+__device__ __forceinline__ bool sweep_wait(const int* f, int epoch, long long poll_limit = SWEEP_POLL_LIMIT) {
    // No agent-scope fence anywhere in the sweeps: an acquire invalidates and a release writes back the whole L2 of the XCD,
    // thousands of times per sweep (measured: 1.45 ms per sweep with the fences against 1.1 ms for the launch-per-column
    // kernels).  Flags and solution pieces are written and read with agent-scope atomics, which go past the caches; everything
@@ -2095,7 +2277,7 @@ __device__ __forceinline__ bool sweep_wait(const int* f, int epoch) {
    long long spins = 0;
    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > SWEEP_POLL_LIMIT) return false;
+      if (++spins > poll_limit) return false;
    }
    return true;
 }
@@ -2150,7 +2332,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDes
    if (j0 < i) {
       tile_load_half(m, Lrow + (long long)j0 * TILE * ld, ld, row, half);
       for (int j = j0;; ++j) {
-         if (tid == 0) sh_ok = sweep_wait(fl + j, a.epoch) ? 1 : 0;
+         if (tid == 0) sh_ok = sweep_wait(fl + j, a.epoch, a.poll_limit) ? 1 : 0;
          __syncthreads();
          if (!sh_ok) { ok = false; break; }
          if (tid < TILE) v[tid] = sweep_load(xt + j * TILE + tid) * dtail[bd.dt_off + j * TILE + tid];
@@ -2215,7 +2397,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
       tile_tload(m, Lcol + (long long)k * TILE, ld, tid);
       for (;;) {
          if (k < bd.ntc) {
-            if (tid == 0) sh_ok = sweep_wait(fl + k, a.epoch) ? 1 : 0;
+            if (tid == 0) sh_ok = sweep_wait(fl + k, a.epoch, a.poll_limit) ? 1 : 0;
             __syncthreads();
             if (!sh_ok) { ok = false; break; }
             if (tid < TILE) v[tid] = sweep_load(xt + k * TILE + tid);

@@ -353,11 +353,15 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          return true;
       };
       // update-matrix offsets first (a parent's record refers to its children's and to its own)
+      out.mf_V.assign(nsn, -1);
+      out.mf_V_total = 0;
       for (int s = 0; s < nsn; ++s) {
          const HeadSupernode& sn = out.sn[s];
          if (is_simple(sn)) continue;
          out.mf_U[s] = out.mf_U_total;
          out.mf_U_total += (int64_t)sn.r * (sn.r + 1) / 2;
+         out.mf_V[s] = out.mf_V_total;
+         out.mf_V_total += sn.r;
       }
       if (out.mf_U_total >= (int64_t)INT32_MAX || 18 * (int64_t)nsn >= (int64_t)INT32_MAX) out.mf_ok = false;
       std::vector<int> pos;
@@ -375,6 +379,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          for (int c : kids[s]) {
             out.mf_int.push_back((int)(out.mf_U[c] - out.mf_U[s]));
             out.mf_int.push_back(out.sn[c].r);
+            out.mf_int.push_back((int)(out.mf_V[c] - out.mf_V[s]));
          }
          for (int c : kids[s]) {
             pos.clear();
@@ -383,11 +388,11 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             out.mf_int.insert(out.mf_int.end(), pos.begin(), pos.end());
          }
          if (n_leaf == 0) continue;
-         // leaf part: colptr | items | position lists
-         std::vector<int> lists, item_col, item_a, item_b;
+         // leaf part: colptr | items | leaf table | position lists
+         std::vector<int> lists, item_col, item_a, item_b, tab;
          int n_vals = 0, n_items = 0;
          for (int c : leaves[s]) n_items += out.sn[c].r;
-         const int list_base = (nf + 1) + 2 * n_items;   // offset of the first position list inside the leaf part
+         const int list_base = (nf + 1) + 2 * n_items + 4 * n_leaf;   // offset of the first position list inside the leaf part
          out.mf_int[hpos + 7] = (int)out.mf_LV_total;
          for (int c : leaves[s]) {
             const HeadSupernode& lf = out.sn[c];
@@ -396,6 +401,10 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
                PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, rows of leaf column %d missing in its parent front", lf.c0);
             const int loff = list_base + (int)lists.size();
             out.mf_U[c] = out.mf_LV_total + n_vals;
+            tab.push_back(lf.c0);
+            tab.push_back(n_vals);
+            tab.push_back(lf.r);
+            tab.push_back(loff);
             lists.insert(lists.end(), pos.begin(), pos.end());
             for (int b = 0; b < lf.r; ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (lf.r << 4) | b); item_b.push_back(loff); }
             n_vals += 1 + lf.r;
@@ -413,6 +422,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          }
          out.mf_int.insert(out.mf_int.end(), colptr.begin(), colptr.end());
          out.mf_int.insert(out.mf_int.end(), items.begin(), items.end());
+         out.mf_int.insert(out.mf_int.end(), tab.begin(), tab.end());
          out.mf_int.insert(out.mf_int.end(), lists.begin(), lists.end());
          out.mf_int[hpos + 3] = list_base + (int)lists.size();
          out.mf_int[hpos + 4] = n_items;
@@ -425,6 +435,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_meta.assign(nsn, -1);
          out.mf_U_total = 0;
          out.mf_LV_total = 0;
+         out.mf_V_total = 0;
       }
    }
 

@@ -157,3 +157,26 @@ def test_row_sweeps_several_right_hand_sides(nrhs, monkeypatch):
     Kf = prob.K_full(0)
     for r in range(nrhs):
         assert np.abs(Kf @ got[1][0][r] - rhs[r]).max() / np.abs(rhs[r]).max() < 1e-9
+
+
+def test_sweep_that_gives_up_is_reported(monkeypatch):
+    """A wait inside the single-launch sweeps that exceeds its poll limit poisons its output with NaN and raises an error word; the
+    host must hear of it at its next synchronisation point instead of handing NaN back with PIPS_OK.  With a poll limit of zero
+    every wait that is not satisfied at once gives up."""
+    monkeypatch.setenv("PIPS_HIP_SWEEP_POLL_LIMIT", "0")
+    rng = np.random.default_rng(0)
+    n = 1500                                   # 12 tile columns: later rows wait for earlier ones
+    M = rng.standard_normal((n, n))
+    M = M @ M.T + n * np.eye(n)
+    s = pa.HipDenseLdlSolver(n, n_primal=n)
+    s.matrixChanged(np.ascontiguousarray(np.tril(M)))
+    x = rng.standard_normal(n)
+    with pytest.raises(pa.PipsHipError, match="gave up waiting"):
+        for _ in range(20):                    # (a lucky schedule can satisfy every wait once)
+            s.solve(x.copy())
+    monkeypatch.delenv("PIPS_HIP_SWEEP_POLL_LIMIT")
+    s2 = pa.HipDenseLdlSolver(n, n_primal=n)
+    s2.matrixChanged(np.ascontiguousarray(np.tril(M)))
+    y = x.copy()
+    s2.solve(y)
+    assert np.linalg.norm(M @ y - x) / np.linalg.norm(x) < 1e-12
