@@ -533,7 +533,12 @@ struct BlockInput {
    std::vector<double> btval;
 };
 
-constexpr long long CHAIN_LAUNCH_MAX = 1024;   // waves per launch below which the head solve kernels are latency-bound
+// Waves per launch up to which the head solve sweeps use the register-lean "chain" kernels (k_head_fwd_chain / k_head_bwd_chain: all
+// loads up front, partial sums in registers, one LDS transpose) instead of k_head_fwd / k_head_bwd (a wave reduction per column).
+// Round 2 drew the line at 1024 waves; with supernodes capped at 16 columns the chain kernels win at every size (configs[3] share,
+// 256 x 50 000: leaf solve 13.5 -> 11.6 ms), so the line is gone; PIPS_HIP_CHAIN_MAX brings it back for tuning runs.  Deterministic
+// mode keeps k_head_fwd / k_head_bwd throughout (one kernel whatever the batch size).
+static const long long CHAIN_LAUNCH_MAX = getenv("PIPS_HIP_CHAIN_MAX") ? atoll(getenv("PIPS_HIP_CHAIN_MAX")) : (1LL << 40);
 
 struct LevelRange {
    int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt;
@@ -1702,7 +1707,11 @@ struct Engine {
       int rc = tail_fwd(c, xw, nrhs, xws);
       if (rc) return rc;
       const bool mfs = mf_solves && nrhs == 1;
-      if (nsn_total > 0)
+      // D^-1 of the head columns: fused into the backward kernels of the common path (chain kernels + thread-per-leaf kernel: they
+      // read the diagonal's cache line anyway; the separate pass reads 88 bytes of descriptor per supernode - 12.9 M of them on the
+      // configs[3] share); the other paths (spine kernels, deterministic mode, k_head_bwd) keep the pass
+      const bool fused_d = !mfs && spine_total == 0 && !deterministic && CHAIN_LAUNCH_MAX >= (1LL << 40);
+      if (nsn_total > 0 && !fused_d)
          hipLaunchKernelGGL(k_head_dscale, dim3(grid_for(nsn_total, 256), nrhs), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
                             d_arena, xw, xws, mfs ? 1 : 0);
       rc = tail_bwd(c, xw, nrhs, xws);
@@ -1728,12 +1737,12 @@ struct Engine {
          const int cnt = L.small_cnt + L.large_cnt;
          // (deterministic mode: always the same kernel, whatever the batch size - the two variants add in different orders)
          if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX && !deterministic)
-            hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
+            hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws, 0, fused_d ? 1 : 0);
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
          if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
-                               L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 1);
+                               L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 1, sx_atomic(), 0, 0, fused_d ? 1 : 0);
       }
       timer.end(stream);
       timer.begin(stream, 7);

@@ -1052,7 +1052,8 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
                                                           const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                           const double* __restrict__ arena, double* __restrict__ xw,
                                                           long long xw_stride, int backward,
-                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int border = 0, int mf = 0) {
+                                                          ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int border = 0, int mf = 0,
+                                                          int dscale = 0) {
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= cnt) return;
    const SnDesc sn = sns[sn_begin + t];
@@ -1075,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
          if (ra >= bd.n && !border) break;
          s += P[1 + a] * xb[xw_row(bd, ra)];
       }
-      xb[sn.c0] -= s;
+      xb[sn.c0] = (dscale ? xb[sn.c0] / P[0] : xb[sn.c0]) - s;
    }
 }
 
@@ -1967,6 +1968,7 @@ __device__ __forceinline__ void head_fwd_any(const SnDesc& sn, const BlkDesc& bd
                                              const double* __restrict__ arena, double* __restrict__ xb, double* ys) {
    if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xb, ys);
    else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xb, ys);
+   else if (sn.w <= 16) head_fwd_body<16>(sn, bd, rowidx, arena, xb, ys);
    else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, ys);
 }
 
@@ -1999,7 +2001,8 @@ constexpr int RED_ROWS = 16;   // dot products finished per pass through the wav
 
 template <int WB>
 __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0) {
+                                              const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0,
+                                              int dscale = 0) {
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
@@ -2007,6 +2010,7 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
 #pragma unroll
    for (int k = 0; k < WB; ++k) c[k] = (k > tid && k < w) ? P[k + (long long)tid * ld] : 0.0;
    double y = tid < w ? xb[sn.c0 + tid] : 0.0;
+   if (dscale && tid < w) y /= P[tid + (long long)tid * ld];   // D^-1 fused: no separate pass over every supernode descriptor
    double part[WB];
 #pragma unroll
    for (int k = 0; k < WB; ++k) part[k] = 0.0;
@@ -2049,20 +2053,22 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
 
 template <int DUMMY = 0>
 __device__ __forceinline__ void head_bwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                             const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0) {
-   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xb, red, border);
-   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xb, red, border);
-   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, red, border);
+                                             const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0,
+                                             int dscale = 0) {
+   if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xb, red, border, dscale);
+   else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xb, red, border, dscale);
+   else if (sn.w <= 16) head_bwd_body<16>(sn, bd, rowidx, arena, xb, red, border, dscale);
+   else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, red, border, dscale);
 }
 
 __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                 const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
-                                                int border = 0) {
+                                                int border = 0, int dscale = 0) {
    __shared__ double red[RED_ROWS][65];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_bwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red, border);
+   head_bwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red, border, dscale);
 }
 
 // spine sweeps of the solve: one wave per (block, right-hand side) walks the block's spine supernodes inside one launch
