@@ -8,12 +8,14 @@
 #include "DenseMatrix.h"
 #include "DoubleLinearSolver.h"
 #include "SparseSymmetricMatrix.h"
+#include "SparseMatrix.h"
 #include "DenseVector.hpp"
 #include "pipsdef.h"
 #include "pips_hip.h"
 
 class HipLdlSolver : public DoubleLinearSolver {
    const SparseSymmetricMatrix& mat;   // non-owning, like PardisoSolver.h:49-50
+   const SparseMatrix* border{};       // non-owning (level 1.5)
    void* h{};
    static void check(int rc, const char* what) {       // reference convention: print + abort (PardisoSolver.C:201-204)
       if (rc) { printf("HipLdlSolver - ERROR in %s: %s\n", what, pips_hip_last_error()); MPI_Abort(MPI_COMM_WORLD, -1); }
@@ -38,6 +40,18 @@ public:
       auto& rhs = dynamic_cast<DenseMatrix&>(rhs_in);
       const auto [nrows, ncols] = rhs.n_rows_columns();
       check(pips_hip_ldl_solve(h, (int)nrows, &rhs[0][0], (int)ncols), "solve(matrix)");
+   }
+   // ---- level 1.5: the leaf's Schur term formed where the factor lives.  Not part of DoubleLinearSolver:
+   //      DistributedLeafLinearSystem::addTermToSchurComplBlocked (:214-252) calls these two instead of the K4-K6 chunk loop when its
+   //      solver is a HipLdlSolver.  border_left_transp is the S x N_i CSR matrix the loop walks (rows = Schur column ids).
+   void declare_border(const SparseMatrix& border_left_transp) {      // once, before the first factorisation
+      const auto& st = border_left_transp.getStorage();
+      check(pips_hip_ldl_set_border(h, st.m, st.krowM, st.jcolM), "set_border");
+      border = &border_left_transp;
+   }
+   // = matrixChanged() followed by addTermToSchurComplBlocked(): SC is the S x S DenseSymmetricMatrix storage (row-major, lower triangle)
+   void matrixChanged_and_add_schur_term(double* SC, int ldSC) {
+      check(pips_hip_ldl_factor_schur(h, mat.getStorage().M, border->getStorage().M, SC, ldSC), "factor_schur");
    }
    [[nodiscard]] bool reports_inertia() const override { return true; }
    [[nodiscard]] std::tuple<unsigned, unsigned, unsigned> get_inertia() const override {

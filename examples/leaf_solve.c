@@ -1,10 +1,14 @@
 /* Plain-C use of the C ABI (include/pips_hip.h): what the DoubleLinearSolver adapter of INTEGRATION.md does for one leaf.
  * Generates one synthetic KKT block K = [D W^T; W -E], factorises it on the GPU, solves two right-hand sides, checks the
- * residual on the host and prints the inertia.
+ * residual on the host and prints the inertia.  Then the leaf's Schur term  -Br^T K^-1 Br  twice: by the reference's K4-K6 chunk
+ * loop on the host (addBiTLeftKiBiRightToResBlockedParallelSolvers, DistributedLinearSystem.C:766-1047: 20 border columns
+ * dense-ified per chunk with their colSparsity flags, solve(nrhs, ...), sparse product back - INTEGRATION.md level 1) and by
+ * pips_hip_ldl_set_border + pips_hip_ldl_factor_schur (level 1.5: the CSR border goes up, the S x S term comes down).
  *   gcc -std=c11 -O2 -Iinclude examples/leaf_solve.c -Lpips-ipmpp_amd -lpipship -Wl,-rpath,$PWD/pips-ipmpp_amd -lm -o leaf_solve */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "pips_hip.h"
 
@@ -64,6 +68,54 @@ int main(void) {
       free(y);
    }
    printf("inertia (%d, %d, %d), relative residual %.2e\n", pos, neg, zero, worst);
+
+   /* ---- border Br^T: S rows (Schur column ids) over the n rows of K; rows 0 .. n0-1 = columns of T, rows n0 .. = rows of F */
+   const int S = n0 + myl;
+   int* Brp = malloc((S + 1) * sizeof(int));
+   CHECK(pips_border_assemble(nx, my, 0, n0, 0, myl, 0, NULL, NULL, NULL, Trp, Tci, Tv, NULL, NULL, NULL, Frp, Fci, Fv, NULL, NULL, NULL, Brp, NULL, NULL));
+   const int bnnz = Brp[S];
+   int* Bci = malloc((size_t)(bnnz > 0 ? bnnz : 1) * sizeof(int)); double* Bv = malloc((size_t)(bnnz > 0 ? bnnz : 1) * sizeof(double));
+   CHECK(pips_border_assemble(nx, my, 0, n0, 0, myl, 0, NULL, NULL, NULL, Trp, Tci, Tv, NULL, NULL, NULL, Frp, Fci, Fv, NULL, NULL, NULL, Brp, Bci, Bv));
+
+   /* level 1: the host's chunk loop around solve(nrhs, rhss, colSparsity) - columns "lie as rows" (:895-901) */
+   double* SC1 = calloc((size_t)S * S, sizeof(double));
+   const int chunk = 20;
+   double* dense = malloc((size_t)chunk * n * sizeof(double));
+   int* ids = malloc(chunk * sizeof(int));
+   for (int s0 = 0; s0 < S;) {
+      int cnt = 0;
+      memset(dense, 0, (size_t)chunk * n * sizeof(double));
+      for (; s0 < S && cnt < chunk; ++s0) {
+         if (Brp[s0 + 1] == Brp[s0]) continue;                 /* empty border columns are skipped (:870-874) */
+         for (int p = Brp[s0]; p < Brp[s0 + 1]; ++p) dense[(size_t)cnt * n + Bci[p]] = Bv[p];
+         ids[cnt++] = s0;
+      }
+      if (cnt == 0) break;
+      CHECK(pips_hip_ldl_solve(h, cnt, dense, n));
+      for (int q = 0; q < cnt; ++q)                            /* K6: SC[id][:] -= Br^T x (addLeftBorderTimesDenseColsToResTranspDense) */
+         for (int t = 0; t < S; ++t) {
+            double acc = 0.0;
+            for (int p = Brp[t]; p < Brp[t + 1]; ++p) acc += Bv[p] * dense[(size_t)q * n + Bci[p]];
+            SC1[(size_t)ids[q] * S + t] -= acc;
+         }
+   }
    pips_hip_ldl_destroy(h);
-   return (pos == nx && neg == my && zero == 0 && worst < 1e-10) ? 0 : 3;
+
+   /* level 1.5: border declared to the handle, Schur term formed on the device */
+   void* h2 = NULL;
+   CHECK(pips_hip_ldl_create(&h2, n, Krp, Kci, -1, 0));
+   CHECK(pips_hip_ldl_set_inertia_hint(h2, nx));
+   CHECK(pips_hip_ldl_set_border(h2, S, Brp, Bci));
+   double* SC2 = calloc((size_t)S * S, sizeof(double));
+   CHECK(pips_hip_ldl_factor_schur(h2, Kv, Bv, SC2, S));
+   double diff = 0.0, big = 0.0;
+   for (int i = 0; i < S; ++i)
+      for (int j = 0; j <= i; ++j) {                            /* lower triangle (DenseSymmetricMatrix) */
+         const double a1 = SC1[(size_t)i * S + j], a2 = SC2[(size_t)i * S + j];
+         if (fabs(a1 - a2) > diff) diff = fabs(a1 - a2);
+         if (fabs(a1) > big) big = fabs(a1);
+      }
+   printf("Schur term: chunk loop vs pips_hip_ldl_factor_schur, max difference %.2e of %.2e\n", diff, big);
+   pips_hip_ldl_destroy(h2);
+   return (pos == nx && neg == my && zero == 0 && worst < 1e-10 && diff <= 1e-9 * big) ? 0 : 3;
 }

@@ -45,6 +45,16 @@ int pips_hip_ldl_factor(void* handle, const double* vals_host);
 int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs_inout_host, int ld);
 /* = DoubleLinearSolver::get_inertia(): (positive, negative, zero/perturbed) pivots of the last factorisation */
 int pips_hip_ldl_inertia(void* handle, int* pos, int* neg, int* zero);
+/* The leaf's Schur term computed where the factor lives (INTEGRATION.md level 1.5): replaces the host's K4-K6 chunk loop
+ * (addBiTLeftKiBiRightToResBlockedParallelSolvers, DistributedLinearSystem.C:766-1047; caller DistributedLeafLinearSystem.C:214-252),
+ * which ships every border column dense over PCIe and back.
+ *   set_border     before the analysis: pattern of Br_i^T, CSR with S rows (Schur column ids) over the n rows of K_i
+ *                  (border_left_transp); empty rows are skipped as the reference skips empty border columns (:870-874)
+ *   factor_schur   = matrixChanged() + addTermToSchurComplBlocked(): factorises K_i (values as in pips_hip_ldl_factor) and adds
+ *                  -Br_i^T K_i^-1 Br_i to SC_host, the S x S row-major DenseSymmetricMatrix storage (lower triangle, ldSC >= S);
+ *                  solves and inertia queries work afterwards as after pips_hip_ldl_factor */
+int pips_hip_ldl_set_border(void* handle, int S, const int* Bt_rowptr, const int* Bt_colidx);
+int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const double* Bt_vals_host, double* SC_host, int ldSC);
 /* diagnostics of the symbolic phase: what[0]=nnz(L) what[1]=n_head what[2]=tail m what[3]=#head supernodes
  * what[4]=#levels what[5]=factor flops (rounded) */
 int pips_hip_ldl_info(void* handle, int64_t* what, int n_what);

@@ -2554,6 +2554,9 @@ void pips_hip_batch_destroy(void* handle) { delete (Engine*)handle; }
 struct LdlHandle {
    Engine eng;
    bool have_perm = false;
+   double* d_sc = nullptr;        // S x S Schur term of this leaf (pips_hip_ldl_factor_schur)
+   std::vector<double> h_sc;
+   ~LdlHandle() { if (d_sc) (void)hipFree(d_sc); }
 };
 
 int pips_hip_ldl_create(void** handle, int n, const int* krow, const int* jcol, int device, int flags) {
@@ -2614,6 +2617,54 @@ int pips_hip_ldl_factor(void* handle, const double* vals_host) {
    if (rc) return rc;
    HIP_TRY(hipStreamSynchronize(h->eng.stream));
    return PIPS_OK;
+}
+
+// The leaf's Schur term without dense border columns over PCIe.  The border Br_i^T (S x n CSR, rows = Schur column ids: the
+// reference's border_left_transp, DistributedLeafLinearSystem.C:214-252) is declared before the analysis; factor_schur factorises
+// K_i and adds  -Br_i^T K_i^-1 Br_i  to the caller's Schur complement: what the K4-K6 chunk loop
+// (addBiTLeftKiBiRightToResBlockedParallelSolvers, DistributedLinearSystem.C:766-1047: densify <= 20 T border columns,
+// solve(nrhs, ...), sparse product back) computes, but with only the CSR values going up and the S x S term coming down.
+int pips_hip_ldl_set_border(void* handle, int S, const int* Bt_rowptr, const int* Bt_colidx) {
+   LdlHandle* h = (LdlHandle*)handle;
+   if (!h || S <= 0 || !Bt_rowptr || !Bt_colidx) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_set_border: bad arguments");
+   if (h->eng.analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_set_border: declare the border before pips_hip_ldl_analyze / the first factor");
+   BlockInput& in = h->eng.in[0];
+   for (int p = 0; p < Bt_rowptr[S]; ++p)
+      if (Bt_colidx[p] < 0 || Bt_colidx[p] >= in.n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_set_border: column %d outside the leaf (n = %d)", Bt_colidx[p], in.n);
+   h->eng.S = S;
+   in.btrow.assign(Bt_rowptr, Bt_rowptr + S + 1);
+   in.btcol.assign(Bt_colidx, Bt_colidx + Bt_rowptr[S]);
+   in.btval.assign((size_t)Bt_rowptr[S], 0.0);
+   return PIPS_OK;
+}
+
+int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const double* Bt_vals_host, double* SC_host, int ldSC) {
+   LdlHandle* h = (LdlHandle*)handle;
+   if (!h || !K_vals_host || !Bt_vals_host || !SC_host) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_factor_schur: bad arguments");
+   Engine& e = h->eng;
+   const int S = e.S;
+   if (S <= 0 || e.in[0].btrow.empty()) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_factor_schur: no border declared (pips_hip_ldl_set_border)");
+   if (ldSC < S) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_factor_schur: ldSC %d < S %d", ldSC, S);
+   int rc;
+   if (!e.analyzed && (rc = pips_hip_ldl_analyze(handle))) return rc;
+   HIP_TRY(hipSetDevice(e.device));
+   if ((rc = pips_hip_batch_set_values(&e, 0, K_vals_host))) return rc;
+   if (e.nnzB_total > 0) HIP_TRY(hipMemcpyAsync(e.d_bval, Bt_vals_host, (size_t)e.nnzB_total * sizeof(double), hipMemcpyHostToDevice, e.stream));
+   if (!h->d_sc) HIP_TRY(hipMalloc((void**)&h->d_sc, (size_t)S * S * sizeof(double)));
+   HIP_TRY(hipMemsetAsync(h->d_sc, 0, (size_t)S * S * sizeof(double), e.stream));
+   if ((rc = e.factor(h->d_sc, S))) return rc;
+   h->h_sc.resize((size_t)S * S);
+   HIP_TRY(hipMemcpyAsync(h->h_sc.data(), h->d_sc, (size_t)S * S * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+   HIP_TRY(hipStreamSynchronize(e.stream));
+   // device: column-major with the lower triangle valid; caller: row-major DenseSymmetricMatrix, lower triangle meaningful
+   // (DenseStorage.C:64-83): entry [i][j], i >= j, takes the device's (i, j) - only the rows of this leaf's non-empty border columns differ from zero
+   const BlockSym& bs = e.sym[0];
+   for (int cb : bs.bmap)
+      for (int ra : bs.bmap) {
+         if (ra < cb) continue;
+         SC_host[(size_t)ra * ldSC + cb] += h->h_sc[(size_t)ra + (size_t)cb * S];
+      }
+   return e.sweep.take_error("pips_hip_ldl_factor_schur");
 }
 
 int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {

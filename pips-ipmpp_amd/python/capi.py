@@ -47,7 +47,7 @@ SYMBOLS = [
     "pips_hip_last_error", "pips_hip_device_count",
     "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement",
     "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
-    "pips_hip_ldl_get_perm", "pips_hip_ldl_destroy",
+    "pips_hip_ldl_get_perm", "pips_hip_ldl_set_border", "pips_hip_ldl_factor_schur", "pips_hip_ldl_destroy",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
     "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_destroy",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
@@ -252,6 +252,17 @@ class HipLdlSolver:
 
     def matrixChanged(self):
         _check(lib.pips_hip_ldl_factor(self._h, _ptr(self.K.val)), "pips_hip_ldl_factor")
+
+    def set_border(self, Bt):
+        """Declare Br^T (Csr, S rows = Schur column ids over the n rows of K) before analyze(): level 1.5 of INTEGRATION.md."""
+        self.Bt = Bt
+        _check(lib.pips_hip_ldl_set_border(self._h, C.c_int(Bt.nrows), _ptr(Bt.rowptr), _ptr(Bt.colidx)), "pips_hip_ldl_set_border")
+
+    def matrixChanged_with_schur_term(self, SC):
+        """matrixChanged() + addTermToSchurComplBlocked(): SC (S x S float64 C-contiguous, lower triangle) -= Br^T K^-1 Br."""
+        assert SC.dtype == np.float64 and SC.flags.c_contiguous and SC.shape[0] == SC.shape[1] == self.Bt.nrows
+        _check(lib.pips_hip_ldl_factor_schur(self._h, _ptr(self.K.val), _ptr(self.Bt.val), _ptr(SC), C.c_int(SC.shape[1])),
+               "pips_hip_ldl_factor_schur")
 
     def diagonalChanged(self, idiag=0, extent=0):
         self.matrixChanged()

@@ -38,6 +38,7 @@ def test_c_example_runs_on_the_gpu(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "inertia (2000, 1000, 0)" in out.stdout
+    assert "Schur term: chunk loop vs pips_hip_ldl_factor_schur" in out.stdout   # level 1 (K4-K6 on the host) == level 1.5
 
 
 @pytest.mark.gpu

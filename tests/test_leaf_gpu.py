@@ -4,6 +4,7 @@ import pytest
 import scipy.sparse.linalg as spl
 
 import pips_ipmpp_amd as pa
+from oracle import oracle as orc
 from tests.util import Problem, hip_lower_as_rowmajor
 
 pytestmark = pytest.mark.gpu
@@ -485,3 +486,37 @@ def test_degenerate_leaf_shapes():
     empty = np.zeros((0, 1))
     s.solve(empty)          # zero right-hand sides: a no-op, not an error
     assert s.get_inertia() == (1, 0, 0)
+
+
+@pytest.mark.parametrize("shape", ["random", "time_coupled"])
+def test_leaf_handle_schur_term_matches_the_blocked_loop(shape):
+    """pips_hip_ldl_set_border + pips_hip_ldl_factor_schur (INTEGRATION.md level 1.5): the leaf's Schur term formed on the device from
+    the CSR border, against the oracle's restatement of the K4-K6 chunk loop (addTermToSchurComplBlocked,
+    DistributedLeafLinearSystem.C:214-252) and against that loop run through the drop-in solve(nrhs, ...) of the same handle."""
+    if shape == "random":
+        prob = Problem(11, 2, 700, 350, 30, 20, 0.01)
+    else:
+        prob = _TimeCoupledProblem(5, 2, 900, 450, 10, 8, 6)
+    S = prob.S
+    for b in range(prob.N):
+        blk = prob.blocks[b]
+        s = pa.HipLdlSolver(blk["K"], n_primal=prob.n_i)
+        s.set_border(blk["Bt"])
+        got = np.zeros((S, S))
+        s.matrixChanged_with_schur_term(got)
+        want = orc.add_term_to_schur_compl_blocked(np.zeros((S, S)), prob.oracle_leaf(b), prob.Bt_scipy(b))
+        scale = np.abs(want).max()
+        assert np.abs(np.tril(got) - np.tril(want)).max() / scale < RTOL_SC
+        assert np.abs(np.triu(got, 1)).max() == 0.0              # only the lower triangle is touched
+        assert s.get_inertia() == (prob.n_i, prob.my_i, 0)
+        # the handle still solves (the adapter's solve(Vector&) / solve(nrhs, ...) after matrixChanged)
+        Bt = prob.Bt_scipy(b)
+        loop = np.zeros((S, S))
+        cols = np.nonzero(np.diff(Bt.indptr) > 0)[0]
+        for k in range(0, len(cols), 20):
+            ids = cols[k:k + 20]
+            dense = np.ascontiguousarray(Bt[ids].toarray())
+            s.solve(dense)
+            loop[ids, :] -= (Bt @ dense.T).T
+        assert np.abs(np.tril(loop) - np.tril(got)).max() / scale < RTOL_SC
+        s.close()

@@ -12,6 +12,8 @@ import pips_ipmpp_amd as pa
 ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=4)
 ap.add_argument("--chunk", type=int, default=160, help="border columns per multi-RHS solve (the reference: 20 x OMP threads)")
+ap.add_argument("--level", choices=["1", "1.5"], default="1", help="1: adapters only, the host's K4-K6 loop ships dense border columns; "
+                "1.5: pips_hip_ldl_set_border + pips_hip_ldl_factor_schur - CSR border up, S x S term down")
 a = ap.parse_args()
 seed, N_total, n_i, S, rho = 20261002, 64, 10000, 2000, 1e-3
 my_i, n0, myl = n_i // 2, S // 2, S // 2
@@ -24,17 +26,23 @@ for b in range(a.blocks):
     K.val[dpos] = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
     Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F).to_scipy()
     s = pa.HipLdlSolver(K, n_primal=n_i, refine_steps=1)
+    if a.level == "1.5":
+        s.set_border(pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F))
     t0 = time.perf_counter(); s.analyze(); t_an += time.perf_counter() - t0
-    s.matrixChanged()                                   # warm-up (first-touch allocations)
-    t0 = time.perf_counter(); s.matrixChanged(); t_fac += time.perf_counter() - t0
-    t0 = time.perf_counter()
-    cols = np.nonzero(np.diff(Bt.indptr) > 0)[0]
-    for k in range(0, len(cols), a.chunk):               # K4: dense-ify, K5: multi-RHS solve, K6: sparse product
-        ids = cols[k:k + a.chunk]
-        dense = np.ascontiguousarray(Bt[ids].toarray())
-        s.solve(dense)
-        SC[ids, :] -= (Bt @ dense.T).T
-    t_schur += time.perf_counter() - t0
+    if a.level == "1.5":
+        s.matrixChanged_with_schur_term(np.zeros((S, S)))   # warm-up (first-touch allocations)
+        t0 = time.perf_counter(); s.matrixChanged_with_schur_term(SC); t_schur += time.perf_counter() - t0   # factor + Schur term in one call
+    else:
+        s.matrixChanged()                                   # warm-up (first-touch allocations)
+        t0 = time.perf_counter(); s.matrixChanged(); t_fac += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cols = np.nonzero(np.diff(Bt.indptr) > 0)[0]
+        for k in range(0, len(cols), a.chunk):               # K4: dense-ify, K5: multi-RHS solve, K6: sparse product
+            ids = cols[k:k + a.chunk]
+            dense = np.ascontiguousarray(Bt[ids].toarray())
+            s.solve(dense)
+            SC[ids, :] -= (Bt @ dense.T).T
+        t_schur += time.perf_counter() - t0
     solvers.append(s); Bts.append(Bt)
     print(f"block {b}: factor {t_fac / (b + 1) * 1e3:.1f} ms, Schur term {t_schur / (b + 1):.2f} s (running means)", file=sys.stderr, flush=True)
 F0, c0, x0s = pa.gen_root(seed, n0, myl)
@@ -57,7 +65,8 @@ for r in range(4):
     t_sc.append(time.perf_counter() - t0)
 scale = N_total / a.blocks
 unit = (t_fac + t_schur) * scale + t_root + 4 * np.median(t_sc) * scale
-print(json.dumps({"path": "drop-in DoubleLinearSolver adapters only (host pointers, reference K4-K6 host loop)", "blocks_run": a.blocks, "chunk_columns": a.chunk,
+print(json.dumps({"path": "drop-in DoubleLinearSolver adapters only (host pointers, reference K4-K6 host loop)" if a.level == "1" else
+                          "level 1.5: adapters + pips_hip_ldl_factor_schur (CSR border up, S x S Schur term down; solves through host pointers)", "blocks_run": a.blocks, "chunk_columns": a.chunk,
                   "seconds_per_block": {"analyze_once": t_an / a.blocks, "factor": t_fac / a.blocks, "schur_term": t_schur / a.blocks},
                   "seconds_per_unit": {"leaf_factor": t_fac * scale, "leaf_schur": t_schur * scale, "root_factor": t_root, "solve_compressed_x4": 4 * float(np.median(t_sc)) * scale,
                                        "total": unit}, "units_per_s": 1.0 / unit}))
