@@ -440,8 +440,9 @@ def main():
                         + (" [per-GPU share of BASELINE configs[3]]" if bpg == 256 and n_i == 50000 else "")),
                        "family": a.family, "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
-                       "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed (DESIGN.md 4.5)"
-                                   if info.get("ltsolve_from_augmented_factor") else "border product + refined leaf solve"),
+                       "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed and the "
+                                   "refined Lsolve of the same call needed no step (DESIGN.md 4.5)"
+                                   if kkt.last_ltsolve_from_factor() else "border product + refined leaf solve"),
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},

@@ -211,6 +211,9 @@ int pips_hip_kkt_set_root_pivoting(void* handle, int mode);
  * ms[8]=Ltsolve  ms[9]=x_i = z_i - u_i  ms[10]=panel-wise Schur reduction on its own stream, summed over the panels (ms[2] is
  * then what the main stream waited for it: the exposed part).  What bench.py's phase table is made of. */
 int pips_hip_kkt_get_timing(void* handle, double* ms, int64_t* cnt, int n);
+/* 1 if the last pips_hip_kkt_solve_compressed took its Ltsolve from the augmented factor (one unrefined backward sweep: only while no
+ * pivot is perturbed and the refined leaf solve of the same call needed no refinement step), 0 if by border product + refined solve */
+int pips_hip_kkt_last_ltsolve_from_factor(void* handle, int* flag);
 void pips_hip_kkt_destroy(void* handle);
 
 /* plain device buffers for hosts that do not bring their own allocator */

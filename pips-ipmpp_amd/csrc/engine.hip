@@ -2134,6 +2134,7 @@ struct KktSystem {
    }
    size_t packed_cap = 0;
    bool use_rsag = false, force_reduce = false;
+   bool last_ltsolve_from_factor = false;   // which Ltsolve the last solveCompressed took (reported per solve, not only at analyze time)
    bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
    // 0 diagonals + zero SC, 1 leaf factorisation, 2 Schur reduction, 3 finalize, 4 root factorisation (its own stream),
@@ -3281,9 +3282,15 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    // (Engine::solve_border_backward); else border product + full solve with refinement.
    k->timer.end(e->stream);
    k->timer.begin(e->stream, 8);
+   // The sweep carries no refinement, so it is taken only on evidence that the factors are accurate: no perturbed pivot (the
+   // counters reached pinned memory with the factorisation: no wait for the solves queued behind it) AND, with adaptive refinement,
+   // the refined leaf solve of this call's Lsolve - same factors - was satisfied by its first solve (backward error below the
+   // tolerance without a step).  A pivot that kept its sign but is rounding noise passes the first test, not the second.
    int pert = 1;
    if (e->border_backward_ok && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
-   if (e->border_backward_ok && !k->sparse && pert == 0) {
+   const bool lsolve_clean = e->refine_tol > 0.0 ? e->last_refine_steps == 0 : true;
+   k->last_ltsolve_from_factor = e->border_backward_ok && !k->sparse && pert == 0 && lsolve_clean;
+   if (k->last_ltsolve_from_factor) {
       if ((rc = e->solve_border_backward(red, k->d_t))) return rc;
    } else {
       HIP_TRY(hipMemsetAsync(k->d_t, 0, (size_t)e->n_total * sizeof(double), e->stream));
@@ -3295,6 +3302,13 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    k->timer.end(e->stream);
    HIP_TRY(hipGetLastError());
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_last_ltsolve_from_factor(void* handle, int* flag) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || !flag) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_last_ltsolve_from_factor: bad arguments");
+   *flag = k->last_ltsolve_from_factor ? 1 : 0;
    return PIPS_OK;
 }
 

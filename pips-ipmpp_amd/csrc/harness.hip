@@ -246,6 +246,12 @@ __global__ void k_diagonals(Lay d, const double* __restrict__ G, const double* _
    }
 }
 
+// OUTER_BICG_TEST_PRECOND (test hook, see Ipm::precond): z := 0, or z[i] *= 1 - 2 i / (n - 1)
+__global__ void k_test_distort(long long n, int mode, double* __restrict__ z) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      z[i] = mode == 1 ? 0.0 : z[i] * (n > 1 ? 1.0 - 2.0 * (double)i / (double)(n - 1) : 1.0);
+}
+
 // out[k] = in[k] - reg: the regularised dual diagonal of the eliminated root inequality rows (sLinsysRootAug.C:384-466 eliminates z0 with
 // dual_inequality_diagonal_regularized)
 __global__ void k_shift_diag(const double* __restrict__ in, double reg, double* __restrict__ out, int n) {
@@ -580,6 +586,7 @@ struct Ipm {
    long long n_gondzio = 0, n_precond = 0, n_bicg_iter = 0, n_host_syncs = 0;
    int outer_mode = 2, outer_max = 10, last_outer_steps = 0, last_outer_flag = 0;
    int bicg_max_iter = 75, bicg_max_div = 4, bicg_max_stag = 4;
+   double bicg_eps = 1e-15;   // OUTER_BICG_EPSILON (PIPSIPMppOptions.C:303-310): absolute floor of the target, scale of the stagnation test
    bool regularize = true;
    double outer_tol = 1e-10, last_outer_res = 0.0, last_outer_abs = 0.0;
    int n_regularised = 0, n_factorize = 0, n_refactor_outer = 0, verbose_run = 0;
@@ -781,10 +788,16 @@ struct Ipm {
    }
 
    // ---- outer solve on z = [x | y | z] ------------------------------------------------------------------------------------------
+   // Test hook (option OUTER_BICG_TEST_PRECOND): distort the preconditioner so that the exits of the outer BiCGStab that a healthy
+   // factorisation never takes can be driven on the device - 1: it returns zero (breakdown: r0^T v = 0, LinearSystem.C:640-647),
+   // 2: its output is scaled entry-wise by a ramp from +1 to -1 (an operator far from normal: the residual norm climbs, the
+   // divergence counter runs up and the best iterate is restored, :741-760).  0 in every production path.
+   int test_precond = 0;
    int precond(double* z_) {   // z := solveCompressed(z)
       hipLaunchKernelGGL(k_gather, dim3(egrid(npack)), dim3(256), 0, stream, npack, d_pack, z_, b0, 0);   // b0 and bl are one array
       TRY(pips_hip_kkt_solve_compressed(kkt, b0, bl));
       hipLaunchKernelGGL(k_gather, dim3(egrid(npack)), dim3(256), 0, stream, npack, d_pack, b0, z_, 1);
+      if (test_precond) hipLaunchKernelGGL(k_test_distort, dim3(egrid(nxyz)), dim3(256), 0, stream, nxyz, test_precond, z_);
       ++n_precond;
       return PIPS_OK;
    }
@@ -842,7 +855,7 @@ struct Ipm {
    int bicgstab(const double* b_, double* x_) {
       const long long n = nxyz;
       double init[B_SLOTS] = {0};
-      init[B_EPS] = 1e-15; init[B_MAX_DIV] = bicg_max_div; init[B_MAX_STAG] = bicg_max_stag;
+      init[B_EPS] = bicg_eps; init[B_MAX_DIV] = bicg_max_div; init[B_MAX_STAG] = bicg_max_stag;
       HIP_TRYH(hipMemcpyAsync(d_bst, init, sizeof(init), hipMemcpyHostToDevice, stream));
       TRY(pips_hip_vec_copy(n, b_, x_, stream));
       TRY(precond(x_));
@@ -1657,6 +1670,14 @@ int pips_ipm_set_option(void* handle, const char* name, double value) {
    else if (key == "OUTER_BICG_MAX_NORMR_DIVERGENCES") {
       if (value < 0) PIPS_FAIL(PIPS_ERR_ARG, "OUTER_BICG_MAX_NORMR_DIVERGENCES must be >= 0");
       p->bicg_max_div = (int)value;
+   }
+   else if (key == "OUTER_BICG_EPSILON") {
+      if (!(value > 0.0)) PIPS_FAIL(PIPS_ERR_ARG, "OUTER_BICG_EPSILON must be > 0");
+      p->bicg_eps = value;
+   }
+   else if (key == "OUTER_BICG_TEST_PRECOND") {
+      if (value != 0.0 && value != 1.0 && value != 2.0) PIPS_FAIL(PIPS_ERR_ARG, "OUTER_BICG_TEST_PRECOND: 0 (off), 1 (zero preconditioner) or 2 (ramp-scaled preconditioner)");
+      p->test_precond = (int)value;
    }
    else if (key == "OUTER_BICG_MAX_STAGNATIONS") {
       if (value < 1) PIPS_FAIL(PIPS_ERR_ARG, "OUTER_BICG_MAX_STAGNATIONS must be >= 1");

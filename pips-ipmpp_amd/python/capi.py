@@ -59,7 +59,7 @@ SYMBOLS = [
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
     "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
-    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
+    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_last_ltsolve_from_factor", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
@@ -630,6 +630,11 @@ class KktSystem:
         names = ["diag_zero", "leaf_factor", "reduce", "finalize", "root_factor", "lsolve_leaf", "lsolve_border_reduce", "dsolve", "ltsolve", "combine",
                  "reduce_panels"]
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(names)}
+
+    def last_ltsolve_from_factor(self):
+        f = C.c_int()
+        _check(lib.pips_hip_kkt_last_ltsolve_from_factor(self._h, C.byref(f)), "pips_hip_kkt_last_ltsolve_from_factor")
+        return bool(f.value)
 
     def set_root_pivoting(self, mode):
         _check(lib.pips_hip_kkt_set_root_pivoting(self._h, C.c_int(mode)), "pips_hip_kkt_set_root_pivoting")

@@ -55,7 +55,7 @@ def apply_options(opts, batch=None, ipm=None):
                 batch.set_options(repl_rel=10.0 ** (-int(value)))
                 done = True
         if ipm is not None and ident in ("GONDZIO_MAX_CORRECTORS", "OUTER_SOLVE", "OUTER_BICG_MAX_ITER", "OUTER_BICG_MAX_NORMR_DIVERGENCES",
-                                         "OUTER_BICG_MAX_STAGNATIONS", "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM", "REGULARIZATION"):
+                                         "OUTER_BICG_MAX_STAGNATIONS", "OUTER_BICG_EPSILON", "OUTER_SOLVE_REFINE_ORIGINAL_SYSTEM", "REGULARIZATION"):
             if ident == "OUTER_SOLVE" and value == 0:
                 ignored.append(ident)   # the harness always refines against the original system
                 continue
