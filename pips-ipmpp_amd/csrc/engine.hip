@@ -611,6 +611,11 @@ struct Engine {
    double* d_mfU = nullptr;    // update matrices of the fronts
    double* d_mfLV = nullptr;   // d and l of the simple leaves below fronts, front by front
    double* d_mfV = nullptr;    // update vectors of the fronts (multifrontal solves)
+   int *d_roots = nullptr, *d_root_off = nullptr;   // fronts without a head parent, per block (k_root_assemble)
+   std::vector<int> h_root_off_keep;
+   int n_roots = 0;
+   int* d_round_blk = nullptr;                       // deterministic mode: the blocks of round k at [round_off[k], round_off[k + 1])
+   std::vector<int> round_off;
    int* d_mfint = nullptr;     // front records (common.h)
    long long mfU_total = 0;
    int spine_total = 0, n_levels_all = 0;   // supernodes handled by the per-block spine kernels; tree height before the cut
@@ -647,6 +652,10 @@ struct Engine {
       if (d_mfLV) (void)hipFree(d_mfLV);
       if (d_mfV) (void)hipFree(d_mfV);
       d_mfV = nullptr;
+      for (void* q : {(void*)d_roots, (void*)d_root_off, (void*)d_round_blk})
+         if (q) (void)hipFree(q);
+      d_roots = d_root_off = d_round_blk = nullptr;
+      n_roots = 0;
       if (d_mfint) (void)hipFree(d_mfint);
       d_mfU = nullptr; d_mfLV = nullptr; d_mfint = nullptr;
       mf_launches.clear();
@@ -747,6 +756,19 @@ struct Engine {
          const int nt = h_blks[b].nb_pad / TILE;
          for (int ti = 0; ti < nt; ++ti)
             for (int tj = 0; tj <= ti; ++tj) rounds[b % gs].push_back({b, ti, tj, 0});
+      }
+      if (mf) {   // root fronts of round k = those of the k-th block of every group: one block per group and launch
+         std::vector<int> rb;
+         round_off.assign(1, 0);
+         for (int k = 0; k < gs; ++k) {
+            for (int b = k; b < nblk; b += gs)
+               if (h_root_off_keep[b + 1] > h_root_off_keep[b]) rb.push_back(b);
+            round_off.push_back((int)rb.size());
+         }
+         if (d_round_blk) { (void)hipFree(d_round_blk); d_round_blk = nullptr; }
+         if (rb.empty()) rb.push_back(0);
+         int rcb = dev_upload(&d_round_blk, rb, stream);
+         if (rcb) return rcb;
       }
       det_rounds.clear();
       std::vector<TileTask> all;
@@ -917,7 +939,7 @@ struct Engine {
       {  // multifrontal head: every block's fronts must fit the LDS; the slot machinery of deterministic mode records scatters
          const char* env = getenv("PIPS_HIP_MF");
          const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
-         mf = !(env && atoi(env) == 0) && !deterministic && !(hs && atoi(hs) != 0);
+         mf = !(env && atoi(env) == 0) && !(hs && atoi(hs) != 0 && !deterministic);
          mf_solves = getenv("PIPS_HIP_MF_SOLVES") && atoi(getenv("PIPS_HIP_MF_SOLVES")) != 0;
          for (int b = 0; b < nblk && mf; ++b) {
             mf = sym[b].mf_ok;
@@ -932,7 +954,7 @@ struct Engine {
                if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) mf = false;   // 159 KB of the 160
             }
          }
-         mf_solves = mf_solves && mf;
+         mf_solves = mf_solves && mf && !deterministic;   // (deterministic mode keeps its slot-based forward substitution)
       }
 
       // ---- offsets
@@ -1058,6 +1080,7 @@ struct Engine {
          if (nlev - lstar < 8 || (env && atoi(env) == 0) || deterministic || mf) lstar = nlev;   // the spine kernels hand over through atomics
       }
       std::vector<SnDesc> h_sns(nsn_total);
+      std::vector<std::vector<int>> roots_of(nblk);   // multifrontal head: fronts without a head parent, ascending
       long long slots_acc = 0, vslots_acc = 0;
       std::vector<std::vector<int>> sorted_id(nblk);
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
@@ -1068,13 +1091,16 @@ struct Engine {
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
                            s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1};
+         if (mf && k.cls > 0 && s.r > 0 && sym[k.blk].sn_parent[k.loc] < 0) roots_of[k.blk].push_back(i);
          if (mf) {
             const BlockSym& bs = sym[k.blk];
             if (bs.mf_U[k.loc] >= 0) h_sns[i].U = (k.cls == 0 ? mfLV_base[k.blk] : mfU_base[k.blk]) + bs.mf_U[k.loc];
             if (bs.mf_meta[k.loc] >= 0) h_sns[i].mf = mfint_base[k.blk] + bs.mf_meta[k.loc];
-            if (bs.mf_V[k.loc] >= 0) h_sns[i].vslot = mfV_base[k.blk] + bs.mf_V[k.loc];   // (the slot machinery of deterministic mode is off)
+            if (mf_solves && bs.mf_V[k.loc] >= 0) h_sns[i].vslot = mfV_base[k.blk] + bs.mf_V[k.loc];   // (never together with the slot-based sweeps)
          }
-         slots_acc += (long long)s.r * (s.r + 1) / 2;
+         // factorisation slots: every scattering supernode; multifrontal head: only the simple leaves without a front above them scatter
+         // (the fronts hand their update matrices on, k_root_assemble adds the last ones in a fixed order)
+         if (!mf || (k.cls == 0 && s.n_useg == 0)) slots_acc += (long long)s.r * (s.r + 1) / 2;
          vslots_acc += s.r;
          sorted_id[k.blk][k.loc] = i;
          LevelRange& L = k.level >= lstar ? levels_top[k.level - lstar] : levels[k.level];
@@ -1103,6 +1129,16 @@ struct Engine {
          const long long need = (long long)s.r * (s.w | 1);
          if (k.cls == 1) L.small_lds = (int)std::max<long long>(L.small_lds, std::min<long long>(need, 640));
          else if (k.cls == 2) L.large_lds = (int)std::max<long long>(L.large_lds, std::min<long long>(need, 6144));
+      }
+      if (mf) {
+         std::vector<int> h_roots, h_root_off(nblk + 1, 0);
+         for (int b = 0; b < nblk; ++b) {
+            h_roots.insert(h_roots.end(), roots_of[b].begin(), roots_of[b].end());
+            h_root_off[b + 1] = (int)h_roots.size();
+         }
+         n_roots = (int)h_roots.size();
+         h_root_off_keep = h_root_off;
+         if ((rc = dev_upload(&d_roots, h_roots, stream)) || (rc = dev_upload(&d_root_off, h_root_off, stream))) return rc;
       }
       // spine lists: per block, ascending local index = postorder (children before parents)
       std::vector<int> h_spine, h_spine_off(nblk + 1, 0);
@@ -1466,6 +1502,7 @@ struct Engine {
       }
       for (int i = 0; i < nsn_total; ++i) {
          const SnDesc& sn = h_sns_keep[i];
+         if (mf && !(sn.mf < 0 && sn.n_useg == 0)) continue;   // multifrontal head: only the leaves without a front above them own slots
          const long long cnt = (long long)sn.r * (sn.r + 1) / 2;
          const BlkDesc& bd = h_blks[sn.blk];
          for (long long q = 0; q < cnt; ++q) {
@@ -1593,6 +1630,20 @@ struct Engine {
             HIP_TRY(hipMemsetAsync(d_gbuf, 0, (size_t)det_n_groups * S * S * sizeof(double), stream));
             gather(g_sc_grp, d_slot_val, d_gbuf);
          } else if (SC) gather(g_sc, d_slot_val, SC);
+         if (timer.on) timer.end(stream);
+      }
+      if (mf && n_roots > 0) {   // the last update matrices: into the tail and the Schur complement, front by front
+         if (timer.on) timer.begin(stream, 1);
+         if (deterministic && d_gbuf && SC && d_round_blk) {
+            for (size_t k = 0; k + 1 < round_off.size(); ++k) {
+               const int cnt = round_off[k + 1] - round_off[k];
+               if (cnt > 0)
+                  hipLaunchKernelGGL(k_root_assemble, dim3(cnt), dim3(256), 0, stream, d_round_blk + round_off[k], d_root_off, d_roots, d_sns, d_blks, d_rowidx,
+                                     d_bmap, d_arena, d_mfU, SC, ldSC, d_sctab, d_gbuf, (long long)S * S, d_blk_group);
+            }
+         } else
+            hipLaunchKernelGGL(k_root_assemble, dim3(nblk), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
+                               d_arena, d_mfU, SC, ldSC, d_sctab, (double*)nullptr, 0LL, (const int*)nullptr);
          if (timer.on) timer.end(stream);
       }
       if (spine_total > 0) {

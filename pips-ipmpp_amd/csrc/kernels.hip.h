@@ -837,31 +837,54 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    // ---- 4. the update matrix leaves
    MF_STAMP(6);
    if (r == 0) { MF_STAMP(7); return; }
-   if (has_parent) {   // the parent front picks it up from the update arena
-      if (!UG) {
-         double* Ug = uarena + sn.U;
-         for (int idx = tid; idx < np; idx += BLOCK) Ug[idx] = FU[idx];
-      }
-      MF_STAMP(7);
-      return;
-   }
-   // no head parent: the below-rows are tail rows [0, rb) and border rows [rb, r)
-   const int* rows = rowidx + sn.rows;
-   const int n = bd.n, n_head = bd.n_head, rb = sn.rb;
-   double* T = arena + bd.T;
-   const int* bm = bmap + bd.bmap_off;
-   for (int idx = tid; idx < r * r; idx += BLOCK) {
-      const int b = idx / r, a = idx - b * r;
-      if (a < b) continue;
-      const double u = FU[cu(b) + a - b];
-      const int ra = rows[a], cb = rows[b];
-      if (b < rb) {
-         const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
-         atomic_add_f64(T + tr + (long long)(cb - n_head) * bd.ldT, u);
-      } else if (SC)
-         atomic_add_f64(sc_entry(SC, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n), u);
+   // the update matrix goes to the update arena: the parent front picks it up there; for a front without a head parent (parent
+   // column in the dense tail) k_root_assemble adds it to the tail / Schur complement after the last level, front by front in a
+   // fixed order - no atomics on targets that several fronts of a block share
+   (void)has_parent;
+   if (!UG) {
+      double* Ug = uarena + sn.U;
+      for (int idx = tid; idx < np; idx += BLOCK) Ug[idx] = FU[idx];
    }
    MF_STAMP(7);
+}
+
+// Update matrices of the fronts without a head parent -> tail panel and Schur complement.  One workgroup per block walks the
+// block's root fronts in ascending order (inside a front the targets are distinct; a barrier separates the fronts): plain adds on
+// the block's own tail.  Schur targets are shared between blocks: FP64 atomics by default; in deterministic mode (gbuf != nullptr)
+// a launch holds at most one block of every group and adds into the group's buffer, so the blocks of a group arrive in order.
+__global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ blk_list, const int* __restrict__ root_off,
+                                                      const int* __restrict__ roots, const SnDesc* __restrict__ sns,
+                                                      const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
+                                                      const int* __restrict__ bmap, double* __restrict__ arena,
+                                                      const double* __restrict__ uarena, double* __restrict__ SC, int ldSC,
+                                                      const int* __restrict__ sctab, double* __restrict__ gbuf, long long gstride,
+                                                      const int* __restrict__ blk_group) {
+   const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
+   const BlkDesc bd = blks[blk];
+   double* T = arena + bd.T;
+   const int* bm = bmap + bd.bmap_off;
+   const int n = bd.n, n_head = bd.n_head;
+   double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
+   for (int q = root_off[blk]; q < root_off[blk + 1]; ++q) {
+      const SnDesc sn = sns[roots[q]];
+      const int r = sn.r, rb = sn.rb;
+      const int* rows = rowidx + sn.rows;
+      const double* U = uarena + sn.U;
+      for (int idx = threadIdx.x; idx < r * r; idx += 256) {
+         const int b = idx / r, a = idx - b * r;
+         if (a < b) continue;
+         const double u = U[b * r - b * (b - 1) / 2 + a - b];
+         const int ra = rows[a], cb = rows[b];
+         if (b < rb) {
+            const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
+            T[tr + (long long)(cb - n_head) * bd.ldT] += u;
+         } else if (S_) {
+            double* tgt = sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n);
+            if (gbuf) *tgt += u; else atomic_add_f64(tgt, u);
+         }
+      }
+      __syncthreads();
+   }
 }
 
 // Position of row `ra` of a supernode's row list in the block's work vector: rows of K_i at ra, border rows (ra >= n, only
