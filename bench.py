@@ -57,7 +57,9 @@ def update_kernel_algorithmic_flops(m, nb):
 def update_kernel_traffic(n_blocks, n_i, S, world):
     """HBM bytes of the update kernel per factorize from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes over this very command, FETCH_SIZE doubled per MI355X_MICROARCH.md); only valid for the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r2_bench_update_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_bench_update_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r2_bench_update_traffic.json")
     if world != 1 or n_blocks != 64 or n_i != 10000 or S != 2000 or not os.path.exists(path):
         return None
     try:
@@ -441,7 +443,7 @@ def main():
                        "family": a.family, "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed and the "
-                                   "refined Lsolve of the same call needed no step (DESIGN.md 4.5)"
+                                   "refined Lsolve of the same call needed no step (DESIGN.md 2)"
                                    if kkt.last_ltsolve_from_factor() else "border product + refined leaf solve"),
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),

@@ -65,7 +65,7 @@ def test_random_configuration(case, monkeypatch):
     ctx = (case, N, n_i, my_i, n0, myl, cut, structured, bt.schur_mode(), bt.info())
     got = hip_lower_as_rowmajor(SC.cpu().numpy(), S)
     want = np.tril(prob.oracle_schur())
-    # Accuracy note (tools/fuzz_debug.py): Schur mode 1 forms SC from the factors without iterative
+    # Accuracy note (tools/fuzz_debug.py, docs/HISTORY_r1_r2.md section 6): Schur mode 1 forms SC from the factors without iterative
     # refinement, so its forward error is cond(K_i) * eps (1e-7 for a block of cond 3e10 in this sweep); the oracle's
     # solve-based K4-K6 refines every column and stays at 1e-14.  The fixed tests (well-posed shapes) hold 1e-9.
     assert np.abs(got - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-300), ctx
