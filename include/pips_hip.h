@@ -71,6 +71,12 @@ void pips_hip_ldl_destroy(void* handle);
  * pips_hip_dense_ldl_set_pivoting overrides: 0 static order, 1 Bunch-Kaufman. */
 int pips_hip_dense_ldl_create(void** handle, int n, int n_primal, int device);
 int pips_hip_dense_ldl_set_pivoting(void* handle, int mode);
+/* Several ranks hold the same matrix (the reduced Schur complement): factorise it column-cyclically over the ranks instead of
+ * redundantly on each (DistributedRootLinearSystem.C:1436-1464 does the latter).  Tile column j belongs to rank j mod n_ranks; the
+ * owner's panel reaches every rank through the communicator (pips_hip_comm_create / _create_external), every rank ends with the
+ * complete factor and solves locally.  Collective: every rank must call factor with the same matrix.  comm == NULL or n_ranks <= 1
+ * switches it off.  Fused path: PIPS_HIP_ROOT_DISTRIBUTED=1. */
+int pips_hip_dense_ldl_set_distributed(void* handle, void* comm, int rank, int n_ranks);
 /* = DeSymIndefSolver::matrixChanged(): A is the n x n row-major DenseSymmetricMatrix storage (DenseStorage.C:64-83,
  * lower triangle authoritative, lda = n); it is copied to the device and factorised */
 int pips_hip_dense_ldl_factor(void* handle, const double* A_host, int lda);

@@ -2033,6 +2033,12 @@ struct Engine {
 // ---------------------------------------------------------------------------------------------------------------
 // dense root solver (DeSymIndefSolver replacement) on the same tile kernels
 // ---------------------------------------------------------------------------------------------------------------
+extern "C" int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
+
+__global__ void k_inertia_to_double(const int* __restrict__ in, double* __restrict__ out, int back, int* __restrict__ in_out) {
+   if (threadIdx.x < 3) { if (!back) out[threadIdx.x] = (double)in[threadIdx.x]; else in_out[threadIdx.x] = (int)(out[threadIdx.x] + 0.5); }
+}
+
 struct DenseLdl {
    int device = 0, n = 0, npad = 0, n_primal = -1;
    // 0: static pivot order with the expected signs of the inertia hint (right for the quasi-definite Schur complement the fused
@@ -2064,7 +2070,7 @@ struct DenseLdl {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -2118,6 +2124,98 @@ struct DenseLdl {
       return c;
    }
 
+   // ---- distributed factorisation (several ranks, each with the whole reduced Schur complement): tile column j belongs to rank
+   // j mod P (1-D column-cyclic).  The owner factorises the diagonal tile and solves the column's panel, the panel (Winv_j, d_j, L(:, j),
+   // U(:, j)) goes to every rank, and every rank applies it to the tile columns it owns - 1 / P of the S^3 / 3 flops per rank instead
+   // of all of them on every rank (DistributedRootLinearSystem.C:1436-1464 has every rank call dsytrf on the same matrix).  At the
+   // end every rank holds the complete factor, so the solves stay local and replicated.  The panel travels as an all-reduce in which
+   // the other ranks contribute zeros (exact: x + 0): the communicator abstraction has no broadcast yet, which doubles the bytes on
+   // the wire.  NOT TIMED: the GPU box has one device; correctness with 2 and 4 processes sharing it (tests/test_dist_root_gpu.py).
+   void* dist_comm = nullptr;
+   int dist_rank = 0, dist_P = 1;
+   std::vector<TaskList> dist_diag, dist_trsm, dist_upd;
+   TileTask* d_dist_tasks = nullptr;
+   double* d_panel = nullptr;
+   int set_distributed(void* comm, int rank, int P) {
+      if (P <= 1 || !comm) { dist_comm = nullptr; dist_P = 1; return PIPS_OK; }
+      if (rank < 0 || rank >= P) PIPS_FAIL(PIPS_ERR_ARG, "distributed root: rank %d of %d", rank, P);
+      HIP_TRY(hipSetDevice(device));
+      dist_comm = comm; dist_rank = rank; dist_P = P;
+      const int ntc = npad / TILE;
+      std::vector<TileTask> all;
+      dist_diag.assign(ntc, {}); dist_trsm.assign(ntc, {}); dist_upd.assign(ntc, {});
+      for (int j = 0; j < ntc; ++j) {
+         dist_diag[j].off = (long long)all.size();
+         all.push_back({0, j, j, 0});
+         dist_diag[j].cnt = 1;
+         dist_trsm[j].off = (long long)all.size();
+         for (int ti = j + 1; ti < ntc; ++ti) all.push_back({0, ti, j, 0});
+         dist_trsm[j].cnt = (int)((long long)all.size() - dist_trsm[j].off);
+         dist_upd[j].off = (long long)all.size();
+         for (int tk = j + 1; tk < ntc; ++tk)
+            if (tk % P == rank)
+               for (int ti = tk; ti < ntc; ++ti) all.push_back({0, ti, tk, j | ((j + 1) << 16)});   // C(ti, tk) -= L(ti, j) U(tk, j)^T
+         dist_upd[j].cnt = (int)((long long)all.size() - dist_upd[j].off);
+      }
+      if (d_dist_tasks) { (void)hipFree(d_dist_tasks); d_dist_tasks = nullptr; }
+      int rc = dev_upload(&d_dist_tasks, all, stream);
+      if (rc) return rc;
+      if (!d_panel) HIP_TRY(hipMalloc((void**)&d_panel, ((size_t)TILE * TILE + TILE + 8 + 2 * (size_t)npad * TILE) * sizeof(double)));
+      return PIPS_OK;
+   }
+   int factor_distributed() {
+      const TailCtx c = ctx();
+      const int ntc = npad / TILE;
+      const size_t ld_bytes = (size_t)npad * sizeof(double);
+      for (int j = 0; j < ntc; ++j) {
+         const int owner = j % dist_P;
+         const size_t rows = (size_t)npad - (size_t)(j + 1) * TILE;
+         const size_t head = (size_t)TILE * TILE + TILE + 8, count = head + 2 * rows * TILE;
+         double* Lp = d_panel + head;
+         double* Up = Lp + rows * TILE;
+         const size_t col0 = (size_t)(j + 1) * TILE + (size_t)j * TILE * npad;   // first entry below the diagonal tile of column j
+         if (owner == dist_rank) {
+            if (c.bunch_kaufman)
+               hipLaunchKernelGGL(k_tile_diag_bk, dim3(1), dim3(256), 0, stream, d_dist_tasks + dist_diag[j].off, c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_inertia);
+            else
+               hipLaunchKernelGGL(k_tile_diag, dim3(1), dim3(256), 0, stream, d_dist_tasks + dist_diag[j].off, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
+                                  c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
+            if (dist_trsm[j].cnt > 0)
+               hipLaunchKernelGGL(k_tile_gemm<1>, dim3((dist_trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, stream, d_dist_tasks + dist_trsm[j].off, dist_trsm[j].cnt,
+                                  c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+            HIP_TRY(hipMemcpyAsync(d_panel, d_winv + (size_t)j * TILE * TILE, (size_t)TILE * TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_panel + (size_t)TILE * TILE, d_dtail + (size_t)j * TILE, TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemsetAsync(d_panel + (size_t)TILE * TILE + TILE, 0, 8 * sizeof(double), stream));
+            if (rows > 0) {
+               HIP_TRY(hipMemcpy2DAsync(Lp, rows * sizeof(double), d_R + col0, ld_bytes, rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
+               HIP_TRY(hipMemcpy2DAsync(Up, rows * sizeof(double), d_U + col0, ld_bytes, rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
+            }
+         } else
+            HIP_TRY(hipMemsetAsync(d_panel, 0, count * sizeof(double), stream));
+         int rc = pips_hip_allreduce_sum(dist_comm, d_panel, count, stream);
+         if (rc) return rc;
+         if (owner != dist_rank) {
+            HIP_TRY(hipMemcpyAsync(d_winv + (size_t)j * TILE * TILE, d_panel, (size_t)TILE * TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_dtail + (size_t)j * TILE, d_panel + (size_t)TILE * TILE, TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            if (rows > 0) {
+               HIP_TRY(hipMemcpy2DAsync(d_R + col0, ld_bytes, Lp, rows * sizeof(double), rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
+               HIP_TRY(hipMemcpy2DAsync(d_U + col0, ld_bytes, Up, rows * sizeof(double), rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
+            }
+         }
+         if (dist_upd[j].cnt > 0)
+            hipLaunchKernelGGL(k_tile_gemm<3>, dim3((dist_upd[j].cnt + 7) / 8 * 8), dim3(512), 0, stream, d_dist_tasks + dist_upd[j].off, dist_upd[j].cnt, c.d_blks,
+                               c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+      }
+      // every rank counted the pivots of its own diagonal tiles: the sum is the inertia
+      hipLaunchKernelGGL(k_inertia_to_double, dim3(1), dim3(64), 0, stream, d_inertia, d_panel, 0, d_inertia);
+      HIP_TRY(hipMemsetAsync(d_panel + 3, 0, 5 * sizeof(double), stream));
+      int rc = pips_hip_allreduce_sum(dist_comm, d_panel, 8, stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_inertia_to_double, dim3(1), dim3(64), 0, stream, d_inertia, d_panel, 1, d_inertia);
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
+
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)
    // rowmajor = 1: A_dev is row-major (the reference's DenseStorage), 0: column-major; lower triangle authoritative
    int factor_dev(const double* A_dev, int lda, int rowmajor) {
@@ -2129,7 +2227,7 @@ struct DenseLdl {
       hipLaunchKernelGGL(k_block_absmax, dim3(8, 1), dim3(256), 0, stream, d_pref, d_kptr, d_blks);
       hipLaunchKernelGGL(k_block_absmax_finish, dim3(1), dim3(256), 0, stream, d_blks, 1, thr_rel, repl_rel);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, 3 * sizeof(int), stream));
-      int rc = tail_factor(ctx(), nullptr, 0);
+      int rc = dist_P > 1 ? factor_distributed() : tail_factor(ctx(), nullptr, 0);
       if (rc) return rc;
       factored = true;
       return PIPS_OK;
@@ -2813,6 +2911,13 @@ int pips_hip_dense_ldl_create(void** handle, int n, int n_primal, int device) {
    return PIPS_OK;
 }
 
+int pips_hip_dense_ldl_set_distributed(void* handle, void* comm, int rank, int n_ranks) {
+   DenseLdl* d = (DenseLdl*)handle;
+   if (!d) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   d->factored = false;
+   return d->set_distributed(comm, rank, n_ranks);
+}
+
 int pips_hip_dense_ldl_set_pivoting(void* handle, int mode) {
    DenseLdl* d = (DenseLdl*)handle;
    if (!d || mode < 0 || mode > 1) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_dense_ldl_set_pivoting: mode 0 (static order) or 1 (Bunch-Kaufman inside the diagonal tiles)");
@@ -2929,6 +3034,9 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) { k->root->pivoting = atoi(pv) != 0; k->root_pivoting_set = true; }
    int rc = k->root->init();
    if (rc) return rc;
+   // several ranks: the dense root factorised column-cyclically over the ranks instead of redundantly on every one of them
+   // (PIPS_HIP_ROOT_DISTRIBUTED=1; untimed - see DenseLdl::set_distributed)
+   if (comm && n_ranks > 1 && getenv("PIPS_HIP_ROOT_DISTRIBUTED") && atoi(getenv("PIPS_HIP_ROOT_DISTRIBUTED")) != 0 && (rc = k->root->set_distributed(comm, rank, n_ranks))) return rc;
    HIP_TRY(hipMalloc((void**)&k->d_SC, (size_t)S * S * sizeof(double)));
    HIP_TRY(hipMalloc((void**)&k->d_t, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
    // constant root blocks added by finalizeKKTdense: A0 at row n0, F0 at row n0+my0, G0 at row n0+my0+myl
@@ -3233,7 +3341,8 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
                          k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
    tm.end(e->stream);
-   static const bool root_async = !getenv("PIPS_HIP_ROOT_SYNC");
+   static const bool root_async_env = !getenv("PIPS_HIP_ROOT_SYNC");
+   const bool root_async = root_async_env && k->root->dist_P <= 1;   // the distributed root issues collectives: main stream
    if (!root_async) {
       tm.begin(e->stream, 4);
       rc = k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)

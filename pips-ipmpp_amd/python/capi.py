@@ -49,7 +49,7 @@ SYMBOLS = [
     "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
     "pips_hip_ldl_get_perm", "pips_hip_ldl_set_border", "pips_hip_ldl_factor_schur", "pips_hip_ldl_destroy",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
-    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_destroy",
+    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_set_distributed", "pips_hip_dense_ldl_destroy",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
     "pips_hip_batch_last_refinement_steps", "pips_hip_batch_set_refinement_backward_error",
     "pips_hip_batch_last_refinement_measure", "pips_hip_batch_analyze",
@@ -313,6 +313,12 @@ class HipDenseLdlSolver:
     def set_pivoting(self, mode):
         """0: static pivot order (needs the inertia hint), 1: Bunch-Kaufman 1 x 1 / 2 x 2 pivots inside the diagonal tiles."""
         _check(lib.pips_hip_dense_ldl_set_pivoting(self._h, C.c_int(mode)), "pips_hip_dense_ldl_set_pivoting")
+
+    def set_distributed(self, comm, rank, n_ranks):
+        """Column-cyclic factorisation over the ranks of `comm` (Comm / ExternalComm); every rank calls matrixChanged with the same matrix."""
+        self._comm = comm
+        _check(lib.pips_hip_dense_ldl_set_distributed(self._h, comm._h if comm is not None else None, C.c_int(rank), C.c_int(n_ranks)),
+               "pips_hip_dense_ldl_set_distributed")
 
     def matrixChanged(self, A_rowmajor_lower):
         A = _f64(A_rowmajor_lower)

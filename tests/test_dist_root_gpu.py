@@ -1,0 +1,77 @@
+"""Dense root factorised column-cyclically over the ranks (pips_hip_dense_ldl_set_distributed / PIPS_HIP_ROOT_DISTRIBUTED=1) instead of
+redundantly on every rank (DistributedRootLinearSystem.C:1436-1464): 2 and 4 processes share device 0, the panels travel through a
+host-staged gloo all-reduce behind the external-communicator callback.  Every rank must end with the complete factor: solutions
+equal LAPACK's dsytrf / dsytrs on every rank, the inertia is the sum of the ranks' pivot counts.  Both pivoting modes.
+No timing exists for this: the GPU box has one device."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pips_ipmpp_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrix(n0, m, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, n0)) * (rng.random((m, n0)) < 0.3)
+    A[np.arange(m), rng.permutation(n0)[:m]] += 2.0
+    H = rng.standard_normal((n0, n0)) * 0.05
+    M = np.block([[np.diag(10.0 ** rng.uniform(-2, 2, n0)) + H @ H.T, A.T], [A, -1e-6 * np.eye(m)]])
+    return M, rng.standard_normal((n0 + m, 2))
+
+
+def _worker(rank, world, port, out, n0, m, pivoting):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    M, B = _matrix(n0, m, 17)
+    calls = []
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        torch.cuda.synchronize()
+        calls.append(n)
+
+    comm = pa.ExternalComm(allreduce, n_ranks=world, rank=rank)
+    s = pa.HipDenseLdlSolver(n0 + m, n_primal=n0)
+    s.set_pivoting(pivoting)
+    s.set_distributed(comm, rank, world)
+    for _ in range(2):                           # twice: buffers are reused
+        calls.clear()
+        s.matrixChanged(np.ascontiguousarray(np.tril(M)))
+    X = np.ascontiguousarray(B.T.copy())
+    s.solve(X)
+    np.savez(os.path.join(out, f"rank{rank}.npz"), X=X.T, inertia=np.array(s.get_inertia()), n_calls=len(calls))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n0,m,pivoting", [(2, 600, 400, 0), (2, 600, 400, 1), (4, 700, 330, 0), (4, 300, 90, 1)])
+def test_column_cyclic_root_matches_lapack_on_every_rank(tmp_path, world, n0, m, pivoting):
+    port = 29500 + (os.getpid() % 2000) + 57 + 11 * world + pivoting
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), n0, m, pivoting), nprocs=world, join=True, start_method="spawn")
+    M, B = _matrix(n0, m, 17)
+    ldu, ipiv, info = sla.lapack.dsytrf(M, lower=1)
+    Xl, info = sla.lapack.dsytrs(ldu, ipiv, B, lower=1)
+    n_tiles = (n0 + m + 127) // 128
+    first = None
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert tuple(g["inertia"]) == (n0, m, 0), g["inertia"]
+        assert np.linalg.norm(g["X"] - Xl) / np.linalg.norm(Xl) < 1e-8
+        assert np.linalg.norm(M @ g["X"] - B) / np.linalg.norm(B) < 1e-10
+        assert int(g["n_calls"]) == n_tiles + 1            # one panel per tile column + the inertia counts
+        if first is None:
+            first = g["X"]
+        else:
+            assert np.array_equal(first, g["X"])           # the same factor on every rank

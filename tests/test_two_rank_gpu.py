@@ -30,6 +30,9 @@ def _make_problem(sparse_root):
 def _worker(rank, world, port, out, sparse_root):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if sparse_root == "distributed":     # dense root factorised column-cyclically over the two ranks (DenseLdl::set_distributed)
+        os.environ["PIPS_HIP_ROOT_DISTRIBUTED"] = "1"
+        sparse_root = False
     dist.init_process_group("gloo", rank=rank, world_size=world)
     prob = _make_problem(sparse_root)
     mine = np.nonzero(pa.map_children_to_ranks(prob.N, world) == rank)[0]
@@ -74,11 +77,13 @@ def _worker(rank, world, port, out, sparse_root):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sparse_root", [False, True], ids=["dense_root", "sparse_root"])
+@pytest.mark.parametrize("sparse_root", [False, True, "distributed"], ids=["dense_root", "sparse_root", "distributed_dense_root"])
 def test_two_processes_share_one_gpu(tmp_path, sparse_root):
     world = 2
     port = 29500 + (os.getpid() % 2000) + (7 if sparse_root else 0)
     mp.start_processes(_worker, args=(world, port, str(tmp_path), sparse_root), nprocs=world, join=True, start_method="spawn")
+    distributed = sparse_root == "distributed"
+    sparse_root = sparse_root is True
     prob = _make_problem(sparse_root)
     S = prob.S
     SC1 = np.tril(prob.oracle_finalize(prob.oracle_schur()))
@@ -92,7 +97,8 @@ def test_two_processes_share_one_gpu(tmp_path, sparse_root):
     seen = []
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
-        assert len(g["calls"]) == 2 and g["calls"][1] == S          # Schur complement (packed triangle / CSR values), then b0
+        # Schur complement (packed triangle / CSR values), then b0; the distributed root adds one panel per tile column + the inertia counts
+        assert len(g["calls"]) == 2 + (((S + 127) // 128 + 1) if distributed else 0) and g["calls"][-1] == S
         if not sparse_root:
             assert g["calls"][0] == S * (S + 1) // 2
         assert np.abs(g["SC"] - SC1).max() / np.abs(SC1).max() < 1e-9
