@@ -229,8 +229,10 @@ struct SweepRt {
       enabled = n_tasks > 0 && !getenv("PIPS_HIP_SWEEP_LAUNCHES");
       return PIPS_OK;
    }
-   SweepArgs args(long long xw_stride) {
-      return SweepArgs{d_tasks, n_tasks, d_ints, d_ints + 2 * SWEEP_NRHS_MAX + 2, d_flag_off, d_tfirst, d_tfirst_off, ++epoch,
+   SweepArgs args(long long xw_stride, hipStream_t st) {
+      int* ep = d_ints + 2 * SWEEP_NRHS_MAX + 1;
+      hipLaunchKernelGGL(k_sweep_bump, dim3(1), dim3(1), 0, st, ep);
+      return SweepArgs{d_tasks, n_tasks, d_ints, d_ints + 2 * SWEEP_NRHS_MAX + 2, d_flag_off, d_tfirst, d_tfirst_off, ep,
                        d_ints + 2 * SWEEP_NRHS_MAX, n_flags, xw_stride, poll_limit};
    }
    void release() {
@@ -492,7 +494,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
 static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0) {
    const TailPlan& p = *c.plan;
    if (c.sweep && c.sweep->enabled && nrhs <= SWEEP_NRHS_MAX) {
-      hipLaunchKernelGGL(k_tail_rows_fwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride), c.d_blks, c.d_arena, c.d_dtail,
+      hipLaunchKernelGGL(k_tail_rows_fwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride, c.stream), c.d_blks, c.d_arena, c.d_dtail,
                          c.d_winv, xw);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
@@ -509,7 +511,7 @@ static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_str
    const TailPlan& p = *c.plan;
    if (border && !(c.sweep && c.sweep->enabled)) PIPS_FAIL(PIPS_ERR_STATE, "border-backward sweep needs the single-launch tail sweeps");
    if (c.sweep && c.sweep->enabled && nrhs <= SWEEP_NRHS_MAX) {
-      hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride), c.d_blks, c.d_arena, c.d_dtail,
+      hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride, c.stream), c.d_blks, c.d_arena, c.d_dtail,
                          c.d_winv, xw, border);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
@@ -2283,6 +2285,12 @@ struct KktSystem {
    }
    size_t packed_cap = 0;
    bool use_rsag = false, force_reduce = false;
+   bool solve_graph = false;                // pips_hip_kkt_set_solve_graph
+   hipGraphExec_t graph_exec = nullptr;
+   hipStream_t graph_stream = nullptr;
+   double *graph_b0 = nullptr, *graph_bl = nullptr;
+   bool graph_from_factor = false;
+   long long graph_captures = 0, graph_replays = 0;
    bool last_ltsolve_from_factor = false;   // which Ltsolve the last solveCompressed took (reported per solve, not only at analyze time)
    bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
@@ -2298,6 +2306,8 @@ struct KktSystem {
    long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
    int* d_sc_rowptr = nullptr;
    ~KktSystem() {
+      if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+      if (graph_stream) (void)hipStreamDestroy(graph_stream);
       if (root_stream) { (void)hipStreamSynchronize(root_stream); (void)hipStreamDestroy(root_stream); }
       if (ev_sc_final) (void)hipEventDestroy(ev_sc_final);
       if (ev_root_done) (void)hipEventDestroy(ev_root_done);
@@ -3032,6 +3042,7 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    k->root->thr_rel = e->thr_rel;
    k->root->repl_rel = e->repl_rel;
    if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) { k->root->pivoting = atoi(pv) != 0; k->root_pivoting_set = true; }
+   if (const char* sg = getenv("PIPS_HIP_SOLVE_GRAPH")) k->solve_graph = atoi(sg) != 0;
    int rc = k->root->init();
    if (rc) return rc;
    // several ranks: the dense root factorised column-cyclically over the ranks instead of redundantly on every one of them
@@ -3377,11 +3388,9 @@ int pips_hip_kkt_set_root_regularization(void* handle, double primal, double dua
    return PIPS_OK;
 }
 
-int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev) {
-   KktSystem* k = (KktSystem*)handle;
-   if (!k || !b0_dev || !b_leaf_dev) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_solve_compressed: bad arguments");
+// the launch sequence of one solveCompressed; `capturing`: inside a stream capture (no host-side decisions, no waits on events recorded outside)
+static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_leaf_dev, bool capturing) {
    Engine* e = k->leaves;
-   HIP_TRY(hipSetDevice(e->device));
    int rc;
    // with mz0 > 0 the caller's vector is [x0 | y0 | z0 | ylink | zlink]; the Schur system lives on the reduced vector
    // [x0 | y0 | ylink | zlink] (solveReducedLinkCons, sLinsysRootAug.C:397-433)
@@ -3428,7 +3437,7 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    if (k->sparse) {
       if ((rc = k->root_sp->solve(red))) return rc;
    } else {
-      if ((rc = k->root_wait())) return rc;
+      if (!capturing && (rc = k->root_wait())) return rc;   // (a captured sequence: joined before the capture began)
       if ((rc = k->root->solve_dev(red))) return rc;
    }
    if (k->mz0 > 0) {
@@ -3446,10 +3455,12 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    // counters reached pinned memory with the factorisation: no wait for the solves queued behind it) AND, with adaptive refinement,
    // the refined leaf solve of this call's Lsolve - same factors - was satisfied by its first solve (backward error below the
    // tolerance without a step).  A pivot that kept its sign but is rounding noise passes the first test, not the second.
-   int pert = 1;
-   if (e->border_backward_ok && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
-   const bool lsolve_clean = e->refine_tol > 0.0 ? e->last_refine_steps == 0 : true;
-   k->last_ltsolve_from_factor = e->border_backward_ok && !k->sparse && pert == 0 && lsolve_clean;
+   if (!capturing) {
+      int pert = 1;
+      if (e->border_backward_ok && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
+      const bool lsolve_clean = e->refine_tol > 0.0 ? e->last_refine_steps == 0 : true;
+      k->last_ltsolve_from_factor = e->border_backward_ok && !k->sparse && pert == 0 && lsolve_clean;
+   }
    if (k->last_ltsolve_from_factor) {
       if ((rc = e->solve_border_backward(red, k->d_t))) return rc;
    } else {
@@ -3462,6 +3473,74 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    k->timer.end(e->stream);
    HIP_TRY(hipGetLastError());
+   return PIPS_OK;
+}
+
+// solveCompressed as a replayed HIP graph (pips_hip_kkt_set_solve_graph / PIPS_HIP_SOLVE_GRAPH=1): the launch sequence of one call is
+// fixed between factorisations - dozens of launches on a launch-bound problem (configs[0]: ~50 kernels of a few microseconds each) -
+// so it is captured once per (right-hand-side pointers, Ltsolve path) and replayed.  What a capture cannot contain keeps the
+// direct path: adaptive refinement (it reads norms on the host between steps), reductions over several ranks, the sparse root,
+// deterministic mode, phase timing.  The single-launch sweeps take their epoch from device memory for this (k_sweep_bump).
+static bool kkt_graph_eligible(const KktSystem* k) {
+   const Engine* e = k->leaves;
+   return k->solve_graph && !k->sparse && k->n_ranks <= 1 && !k->force_reduce && e->refine_tol == 0.0 && !e->deterministic && !e->timer.on &&
+          !k->timer.on && !(e->mf_solves);
+}
+
+int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || !b0_dev || !b_leaf_dev) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_solve_compressed: bad arguments");
+   Engine* e = k->leaves;
+   HIP_TRY(hipSetDevice(e->device));
+   if (!kkt_graph_eligible(k)) return kkt_solve_compressed_enqueue(k, b0_dev, b_leaf_dev, false);
+   int rc;
+   // host-side decisions and joins first: they are part of the key, not of the graph
+   if ((rc = k->root_wait())) return rc;
+   int pert = 1;
+   if (e->border_backward_ok && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
+   k->last_ltsolve_from_factor = e->border_backward_ok && pert == 0;
+   if (k->graph_exec && (k->graph_b0 != b0_dev || k->graph_bl != b_leaf_dev || k->graph_from_factor != k->last_ltsolve_from_factor)) {
+      (void)hipGraphExecDestroy(k->graph_exec);
+      k->graph_exec = nullptr;
+   }
+   if (!k->graph_exec) {
+      // The capture runs on a stream of its own (the handle's stream may be the legacy default stream, which cannot be captured):
+      // the engine's and the root's stream members point there for the duration of the enqueue; the graph is then launched into the
+      // handle's own stream like any other work.
+      if (!k->graph_stream) HIP_TRY(hipStreamCreateWithFlags(&k->graph_stream, hipStreamNonBlocking));
+      hipGraph_t g = nullptr;
+      hipStream_t keep_e = e->stream, keep_r = k->root->stream;
+      e->stream = k->graph_stream; k->root->stream = k->graph_stream;
+      hipError_t eb = hipStreamBeginCapture(k->graph_stream, hipStreamCaptureModeRelaxed);
+      rc = eb == hipSuccess ? kkt_solve_compressed_enqueue(k, b0_dev, b_leaf_dev, true) : PIPS_OK;
+      const hipError_t ec = eb == hipSuccess ? hipStreamEndCapture(k->graph_stream, &g) : eb;
+      e->stream = keep_e; k->root->stream = keep_r;
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      if (ec != hipSuccess || !g) PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_kkt_solve_compressed: stream capture failed: %s", hipGetErrorString(ec));
+      const hipError_t ei = hipGraphInstantiate(&k->graph_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ei != hipSuccess) { k->graph_exec = nullptr; PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_kkt_solve_compressed: hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+      k->graph_b0 = b0_dev; k->graph_bl = b_leaf_dev; k->graph_from_factor = k->last_ltsolve_from_factor;
+      ++k->graph_captures;
+   }
+   HIP_TRY(hipGraphLaunch(k->graph_exec, e->stream));
+   ++k->graph_replays;
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_set_solve_graph(void* handle, int on) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   k->solve_graph = on != 0;
+   if (!on && k->graph_exec) { (void)hipGraphExecDestroy(k->graph_exec); k->graph_exec = nullptr; }
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_solve_graph_stats(void* handle, int64_t* captures, int64_t* replays) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (captures) *captures = k->graph_captures;
+   if (replays) *replays = k->graph_replays;
    return PIPS_OK;
 }
 

@@ -2289,7 +2289,8 @@ struct SweepArgs {
    const long long* flag_off;    // per block
    const int* tfirst;            // per (block, tile row): first tile column inside the envelope; nullptr = 0
    const long long* tfirst_off;
-   int epoch;
+   const int* epoch_ptr;         // the sweep's epoch lives in device memory (bumped by k_sweep_bump before every sweep): a captured
+                                 // launch sequence can be replayed, which a value baked into the kernel arguments would forbid
    int* err;
    // several right-hand sides: blockIdx.y = right-hand side, each with its own tickets (2 ints), flags and work vector
    long long flag_stride, xw_stride;
@@ -2297,6 +2298,8 @@ struct SweepArgs {
 };
 constexpr long long SWEEP_POLL_LIMIT = 4000000;   // ~5 s of polling (4e6 polls): three orders of magnitude above the longest legitimate wait
 constexpr int SWEEP_NRHS_MAX = 32;
+
+__global__ void k_sweep_bump(int* epoch) { *epoch += 1; }
 
 __device__ __forceinline__ bool sweep_wait(const int* f, int epoch, long long poll_limit = SWEEP_POLL_LIMIT) {
    // No agent-scope fence anywhere in the sweeps: an acquire invalidates and a release writes back the whole L2 of the XCD,
@@ -2347,6 +2350,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDes
    __shared__ double v[TILE];
    __shared__ double part[TILE];
    __shared__ int sh_t, sh_ok;
+   const int epoch = *a.epoch_ptr;
    const int t = sweep_ticket(a, &sh_t);
    const TileTask task = a.tasks[t];
    const BlkDesc bd = blks[task.blk];
@@ -2361,7 +2365,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDes
    if (j0 < i) {
       tile_load_half(m, Lrow + (long long)j0 * TILE * ld, ld, row, half);
       for (int j = j0;; ++j) {
-         if (tid == 0) sh_ok = sweep_wait(fl + j, a.epoch, a.poll_limit) ? 1 : 0;
+         if (tid == 0) sh_ok = sweep_wait(fl + j, epoch, a.poll_limit) ? 1 : 0;
          __syncthreads();
          if (!sh_ok) { ok = false; break; }
          if (tid < TILE) v[tid] = sweep_load(xt + j * TILE + tid) * dtail[bd.dt_off + j * TILE + tid];
@@ -2391,7 +2395,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_fwd(SweepArgs a, const BlkDes
       if (tid == 0) *a.err = 1;
    }
    if (half == 0) sweep_store(xt + i * TILE + row, acc);
-   sweep_publish(fl + i, a.epoch);
+   sweep_publish(fl + i, epoch);
    sweep_done(a);
 }
 
@@ -2404,6 +2408,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
    __shared__ double v[TILE];
    __shared__ double outp[TILE];
    __shared__ int sh_t, sh_ok;
+   const int epoch = *a.epoch_ptr;
    const int t = sweep_ticket(a, &sh_t);
    const TileTask task = a.tasks[a.n_tasks - 1 - t];   // last tile column first
    const BlkDesc bd = blks[task.blk];
@@ -2426,7 +2431,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
       tile_tload(m, Lcol + (long long)k * TILE, ld, tid);
       for (;;) {
          if (k < bd.ntc) {
-            if (tid == 0) sh_ok = sweep_wait(fl + k, a.epoch, a.poll_limit) ? 1 : 0;
+            if (tid == 0) sh_ok = sweep_wait(fl + k, epoch, a.poll_limit) ? 1 : 0;
             __syncthreads();
             if (!sh_ok) { ok = false; break; }
             if (tid < TILE) v[tid] = sweep_load(xt + k * TILE + tid);
@@ -2458,7 +2463,7 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
       if (tid == 0) *a.err = 1;
    }
    if (tid < TILE) sweep_store(xt + i * TILE + tid, acc);
-   sweep_publish(fl + i, a.epoch);
+   sweep_publish(fl + i, epoch);
    sweep_done(a);
 }
 
