@@ -635,6 +635,14 @@ struct Engine {
              *d_perm_off = nullptr, *d_rowbase = nullptr, *d_bt_xoff = nullptr;
    SnDesc* d_sns = nullptr;
    BlkDesc* d_blks = nullptr;
+   // Forward substitution of the simple leaves as a gather (k_leaf_fwd_gather): the leaves' L entries by TARGET row - row list,
+   // row pointers, source (the leaf's position in the work vector), values (written in this order by k_head_factor_simple through
+   // d_lf_pos, which is indexed like d_rowidx).  No atomics, fixed order of the sums.
+   int *d_lf_rows = nullptr, *d_lf_ptr = nullptr, *d_lf_src = nullptr, *d_lf_pos = nullptr;
+   double* d_lf_val = nullptr;
+   long long lf_rows = 0, lf_entries = 0;
+   LeafDesc* d_leafdesc = nullptr;   // compact records of the level-0 simple leaves, in the order of d_sns (k_leaf_bwd)
+   int head_wcap = HEAD_WMAX;   // widest head supernode of this analysis (picks the register-lean variants of the chain kernels)
    int *d_rowidx = nullptr, *d_upd = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr, *d_nprimal = nullptr;
    int *d_krowptr = nullptr, *d_kcolidx = nullptr, *d_bt_rowptr = nullptr, *d_bt_colidx = nullptr, *d_bt_rowsc = nullptr;
    signed char* d_psign = nullptr;
@@ -650,6 +658,17 @@ struct Engine {
    void release() {
       if (d_uarena) (void)hipFree(d_uarena);
       d_uarena = nullptr;
+      // the row-panel groups of the Schur SYRK belong to the analysis they were cut for (set_sc_panels)
+      for (auto ev : ev_sc) (void)hipEventDestroy(ev);
+      ev_sc.clear(); sc_groups.clear(); sc_row_begin.clear();
+      if (d_sc_tasks) (void)hipFree(d_sc_tasks);
+      d_sc_tasks = nullptr;
+      for (void* q : {(void*)d_lf_rows, (void*)d_lf_ptr, (void*)d_lf_src, (void*)d_lf_pos, (void*)d_lf_val})
+         if (q) (void)hipFree(q);
+      d_lf_rows = d_lf_ptr = d_lf_src = d_lf_pos = nullptr; d_lf_val = nullptr;
+      if (d_leafdesc) (void)hipFree(d_leafdesc);
+      d_leafdesc = nullptr;
+      lf_rows = 0; lf_entries = 0;
       if (d_mfU) (void)hipFree(d_mfU);
       if (d_mfLV) (void)hipFree(d_mfLV);
       if (d_mfV) (void)hipFree(d_mfV);
@@ -1088,9 +1107,11 @@ struct Engine {
       for (int b = 0; b < nblk; ++b) sorted_id[b].resize(sym[b].sn.size());
       levels.assign(lstar, LevelRange{0, 0, 0, 0, 0, 0, 0, 0});
       levels_top.assign(nlev - lstar, LevelRange{0, 0, 0, 0, 0, 0, 0, 0});
+      head_wcap = 1;
       for (int i = 0; i < nsn_total; ++i) {
          const Key& k = keys[i];
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
+         head_wcap = std::max(head_wcap, s.w);
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
                            s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1};
          if (mf && k.cls > 0 && s.r > 0 && sym[k.blk].sn_parent[k.loc] < 0) roots_of[k.blk].push_back(i);
@@ -1298,6 +1319,59 @@ struct Engine {
       if ((rc = dev_upload(&d_sns, h_sns, stream))) return rc;
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
       if ((rc = dev_upload(&d_rowidx, h_rowidx, stream))) return rc;
+      // ---- the simple leaves' L entries by target row (forward substitution as a gather, see d_lf_rows)
+      {
+         const char* env = getenv("PIPS_HIP_LEAF_GATHER");
+         const bool want = env ? atoi(env) != 0 : true;
+         const LevelRange* L0 = levels.empty() ? nullptr : &levels[0];
+         if (want && L0 && L0->simple_cnt > 0 && xw_total < (1LL << 31) && h_rowidx.size() < (1ull << 31)) {
+            std::vector<LeafDesc> h_leaf((size_t)L0->simple_cnt);
+            for (int i = 0; i < L0->simple_cnt; ++i) {
+               const SnDesc& sn = h_sns[L0->simple_begin + i];
+               const BlkDesc& bd = h_blks[sn.blk];
+               int r_in = 0;
+               while (r_in < sn.r && h_rowidx[sn.rows + r_in] < bd.n) ++r_in;
+               h_leaf[i] = LeafDesc{sn.panel, (int)sn.rows, (int)bd.xw_off, sn.c0, r_in};
+            }
+            if ((rc = dev_upload(&d_leafdesc, h_leaf, stream))) return rc;
+            std::vector<int> cnt((size_t)xw_total + 1, 0);
+            long long nent = 0;
+            for (int i = L0->simple_begin; i < L0->simple_begin + L0->simple_cnt; ++i) {
+               const SnDesc& sn = h_sns[i];
+               const BlkDesc& bd = h_blks[sn.blk];
+               for (int a = 0; a < sn.r; ++a) {
+                  const int ra = h_rowidx[sn.rows + a];
+                  if (ra >= bd.n) break;
+                  ++cnt[bd.xw_off + ra];
+                  ++nent;
+               }
+            }
+            if (nent > 0 && nent < (1LL << 31)) {
+               std::vector<int> h_rows, h_ptr(1, 0), h_src((size_t)nent), h_pos(h_rowidx.size(), -1);
+               std::vector<int> slot((size_t)xw_total, -1);   // target row -> its index in the compact list
+               for (long long t = 0; t < xw_total; ++t)
+                  if (cnt[t] > 0) { slot[t] = (int)h_rows.size(); h_rows.push_back((int)t); h_ptr.push_back(h_ptr.back() + cnt[t]); }
+               std::vector<int> fill(h_ptr.begin(), h_ptr.end() - 1);
+               for (int i = L0->simple_begin; i < L0->simple_begin + L0->simple_cnt; ++i) {   // ascending leaves: the order of every sum
+                  const SnDesc& sn = h_sns[i];
+                  const BlkDesc& bd = h_blks[sn.blk];
+                  for (int a = 0; a < sn.r; ++a) {
+                     const int ra = h_rowidx[sn.rows + a];
+                     if (ra >= bd.n) break;
+                     const int q = fill[slot[bd.xw_off + ra]]++;
+                     h_src[q] = (int)(bd.xw_off + sn.c0);
+                     h_pos[sn.rows + a] = q;
+                  }
+               }
+               lf_rows = (long long)h_rows.size(); lf_entries = nent;
+               if ((rc = dev_upload(&d_lf_rows, h_rows, stream))) return rc;
+               if ((rc = dev_upload(&d_lf_ptr, h_ptr, stream))) return rc;
+               if ((rc = dev_upload(&d_lf_src, h_src, stream))) return rc;
+               if ((rc = dev_upload(&d_lf_pos, h_pos, stream))) return rc;
+               HIP_TRY(hipMalloc((void**)&d_lf_val, (size_t)nent * sizeof(double)));
+            }
+         }
+      }
       if ((rc = dev_upload(&d_upd, h_upd, stream))) return rc;
       if ((rc = dev_upload(&d_spine, h_spine, stream))) return rc;
       if ((rc = dev_upload(&d_spine_off, h_spine_off, stream))) return rc;
@@ -1371,7 +1445,7 @@ struct Engine {
       if (L.simple_cnt > 0)
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
                             L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
-                            mf ? 1 : 0, d_mfLV);
+                            mf ? 1 : 0, d_mfLV, d_lf_pos, d_lf_val);
       if (mf) return;
       if (L.small_cnt > 0)
          hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), (size_t)std::max(L.small_lds, 1) * sizeof(double), stream, d_sns,
@@ -1738,7 +1812,10 @@ struct Engine {
          }
       } else
       for (const LevelRange& L : levels) {
-         if (L.simple_cnt > 0)
+         if (L.simple_cnt > 0 && lf_rows > 0)   // the leaves' columns are final as they stand: every target row collects its sum
+            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), nrhs), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
+                               d_lf_val, xw, xws, (int)lf_rows);
+         else if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
                                L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 0);
          // small and large supernodes of one level are contiguous in d_sns
@@ -1746,7 +1823,8 @@ struct Engine {
          const int cnt = L.small_cnt + L.large_cnt;
          // few supernodes in the launch: a chain-like tree, take the latency-lean kernel; many: the high-occupancy one
          if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX)
-            hipLaunchKernelGGL(k_head_fwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
+            hipLaunchKernelGGL(head_wcap <= 16 ? k_head_fwd_chain<16> : k_head_fwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
+                               d_blks, d_rowidx, d_arena, xw, xws);
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_fwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
@@ -1790,10 +1868,14 @@ struct Engine {
          const int cnt = L.small_cnt + L.large_cnt;
          // (deterministic mode: always the same kernel, whatever the batch size - the two variants add in different orders)
          if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX && !deterministic)
-            hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws, 0, fused_d ? 1 : 0);
+            hipLaunchKernelGGL(head_wcap <= 16 ? k_head_bwd_chain<16> : k_head_bwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
+                               d_blks, d_rowidx, d_arena, xw, xws, 0, fused_d ? 1 : 0);
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
-         if (L.simple_cnt > 0)
+         if (L.simple_cnt > 0 && d_leafdesc)
+            hipLaunchKernelGGL(k_leaf_bwd, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_leafdesc, L.simple_cnt, d_rowidx, d_arena,
+                               xw, xws, fused_d ? 1 : 0);
+         else if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
                                L.simple_cnt, d_blks, d_rowidx, d_arena, xw, xws, 1, sx_atomic(), 0, 0, fused_d ? 1 : 0);
       }
@@ -1889,7 +1971,7 @@ struct Engine {
             HIP_TRY(hipMemcpy2DAsync(d_mx_xw, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
                                      (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
             // (d_mx_xw is free between solves; it is at least nr * n_total long because xw_total >= n_total)
-            hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256), nr), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
+            hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total * 8, 256, 65536), nr), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                                d_mx_xw, d_mx_res, n_total, d_rowbase, n_total);
             if (n_flong > 0)
                hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong, nr), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval,
@@ -1922,7 +2004,7 @@ struct Engine {
       for (int it = 0; it < refine_steps; ++it) {
          timer.begin(stream, 11);
          HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
-         hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
+         hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total * 8, 256, 65536)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
                             x_dev, d_res, n_total, d_rowbase, 0LL);
          if (n_flong > 0)
             hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev,
@@ -2019,7 +2101,8 @@ struct Engine {
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
          if (cnt > 0 && (long long)cnt < CHAIN_LAUNCH_MAX)
-            hipLaunchKernelGGL(k_head_bwd_chain, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1);
+            hipLaunchKernelGGL(head_wcap <= 16 ? k_head_bwd_chain<16> : k_head_bwd_chain<HEAD_WMAX>, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin,
+                               d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, 0);
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_bwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1);
          if (L.simple_cnt > 0)

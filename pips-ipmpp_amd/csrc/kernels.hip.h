@@ -478,7 +478,8 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                                                            int* __restrict__ inertia, const double* __restrict__ pref,
                                                            const int* __restrict__ sctab,
                                                            ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int mf = 0,
-                                                           double* __restrict__ lvals = nullptr) {
+                                                           double* __restrict__ lvals = nullptr, const int* __restrict__ lfpos = nullptr,
+                                                           double* __restrict__ lfval = nullptr) {
    __shared__ int cnt_s[3];
    __shared__ int blk_s;
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,6 +502,12 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
 #pragma unroll
       for (int a = 0; a < SIMPLE_RMAX; ++a)
          if (a < r) { ro[a] = rows[a]; l[a] = P[1 + a] / d; P[1 + a] = l[a]; }
+      if (lfpos) {   // ... and once more in the order the forward gather reads them (k_leaf_fwd_gather)
+         const int* lp = lfpos + sn.rows;
+#pragma unroll
+         for (int a = 0; a < SIMPLE_RMAX; ++a)
+            if (a < r && ro[a] < bd.n) lfval[lp[a]] = l[a];
+      }
       double* T = arena + bd.T;
       const int* bm = bmap + bd.bmap_off;
       const int n = bd.n, n_head = bd.n_head;
@@ -1071,6 +1078,49 @@ __global__ __launch_bounds__(64) void k_front_bwd(const SnDesc* __restrict__ sns
 
 
 // forward / backward substitution for the simple leaves: y = b_c (unit pivot block); b[rows] -= l y   /   x_c = z_c - l^T x[rows]
+// Forward substitution of all simple leaves at once, from the side of the rows they update: row rows[t] of the work vector loses
+// sum_p val[p] * x[src[p]] over the leaves p in [ptr[t], ptr[t + 1]) that have an entry in it (ascending leaves: a fixed order).
+// The leaves' own entries are final on entry (no column below them), and no leaf column is a target - reads and writes are disjoint.
+__global__ __launch_bounds__(256) void k_leaf_fwd_gather(const int* __restrict__ rows, const int* __restrict__ ptr, const int* __restrict__ src,
+                                                         const double* __restrict__ val, double* __restrict__ xw, long long xw_stride, int n) {
+   // eight lanes per row (a row holds eight or nine entries on the time-coupled blocks): consecutive rows are consecutive in val / src,
+   // so a wave reads one contiguous piece of both
+   const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7;
+   double* x = xw + xw_stride * blockIdx.y;
+   double s = 0.0;
+   if (t < n) {
+      const int p1 = ptr[t + 1];
+      for (int p = ptr[t] + l; p < p1; p += 8) s += val[p] * x[src[p]];
+   }
+   s += __shfl_xor(s, 1);
+   s += __shfl_xor(s, 2);
+   s += __shfl_xor(s, 4);
+   if (t < n && l == 0) x[rows[t]] -= s;
+}
+
+// Backward substitution of the simple leaves from a compact record (24 bytes instead of the 88-byte SnDesc + BlkDesc the general
+// kernel reads - on the time-coupled blocks the descriptors were most of this kernel's traffic): x_c = x_c / d - sum_a l_a x[rows_a]
+struct LeafDesc {
+   long long panel;   // d, l_0 .. l_{r-1} in the arena
+   int rows;          // offset into rowidx
+   int xoff;          // the block's offset in the work vector
+   int c0;            // the leaf's column (block-local, permuted)
+   int r_in;          // rows inside the block (the border rows behind them take no part in solves with K_i)
+};
+
+__global__ __launch_bounds__(256) void k_leaf_bwd(const LeafDesc* __restrict__ leaves, int cnt, const int* __restrict__ rowidx,
+                                                  const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride, int dscale) {
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= cnt) return;
+   const LeafDesc lf = leaves[t];
+   const double* P = arena + lf.panel;
+   const int* rows = rowidx + lf.rows;
+   double* xb = xw + xw_stride * blockIdx.y + lf.xoff;
+   double s = 0.0;
+   for (int a = 0; a < lf.r_in; ++a) s += P[1 + a] * xb[rows[a]];
+   xb[lf.c0] = (dscale ? xb[lf.c0] / P[0] : xb[lf.c0]) - s;
+}
+
 __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                                           const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                           const double* __restrict__ arena, double* __restrict__ xw,
@@ -1986,22 +2036,25 @@ __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& b
    wave_lds_sync();   // ys is reused by the caller's next supernode / right-hand side
 }
 
-template <int DUMMY = 0>
+// WCAP: the widest supernode the caller can meet (the engine knows it from the analysis): the register budget of the kernel is that
+// of its widest variant, and it decides how many waves share a SIMD
+template <int WCAP = HEAD_WMAX>
 __device__ __forceinline__ void head_fwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
                                              const double* __restrict__ arena, double* __restrict__ xb, double* ys) {
    if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xb, ys);
    else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xb, ys);
-   else if (sn.w <= 16) head_fwd_body<16>(sn, bd, rowidx, arena, xb, ys);
+   else if (sn.w <= 16 || WCAP <= 16) head_fwd_body<16>(sn, bd, rowidx, arena, xb, ys);
    else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, ys);
 }
 
+template <int WCAP>
 __global__ __launch_bounds__(64) void k_head_fwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                 const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
    __shared__ double ys[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_fwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, ys);   // blockIdx.y = right-hand side
+   head_fwd_any<WCAP>(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, ys);   // blockIdx.y = right-hand side
 }
 
 // head diagonal scaling: z = D^-1 y for the head columns
@@ -2020,7 +2073,7 @@ __global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const Blk
 // head backward, latency-lean variant (few supernodes per launch), same structure as k_head_fwd_chain:
 // lane a gathers x[rows[a]] once and forms its share of all w dot products, the w sums are finished through LDS, the
 // transposed substitution runs on shuffles with column tid of L11 in registers.
-constexpr int RED_ROWS = 16;   // dot products finished per pass through the wave's LDS scratch (RED_ROWS x 65 doubles)
+constexpr int RED_ROWS = 8;    // dot products finished per pass through the wave's LDS scratch (RED_ROWS x 65 doubles)
 
 template <int WB>
 __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
@@ -2029,9 +2082,6 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
    const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
-   double c[WB];   // column tid of L11 below the diagonal
-#pragma unroll
-   for (int k = 0; k < WB; ++k) c[k] = (k > tid && k < w) ? P[k + (long long)tid * ld] : 0.0;
    double y = tid < w ? xb[sn.c0 + tid] : 0.0;
    if (dscale && tid < w) y /= P[tid + (long long)tid * ld];   // D^-1 fused: no separate pass over every supernode descriptor
    double part[WB];
@@ -2068,22 +2118,28 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
          }
       }
    }
+   // column tid of L11 below the diagonal - read only now: its cache lines came in with the first rows of L21 above, and the registers
+   // were free for the partial sums until here (96 -> fewer VGPRs: one more wave per SIMD)
+   double c[WB];
+#pragma unroll
+   for (int k = 0; k < WB; ++k) c[k] = (k > tid && k < w) ? P[k + (long long)tid * ld] : 0.0;
 #pragma unroll
    for (int k = WB - 1; k >= 0; --k)
       if (k < w) y -= c[k] * __shfl(y, k);                 // c[k] == 0 for k <= tid
    if (tid < w) xb[sn.c0 + tid] = y;
 }
 
-template <int DUMMY = 0>
+template <int WCAP = HEAD_WMAX>
 __device__ __forceinline__ void head_bwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
                                              const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0,
                                              int dscale = 0) {
    if (sn.w == 1) head_bwd_body<1>(sn, bd, rowidx, arena, xb, red, border, dscale);
    else if (sn.w <= 8) head_bwd_body<8>(sn, bd, rowidx, arena, xb, red, border, dscale);
-   else if (sn.w <= 16) head_bwd_body<16>(sn, bd, rowidx, arena, xb, red, border, dscale);
+   else if (sn.w <= 16 || WCAP <= 16) head_bwd_body<16>(sn, bd, rowidx, arena, xb, red, border, dscale);
    else head_bwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, red, border, dscale);
 }
 
+template <int WCAP>
 __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
                                                 const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
@@ -2091,7 +2147,7 @@ __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict_
    __shared__ double red[RED_ROWS][65];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_bwd_any(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red, border, dscale);
+   head_bwd_any<WCAP>(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red, border, dscale);
 }
 
 // spine sweeps of the solve: one wave per (block, right-hand side) walks the block's spine supernodes inside one launch
@@ -2691,12 +2747,24 @@ __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __re
                                 long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride) {
    x += vec_stride * blockIdx.y;
    y += vec_stride * blockIdx.y;
-   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows_total; i += (long long)gridDim.x * blockDim.x) {
-      if (frowptr[i + 1] - frowptr[i] > FULL_LONG_ROW) continue;   // k_full_spmv_sub_long
-      const long long base = row_blk_base[i];
+   // eight lanes per row (KKT rows hold a handful of entries): a wave reads the entries of eight consecutive rows as one contiguous piece
+   const int l = threadIdx.x & 7;
+   const long long step = ((long long)gridDim.x * blockDim.x) >> 3, i_end = (nrows_total + step - 1) / step * step;   // whole waves to the end (shuffles)
+   for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 3; i < i_end; i += step) {
       double s = 0.0;
-      for (int p = frowptr[i]; p < frowptr[i + 1]; ++p) s += val[fsrc[p]] * x[base + fcol[p]];
-      y[i] -= s;
+      bool mine = false;
+      if (i < nrows_total) {
+         const int p0 = frowptr[i], p1 = frowptr[i + 1];
+         mine = p1 - p0 <= FULL_LONG_ROW;   // the others: k_full_spmv_sub_long
+         if (mine) {
+            const long long base = row_blk_base[i];
+            for (int p = p0 + l; p < p1; p += 8) s += val[fsrc[p]] * x[base + fcol[p]];
+         }
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      if (mine && l == 0) y[i] -= s;
    }
 }
 

@@ -6,5 +6,8 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/tools/co
 T=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_fronts.py $T 1 > $OUT/fronts.txt
 python3 $R/tools/trace_summary.py $T 1 > $OUT/summary.txt
+# the last factorisation of the probe and everything after it: 3 solveCompressed, 3 leaf solves
+python3 $R/tools/trace_summary.py $T 2 > $OUT/summary_last.txt
+python3 $R/tools/trace_solve_levels.py $T > $OUT/solve_levels.txt
 find $OUT -name "*kernel_trace.csv" -delete
-cat $OUT/summary.txt
+cat $OUT/summary_last.txt
