@@ -1714,11 +1714,11 @@ struct Engine {
             for (size_t k = 0; k + 1 < round_off.size(); ++k) {
                const int cnt = round_off[k + 1] - round_off[k];
                if (cnt > 0)
-                  hipLaunchKernelGGL(k_root_assemble, dim3(cnt), dim3(256), 0, stream, d_round_blk + round_off[k], d_root_off, d_roots, d_sns, d_blks, d_rowidx,
+                  hipLaunchKernelGGL(k_root_assemble, dim3(cnt, ROOT_ASM_NT + ROOT_ASM_NS), dim3(256), 0, stream, d_round_blk + round_off[k], d_root_off, d_roots, d_sns, d_blks, d_rowidx,
                                      d_bmap, d_arena, d_mfU, SC, ldSC, d_sctab, d_gbuf, (long long)S * S, d_blk_group);
             }
          } else
-            hipLaunchKernelGGL(k_root_assemble, dim3(nblk), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
+            hipLaunchKernelGGL(k_root_assemble, dim3(nblk, ROOT_ASM_NT + ROOT_ASM_NS), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
                                d_arena, d_mfU, SC, ldSC, d_sctab, (double*)nullptr, 0LL, (const int*)nullptr);
          if (timer.on) timer.end(stream);
       }

@@ -859,6 +859,14 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 // block's root fronts in ascending order (inside a front the targets are distinct; a barrier separates the fronts): plain adds on
 // the block's own tail.  Schur targets are shared between blocks: FP64 atomics by default; in deterministic mode (gbuf != nullptr)
 // a launch holds at most one block of every group and adds into the group's buffer, so the blocks of a group arrive in order.
+// One workgroup per (block, chunk of target columns): blockIdx.y < ROOT_ASM_NT takes a slice of the tail's columns, the others a slice of
+// the block's border columns (Schur complement).  A target entry belongs to the chunk of its column - the smaller of its two block-local
+// indices, the same for every front that reaches it - so each entry has ONE writer, which walks the fronts in ascending order: the sums
+// have a fixed order and the tail needs no atomics.  (One workgroup per block walked all fronts alone: 7.5 ms on the configs[1] blocks,
+// where nearly every front is a root with ~130 tail rows.)  The fronts are scanned 256 at a time, one thread each, for the piece of their
+// (ascending) row list that falls into the chunk.
+constexpr int ROOT_ASM_NT = 32, ROOT_ASM_NS = 32;
+
 __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ blk_list, const int* __restrict__ root_off,
                                                       const int* __restrict__ roots, const SnDesc* __restrict__ sns,
                                                       const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
@@ -866,31 +874,66 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
                                                       const double* __restrict__ uarena, double* __restrict__ SC, int ldSC,
                                                       const int* __restrict__ sctab, double* __restrict__ gbuf, long long gstride,
                                                       const int* __restrict__ blk_group) {
+   __shared__ int s_b0[256], s_b1[256], s_r[256], s_rb[256];
+   __shared__ long long s_rows[256], s_U[256];
    const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
    const BlkDesc bd = blks[blk];
    double* T = arena + bd.T;
    const int* bm = bmap + bd.bmap_off;
-   const int n = bd.n, n_head = bd.n_head;
+   const int n = bd.n, n_head = bd.n_head, c = blockIdx.y;
    double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
-   for (int q = root_off[blk]; q < root_off[blk + 1]; ++q) {
-      const SnDesc sn = sns[roots[q]];
-      const int r = sn.r, rb = sn.rb;
-      const int* rows = rowidx + sn.rows;
-      const double* U = uarena + sn.U;
-      for (int idx = threadIdx.x; idx < r * r; idx += 256) {
-         const int b = idx / r, a = idx - b * r;
-         if (a < b) continue;
-         const double u = U[b * r - b * (b - 1) / 2 + a - b];
-         const int ra = rows[a], cb = rows[b];
-         if (b < rb) {
-            const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
-            T[tr + (long long)(cb - n_head) * bd.ldT] += u;
-         } else if (S_) {
-            double* tgt = sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n);
-            if (gbuf) *tgt += u; else atomic_add_f64(tgt, u);
-         }
+   const bool tail_chunk = c < ROOT_ASM_NT;
+   if (!tail_chunk && !S_) return;
+   // block-local row ids [lo, hi) whose columns this workgroup owns
+   int lo, hi;
+   if (tail_chunk) {
+      const int cw = (bd.m_pad + ROOT_ASM_NT - 1) / ROOT_ASM_NT;
+      lo = n_head + c * cw; hi = min(lo + cw, n);
+   } else {
+      const int cw = (bd.nb + ROOT_ASM_NS - 1) / ROOT_ASM_NS;
+      lo = n + (c - ROOT_ASM_NT) * cw; hi = min(lo + cw, n + bd.nb);
+   }
+   if (lo >= hi) return;
+   const int q_begin = root_off[blk], q_end = root_off[blk + 1];
+   for (int q0 = q_begin; q0 < q_end; q0 += 256) {
+      const int nq = min(256, q_end - q0);
+      __syncthreads();
+      if ((int)threadIdx.x < nq) {
+         const SnDesc sn = sns[roots[q0 + threadIdx.x]];
+         const int* rows = rowidx + sn.rows;
+         // first row >= lo and first row >= hi in the ascending list
+         int a = 0, b = sn.r;
+         while (a < b) { const int m = (a + b) >> 1; if (rows[m] < lo) a = m + 1; else b = m; }
+         const int b0 = a;
+         b = sn.r;
+         while (a < b) { const int m = (a + b) >> 1; if (rows[m] < hi) a = m + 1; else b = m; }
+         s_b0[threadIdx.x] = b0; s_b1[threadIdx.x] = a; s_r[threadIdx.x] = sn.r; s_rb[threadIdx.x] = sn.rb;
+         s_rows[threadIdx.x] = sn.rows; s_U[threadIdx.x] = sn.U;
       }
       __syncthreads();
+      for (int k = 0; k < nq; ++k) {
+         const int b0 = s_b0[k], b1 = s_b1[k];
+         if (b0 >= b1) continue;   // (uniform: every thread reads the same LDS words)
+         const int r = s_r[k], rb = s_rb[k];
+         const int* rows = rowidx + s_rows[k];
+         const double* U = uarena + s_U[k];
+         // entries (a, b), b in [b0, b1), a in [b, r): column b holds r - b of them
+         const int per0 = r - b0, total = (b1 - b0) * per0;   // the rectangle [b0, r) x [b0, b1); its corner above the diagonal is skipped
+         for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int bi = idx / per0, a = b0 + (idx - bi * per0), b = b0 + bi;
+            if (a < b) continue;
+            const double u = U[b * r - b * (b - 1) / 2 + a - b];
+            const int ra = rows[a], cb = rows[b];
+            if (b < rb) {
+               const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
+               T[tr + (long long)(cb - n_head) * bd.ldT] += u;
+            } else {
+               double* tgt = sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, bd.nb, ra - n, cb - n);
+               if (gbuf) *tgt += u; else atomic_add_f64(tgt, u);
+            }
+         }
+         __syncthreads();   // the next front may reach the same entries from other threads
+      }
    }
 }
 
