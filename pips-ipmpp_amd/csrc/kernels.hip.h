@@ -2790,24 +2790,52 @@ __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __re
                                 long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride) {
    x += vec_stride * blockIdx.y;
    y += vec_stride * blockIdx.y;
-   // eight lanes per row (KKT rows hold a handful of entries): a wave reads the entries of eight consecutive rows as one contiguous piece
+   // eight lanes per row (KKT rows hold a handful of entries): a wave reads the entries of eight consecutive rows as one contiguous piece.
+   // Four rows per lane group and trip: a row is four dependent memory round trips (row pointers, entries, x, y) around a handful of
+   // multiply-adds - the kernel is bound by how many of those are in flight, not by bytes (reading the values through fsrc or from
+   // a copy in row order makes no difference: measured)
+   constexpr int RU = 4;
    const int l = threadIdx.x & 7;
-   const long long step = ((long long)gridDim.x * blockDim.x) >> 3, i_end = (nrows_total + step - 1) / step * step;   // whole waves to the end (shuffles)
-   for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 3; i < i_end; i += step) {
-      double s = 0.0;
-      bool mine = false;
-      if (i < nrows_total) {
-         const int p0 = frowptr[i], p1 = frowptr[i + 1];
-         mine = p1 - p0 <= FULL_LONG_ROW;   // the others: k_full_spmv_sub_long
-         if (mine) {
-            const long long base = row_blk_base[i];
-            for (int p = p0 + l; p < p1; p += 8) s += val[fsrc[p]] * x[base + fcol[p]];
-         }
+   const long long step = ((long long)gridDim.x * blockDim.x) >> 3, chunk = step * RU, i_end = (nrows_total + chunk - 1) / chunk * chunk;
+   for (long long i0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 3; i0 < i_end; i0 += chunk) {
+      int p0[RU], p1[RU];
+      long long base[RU];
+      double s[RU];
+      bool mine[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+         const long long i = i0 + u * step;
+         mine[u] = i < nrows_total;
+         p0[u] = mine[u] ? frowptr[i] : 0;
+         p1[u] = mine[u] ? frowptr[i + 1] : 0;
+         base[u] = mine[u] ? row_blk_base[i] : 0;
+         mine[u] = mine[u] && p1[u] - p0[u] <= FULL_LONG_ROW;   // the others: k_full_spmv_sub_long
+         s[u] = 0.0;
       }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      if (mine && l == 0) y[i] -= s;
+      // the first eight entries of the four rows without control flow between their loads, the rest (rows beyond eight entries) after
+      double v[RU];
+      int c[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+         const int p = p0[u] + l;
+         const bool in = mine[u] && p < p1[u];
+         const int q = in ? fsrc[p] : 0;
+         c[u] = in ? fcol[p] : 0;
+         v[u] = in ? val[q] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) s[u] = v[u] * x[base[u] + c[u]];
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+         if (mine[u])
+            for (int p = p0[u] + l + 8; p < p1[u]; p += 8) s[u] += val[fsrc[p]] * x[base[u] + fcol[p]];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+         s[u] += __shfl_xor(s[u], 1);
+         s[u] += __shfl_xor(s[u], 2);
+         s[u] += __shfl_xor(s[u], 4);
+         if (mine[u] && l == 0) y[i0 + u * step] -= s[u];
+      }
    }
 }
 
