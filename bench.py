@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ipm", action="store_true", help="skip the end-to-end IPM run reported next to the metric (N = 1 only)")
+    ap.add_argument("--root", choices=["auto", "dense", "sparse"], default="auto",
+                    help="root system: dense LDL^T of the S x S Schur complement, or the sparse root (2-link structure: the Schur complement is "
+                         "kept as a CSR value array and factorised by a one-block sparse engine); auto = sparse for the time-coupled family")
     ap.add_argument("--family", choices=["random", "time-coupled"], default="random",
                     help="random: the generator of SURVEY 8d (BASELINE configs[1], [2], [4]); time-coupled: banded blocks with 2-link rows "
                          "(configs[3]; --schur-dim and --rho are ignored: S = 95 + 31 (blocks - 1))")
@@ -313,7 +316,17 @@ def main():
         F0 = fam_F0
     else:
         F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
-    kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, comm=comm, rank=rank, n_ranks=world)
+    # time-coupled family: 2-link rows -> sparse root, as the reference does for this class (sLinsysRootAug.C:1629-1739); deterministic
+    # mode has no sparse root yet
+    sparse_root = a.root == "sparse" or (a.root == "auto" and fam_blocks is not None and not os.environ.get("PIPS_HIP_DETERMINISTIC"))
+    all_cols = None
+    if sparse_root:
+        if fam_blocks is None:
+            raise SystemExit("--root sparse needs --family time-coupled (the random family's Schur complement is dense)")
+        # non-empty border columns of EVERY block of the problem (every rank reduces the same pattern): x0 columns T touches, rows of F
+        all_cols = [np.concatenate([np.unique(T.colidx), n0 + np.nonzero(np.diff(F.rowptr) > 0)[0]]).astype(np.int32)
+                    for (_, T, F) in fam_blocks]
+    kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, comm=comm, rank=rank, n_ranks=world, sparse_root=sparse_root, all_block_cols=all_cols)
     dev = torch.device("cuda", local_rank)
     diag = torch.tensor(diag_h, device=dev)
     xd0 = torch.tensor(pa.gen_diagonal(a.seed, 0, n0), device=dev)
@@ -390,7 +403,8 @@ def main():
         group("sparse head", "k_front<*> + k_head_factor_simple" if info.get("multifrontal_head") else "k_head_factor*", "hbm", tm["head"][0], tm["head"][1],
               8.0 * (info["nnzK"] + info["nnzL_head"]) + 4.0 * (info["nnzK"] + info["head_row_indices"]),
               "8 (nnz K + nnz L_head) + 4 (nnz K + row indices of the head supernodes): read K once, write L once"),
-        group("dense root", "k_tile_gemm<3> + k_tile_diag + k_tile_gemm<1>", "mfma", tk["root_factor"][0], 1, S ** 3 / 3.0, "S^3 / 3"),
+    ] + ([group("dense root", "k_tile_gemm<3> + k_tile_diag + k_tile_gemm<1>", "mfma", tk["root_factor"][0], 1, S ** 3 / 3.0, "S^3 / 3")]
+         if not sparse_root else []) + [
         group("leaf solve sweeps", "k_head_fwd / k_head_bwd / k_head_solve_simple / k_tail_rows_fwd / _bwd", "hbm",
               tm["solve_head_fwd"][0] + tm["solve_tail"][0] + tm["solve_head_bwd"][0], n_solve_once, n_solve_once * 16.0 * info["nnzL"],
               "every entry of L read once per sweep, forward and backward: 16 nnz(L) bytes per leaf solve pass"),
@@ -408,7 +422,8 @@ def main():
     # Lsolve's leaf solve; only what exceeds that solve is on the critical path.
     top = {k: round(v[0], 3) for k, v in tk.items()}
     lsolve_first = tk["lsolve_leaf"][0] / max(tk["lsolve_leaf"][1], 1)
-    root_exposed = max(0.0, tk["root_factor"][0] - lsolve_first) if not os.environ.get("PIPS_HIP_ROOT_SYNC") else tk["root_factor"][0]
+    root_exposed = (max(0.0, tk["root_factor"][0] - lsolve_first) if not (os.environ.get("PIPS_HIP_ROOT_SYNC") or sparse_root)
+                    else tk["root_factor"][0])   # (the sparse root is factorised on the main stream)
     accounted = sum(tk[k][0] for k in ("diag_zero", "leaf_factor", "reduce", "finalize", "lsolve_leaf", "lsolve_border_reduce", "dsolve",
                                        "ltsolve", "combine")) + root_exposed
     phase_ms = {"step": top, "root_factor_exposed": round(root_exposed, 3), "accounted": round(accounted, 3),
@@ -440,7 +455,8 @@ def main():
                        (f"time-coupled family: {n_blocks_total} blocks x {n_i} vars ({my_i} banded eq rows, 10 nnz/row), 95 first-stage variables, "
                         f"31 two-link rows per neighbouring pair, Schur dim {S}, {bpg} blocks/GPU"
                         + (" [per-GPU share of BASELINE configs[3]]" if bpg == 256 and n_i == 50000 else "")),
-                       "family": a.family, "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
+                       "family": a.family, "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
+                                                    if sparse_root else "dense LDL^T"), "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed and the "
                                    "refined Lsolve of the same call needed no step (DESIGN.md 2)"

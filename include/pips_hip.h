@@ -194,6 +194,10 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
                                int n_ranks);
 /* pattern and values (host copies) of the sparse Schur complement; any output may be NULL; *nnz = number of entries */
 int pips_hip_kkt_get_schur_sparse(void* handle, int* nnz, int* rowptr, int* colidx, double* val_host);
+/* what[0] = elimination order of the sparse root: 0 minimum degree, 1 linking rows then x0 as a band of dense tiles, 2 linking rows
+ * dissected around x0 / the root equality rows (a chain-like Schur complement becomes a tree of small fronts: default where the tile
+ * envelope is thin; PIPS_HIP_SPARSE_ROOT_BAND=0|1|2 forces one); what[1 + i] = pips_hip_batch_info entry i of the root's engine */
+int pips_hip_kkt_sparse_root_info(void* handle, int64_t* what, int n_what);
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev);
 /* sLinsysRootAug::add_regularization_local_kkt (sLinsysRootAug.C:1545-1600) as a setting of the following factorizations: the
  * x0 diagonal of the Schur complement gets + primal, the diagonal of its dual rows (y0, y_link, z_link) - dual; (0, 0) = off */
@@ -421,6 +425,12 @@ int pips_map_children_to_ranks(int n_children, int n_ranks, int* map);
 /* symbolic analysis only (CPU): fills what[] like pips_hip_ldl_info and optionally perm/colcount (may be NULL) */
 int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, int S, const int* Bt_rowptr,
                         const int* Bt_colidx, int force_n_head, int64_t* what, int n_what, int* perm, int* colcount);
+
+/* the same under the order the sparse root takes for chain-like Schur complements: the hubs (x0, root equality rows) last, the rest
+ * dissected by level structures, minimum degree in segments below min_size rows (order.cpp hub_dissected_order); PIPS_ERR_STATE when
+ * the graph without the hubs has no separators.  CPU only. */
+int pips_symbolic_probe_hubs(int n, int n_primal, const int* krow, const int* jcol, int n_hubs, const int* hubs, int min_size,
+                             int64_t* what, int n_what, int* perm, int* colcount);
 
 /* ---- 6. input files ---------------------------------------------------------------------------------------------------
  * One block of a block-structured LP from a "jacobian" GDX file, the format gmspips_reader opens per block

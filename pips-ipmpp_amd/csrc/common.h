@@ -51,6 +51,11 @@ void constrained_amd(int n, const std::vector<int>& ap, const std::vector<int>& 
 bool dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& ai, int n_primal, int max_depth,
                      std::vector<int>& perm, std::vector<int>& colcount, int min_size = 512);
 
+// Nested dissection around hub vertices (order.cpp): hubs_last are ordered last in the given order, the rest is dissected (segments
+// below min_size rows stay whole, minimum degree inside); unconstrained.  false: no separators found.
+bool hub_dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& ai, const std::vector<int>& hubs_last, int min_size,
+                         std::vector<int>& perm, std::vector<int>& colcount);
+
 // ---- symbolic analysis of one leaf block (symbolic.cpp) --------------------------------------
 struct HeadSupernode {
    int c0;          // first column (permuted index)
@@ -146,6 +151,7 @@ struct AnalyzeOptions {
    int nd_depth = 12;
    int nd_min_size = 128;     // a segment with fewer dual rows is not dissected further
    const int* user_perm = nullptr;   // given elimination order (perm[new] = old) instead of minimum degree / dissection
+   const int* user_colcount = nullptr;   // ... with its column counts (the head / tail cut is priced with them); nullptr: zeros
    bool constrain_order = true;   // dual rows only after their primal neighbours (leaf KKT blocks); false: plain minimum degree,
                                   // the inertia hint still supplies the expected pivot signs (sparse Schur complement)
    int simple_rmax = 16;      // width-1 tree leaves with at most this many rows are "simple leaves" (one thread each on the device)

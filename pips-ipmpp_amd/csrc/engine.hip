@@ -608,6 +608,7 @@ struct Engine {
    // record -> lists / values -> gathered solution entries), and the thread-per-leaf kernels hide that latency behind 12.6 M
    // threads where a wave per front cannot.  PIPS_HIP_MF_SOLVES=1 selects them (tests do).
    bool mf_solves = false;
+   int sn_width = 0;           // > 0: supernode width cap of this engine instead of the tuned default (the sparse root: a single block, every level is latency)
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
    double* d_mfU = nullptr;    // update matrices of the fronts
@@ -943,6 +944,7 @@ struct Engine {
       for (int b = 0; b < nblk; ++b)
          if (in[b].n <= 0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_analyze: block %d was never set", b);
       apply_tuning(opt);
+      if (sn_width > 0 && !getenv("PIPS_HIP_SN_WIDTH")) opt.max_sn_width = std::min(HEAD_WMAX, sn_width);
       if (const char* sm = getenv("PIPS_HIP_SCHUR_MODE")) schur_mode = atoi(sm);
       if (const char* pg = getenv("PIPS_HIP_PERSISTENT_GEMM")) persistent_gemm = atoi(pg) != 0;
       if (const char* bg = getenv("PIPS_HIP_BALANCED_GEMM")) balanced_gemm = atoi(bg) != 0;
@@ -2385,7 +2387,8 @@ struct KktSystem {
    // engine, which factorises and solves it with the leaf machinery (ordering, head / dense tail, refinement)
    bool sparse = false;
    std::unique_ptr<Engine> root_sp;
-   std::vector<int> sc_rowptr, sc_colidx, root_perm;
+   std::vector<int> sc_rowptr, sc_colidx, root_perm, root_colcount;
+   int root_order_mode = 0;   // sparse root: 0 minimum degree, 1 dense-tile band, 2 dissection around the hubs
    long long *d_xdiag_pos = nullptr, *d_zlink_pos = nullptr;
    int* d_sc_rowptr = nullptr;
    ~KktSystem() {
@@ -3162,6 +3165,12 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    return PIPS_OK;
 }
 
+// Largest column count the dissected sparse root admits in its head: a front of colcount + 1 rows must fit the LDS as a packed triangle
+// (19 200 doubles: 195 rows).  Measured (tools/sparse_root_probe.py, 64 blocks): 31 linking rows per pair (fronts <= 188 rows) factorize
+// 4.3 ms as a band, 2.6 ms dissected; 100 rows per pair (fronts of 308 rows: update matrices in device memory) 10.1 ms as a band, 11.1 ms
+// dissected and solveCompressed 2.1 -> 4.3 ms - those stay a band.
+constexpr int ROOT_ND_MAX_COLCOUNT = 192;
+
 // Sparse-root variant (createSchurCompSymbSparseUpper, DistributedProblem.cpp:2235+; finalizeKKTsparse, sLinsysRootAug.C:
 // 1629-1739).  Pattern of SC (lower): the dense x0 block, for every block the clique on its non-empty border columns, the
 // root rows A0 / F0 / G0 and a full diagonal.  With 2-link structure (a linking row touches two blocks) it stays sparse.
@@ -3263,13 +3272,47 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
       double env = 0;
       for (int t = 0; t < nt; ++t) env += t - first[t] + 1;
       bool banded = env <= 0.25 * 0.5 * nt * (nt + 1.0);
-      if (const char* f = getenv("PIPS_HIP_SPARSE_ROOT_BAND")) banded = atoi(f) != 0;   // tests: force either path
-      if (banded) {
+      // A thin band is a chain: as dense tiles its diagonal tiles are factorised one after the other (63 tiles of 86 us at S = 8000 -
+      // as long as the dense root).  Dissected around the hubs x0 / y0 (ordered last) the linking rows become a tree of small fronts
+      // for the multifrontal head, a dozen dependent launches deep; only the hubs and the top separators stay dense.
+      int mode = banded ? 2 : 0;   // 0 minimum degree, 1 dense-tile band, 2 dissection (falls back to 1 without separators)
+      if (const char* f = getenv("PIPS_HIP_SPARSE_ROOT_BAND")) mode = atoi(f);   // tests: force a path
+      if (mode == 2) {
+         std::vector<int> ap(S + 1, 0), ai, hubs, nd_perm;
+         for (int rr = 0; rr < S; ++rr)
+            for (int p = k->sc_rowptr[rr]; p < k->sc_rowptr[rr + 1]; ++p)
+               if (k->sc_colidx[p] != rr) { ++ap[rr + 1]; ++ap[k->sc_colidx[p] + 1]; }
+         for (int i = 0; i < S; ++i) ap[i + 1] += ap[i];
+         ai.resize(ap[S]);
+         {
+            std::vector<int> fill(ap.begin(), ap.end() - 1);
+            for (int rr = 0; rr < S; ++rr)
+               for (int p = k->sc_rowptr[rr]; p < k->sc_rowptr[rr + 1]; ++p) {
+                  const int c = k->sc_colidx[p];
+                  if (c != rr) { ai[fill[rr]++] = c; ai[fill[c]++] = rr; }
+               }
+         }
+         for (int i = 0; i < n0 + my0; ++i) hubs.push_back(i);
+         // head = the dissected rows as long as their fronts stay LDS-resident in k_front (ROOT_ND_MAX_COLCOUNT); the cost model is no
+         // guide here (it prices a scattering head against MFMA throughput, and the band's cost is the latency of its chain of diagonal tiles)
+         int cut = 0;
+         if (hub_dissected_order(S, ap, ai, hubs, 48, nd_perm, k->root_colcount)) {
+            const int n_rest = S - (int)hubs.size();
+            while (cut < n_rest && k->root_colcount[cut] <= ROOT_ND_MAX_COLCOUNT) ++cut;
+         }
+         if (cut >= (S - (int)hubs.size()) / 2) { k->root_perm = nd_perm; r->opt.force_n_head = cut; r->sn_width = HEAD_WMAX; }
+         else mode = 1;
+      }
+      if (mode == 2) {
+         r->opt.user_perm = k->root_perm.data();
+         r->opt.user_colcount = k->root_colcount.data();
+      } else if (mode == 1) {
          r->opt.user_perm = k->root_perm.data();
          r->opt.force_n_head = 0;
       } else {
          r->opt.constrain_order = my0 > 0;
       }
+      k->root_order_mode = mode;
    }
    if ((rc = r->analyze(4))) return rc;
    // ---- constant root entries and the diagonals added by finalizeKKT
@@ -3714,6 +3757,16 @@ int pips_hip_kkt_get_schur_sparse(void* handle, int* nnz, int* rowptr, int* coli
    return PIPS_OK;
 }
 
+// sparse root: what[0] = elimination order taken (0 minimum degree, 1 dense-tile band, 2 dissection around x0 / y0), then the entries
+// of pips_hip_batch_info for the root's one-block engine (what[1 + i] = info[i])
+int pips_hip_kkt_sparse_root_info(void* handle, int64_t* what, int n_what) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || !what || n_what < 1) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_sparse_root_info: bad arguments");
+   if (!k->sparse || !k->root_sp) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_sparse_root_info: not a sparse-root system");
+   what[0] = k->root_order_mode;
+   return n_what > 1 ? pips_hip_batch_info(k->root_sp.get(), what + 1, n_what - 1) : PIPS_OK;
+}
+
 void pips_hip_kkt_destroy(void* handle) { delete (KktSystem*)handle; }
 
 // ---- symbolic probe (CPU only) -------------------------------------------------------------------------------------
@@ -3744,6 +3797,47 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
                  (long long)bs.mf_U_total, bs.mf_int.size());
       }
    }
+   if (perm) std::copy(sym[0].perm.begin(), sym[0].perm.end(), perm);
+   if (colcount) std::copy(sym[0].colcount.begin(), sym[0].colcount.end(), colcount);
+   return PIPS_OK;
+}
+
+// the order the sparse root takes for a chain-like Schur complement (hub_dissected_order: hubs last, the rest dissected) and the
+// symbolic analysis under it; PIPS_ERR_STATE when the graph without the hubs has no separators
+int pips_symbolic_probe_hubs(int n, int n_primal, const int* krow, const int* jcol, int n_hubs, const int* hubs, int min_size, int64_t* what,
+                             int n_what, int* perm, int* colcount) {
+   if (n <= 0 || !krow || !jcol || n_hubs < 0 || (n_hubs > 0 && !hubs)) PIPS_FAIL(PIPS_ERR_ARG, "pips_symbolic_probe_hubs: bad arguments");
+   std::vector<int> ap(n + 1, 0), ai;
+   for (int r = 0; r < n; ++r)
+      for (int p = krow[r]; p < krow[r + 1]; ++p) {
+         if (jcol[p] < 0 || jcol[p] > r) PIPS_FAIL(PIPS_ERR_ARG, "pips_symbolic_probe_hubs: K must be lower-triangular CSR");
+         if (jcol[p] != r) { ++ap[r + 1]; ++ap[jcol[p] + 1]; }
+      }
+   for (int i = 0; i < n; ++i) ap[i + 1] += ap[i];
+   ai.resize(ap[n]);
+   {
+      std::vector<int> fill(ap.begin(), ap.end() - 1);
+      for (int r = 0; r < n; ++r)
+         for (int p = krow[r]; p < krow[r + 1]; ++p)
+            if (jcol[p] != r) { ai[fill[r]++] = jcol[p]; ai[fill[jcol[p]]++] = r; }
+   }
+   std::vector<int> hv(hubs, hubs + n_hubs), pv, cc;
+   if (!hub_dissected_order(n, ap, ai, hv, min_size, pv, cc)) PIPS_FAIL(PIPS_ERR_STATE, "pips_symbolic_probe_hubs: no separators");
+   AnalyzeOptions opt;
+   apply_tuning(opt);
+   opt.user_perm = pv.data();
+   opt.user_colcount = cc.data();
+   {  // (the cut pips_hip_kkt_create_sparse takes)
+      int cut = 0;
+      while (cut < n - n_hubs && cc[cut] <= ROOT_ND_MAX_COLCOUNT) ++cut;
+      opt.force_n_head = cut;
+   }
+   CsrPattern K{n, n, krow, jcol};
+   CsrPattern B{0, n, nullptr, nullptr};
+   std::vector<BlockSym> sym(1);
+   int rc = analyze_block(K, B, n_primal, opt, sym[0]);
+   if (rc) return rc;
+   if (what) sym_info(sym, what, n_what);
    if (perm) std::copy(sym[0].perm.begin(), sym[0].perm.end(), perm);
    if (colcount) std::copy(sym[0].colcount.begin(), sym[0].colcount.end(), colcount);
    return PIPS_OK;

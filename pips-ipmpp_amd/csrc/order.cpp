@@ -186,6 +186,7 @@ struct Dissector {
    std::vector<int> label, level;    // work arrays
    std::vector<Segment> out;
    int max_depth, min_size;
+   int min_levels = 5;   // a level structure with fewer levels is not cut (3 = one separator level between two single levels)
 
    Dissector(int n_, int np_, const std::vector<int>& ap_, const std::vector<int>& ai_) : n(n_), n_primal(np_), nd(n_ - np_), ap(ap_), ai(ai_) {}
 
@@ -277,7 +278,7 @@ struct Dissector {
             bfs(far, id, order, lstart);
          }
          const int nlev = (int)lstart.size() - 1;
-         if (nlev < 5) return emit_leaf();
+         if (nlev < min_levels) return emit_leaf();
          // thinnest level in the middle third (by node count)
          int best = -1;
          for (int k = 1; k + 1 < nlev; ++k) {
@@ -406,6 +407,72 @@ bool dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& 
       for (int t = 0; t < m; ++t) local[nodes[t]] = -1;
    }
    if ((int)perm.size() != n) return false;   // defensive: every node exactly once
+   exact_colcounts(n, ap, ai, perm, colcount);
+   return true;
+}
+
+// Nested dissection of a graph with a few "hub" vertices that touch (nearly) everything - the Schur complement of a 2-link arrowhead
+// problem: the first-stage variables x0 (and root equality rows) are the hubs, the linking rows without them form a chain of cliques.
+// The hubs are ordered LAST, in the given order; the rest is dissected by breadth-first level structures exactly as the dual-row
+// graph of a time-coupled leaf block (Dissector above), minimum degree inside the leaves.  The order carries no constraint: the
+// caller uses it only for quasi-definite matrices (any symmetric permutation has an LDL^T with the pivot signs known in advance).
+bool hub_dissected_order(int n, const std::vector<int>& ap, const std::vector<int>& ai, const std::vector<int>& hubs_last, int min_size,
+                         std::vector<int>& perm, std::vector<int>& colcount) {
+   std::vector<int> local(n, 0);
+   for (int h : hubs_last) {
+      if (h < 0 || h >= n || local[h] < 0) return false;
+      local[h] = -1;
+   }
+   std::vector<int> orig;
+   for (int v = 0; v < n; ++v)
+      if (local[v] >= 0) { local[v] = (int)orig.size(); orig.push_back(v); }
+   const int m = (int)orig.size();
+   if (m < 2 * std::max(min_size, 1)) return false;
+   static const std::vector<int> none_p(1, 0), none_i;
+   Dissector D(m, 0, none_p, none_i);   // (only its graph, bfs and dissect are used: gp / gi are filled here)
+   D.max_depth = 40;
+   D.min_levels = 3;
+   D.min_size = std::max(min_size, 1);
+   D.gp.assign(m + 1, 0);
+   for (int y = 0; y < m; ++y) {
+      const int v = orig[y];
+      for (int q = ap[v]; q < ap[v + 1]; ++q)
+         if (local[ai[q]] >= 0) D.gi.push_back(local[ai[q]]);
+      D.gp[y + 1] = (int)D.gi.size();
+   }
+   D.label.assign(m, -1);
+   D.level.assign(m, -1);
+   std::vector<int> all(m);
+   for (int y = 0; y < m; ++y) all[y] = y;
+   int next_id = 0;
+   D.dissect(all, 0, next_id);
+   int n_leaves = 0;
+   for (auto& sg : D.out) n_leaves += sg.leaf;
+   if (n_leaves < 2) return false;
+   perm.clear();
+   perm.reserve(n);
+   std::vector<int> loc2(m, -1);
+   for (const Segment& sg : D.out) {
+      if (!sg.leaf) {
+         for (int y : sg.duals) perm.push_back(orig[y]);
+         continue;
+      }
+      const std::vector<int>& nodes = sg.duals;
+      const int k = (int)nodes.size();
+      for (int t = 0; t < k; ++t) loc2[nodes[t]] = t;
+      std::vector<int> sp(k + 1, 0), si;
+      for (int t = 0; t < k; ++t) {
+         for (int q = D.gp[nodes[t]]; q < D.gp[nodes[t] + 1]; ++q)
+            if (loc2[D.gi[q]] >= 0) si.push_back(loc2[D.gi[q]]);
+         sp[t + 1] = (int)si.size();
+      }
+      std::vector<int> lperm, lcc;
+      constrained_amd(k, sp, si, -1, lperm, lcc);
+      for (int t = 0; t < k; ++t) perm.push_back(orig[nodes[lperm[t]]]);
+      for (int t = 0; t < k; ++t) loc2[nodes[t]] = -1;
+   }
+   perm.insert(perm.end(), hubs_last.begin(), hubs_last.end());
+   if ((int)perm.size() != n) return false;
    exact_colcounts(n, ap, ai, perm, colcount);
    return true;
 }

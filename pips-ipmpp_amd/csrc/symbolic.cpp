@@ -50,7 +50,8 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    }
    if (opt.user_perm) {
       out.perm.assign(opt.user_perm, opt.user_perm + n);
-      out.colcount.assign(n, 0);
+      if (opt.user_colcount) out.colcount.assign(opt.user_colcount, opt.user_colcount + n);
+      else out.colcount.assign(n, 0);
    } else if (!opt.constrain_order)
       constrained_amd(n, ap, ai, -1, out.perm, out.colcount);
    else if (!dissected_order(n, ap, ai, n_primal, opt.nd_depth, out.perm, out.colcount, opt.nd_min_size))

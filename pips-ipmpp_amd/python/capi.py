@@ -57,7 +57,7 @@ SYMBOLS = [
     "pips_hip_batch_solve_dev", "pips_hip_batch_solve", "pips_hip_batch_border_tmult_dev", "pips_hip_batch_border_mult_dev",
     "pips_hip_batch_inertia", "pips_hip_batch_info", "pips_hip_batch_sync", "pips_hip_batch_set_timing",
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
-    "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
+    "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_sparse_root_info", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_last_ltsolve_from_factor", "pips_hip_kkt_set_solve_graph", "pips_hip_kkt_solve_graph_stats", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
@@ -69,7 +69,7 @@ SYMBOLS = [
     "pips_hip_vec_find_blocking", "pips_hip_vec_weighted_stepbounds", "pips_hip_vec_dot_shifted", "pips_ipm_create", "pips_ipm_create_rank", "pips_ipm_create_general", "pips_ipm_get_dims", "pips_ipm_get_iterate", "pips_ipm_get_stats2", "pips_ipm_mult", "pips_ipm_outer_solve", "pips_ipm_solve", "pips_ipm_set_gondzio", "pips_ipm_set_option", "pips_ipm_set_free_variables", "pips_ipm_get_solution", "pips_ipm_get_trace", "pips_ipm_get_stats", "pips_ipm_destroy",
     "pips_gdx_read_block", "pips_gdx_block_counts", "pips_gdx_block_vector", "pips_gdx_block_matrix", "pips_gdx_block_destroy",
     "pips_gen_row_nnz", "pips_gen_block", "pips_gen_root", "pips_gen_diagonal", "pips_kkt_leaf_assemble",
-    "pips_border_assemble", "pips_symbolic_probe", "pips_map_children_to_ranks",
+    "pips_border_assemble", "pips_symbolic_probe", "pips_symbolic_probe_hubs", "pips_map_children_to_ranks",
 ]
 
 
@@ -221,6 +221,20 @@ def symbolic_probe(K, n_primal=-1, Bt=None, force_n_head=-1, want_perm=False):
         info["perm"] = perm
         info["colcount"] = cc
     return info
+
+
+def symbolic_probe_hubs(K, hubs, n_primal=-1, min_size=48):
+    """Symbolic analysis under the sparse root's dissection order (hubs last); returns the info dict with perm and colcount."""
+    what = np.zeros(11, np.int64)
+    perm = np.zeros(K.nrows, np.int32)
+    cc = np.zeros(K.nrows, np.int32)
+    hubs = _i32(hubs)
+    _check(lib.pips_symbolic_probe_hubs(C.c_int(K.nrows), C.c_int(n_primal), _ptr(K.rowptr), _ptr(K.colidx), C.c_int(len(hubs)),
+                                        _ptr(hubs), C.c_int(min_size), _ptr(what), C.c_int(11), _ptr(perm), _ptr(cc)),
+           "pips_symbolic_probe_hubs")
+    return dict(nnzL=int(what[0]), n=int(what[1]), n_head=int(what[2]), m=int(what[3]), n_sn=int(what[4]), n_levels=int(what[5]),
+                flops_factor=int(what[6]), flops_border=int(what[7]), arena_bytes=int(what[8]), ntc=int(what[9]),
+                upd_bytes=int(what[10]), perm=perm, colcount=cc)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -614,6 +628,13 @@ class KktSystem:
         rp, ci, v = np.zeros(self.S + 1, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nnz.value)
         _check(lib.pips_hip_kkt_get_schur_sparse(self._h, C.byref(nnz), _ptr(rp), _ptr(ci), _ptr(v)), "pips_hip_kkt_get_schur_sparse")
         return sp.csr_matrix((v, ci, rp), shape=(self.S, self.S))
+
+    def sparse_root_info(self):
+        """Sparse-root systems: elimination order taken ("amd" | "band" | "dissected") and the symbolic figures of the root's engine."""
+        what = np.zeros(16, np.int64)
+        _check(lib.pips_hip_kkt_sparse_root_info(self._h, _ptr(what), C.c_int(16)), "pips_hip_kkt_sparse_root_info")
+        return dict(order=("amd", "band", "dissected")[int(what[0])], nnzL=int(what[1]), n=int(what[2]), n_head=int(what[3]), m=int(what[4]),
+                    n_sn=int(what[5]), n_levels=int(what[6]), flops_factor=int(what[7]), multifrontal_head=int(what[15]))
 
     def schur_ptr(self):
         p = C.c_void_p()

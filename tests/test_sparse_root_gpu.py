@@ -50,19 +50,28 @@ def _build(prob, sparse_root, **kw):
     return bt, pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, sparse_root=sparse_root, **kw)
 
 
-@pytest.mark.parametrize("root_path", ["band", "amd"])
+@pytest.mark.parametrize("root_path", ["band", "amd", "dissected"])
 @pytest.mark.parametrize("shape", [(6, 120, 60, 4, 3), (9, 300, 150, 6, 8), (24, 90, 45, 3, 6), (30, 60, 30, 5, 20)])
 def test_sparse_root_matches_dense_oracle(shape, root_path, monkeypatch):
-    """root_path: the banded all-tile elimination (linking rows, then x0) or minimum degree with the head / tail split - the
-    library picks by the thickness of the tile envelope, the test forces both.  The last shape spans five tiles."""
+    """root_path: the banded all-tile elimination (linking rows, then x0), minimum degree with the head / tail split, or the linking
+    rows dissected around x0 (a tree of fronts for the multifrontal head; needs >= 96 linking rows, else it falls back to the band) - the
+    library picks by the thickness of the tile envelope, the test forces each.  The last shape spans five tiles."""
     import torch
-    monkeypatch.setenv("PIPS_HIP_SPARSE_ROOT_BAND", "1" if root_path == "band" else "0")
+    monkeypatch.setenv("PIPS_HIP_SPARSE_ROOT_BAND", {"band": "1", "amd": "0", "dissected": "2"}[root_path])
     N, n_i, my_i, n0, L = shape
     prob = TwoLinkProblem(77, N, n_i, my_i, n0, L, 5.0 / n_i)
     S = prob.S
     bt, kkt = _build(prob, True)
     diag = torch.tensor(np.concatenate([b["diag"] for b in prob.blocks]), device="cuda")
     xd0 = torch.tensor(prob.x_diag0, device="cuda")
+    ri = kkt.sparse_root_info()
+    if root_path == "dissected":
+        # (N - 1) L linking rows: dissected where there are enough of them, and then every linking row is in the head, x0 in the tail
+        assert ri["order"] == ("dissected" if (N - 1) * L >= 96 else "band")
+        if ri["order"] == "dissected":
+            assert ri["n_head"] == (N - 1) * L and ri["m"] == n0 and ri["multifrontal_head"] == 1 and ri["n_levels"] >= 3
+    else:
+        assert ri["order"] == root_path
     kkt.factorize(diag, xd0)
     SCs = kkt.schur_sparse_to_host()
     want = np.tril(prob.oracle_finalize(prob.oracle_schur()))

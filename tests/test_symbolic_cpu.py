@@ -144,3 +144,58 @@ def test_deep_dissection_beats_the_round_one_setting():
     assert new["n_levels"] * 3 < old["n_levels"], (new["n_levels"], old["n_levels"])
     assert new["nnzL"] <= 1.10 * old["nnzL"], (new["nnzL"], old["nnzL"])
     assert sorted(new["perm"].tolist()) == list(range(K.nrows))
+
+
+def _two_link_schur_pattern(N, L, n0):
+    """Lower-triangular pattern of the Schur complement of a 2-link arrowhead problem: x0 block dense, every linking row coupled to x0,
+    to the rows of its own block pair and to those of the pair before."""
+    import scipy.sparse as sp
+    S = n0 + (N - 1) * L
+    rows, cols = [], []
+    for i in range(n0):
+        rows += [i] * (i + 1); cols += list(range(i + 1))
+    for p in range(N - 1):
+        r0 = n0 + p * L
+        for a in range(L):
+            i = r0 + a
+            c = list(range(n0)) + list(range(max(n0, r0 - L), i + 1))
+            rows += [i] * len(c); cols += c
+    A = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(S, S))
+    A.sort_indices()
+    return pa.Csr(S, S, A.indptr, A.indices, A.data)
+
+
+def test_sparse_root_order_dissects_the_chain_around_the_hubs():
+    """pips_symbolic_probe_hubs = the order pips_hip_kkt_create_sparse takes for a chain-like Schur complement: x0 last, the linking rows
+    a tree.  Against the reference's root structure (sLinsysRootAug.C:1629-1739 hands the same pattern to PARDISO, which runs METIS on
+    it): the constrained order of the leaves would eliminate x0 first and fill the matrix completely."""
+    N, L, n0 = 64, 31, 95
+    K = _two_link_schur_pattern(N, L, n0)
+    S = K.nrows
+    info = pa.capi.symbolic_probe_hubs(K, np.arange(n0), n_primal=n0)
+    perm = info["perm"]
+    assert sorted(perm.tolist()) == list(range(S))
+    assert perm[-n0:].tolist() == list(range(n0))                    # the hubs last, in the given order
+    assert info["n_head"] == S - n0 and info["m"] == n0              # every linking row in the head, x0 the dense tail
+    assert info["colcount"].max() <= 2 * L + n0 + L                  # fronts: a block's rows + two neighbouring separators + x0
+    # a tree, not a chain: depth ~ 2 log2(N) supernode levels (31 columns = two supernodes of <= 16) against N * L / 16 for the band
+    assert info["n_levels"] <= 4 * int(np.ceil(np.log2(N))) and info["n_sn"] >= 2 * (N - 1)
+    dense = pa.symbolic_probe(K, n0)                                  # x0 first (the leaves' constraint): all of it becomes a dense tail
+    assert dense["n_head"] == 0 and dense["flops_factor"] > 20 * info["flops_factor"]
+    # the fill under the order matches an explicit symbolic elimination (oracle)
+    import scipy.sparse as sp
+    A = K.to_scipy()
+    A = (A + sp.tril(A, -1).T).tocsr()
+    o = orc.OracleLdl(A, perm=perm)
+    assert int(info["colcount"].sum()) == o.nnzL()
+
+
+def test_sparse_root_order_reports_missing_separators():
+    """a Schur complement without chain structure (every linking row touches every other): no separators, PIPS_ERR_STATE - the library
+    then keeps the band / minimum-degree paths"""
+    import scipy.sparse as sp
+    S, n0 = 300, 4
+    A = sp.csr_matrix(np.tril(np.ones((S, S))))
+    K = pa.Csr(S, S, A.indptr, A.indices, A.data)
+    with pytest.raises(RuntimeError):
+        pa.capi.symbolic_probe_hubs(K, np.arange(n0), n_primal=n0)

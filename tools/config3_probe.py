@@ -38,3 +38,8 @@ ts = timed(lambda: kkt.solve_compressed(x0, xl))
 xs = bl.clone()
 tl = timed(lambda: bt.solve(xs))
 print(f"{N} x {n_i}, S = {S}: analyze {t_an:.1f} s, factorize {tf:.1f} ms, solveCompressed {ts:.1f} ms, leaf solve {tl:.1f} ms; info {info}")
+if os.environ.get("PROBE_PHASES"):   # phase table of one factorize + one solveCompressed (HIP events)
+    bt.set_timing(True)
+    kkt.factorize(leaf_diag, xd0); x0, xl = b0.clone(), bl.clone(); kkt.solve_compressed(x0, xl); bt.sync(); torch.cuda.synchronize()
+    print("kkt phases:", {k: round(v, 3) if not isinstance(v, tuple) else (round(v[0], 3), v[1]) for k, v in kkt.get_timing().items()})
+    print("leaf phases:", {k: (round(v[0], 3), v[1]) for k, v in bt.get_timing().items()})
