@@ -2701,7 +2701,7 @@ int pips_hip_batch_border_tmult_dev(void* handle, const double* z_dev, double* b
                          e->d_bt_xoff, z_dev, e->d_bt_tmp, e->bt_rows_total, alpha);
       e->gather(e->g_btm, e->d_bt_tmp, b0_dev);
    } else if (e->bt_rows_total > 0)
-      hipLaunchKernelGGL(k_border_tmult, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr,
+      hipLaunchKernelGGL(k_border_tmult, dim3(grid_for(e->bt_rows_total * BT_LANES, 256, 65536)), dim3(256), 0, e->stream, e->d_bt_rowptr,
                          e->d_bt_colidx, e->d_bval, e->d_bt_rowsc, e->d_bt_xoff, z_dev, b0_dev, e->bt_rows_total, alpha);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;
@@ -2716,7 +2716,7 @@ int pips_hip_batch_border_mult_dev(void* handle, const double* x0_dev, double* t
                          e->d_bt_rowsc, x0_dev, e->d_bt_tmp, e->bt_rows_total, alpha);
       e->gather(e->g_bm, e->d_bt_tmp, t_dev);
    } else if (e->bt_rows_total > 0)
-      hipLaunchKernelGGL(k_border_mult, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr,
+      hipLaunchKernelGGL(k_border_mult, dim3(grid_for(e->bt_rows_total * BT_LANES, 256, 65536)), dim3(256), 0, e->stream, e->d_bt_rowptr,
                          e->d_bt_colidx, e->d_bval, e->d_bt_rowsc, e->d_bt_xoff, x0_dev, t_dev, e->bt_rows_total, alpha);
    HIP_TRY(hipGetLastError());
    return PIPS_OK;

@@ -2865,15 +2865,28 @@ __global__ __launch_bounds__(256) void k_full_spmv_sub_long(const long long* __r
 // border products (K12 / K15):  b0 -= sum_i Br_i^T z_i   and   t_i = Br_i x0
 // Bt is the CSR of Br_i^T (rows = Schur column ids), concatenated over blocks.
 // ------------------------------------------------------------------------------------------------
+// Sixteen lanes per row of Bt: its rows are very uneven (time-coupled blocks: 95 first-stage columns with ~500 entries each beside 62
+// linking rows with three, and most (block, Schur column) pairs empty) - a thread per row walked the long rows alone, entry by entry.
+constexpr int BT_LANES = 16;
+
 __global__ void k_border_tmult(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                                const double* __restrict__ val, const int* __restrict__ row_sc,
                                const long long* __restrict__ row_xoff, const double* __restrict__ z,
                                double* __restrict__ b0, long long nrows, double alpha) {
-   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+   const int l = threadIdx.x & (BT_LANES - 1);
+   const long long step = ((long long)gridDim.x * blockDim.x) / BT_LANES, i_end = (nrows + step - 1) / step * step;   // whole waves (shuffles)
+   for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) / BT_LANES; i < i_end; i += step) {
       double s = 0.0;
-      const long long xo = row_xoff[i];
-      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * z[xo + colidx[p]];
-      if (s != 0.0) atomic_add_f64(b0 + row_sc[i], alpha * s);
+      if (i < nrows) {
+         const int p1 = rowptr[i + 1];
+         const long long xo = row_xoff[i];
+         for (int p = rowptr[i] + l; p < p1; p += BT_LANES) s += val[p] * z[xo + colidx[p]];
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 8);
+      if (i < nrows && l == 0 && s != 0.0) atomic_add_f64(b0 + row_sc[i], alpha * s);
    }
 }
 
@@ -2901,11 +2914,15 @@ __global__ void k_border_mult(const int* __restrict__ rowptr, const int* __restr
                               const double* __restrict__ val, const int* __restrict__ row_sc,
                               const long long* __restrict__ row_xoff, const double* __restrict__ x0,
                               double* __restrict__ t, long long nrows, double alpha) {
-   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+   const int l = threadIdx.x & (BT_LANES - 1);
+   const long long step = ((long long)gridDim.x * blockDim.x) / BT_LANES;
+   for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) / BT_LANES; i < nrows; i += step) {
+      const int p0 = rowptr[i], p1 = rowptr[i + 1];
+      if (p0 == p1) continue;
       const double xs = alpha * x0[row_sc[i]];
       if (xs == 0.0) continue;
       const long long xo = row_xoff[i];
-      for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) atomic_add_f64(t + xo + colidx[p], val[p] * xs);
+      for (int p = p0 + l; p < p1; p += BT_LANES) atomic_add_f64(t + xo + colidx[p], val[p] * xs);
    }
 }
 
