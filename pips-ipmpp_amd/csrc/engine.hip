@@ -645,6 +645,7 @@ struct Engine {
    LeafDesc* d_leafdesc = nullptr;   // compact records of the level-0 simple leaves, in the order of d_sns (k_leaf_bwd)
    int head_wcap = HEAD_WMAX;   // widest head supernode of this analysis (picks the register-lean variants of the chain kernels)
    int *d_rowidx = nullptr, *d_upd = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr, *d_nprimal = nullptr;
+   int *d_br_rowptr = nullptr, *d_br_sc = nullptr, *d_br_src = nullptr;   // the border by leaf row (k_border_mult_rows)
    int *d_krowptr = nullptr, *d_kcolidx = nullptr, *d_bt_rowptr = nullptr, *d_bt_colidx = nullptr, *d_bt_rowsc = nullptr;
    signed char* d_psign = nullptr;
    std::vector<int> h_inertia;
@@ -667,6 +668,9 @@ struct Engine {
       for (void* q : {(void*)d_lf_rows, (void*)d_lf_ptr, (void*)d_lf_src, (void*)d_lf_pos, (void*)d_lf_val})
          if (q) (void)hipFree(q);
       d_lf_rows = d_lf_ptr = d_lf_src = d_lf_pos = nullptr; d_lf_val = nullptr;
+      for (void* q : {(void*)d_br_rowptr, (void*)d_br_sc, (void*)d_br_src})
+         if (q) (void)hipFree(q);
+      d_br_rowptr = d_br_sc = d_br_src = nullptr;
       if (d_leafdesc) (void)hipFree(d_leafdesc);
       d_leafdesc = nullptr;
       lf_rows = 0; lf_entries = 0;
@@ -1386,6 +1390,22 @@ struct Engine {
       if ((rc = dev_upload(&d_bt_rowptr, h_bt_rowptr, stream))) return rc;
       if ((rc = dev_upload(&d_bt_colidx, h_bt_colidx, stream))) return rc;
       if ((rc = dev_upload(&d_bt_rowsc, h_bt_rowsc, stream))) return rc;
+      // ---- the border by LEAF row (t += alpha Br x0 as a gather, k_border_mult_rows): row pointers over the flat leaf space, Schur
+      //      column and position in d_bval of every entry
+      if (bt_rows_total > 0 && nnzB_total > 0 && nnzB_total < (1LL << 31) && !getenv("PIPS_HIP_NO_BORDER_ROWS")) {
+         std::vector<int> rp((size_t)n_total + 1, 0);
+         for (long long r = 0; r < bt_rows_total; ++r)
+            for (int p = h_bt_rowptr[r]; p < h_bt_rowptr[r + 1]; ++p) ++rp[h_bt_xoff[r] + h_bt_colidx[p] + 1];
+         for (long long i = 0; i < n_total; ++i) rp[i + 1] += rp[i];
+         std::vector<int> sc((size_t)nnzB_total), src((size_t)nnzB_total), fill(rp.begin(), rp.end() - 1);
+         for (long long r = 0; r < bt_rows_total; ++r)   // ascending (block, Schur column): the order of every row's sum
+            for (int p = h_bt_rowptr[r]; p < h_bt_rowptr[r + 1]; ++p) {
+               const int q = fill[h_bt_xoff[r] + h_bt_colidx[p]]++;
+               sc[q] = h_bt_rowsc[r]; src[q] = p;
+            }
+         if ((rc = dev_upload(&d_br_rowptr, rp, stream)) || (rc = dev_upload(&d_br_sc, sc, stream)) || (rc = dev_upload(&d_br_src, src, stream)))
+            return rc;
+      }
       {
          std::vector<int> np(nblk);
          for (int b = 0; b < nblk; ++b) np[b] = in[b].n_primal;
@@ -2715,7 +2735,10 @@ int pips_hip_batch_border_mult_dev(void* handle, const double* x0_dev, double* t
       hipLaunchKernelGGL(k_border_entry_products, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr, e->d_bval,
                          e->d_bt_rowsc, x0_dev, e->d_bt_tmp, e->bt_rows_total, alpha);
       e->gather(e->g_bm, e->d_bt_tmp, t_dev);
-   } else if (e->bt_rows_total > 0)
+   } else if (e->bt_rows_total > 0 && e->d_br_rowptr)
+      hipLaunchKernelGGL(k_border_mult_rows, dim3(grid_for(e->n_total, 256, 1 << 20)), dim3(256), 0, e->stream, e->d_br_rowptr, e->d_br_sc, e->d_br_src,
+                         e->d_bval, x0_dev, t_dev, e->n_total, alpha);
+   else if (e->bt_rows_total > 0)
       hipLaunchKernelGGL(k_border_mult, dim3(grid_for(e->bt_rows_total * BT_LANES, 256, 65536)), dim3(256), 0, e->stream, e->d_bt_rowptr,
                          e->d_bt_colidx, e->d_bval, e->d_bt_rowsc, e->d_bt_xoff, x0_dev, t_dev, e->bt_rows_total, alpha);
    HIP_TRY(hipGetLastError());

@@ -2910,6 +2910,20 @@ __global__ void k_border_entry_products(const int* __restrict__ rowptr, const do
    }
 }
 
+// t += alpha Br x0 from the side of the leaf rows (Engine::d_br_rowptr: the border transposed once at analyze time): a thread per row
+// sums its few entries in a fixed order - no atomics
+__global__ void k_border_mult_rows(const int* __restrict__ rowptr, const int* __restrict__ sc, const int* __restrict__ src,
+                                   const double* __restrict__ val, const double* __restrict__ x0, double* __restrict__ t, long long nrows,
+                                   double alpha) {
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nrows; i += (long long)gridDim.x * blockDim.x) {
+      const int p0 = rowptr[i], p1 = rowptr[i + 1];
+      if (p0 == p1) continue;
+      double s = 0.0;
+      for (int p = p0; p < p1; ++p) s += val[src[p]] * x0[sc[p]];
+      t[i] += alpha * s;
+   }
+}
+
 __global__ void k_border_mult(const int* __restrict__ rowptr, const int* __restrict__ colidx,
                               const double* __restrict__ val, const int* __restrict__ row_sc,
                               const long long* __restrict__ row_xoff, const double* __restrict__ x0,
