@@ -766,8 +766,9 @@ struct Engine {
    int* d_blk_group = nullptr;
    int det_n_groups = 0, det_first_slot = 0;
    // groups for the deterministic Schur accumulation: the global problem has eight group slots; this rank (rank of n_ranks, blocks
-   // sharded contiguously and evenly) fills 8 / n_ranks of them (all eight when n_ranks does not divide 8: then only run-to-run
-   // reproducibility holds, not equality with other rank counts)
+   // sharded contiguously and evenly) fills 8 / n_ranks of them (all eight when n_ranks does not divide 8).  What holds across rank
+   // counts: 1 and 2 ranks give equal bits; 4 and 8 ranks are reproducible run to run only - the all-reduce, not the fixed tree,
+   // associates the ranks' partial sums
    int set_det_groups(int rank, int n_ranks) {
       if (!analyzed || !deterministic) return PIPS_OK;
       const int slots = (n_ranks >= 1 && n_ranks <= 8 && 8 % n_ranks == 0) ? 8 / n_ranks : 8;
@@ -3552,8 +3553,9 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    }
    if (e->deterministic && e->d_gvec && !k->sparse) {
       // deterministic Lsolve: t = -sum_i Br_i^T K_i^-1 b_i is formed on its own - group-wise in block order, the (at most eight)
-      // groups in the fixed tree of k_reduce_groups, the ranks' parts by the all-reduce - and added to b0 on every rank: the
-      // association no longer depends on how the blocks are spread over 1, 2, 4 or 8 ranks
+      // groups in the fixed tree of k_reduce_groups, the ranks' parts by the all-reduce - and added to b0 on every rank.  Guarantee:
+      // run-to-run reproducibility for any rank count, and equal bits for 1 and 2 ranks (a two-operand all-reduce has one order);
+      // with 4 or 8 ranks the association of the per-rank partial sums is the all-reduce's (ring / tree, per chunk), not this tree
       if ((rc = e->solve(b_leaf_dev))) return rc;
       HIP_TRY(hipMemsetAsync(e->d_gvec, 0, (size_t)8 * k->S * sizeof(double), e->stream));
       HIP_TRY(hipMemsetAsync(e->d_tvec, 0, (size_t)k->S * sizeof(double), e->stream));

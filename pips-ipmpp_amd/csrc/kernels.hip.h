@@ -1498,7 +1498,8 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm_bal(const TileTask* __rest
 
 // deterministic mode: SC += ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)) over the (at most eight) group buffers, lower triangle.
 // The order is a function of the global block partition only, so one rank with eight groups and two ranks with four groups each
-// followed by the two-operand sum of the all-reduce give the same bits.
+// followed by the two-operand sum of the all-reduce give the same bits.  (Not so for 4 or 8 ranks: there the all-reduce associates
+// the ranks' partial sums in its own order - reproducible run to run, but not this tree.)
 __global__ void k_reduce_groups(double* __restrict__ SC, int ld, int S, const double* __restrict__ gbuf, long long gstride, int n_groups,
                                 int first_slot) {
    const int c = blockIdx.y;
