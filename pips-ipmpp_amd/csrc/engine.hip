@@ -608,6 +608,7 @@ struct Engine {
    // record -> lists / values -> gathered solution entries), and the thread-per-leaf kernels hide that latency behind 12.6 M
    // threads where a wave per front cannot.  PIPS_HIP_MF_SOLVES=1 selects them (tests do).
    bool mf_solves = false;
+   bool mf_bucket_by_class = true;   // launches of a level cut at occupancy classes (PIPS_HIP_MF_BUCKETS=spread: at 25 % LDS spread)
    int sn_width = 0;           // > 0: supernode width cap of this engine instead of the tuned default (the sparse root: a single block, every level is latency)
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
@@ -969,6 +970,7 @@ struct Engine {
          const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
          mf = !(env && atoi(env) == 0) && !(hs && atoi(hs) != 0 && !deterministic);
          mf_solves = getenv("PIPS_HIP_MF_SOLVES") && atoi(getenv("PIPS_HIP_MF_SOLVES")) != 0;
+         if (const char* bk = getenv("PIPS_HIP_MF_BUCKETS")) mf_bucket_by_class = std::string(bk) != "spread";
          for (int b = 0; b < nblk && mf; ++b) {
             mf = sym[b].mf_ok;
             // fronts with very many leaves below them: the staged leaf data must fit beside the front
@@ -1144,7 +1146,16 @@ struct Engine {
             if (!open) {
                const MfLaunch& m = mf_launches.back();
                const int first_lds = keys[m.begin].lds;
-               if (m.cnt >= 2048 && k.lds > std::max(first_lds + first_lds / 4, first_lds + 256)) open = true;
+               if (mf_bucket_by_class) {
+                  // how many fronts of the variant share a compute unit: the LDS decides up to the limit the registers set (123 VGPRs: four
+                  // waves per SIMD - four workgroups of 256 threads, sixteen of 64); a bucket = one such class, since inside a class a
+                  // smaller front gains nothing from a launch of its own and across a boundary every front of the launch loses a slot
+                  auto cls_of = [&](int lds_doubles) {
+                     const int c = k.cls - 1, kmax = c == 0 ? 16 : c == 3 ? 12 : c == 2 ? 4 : 3;   // (154 VGPRs for the 32-wide variants)
+                     return std::min(kmax, (int)(163840 / ((long long)lds_doubles * 8 + 1024)));
+                  };
+                  if (m.cnt >= 256 && cls_of(k.lds) < cls_of(first_lds)) open = true;
+               } else if (m.cnt >= 2048 && k.lds > std::max(first_lds + first_lds / 4, first_lds + 256)) open = true;
             }
             if (open) mf_launches.push_back({k.level, k.cls - 1, i, 0, 0});
             ++mf_launches.back().cnt;
