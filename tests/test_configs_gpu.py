@@ -172,6 +172,10 @@ def test_config4_share_energy_like(sparse_root):
     info = bt.info()
     xd0 = pa.gen_diagonal(seed, 0, n0)
     kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, sparse_root=sparse_root)
+    if sparse_root and (N - 1) * L >= 96:
+        # a chain of 31-row cliques around 95 hubs: dissected (fronts of <= 188 rows), every linking row in the multifrontal head
+        ri = kkt.sparse_root_info()
+        assert ri["order"] == "dissected" and ri["n_head"] == myl and ri["m"] == n0 and ri["multifrontal_head"] == 1
     leaf_diag = torch.tensor(np.concatenate(diags), device="cuda")
     xd0_d = torch.tensor(xd0, device="cuda")
     kkt.factorize(leaf_diag, xd0_d)
