@@ -432,7 +432,8 @@ def main():
                 "leaf_solve_passes": n_solve_once}
     collective = None
     if use_dist:
-        payload = 8.0 * S * (S + 1) / 2
+        # bytes of the Schur reduction: the packed triangle of the dense root, or the value array of the sparse root's pattern
+        payload = 8.0 * kkt.schur_sparse_nnz() if sparse_root else 8.0 * S * (S + 1) / 2
         P = max(world, 1)
         tot = tk["reduce_panels"][0] if tk["reduce_panels"][1] > 0 else tk["reduce"][0]
         collective = {"schur_reduce_exposed_ms": round(tk["reduce"][0], 3), "schur_reduce_total_ms": round(tot, 3),

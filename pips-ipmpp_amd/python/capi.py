@@ -620,6 +620,12 @@ class KktSystem:
     def solve_compressed(self, b0_dev, b_leaf_dev):
         _check(lib.pips_hip_kkt_solve_compressed(self._h, _ptr(b0_dev), _ptr(b_leaf_dev)), "pips_hip_kkt_solve_compressed")
 
+    def schur_sparse_nnz(self):
+        """Sparse-root systems: stored entries of the Schur complement (= doubles every rank reduces per factorisation)."""
+        nnz = C.c_int()
+        _check(lib.pips_hip_kkt_get_schur_sparse(self._h, C.byref(nnz), None, None, None), "pips_hip_kkt_get_schur_sparse")
+        return int(nnz.value)
+
     def schur_sparse_to_host(self):
         """Sparse-root systems: the Schur complement as a scipy CSR matrix (lower triangle)."""
         import scipy.sparse as sp
