@@ -89,6 +89,7 @@ struct BlockSym {
                                         //   value < n : permuted row of K ; value >= n : n + compressed border index
    std::vector<int> upd;                // head-to-head update segments, see symbolic.cpp "update segments"
    std::vector<int64_t> a_dst;          // [nnz(K lower)] arena offset of every CSR entry
+   std::vector<char> a_front, b_front;  // 1: the entry lands in the panel of a front (k_front takes it from the value array itself: no scatter)
    std::vector<int64_t> b_dst;          // [nnz(border)]  arena offset of every border entry, -1 if it lands in SC (never)
    std::vector<signed char> psign;      // [n] expected pivot sign in permuted order (+1/-1/0)
    int64_t nnzL = 0;                    // stored entries of L (head panels + dense tail lower triangle)
@@ -132,6 +133,8 @@ struct BlockSym {
 //   leaf item              { offset of the leaf's 1 + r_c values << 9 | r_c << 4 | b,  offset of its position list inside the leaf part }
 //                          - the leaf's b-th row is this front column; items are sorted by front column, inside a column by leaf
 //   position list          position of each of the leaf's r_c rows inside the front
+//   behind the leaf part   the front's own entries of K and of the border: count, then (position in the packed panel, index into the
+//                          block's K values; border entries as -1 - index into the block's border values) pairs
 constexpr int MF_HDR = 8;
 constexpr int MF_MAX_FRONT = 512;    // a thread per front row
 

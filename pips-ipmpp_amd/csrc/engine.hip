@@ -1027,6 +1027,7 @@ struct Engine {
          mfLV_base[b + 1] = mfLV_base[b] + (mf ? s.mf_LV_total : 0);
          mfV_base[b + 1] = mfV_base[b] + (mf ? s.mf_V_total : 0);
          d.lv_off = mfLV_base[b];
+         d.k_off = kptr[b]; d.b_off = bptr[b];
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
          bmap_off[b + 1] = bmap_off[b] + s.nb;
       }
@@ -1208,8 +1209,9 @@ struct Engine {
          h_psign.insert(h_psign.end(), s.psign.begin(), s.psign.end());
          h_perm_off[b] = (long long)h_perm.size();
          h_perm.insert(h_perm.end(), s.perm.begin(), s.perm.end());
-         for (size_t p = 0; p < s.a_dst.size(); ++p) h_kdst[kptr[b] + p] = h_blks[b].arena_off + s.a_dst[p];
-         for (size_t p = 0; p < s.b_dst.size(); ++p) h_bdst[bptr[b] + p] = h_blks[b].arena_off + s.b_dst[p];
+         // multifrontal head: the fronts read their panel entries from the value arrays (k_front), nobody reads them from the arena
+         for (size_t p = 0; p < s.a_dst.size(); ++p) h_kdst[kptr[b] + p] = (mf && s.a_front[p]) ? -1 : h_blks[b].arena_off + s.a_dst[p];
+         for (size_t p = 0; p < s.b_dst.size(); ++p) h_bdst[bptr[b] + p] = (mf && s.b_front[p]) ? -1 : h_blks[b].arena_off + s.b_dst[p];
          for (int i = 0; i < s.n; ++i) {
             long long dp = -1;
             for (int p = in[b].krow[i]; p < in[b].krow[i + 1]; ++p)
@@ -1495,7 +1497,7 @@ struct Engine {
       const size_t lds = (size_t)m.lds_doubles * sizeof(double);
       if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front<BLOCK, WMAX, UG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_front<BLOCK, WMAX, UG>), dim3(m.cnt), dim3(BLOCK), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_psign,
-                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV);
+                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval);
       return PIPS_OK;
    }
    long long* d_mfdbg = nullptr;   // PIPS_HIP_MF_CLOCKS: phase stamps of every front (8 per supernode), dumped after the factorisation
@@ -1708,7 +1710,9 @@ struct Engine {
       hipLaunchKernelGGL(k_block_absmax, dim3(std::max(1, std::min(64, (int)(nnzK_total / nblk / 4096))), nblk), dim3(256), 0, stream, d_kval,
                          d_kptr, d_blks);
       hipLaunchKernelGGL(k_block_absmax_finish, dim3((nblk + 255) / 256), dim3(256), 0, stream, d_blks, nblk, thr_rel, repl_rel);
-      hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena);
+      // multifrontal head: no panel of the head is read before it is written (simple leaves: every entry of the panel is an entry of K or
+      // of the border and comes with k_scatter; fronts: assembled in LDS, written out whole) - only the tails are cleared
+      hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena, mf ? 1 : 0);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
       if (persistent_gemm || balanced_gemm) {
          if (!d_gemm_ctr) HIP_TRY(hipMalloc((void**)&d_gemm_ctr, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int)));

@@ -55,6 +55,7 @@ struct BlkDesc {
    double thr_rel, repl_rel;  // pivot threshold / replacement relative to the pivot's reference magnitude pref[k]
    double repl_abs;           // replacement when no reference magnitude exists (structurally zero diagonal)
    long long lv_off;          // multifrontal head: offset of the block's leaf values inside the leaf-value arena
+   long long k_off, b_off;    // offsets of the block's K values / border values (Engine::d_kval, d_bval): k_front reads its panel entries there
 };
 
 struct TileTask { int blk, ti, tj, pad; };
@@ -126,20 +127,24 @@ __device__ __forceinline__ double fix_pivot(double d, int sign, double pref, dou
 __global__ void k_scatter(const long long* __restrict__ dst, const double* __restrict__ val, double* __restrict__ arena,
                           long long n) {
    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-      arena[dst[i]] = val[i];
+   {
+      const long long d = dst[i];
+      if (d >= 0) arena[d] = val[i];   // (< 0: an entry a front takes from the value array itself)
+   }
 }
 
 // arena := 0 where a factorisation reads or accumulates: the head panels and, in the dense tail, every column from the
 // top of its diagonal tile down (the tiles above the diagonal are never touched: a third of the arena at config 2).
 // grid (x, block); 16-byte stores
-__global__ __launch_bounds__(256) void k_arena_clear(const BlkDesc* __restrict__ blks, double* __restrict__ arena) {
+__global__ __launch_bounds__(256) void k_arena_clear(const BlkDesc* __restrict__ blks, double* __restrict__ arena, int tail_only = 0) {
    const BlkDesc bd = blks[blockIdx.y];
    typedef double double2_t __attribute__((ext_vector_type(2)));
    const double2_t z = {0.0, 0.0};
    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
    double2_t* head = (double2_t*)(arena + bd.arena_off);
    const long long nh = (bd.T - bd.arena_off) / 2;   // panels are padded to 16 doubles
-   for (long long i = gtid; i < nh; i += gstride) head[i] = z;
+   if (!tail_only)
+      for (long long i = gtid; i < nh; i += gstride) head[i] = z;
    // tail: a workgroup takes whole columns, its threads run down the rows
    for (int c = blockIdx.x; c < bd.m_pad; c += gridDim.x) {
       const int r0 = c / TILE * TILE;
@@ -620,7 +625,8 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
                                                 double* __restrict__ uarena, double* __restrict__ SC, int ldSC,
                                                 int* __restrict__ inertia, const double* __restrict__ pref,
                                                 const int* __restrict__ sctab, long long* __restrict__ dbg,
-                                                const double* __restrict__ lvals) {
+                                                const double* __restrict__ lvals, const double* __restrict__ kval,
+                                                const double* __restrict__ bval) {
    extern __shared__ __attribute__((aligned(16))) double mf_F[];
    __shared__ double dk[WMAX];
    // development aid (PIPS_HIP_MF_CLOCKS): thread 0 stamps the phase boundaries, 8 stamps per front
@@ -674,6 +680,17 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    if (n_leaf) {   // the leaves' d and l: written as one piece by the leaf kernel
       const double* lv = lvals + bd.lv_off + H[7];
       for (int idx = tid; idx < n_vals; idx += BLOCK) vals[idx] = lv[idx];
+   }
+   {  // the panel's own entries of K and of the border, straight from the value arrays (the record lists them behind the leaf part):
+      // the panel in the arena holds nothing else but zeros, and reading it cost 16 loads per row at the head of the pivot chain
+      const int* E = H + MF_HDR + 3 * n_child + sum_rc + n_leafpart;
+      const int n_ent = E[0];
+      const double* kv = kval + bd.k_off;
+      const double* bv = bval + bd.b_off;
+      for (int e = tid; e < n_ent; e += BLOCK) {
+         const int pos = E[1 + 2 * e], src = E[2 + 2 * e];
+         lds_add(F + pos, src >= 0 ? kv[src] : bv[-1 - src]);
+      }
    }
    {
       // A wave takes a PAIR of columns (b, rc - 1 - b) of a child's packed update matrix - together rc + 1 entries whatever b is -
@@ -737,13 +754,9 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    const bool wave_has_rows = (tid & ~63) < nf;               // wave-uniform: the waves beyond the last row only help in the other phases
    if (wave_has_rows) {
 #pragma unroll
-   for (int k = 0; k < WMAX; ++k) y[k] = (i < nf && k < w && k <= i) ? P[i + (long long)k * nf] : 0.0;
+   for (int k = 0; k < WMAX; ++k) y[k] = (i < nf && k < w && k <= i) ? F[co(k) + i - k] : 0.0;
 #pragma unroll
-   for (int k = 0; k < WMAX; ++k) yp[k] = (lane < w && k <= lane) ? P[lane + (long long)k * nf] : 0.0;
-#pragma unroll
-   for (int k = 0; k < WMAX; ++k) if (i < nf && k < w && k <= i) y[k] += F[co(k) + i - k];
-#pragma unroll
-   for (int k = 0; k < WMAX; ++k) if (lane < w && k <= lane) yp[k] += F[co(k) + lane - k];
+   for (int k = 0; k < WMAX; ++k) yp[k] = (lane < w && k <= lane) ? F[co(k) + lane - k] : 0.0;
    int c_pos = 0, c_neg = 0, c_pert = 0;
    // The pivot of column k + 1 is known as soon as column k has been applied to row k + 1: it is fixed and inverted right there, so
    // that the reciprocal's dependent chain runs beside the other updates of column k instead of after them.

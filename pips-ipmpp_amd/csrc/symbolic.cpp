@@ -365,6 +365,36 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_V_total += sn.r;
       }
       if (out.mf_U_total >= (int64_t)INT32_MAX || 18 * (int64_t)nsn >= (int64_t)INT32_MAX) out.mf_ok = false;
+      // entries of K and of the border that fall into the panel of a front: (position in the packed panel, index into the block's
+      // value array; border entries as -1 - index) - k_front adds them to its zeroed LDS panel instead of reading the panel from the
+      // arena, which holds these few entries among zeros (an LP's dual columns: the diagonal and two border entries in ~100 rows)
+      std::vector<std::vector<int>> kent(nsn);
+      if (out.mf_ok) {
+         auto add_entry = [&](int c, int r, int src) {
+            const int si = out.sn_of_col[c];
+            const HeadSupernode& sn = out.sn[si];
+            if (is_simple(sn)) return;
+            const int k = c - sn.c0, nf = sn.w + sn.r;
+            int fi;
+            if (r < sn.c0 + sn.w) fi = r - sn.c0;
+            else {
+               const int* b = out.rowidx.data() + sn.rows;
+               fi = sn.w + (int)(std::lower_bound(b, b + sn.r, r) - b);
+            }
+            kent[si].push_back(k * nf - k * (k - 1) / 2 + fi - k);
+            kent[si].push_back(src);
+         };
+         for (int i = 0; i < n; ++i)
+            for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
+               const int a = out.iperm[i], b = out.iperm[K.colidx[p]];
+               if (std::min(a, b) < n_head) add_entry(std::min(a, b), std::max(a, b), p);
+            }
+         for (int sc = 0; sc < border.nrows; ++sc)
+            for (int p = border.rowptr[sc]; p < border.rowptr[sc + 1]; ++p) {
+               const int c = out.iperm[border.colidx[p]];
+               if (c < n_head) add_entry(c, n + bidx[sc], -1 - p);
+            }
+      }
       std::vector<int> pos;
       for (int s = 0; s < nsn && out.mf_ok; ++s) {
          const HeadSupernode& sn = out.sn[s];
@@ -388,7 +418,13 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
                PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, rows of supernode %d missing in its parent front", out.sn[c].c0);
             out.mf_int.insert(out.mf_int.end(), pos.begin(), pos.end());
          }
-         if (n_leaf == 0) continue;
+         // behind the (optional) leaf part: the panel's entries of K / the border: count, then (position, source) pairs
+         auto append_entries = [&]() {
+            out.mf_int.push_back((int)(kent[s].size() / 2));
+            out.mf_int.insert(out.mf_int.end(), kent[s].begin(), kent[s].end());
+            std::vector<int>().swap(kent[s]);
+         };
+         if (n_leaf == 0) { append_entries(); continue; }
          // leaf part: colptr | items | leaf table | position lists
          std::vector<int> lists, item_col, item_a, item_b, tab;
          int n_vals = 0, n_items = 0;
@@ -428,6 +464,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_int[hpos + 3] = list_base + (int)lists.size();
          out.mf_int[hpos + 4] = n_items;
          out.mf_int[hpos + 5] = n_vals;
+         append_entries();
       }
       if (!out.mf_ok) {
          std::vector<int>().swap(out.mf_int);
@@ -456,6 +493,12 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       return sn.panel + pos + (int64_t)(c - sn.c0) * ld;
    };
    out.a_dst.resize(K.rowptr[n]);
+   out.a_front.assign(K.rowptr[n], 0);
+   auto in_front = [&](int c) {   // (meaningful when the block is multifrontal: every head supernode that is not a simple leaf is a front)
+      if (c >= n_head) return false;
+      const HeadSupernode& sn = out.sn[out.sn_of_col[c]];
+      return !(sn.w == 1 && sn.r <= opt.simple_rmax && sn.level == 0);
+   };
    for (int i = 0; i < n; ++i)
       for (int p = K.rowptr[i]; p < K.rowptr[i + 1]; ++p) {
          const int a = out.iperm[i], b = out.iperm[K.colidx[p]];
@@ -467,9 +510,11 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             d = out.T_off + (r - n_head) + (int64_t)(c - n_head) * out.ldT;
          if (d < 0) PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, entry (%d,%d) not in the symbolic structure", i, K.colidx[p]);
          out.a_dst[p] = d;
+         out.a_front[p] = in_front(c) ? 1 : 0;
       }
    if (border.nrows > 0) {
       out.b_dst.resize(border.rowptr[border.nrows]);
+      out.b_front.assign(border.rowptr[border.nrows], 0);
       for (int s = 0; s < border.nrows; ++s)
          for (int p = border.rowptr[s]; p < border.rowptr[s + 1]; ++p) {
             const int c = out.iperm[border.colidx[p]];
@@ -480,6 +525,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
                d = out.T_off + (out.m_pad + bidx[s]) + (int64_t)(c - n_head) * out.ldT;
             if (d < 0) PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, border entry (%d,%d) not in the structure", s, border.colidx[p]);
             out.b_dst[p] = d;
+            out.b_front[p] = in_front(c) ? 1 : 0;
          }
    }
    return PIPS_OK;
