@@ -117,7 +117,8 @@ struct BlockSym {
 // Front record of supernode J inside BlockSym::mf_int (offsets relative to the record's start):
 //   [0]                    number of child fronts
 //   [1]                    number of simple leaves hanging below this front
-//   [2]                    1 if the front has a parent front (its update matrix stays in the update arena), 0 if it is scattered
+//   [2]                    bit 0: the front has a parent front (its update matrix / vector is picked up there); bits 1..: number of
+//                          entries of K and of the border in the front's panel (listed behind the leaf part)
 //   [3]                    length of the leaf part
 //   [4]                    number of leaf items
 //   [5]                    doubles of leaf values, sum of (1 + r_c)

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    const BlkDesc bd = blks[sn.blk];
    const int w = sn.w, r = sn.r, nf = w + r, tid = threadIdx.x, lane = tid & 63, i = tid;
    const int* H = mfint + sn.mf;
-   const int n_child = H[0], n_leaf = H[1], has_parent = H[2], n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
+   const int n_child = H[0], n_leaf = H[1], n_ent = H[2] >> 1, n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
    const int np = r * (r + 1) / 2;
    auto co = [nf](int j) { return j * nf - j * (j - 1) / 2; };
    const int cw = co(w);                                       // packed size of the panel columns
@@ -681,14 +681,14 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
       const double* lv = lvals + bd.lv_off + H[7];
       for (int idx = tid; idx < n_vals; idx += BLOCK) vals[idx] = lv[idx];
    }
-   {  // the panel's own entries of K and of the border, straight from the value arrays (the record lists them behind the leaf part):
-      // the panel in the arena holds nothing else but zeros, and reading it cost 16 loads per row at the head of the pivot chain
-      const int* E = H + MF_HDR + 3 * n_child + sum_rc + n_leafpart;
-      const int n_ent = E[0];
+   {  // the panel's own entries of K and of the border, straight from the value arrays (the record lists them behind the leaf part; the
+      // panel in the arena is neither cleared nor scattered into).  (Requested here and not ahead of the zeroing: holding them across it
+      // costs the registers that keep four waves on a SIMD - measured 27.5 against 25.7 ms.)
+      const int* E = H + MF_HDR + 3 * n_child + sum_rc + n_leafpart + 1;
       const double* kv = kval + bd.k_off;
       const double* bv = bval + bd.b_off;
       for (int e = tid; e < n_ent; e += BLOCK) {
-         const int pos = E[1 + 2 * e], src = E[2 + 2 * e];
+         const int pos = E[2 * e], src = E[2 * e + 1];
          lds_add(F + pos, src >= 0 ? kv[src] : bv[-1 - src]);
       }
    }
@@ -860,7 +860,6 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    // the update matrix goes to the update arena: the parent front picks it up there; for a front without a head parent (parent
    // column in the dense tail) k_root_assemble adds it to the tail / Schur complement after the last level, front by front in a
    // fixed order - no atomics on targets that several fronts of a block share
-   (void)has_parent;
    if (!UG) {
       double* Ug = uarena + sn.U;
       for (int idx = tid; idx < np; idx += BLOCK) Ug[idx] = FU[idx];
@@ -975,7 +974,7 @@ __global__ __launch_bounds__(64) void k_front_fwd(const SnDesc* __restrict__ sns
    const BlkDesc bd = blks[sn.blk];
    const int w = sn.w, r = sn.r, nf = w + r, lane = threadIdx.x;
    const int* H = mfint + sn.mf;
-   const int n_child = H[0], n_leaf = H[1], has_parent = H[2], n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
+   const int n_child = H[0], n_leaf = H[1], has_parent = H[2] & 1, n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
    double* t = mf_S;
    double* vals = t + nf;
    int* relbuf = (int*)(vals + n_vals);

@@ -422,6 +422,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          auto append_entries = [&]() {
             out.mf_int.push_back((int)(kent[s].size() / 2));
             out.mf_int.insert(out.mf_int.end(), kent[s].begin(), kent[s].end());
+            out.mf_int[hpos + 2] |= (int)(kent[s].size() / 2) << 1;   // (the count also in the header: the kernel requests the entries at once)
             std::vector<int>().swap(kent[s]);
          };
          if (n_leaf == 0) { append_entries(); continue; }
