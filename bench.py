@@ -68,14 +68,14 @@ def update_kernel_traffic(n_blocks, n_i, S, world):
         return None
 
 
-def head_traffic(family, n_blocks, n_i):
-    """HBM bytes of the sparse-head kernels per factorize from the committed PMC summary (tools/profile_cfg3.sh pmc); only valid for
-    the profiled workload."""
+def head_traffic(family, n_blocks, n_i, key="hbm_bytes_per_factorize"):
+    """HBM bytes of the sparse-head kernels per factorize (or, key = "solve_hbm_bytes_per_step", of the leaf solve sweeps per step)
+    from the committed PMC summary (tools/profile_cfg3.sh); only valid for the profiled workload."""
     path = os.path.join(ROOT, "profiles", "r3_cfg3_head_traffic.json")
     if family != "time-coupled" or n_blocks != 256 or n_i != 50000 or not os.path.exists(path):
         return None
     try:
-        return json.load(open(path))["hbm_bytes_per_factorize"]
+        return json.load(open(path)).get(key)
     except Exception:
         return None
 
@@ -411,8 +411,13 @@ def main():
     ]
     dominant = max(groups, key=lambda g: g["ms_per_step"])
     roofline = dict(dominant)
-    traffic = update_kernel_traffic(n_blocks_total, n_i, S, world) if dominant["group"] == "tail update" else head_traffic(a.family, n_blocks_total, n_i)
-    if dominant["group"] not in ("tail update", "sparse head"):
+    if dominant["group"] == "tail update":
+        traffic = update_kernel_traffic(n_blocks_total, n_i, S, world)
+    elif dominant["group"] == "sparse head":
+        traffic = head_traffic(a.family, n_blocks_total, n_i)
+    elif dominant["group"] == "leaf solve sweeps":
+        traffic = head_traffic(a.family, n_blocks_total, n_i, "solve_hbm_bytes_per_step")
+    else:
         traffic = None
     # per launch, like `achieved` (the rocprofv3 average duration of the kernel is ms_per_step / launches_per_step)
     roofline["traffic"] = (traffic / dominant["launches_per_step"] if traffic and dominant["launches_per_step"] else None)

@@ -40,7 +40,10 @@ def stats():
 fetch, write, st = counter_by_kernel("fetch", "FETCH_SIZE"), counter_by_kernel("write", "WRITE_SIZE"), stats()
 # the PMC passes run warmup 0 + 1 timed step + 1 instrumented step = 2 factorizations and 8 solveCompressed
 N_FACT = 2
-rows, head_bytes = [], 0.0
+rows, head_bytes, solve_bytes = [], 0.0, 0.0
+# the kernels of a leaf solve pass (bench.py's "leaf solve sweeps" group)
+SOLVE_KERNELS = {"k_permute_in", "k_permute_out", "k_leaf_fwd_gather", "k_leaf_bwd", "k_head_fwd_chain", "k_head_bwd_chain", "k_head_fwd",
+                 "k_head_bwd", "k_head_solve_simple", "k_head_dscale", "k_tail_rows_fwd", "k_tail_rows_bwd", "k_tail_fwd", "k_tail_bwd"}
 for k in sorted(set(fetch) | set(write)):
     fk, nd = fetch.get(k, (0.0, 0))
     wk, nw = write.get(k, (0.0, 0))
@@ -51,10 +54,13 @@ for k in sorted(set(fetch) | set(write)):
                  "avg_launch_us": avg_ns / 1e3, "achieved_TBps": ((rd + wr) / n) / (avg_ns * 1e-9) / 1e12 if avg_ns > 0 else None})
     if k.startswith("k_front") or k.startswith("k_head_factor"):
         head_bytes += rd + wr
+    if k.split("<")[0] in SOLVE_KERNELS:
+        solve_bytes += rd + wr
 rows.sort(key=lambda r: -(r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]) * r["dispatches_in_pmc_pass"])
 json.dump({"note": "FETCH_SIZE x 2048, WRITE_SIZE x 1024 bytes per counter KiB (see docstring); separate --pmc passes", "kernels": rows},
           open(os.path.join(out, f"{tag}_cfg3_hbm_by_kernel.json"), "w"), indent=1)
 json.dump({"hbm_bytes_per_factorize": head_bytes / N_FACT, "kernels": "k_front<*> + k_head_factor_simple",
+           "solve_hbm_bytes_per_step": solve_bytes / N_FACT, "solve_kernels": sorted(SOLVE_KERNELS),
            "source": f"{tag}_cfg3_hbm_by_kernel.json", "factorizations_in_pass": N_FACT},
           open(os.path.join(out, f"{tag}_cfg3_head_traffic.json"), "w"), indent=1)
 print(json.dumps({"head_hbm_bytes_per_factorize": head_bytes / N_FACT, "top": rows[:12]}, indent=1))
