@@ -405,7 +405,7 @@ def main():
               "8 (nnz K + nnz L_head) + 4 (nnz K + row indices of the head supernodes): read K once, write L once"),
     ] + ([group("dense root", "k_tile_gemm<3> + k_tile_diag + k_tile_gemm<1>", "mfma", tk["root_factor"][0], 1, S ** 3 / 3.0, "S^3 / 3")]
          if not sparse_root else []) + [
-        group("leaf solve sweeps", "k_head_fwd / k_head_bwd / k_head_solve_simple / k_tail_rows_fwd / _bwd", "hbm",
+        group("leaf solve sweeps", "k_leaf_fwd_gather / k_head_fwd_chain / k_tail_rows_fwd / k_tail_rows_bwd / k_head_bwd_chain / k_leaf_bwd", "hbm",
               tm["solve_head_fwd"][0] + tm["solve_tail"][0] + tm["solve_head_bwd"][0], n_solve_once, n_solve_once * 16.0 * info["nnzL"],
               "every entry of L read once per sweep, forward and backward: 16 nnz(L) bytes per leaf solve pass"),
     ]
