@@ -487,6 +487,8 @@ def main():
             # "report units/s, and separately end-to-end IPM iterations/s of a full solve with the host driver" - the
             # device-resident harness on the LP of the same generator and shape, outside the timed region of the metric
             try:
+                if sparse_root:   # the harness takes the same root as the metric's run
+                    os.environ["PIPS_IPM_SPARSE_ROOT"] = "1"
                 out["ipm_end_to_end"] = ipm_end_to_end(pa, a.seed, n_blocks_total, n_i, my_i, n0, myl, a.rho, fam_blocks, fam_F0)
             except Exception as e:
                 out["ipm_end_to_end"] = {"error": str(e)}

@@ -7,7 +7,8 @@ OUT=$R/gpurun_out/cfg3_$TAG
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--family time-coupled --blocks-per-gpu $NB --n $NI --no-ipm"
 cd /tmp && export TMPDIR=/tmp
-timeout 1200 python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
+# (the bench line proper also carries the end-to-end IPM of the share: 12.8 M variables at 256 x 50 000)
+timeout 1800 python3 $R/bench.py ${ARGS/ --no-ipm/} > $OUT/bench.json 2> $OUT/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o cfg3 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o cfg3 -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o cfg3 -- python3 $R/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/write.log 2>&1
