@@ -1748,16 +1748,19 @@ struct Engine {
       }
       if (mf && n_roots > 0) {   // the last update matrices: into the tail and the Schur complement, front by front
          if (timer.on) timer.begin(stream, 1);
+         // about 2048 workgroups in the launch (what is resident at once): half of a block's chunks on the tail's columns, half on the border's
+         const int asm_env = getenv("PIPS_HIP_ROOT_ASM_CHUNKS") ? atoi(getenv("PIPS_HIP_ROOT_ASM_CHUNKS")) : 0;
+         const int asm_half = asm_env > 0 ? asm_env : std::max(1, std::min(32, 1024 / std::max(nblk, 1)));
          if (deterministic && d_gbuf && SC && d_round_blk) {
             for (size_t k = 0; k + 1 < round_off.size(); ++k) {
                const int cnt = round_off[k + 1] - round_off[k];
                if (cnt > 0)
-                  hipLaunchKernelGGL(k_root_assemble, dim3(cnt, ROOT_ASM_NT + ROOT_ASM_NS), dim3(256), 0, stream, d_round_blk + round_off[k], d_root_off, d_roots, d_sns, d_blks, d_rowidx,
-                                     d_bmap, d_arena, d_mfU, SC, ldSC, d_sctab, d_gbuf, (long long)S * S, d_blk_group);
+                  hipLaunchKernelGGL(k_root_assemble, dim3(cnt, 2 * asm_half), dim3(256), 0, stream, d_round_blk + round_off[k], d_root_off, d_roots, d_sns, d_blks, d_rowidx,
+                                     d_bmap, d_arena, d_mfU, SC, ldSC, d_sctab, d_gbuf, (long long)S * S, d_blk_group, asm_half, asm_half);
             }
          } else
-            hipLaunchKernelGGL(k_root_assemble, dim3(nblk, ROOT_ASM_NT + ROOT_ASM_NS), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
-                               d_arena, d_mfU, SC, ldSC, d_sctab, (double*)nullptr, 0LL, (const int*)nullptr);
+            hipLaunchKernelGGL(k_root_assemble, dim3(nblk, 2 * asm_half), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
+                               d_arena, d_mfU, SC, ldSC, d_sctab, (double*)nullptr, 0LL, (const int*)nullptr, asm_half, asm_half);
          if (timer.on) timer.end(stream);
       }
       if (spine_total > 0) {
@@ -3826,11 +3829,14 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
    if (const char* dump = getenv("PIPS_HIP_DUMP_SN")) {   // development aid: one line per head supernode
       if (FILE* f = fopen(dump, "w")) {
          const BlockSym& bs = sym[0];
-         for (const HeadSupernode& s : bs.sn) {
+         for (size_t si = 0; si < bs.sn.size(); ++si) {
+            const HeadSupernode& s = bs.sn[si];
             const int* rows = bs.rowidx.data() + s.rows;
             int nh = 0, nt = 0;
             for (int a = 0; a < s.r; ++a) { if (rows[a] < bs.n_head) ++nh; else if (rows[a] < bs.n) ++nt; }
-            fprintf(f, "%d %d %d %d %d %d %d %d\n", s.c0, s.w, s.r, s.level, nh, nt, s.r - nh - nt, s.n_useg);
+            // c0 w r level rows-in-head rows-in-tail border-rows update-segments parent-supernode (index, -1: none in the head)
+            fprintf(f, "%d %d %d %d %d %d %d %d %d\n", s.c0, s.w, s.r, s.level, nh, nt, s.r - nh - nt, s.n_useg,
+                    si < bs.sn_parent.size() ? bs.sn_parent[si] : -1);
          }
          fclose(f);
          fprintf(stderr, "[pips_hip] multifrontal: ok %d, largest front %d, update matrices %lld doubles, records %zu ints\n", (int)bs.mf_ok, bs.mf_max_front,

@@ -871,13 +871,14 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 // block's root fronts in ascending order (inside a front the targets are distinct; a barrier separates the fronts): plain adds on
 // the block's own tail.  Schur targets are shared between blocks: FP64 atomics by default; in deterministic mode (gbuf != nullptr)
 // a launch holds at most one block of every group and adds into the group's buffer, so the blocks of a group arrive in order.
-// One workgroup per (block, chunk of target columns): blockIdx.y < ROOT_ASM_NT takes a slice of the tail's columns, the others a slice of
+// One workgroup per (block, chunk of target columns): blockIdx.y < nt takes a slice of the tail's columns, the others a slice of
 // the block's border columns (Schur complement).  A target entry belongs to the chunk of its column - the smaller of its two block-local
 // indices, the same for every front that reaches it - so each entry has ONE writer, which walks the fronts in ascending order: the sums
 // have a fixed order and the tail needs no atomics.  (One workgroup per block walked all fronts alone: 7.5 ms on the configs[1] blocks,
 // where nearly every front is a root with ~130 tail rows.)  The fronts are scanned 256 at a time, one thread each, for the piece of their
 // (ascending) row list that falls into the chunk.
-constexpr int ROOT_ASM_NT = 32, ROOT_ASM_NS = 32;
+// The launch is latency (a barrier and a read-modify-write round trip per front and workgroup), so the engine asks for about as many
+// workgroups as are resident at once (8 per compute unit): nt + ns chunks per block, between 2 and 64.
 
 __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ blk_list, const int* __restrict__ root_off,
                                                       const int* __restrict__ roots, const SnDesc* __restrict__ sns,
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
                                                       const int* __restrict__ bmap, double* __restrict__ arena,
                                                       const double* __restrict__ uarena, double* __restrict__ SC, int ldSC,
                                                       const int* __restrict__ sctab, double* __restrict__ gbuf, long long gstride,
-                                                      const int* __restrict__ blk_group) {
+                                                      const int* __restrict__ blk_group, int nt, int ns) {
    __shared__ int s_b0[256], s_b1[256], s_r[256], s_rb[256];
    __shared__ long long s_rows[256], s_U[256];
    const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
@@ -894,16 +895,16 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
    const int* bm = bmap + bd.bmap_off;
    const int n = bd.n, n_head = bd.n_head, c = blockIdx.y;
    double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
-   const bool tail_chunk = c < ROOT_ASM_NT;
+   const bool tail_chunk = c < nt;
    if (!tail_chunk && !S_) return;
    // block-local row ids [lo, hi) whose columns this workgroup owns
    int lo, hi;
    if (tail_chunk) {
-      const int cw = (bd.m_pad + ROOT_ASM_NT - 1) / ROOT_ASM_NT;
+      const int cw = (bd.m_pad + nt - 1) / nt;
       lo = n_head + c * cw; hi = min(lo + cw, n);
    } else {
-      const int cw = (bd.nb + ROOT_ASM_NS - 1) / ROOT_ASM_NS;
-      lo = n + (c - ROOT_ASM_NT) * cw; hi = min(lo + cw, n + bd.nb);
+      const int cw = (bd.nb + ns - 1) / ns;
+      lo = n + (c - nt) * cw; hi = min(lo + cw, n + bd.nb);
    }
    if (lo >= hi) return;
    const int q_begin = root_off[blk], q_end = root_off[blk + 1];
