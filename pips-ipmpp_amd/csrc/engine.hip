@@ -1497,7 +1497,7 @@ struct Engine {
       const size_t lds = (size_t)m.lds_doubles * sizeof(double);
       if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front<BLOCK, WMAX, UG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_front<BLOCK, WMAX, UG>), dim3(m.cnt), dim3(BLOCK), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_psign,
-                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval);
+                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval, deterministic ? 1 : 0);
       return PIPS_OK;
    }
    long long* d_mfdbg = nullptr;   // PIPS_HIP_MF_CLOCKS: phase stamps of every front (8 per supernode), dumped after the factorisation

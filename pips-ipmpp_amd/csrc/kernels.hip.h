@@ -626,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
                                                 int* __restrict__ inertia, const double* __restrict__ pref,
                                                 const int* __restrict__ sctab, long long* __restrict__ dbg,
                                                 const double* __restrict__ lvals, const double* __restrict__ kval,
-                                                const double* __restrict__ bval) {
+                                                const double* __restrict__ bval, int ordered) {
    extern __shared__ __attribute__((aligned(16))) double mf_F[];
    __shared__ double dk[WMAX];
    // development aid (PIPS_HIP_MF_CLOCKS): thread 0 stamps the phase boundaries, 8 stamps per front
@@ -733,12 +733,25 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
       if (n_child == 0) __syncthreads();   // the leaf values are in place
       const int* colptr = leafpart;
       const int* it2 = leafpart + (nf + 1);
-      for (int q = tid; q < nf; q += BLOCK) {
-         for (int it = colptr[q]; it < colptr[q + 1]; ++it) {
+      if (ordered || UG) {   // a thread per front column walks that column's items: every sum in a fixed order (deterministic mode), and
+                             // one writer per target (the update matrix in device memory takes plain adds)
+         for (int q = tid; q < nf; q += BLOCK) {
+            for (int it = colptr[q]; it < colptr[q + 1]; ++it) {
+               const int i0 = it2[2 * it], i1 = it2[2 * it + 1];
+               const int b = i0 & 15, rc = (i0 >> 4) & 31;
+               const double* lv = vals + (i0 >> 9);
+               const int* rel = leafpart + i1;
+               const double lbd = -lv[1 + b] * lv[0];
+               for (int a = b; a < rc; ++a) front_add(rel[a], q, lv[1 + a] * lbd);
+            }
+         }
+      } else {         // a thread per item (leaf, b): all threads busy instead of one per front column; the adds are atomic
+         for (int it = tid; it < n_items; it += BLOCK) {
             const int i0 = it2[2 * it], i1 = it2[2 * it + 1];
             const int b = i0 & 15, rc = (i0 >> 4) & 31;
             const double* lv = vals + (i0 >> 9);
             const int* rel = leafpart + i1;
+            const int q = rel[b];
             const double lbd = -lv[1 + b] * lv[0];
             for (int a = b; a < rc; ++a) front_add(rel[a], q, lv[1 + a] * lbd);
          }
