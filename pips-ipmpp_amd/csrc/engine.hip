@@ -2044,9 +2044,10 @@ struct Engine {
       if (rc) return rc;
       for (int it = 0; it < refine_steps; ++it) {
          timer.begin(stream, 11);
-         HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
+         // r = rhs - K x; without long rows the copy of rhs is folded into the product
+         if (n_flong > 0) HIP_TRY(hipMemcpyAsync(d_res, d_rhs, bytes, hipMemcpyDeviceToDevice, stream));
          hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total * 8, 256, 65536)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
-                            x_dev, d_res, n_total, d_rowbase, 0LL);
+                            x_dev, d_res, n_total, d_rowbase, 0LL, n_flong > 0 ? (const double*)nullptr : d_rhs);
          if (n_flong > 0)
             hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev,
                                d_res, d_rowbase, 0LL);

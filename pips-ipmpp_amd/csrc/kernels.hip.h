@@ -2812,9 +2812,11 @@ __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ 
 //   y_i -= sum_j K_ij x_j
 constexpr int FULL_LONG_ROW = 512;
 
+// y0 != nullptr: y = y0 - K x (every row must then be short: the caller checks that no row goes to k_full_spmv_sub_long)
 __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __restrict__ fcol, const int* __restrict__ fsrc,
                                 const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
-                                long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride) {
+                                long long nrows_total, const long long* __restrict__ row_blk_base, long long vec_stride,
+                                const double* __restrict__ y0 = nullptr) {
    x += vec_stride * blockIdx.y;
    y += vec_stride * blockIdx.y;
    // eight lanes per row (KKT rows hold a handful of entries): a wave reads the entries of eight consecutive rows as one contiguous piece.
@@ -2861,7 +2863,7 @@ __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __re
          s[u] += __shfl_xor(s[u], 1);
          s[u] += __shfl_xor(s[u], 2);
          s[u] += __shfl_xor(s[u], 4);
-         if (mine[u] && l == 0) y[i0 + u * step] -= s[u];
+         if (mine[u] && l == 0) y[i0 + u * step] = (y0 ? y0[i0 + u * step] : y[i0 + u * step]) - s[u];
       }
    }
 }
