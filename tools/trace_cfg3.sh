@@ -9,5 +9,6 @@ python3 $R/tools/trace_summary.py $T 1 > $OUT/summary.txt
 # the last factorisation of the probe and everything after it: 3 solveCompressed, 3 leaf solves
 python3 $R/tools/trace_summary.py $T 2 > $OUT/summary_last.txt
 python3 $R/tools/trace_solve_levels.py $T > $OUT/solve_levels.txt
+python3 $R/tools/trace_solve_compressed.py $T > $OUT/solve_compressed.txt
 find $OUT -name "*kernel_trace.csv" -delete
 cat $OUT/summary_last.txt
