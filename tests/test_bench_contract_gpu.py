@@ -1,0 +1,67 @@
+"""bench.py's one-line contract on small workloads (the driver reads this line): required keys, the self-accounting objects, the root
+the time-coupled family takes, and the N > 1 control flow with two processes sharing the one GPU (gloo, host-staged reductions:
+validation, not a measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "phase_ms"]
+
+
+def _run(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_line(d, n_gpus):
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 / n_gpus - 1.0) < 0.02      # units/s = ranks / (s per step)
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
+    step = d["phase_ms"]["step"]
+    assert step["leaf_factor"] > 0 and step["lsolve_leaf"] > 0 and d["phase_ms"]["leaf_solve_passes"] >= 4
+
+
+def test_default_family_small():
+    d = _run(["--blocks-per-gpu", "4", "--n", "1000", "--schur-dim", "200", "--rho", "0.01", "--steps", "2", "--warmup", "1", "--no-ipm"])
+    _check_line(d, 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and (cb["value"] is None or cb["value"] > 0)
+    assert d["config"]["root"] == "dense LDL^T"
+    assert any(g["group"] == "dense root" for g in d["roofline_all"])
+
+
+@pytest.mark.parametrize("root", ["auto", "dense"])
+def test_time_coupled_family_small(root):
+    d = _run(["--family", "time-coupled", "--blocks-per-gpu", "8", "--n", "2000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+              "--root", root])
+    _check_line(d, 1)
+    assert d["config"]["family"] == "time-coupled"
+    assert d["config"]["root"].startswith("sparse" if root == "auto" else "dense")
+    ipm = d["ipm_end_to_end"]            # the harness on the same family (and the same root)
+    assert ipm["status"] == 0 and ipm["rel_residual"] < 1e-7
+
+
+def test_two_processes_share_the_gpu():
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(29700 + os.getpid() % 200)]
+    d = _run(["--gpus", "2", "--family", "time-coupled", "--blocks-per-gpu", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+              "--no-ipm"], env={"PIPS_BENCH_SHARE_GPU": "1"}, launcher=launcher)
+    _check_line(d, 2)
+    c = d["collective"]
+    assert c is not None and c["payload_bytes_per_step"] > 0
+    assert d["config"]["root"].startswith("sparse") and "gloo" in d["config"]["collective"]
