@@ -1641,7 +1641,8 @@ struct Engine {
          HIP_TRY(hipMemsetAsync(d_rec, 0xff, (size_t)vslots_total * sizeof(long long), stream));
          const ScatterCtx sxv{1, d_rec, nullptr, d_xw, nullptr};
          for (const LevelRange& L : levels) {
-            if (L.simple_cnt > 0)
+            // (the simple leaves own no slots where their forward substitution is the gather by target row: fixed order by construction)
+            if (L.simple_cnt > 0 && lf_rows == 0)
                hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
                                   L.simple_cnt, d_blks, d_rowidx, d_arena, d_xw, 0LL, 0, sxv);
             const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
@@ -1834,7 +1835,10 @@ struct Engine {
          for (size_t li = 0; li < levels.size(); ++li) {
             const LevelRange& L = levels[li];
             gather(gv_levels[li], d_vslot_val, xw);
-            if (L.simple_cnt > 0)
+            if (L.simple_cnt > 0 && lf_rows > 0)
+               hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
+                                  d_lf_val, xw, 0LL, (int)lf_rows);
+            else if (L.simple_cnt > 0)
                hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
                                   L.simple_cnt, d_blks, d_rowidx, d_arena, xw, 0LL, 0, sxv);
             const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
