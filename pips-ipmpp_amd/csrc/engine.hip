@@ -539,7 +539,7 @@ struct BlockInput {
 // loads up front, partial sums in registers, one LDS transpose) instead of k_head_fwd / k_head_bwd (a wave reduction per column).
 // Round 2 drew the line at 1024 waves; with supernodes capped at 16 columns the chain kernels win at every size (configs[3] share,
 // 256 x 50 000: leaf solve 13.5 -> 11.6 ms), so the line is gone; PIPS_HIP_CHAIN_MAX brings it back for tuning runs.  Deterministic
-// mode keeps k_head_fwd / k_head_bwd throughout (one kernel whatever the batch size).
+// mode takes one kernel whatever the batch size: k_head_fwd (it writes slots) forward, the chain kernel backward.
 static const long long CHAIN_LAUNCH_MAX = getenv("PIPS_HIP_CHAIN_MAX") ? atoll(getenv("PIPS_HIP_CHAIN_MAX")) : (1LL << 40);
 
 struct LevelRange {
@@ -1886,7 +1886,7 @@ struct Engine {
       // D^-1 of the head columns: fused into the backward kernels of the common path (chain kernels + thread-per-leaf kernel: they
       // read the diagonal's cache line anyway; the separate pass reads 88 bytes of descriptor per supernode - 12.9 M of them on the
       // configs[3] share); the other paths (spine kernels, deterministic mode, k_head_bwd) keep the pass
-      const bool fused_d = !mfs && spine_total == 0 && !deterministic && CHAIN_LAUNCH_MAX >= (1LL << 40);
+      const bool fused_d = !mfs && spine_total == 0 && CHAIN_LAUNCH_MAX >= (1LL << 40);
       if (nsn_total > 0 && !fused_d)
          hipLaunchKernelGGL(k_head_dscale, dim3(grid_for(nsn_total, 256), nrhs), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
                             d_arena, xw, xws, mfs ? 1 : 0);
@@ -1911,8 +1911,9 @@ struct Engine {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         // (deterministic mode: always the same kernel, whatever the batch size - the two variants add in different orders)
-         if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX && !deterministic)
+         // (deterministic mode: always the same kernel, whatever the batch size - the two variants add in different orders; the
+         // chain kernel it is, unless the tuning switch brings the size-dependent choice back)
+         if (cnt > 0 && ((long long)cnt * nrhs < CHAIN_LAUNCH_MAX || (deterministic && CHAIN_LAUNCH_MAX >= (1LL << 40))))
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_bwd_chain<16> : k_head_bwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
                                d_blks, d_rowidx, d_arena, xw, xws, 0, fused_d ? 1 : 0);
          else if (cnt > 0)
