@@ -1818,6 +1818,8 @@ struct Engine {
       return PIPS_OK;
    }
 
+   // workgroups per block of the vector norms: slices of about 16 K rows, the launch kept near the number resident at once
+   int absmax_chunks() const { return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(64, 2048 / std::max(nblk, 1) + 1), n_total / std::max(nblk, 1) / 16384 + 1)); }
    // nrhs right-hand sides at x_dev + r * x_stride (flat over all blocks each); work vectors at xw + r * xw_total
    int solve_once(double* x_dev, int nrhs = 1, long long x_stride = 0, double* xw = nullptr) {
       if (!xw) xw = d_xw;
@@ -2043,8 +2045,10 @@ struct Engine {
       if (refine_steps <= 0) return solve_once(x_dev);
       const size_t bytes = (size_t)n_total * sizeof(double);
       HIP_TRY(hipMemcpyAsync(d_rhs, x_dev, bytes, hipMemcpyDeviceToDevice, stream));
-      if (refine_tol > 0.0)
-         hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_rhs, d_blks, d_norms + nblk);
+      if (refine_tol > 0.0) {
+         HIP_TRY(hipMemsetAsync(d_norms + nblk, 0, (size_t)nblk * sizeof(double), stream));
+         hipLaunchKernelGGL(k_vec_block_absmax, dim3(absmax_chunks(), nblk), dim3(256), 0, stream, d_rhs, d_blks, d_norms + nblk);
+      }
       int rc = solve_once(x_dev);
       if (rc) return rc;
       for (int it = 0; it < refine_steps; ++it) {
@@ -2057,9 +2061,12 @@ struct Engine {
             hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev,
                                d_res, d_rowbase, 0LL);
          if (refine_tol > 0.0) {
-            hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
-            if (refine_mode == 1)
-               hipLaunchKernelGGL(k_vec_block_absmax, dim3(nblk), dim3(256), 0, stream, x_dev, d_blks, d_norms + 2 * nblk);
+            HIP_TRY(hipMemsetAsync(d_norms, 0, (size_t)nblk * sizeof(double), stream));
+            hipLaunchKernelGGL(k_vec_block_absmax, dim3(absmax_chunks(), nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
+            if (refine_mode == 1) {
+               HIP_TRY(hipMemsetAsync(d_norms + 2 * nblk, 0, (size_t)nblk * sizeof(double), stream));
+               hipLaunchKernelGGL(k_vec_block_absmax, dim3(absmax_chunks(), nblk), dim3(256), 0, stream, x_dev, d_blks, d_norms + 2 * nblk);
+            }
             HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)3 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
             timer.end(stream);
             if (refine_mode == 1 && h_amax.empty()) {

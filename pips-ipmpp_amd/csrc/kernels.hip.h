@@ -210,11 +210,14 @@ __global__ void k_pref_tail(const BlkDesc* __restrict__ blks, const double* __re
    }
 }
 
-// out[b] = max |v| over the rows of block b (flat block-after-block vector); one workgroup per block
+// out[b] = max(out[b], max |v| over the rows of block b) (flat block-after-block vector); grid (chunks, block): every workgroup
+// reduces a slice and folds it in with an integer atomic max (bit patterns of non-negative doubles are ordered like the numbers) - the
+// caller zeroes out[] first.  (One workgroup per block streamed 600 KB alone on the time-coupled share: 115 us per call, three calls
+// per refinement check.)
 __global__ void k_vec_block_absmax(const double* __restrict__ v, const BlkDesc* __restrict__ blks, double* __restrict__ out) {
-   const BlkDesc bd = blks[blockIdx.x];
+   const BlkDesc bd = blks[blockIdx.y];
    double mx = 0.0;
-   for (int i = threadIdx.x; i < bd.n; i += blockDim.x) mx = fmax(mx, fabs(v[bd.x_off + i]));
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bd.n; i += gridDim.x * blockDim.x) mx = fmax(mx, fabs(v[bd.x_off + i]));
    __shared__ double red[256];
    red[threadIdx.x] = mx;
    __syncthreads();
@@ -222,7 +225,7 @@ __global__ void k_vec_block_absmax(const double* __restrict__ v, const BlkDesc* 
       if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
       __syncthreads();
    }
-   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+   if (threadIdx.x == 0 && red[0] > 0.0) atomicMax((unsigned long long*)(out + blockIdx.y), (unsigned long long)__double_as_longlong(red[0]));
 }
 
 // max |K| per block -> fallback replacement magnitude.  grid (chunks, block): every workgroup reduces a slice of the block's
