@@ -80,7 +80,7 @@ def head_traffic(family, n_blocks, n_i, key="hbm_bytes_per_factorize"):
         return None
 
 
-def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device, block_data=None):
+def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device, block_data=None, threads=None):
     """block_data: b -> (W, T, F) for families other than the generator's"""
     S = n0 + myl
     bt = pa.LeafBatch(len(blocks), S, device=device)
@@ -97,7 +97,7 @@ def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device, block_
         bt.set_block(i, K, n_i, Bt)
         vals.append(K.val)
         diags.append(diag)
-    bt.analyze(min(16, os.cpu_count() or 8))
+    bt.analyze(threads or min(16, os.cpu_count() or 8))
     # PARDISO-style adaptive iterative refinement (iparm[7]=2 in the reference, PardisoProjectSolver.C:72: at most 2 steps,
     # stop when the backward error is satisfactory): normwise backward error <= 1e-15 for every block
     bt.set_refinement_backward_error(2, 1e-15)
@@ -202,6 +202,28 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, bloc
     }
 
 
+def launch_ranks(n):
+    """One process per GPU (the reference maps blocks to MPI ranks the same way: Readers/Distributed/DistributedTree.C:62-89).
+    Children are started through torch.distributed.run with this script's own arguments; the parent never initialises HIP
+    (torch.cuda.device_count() does not) and only forwards the children's exit code; rank 0's JSON line goes to the inherited stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("PIPS_BENCH_SHARE_GPU"):
+        sys.stderr.write(f"bench.py: --gpus {n} but this node shows {have} device(s) (PIPS_BENCH_SHARE_GPU=1 lets the ranks share device 0 "
+                         "for a validation run)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,7 +231,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks-per-gpu", type=int, default=64)
     ap.add_argument("--n", type=int, default=10000, help="variables per block")
-    ap.add_argument("--schur-dim", type=int, default=2000)
+    ap.add_argument("--schur-dim", type=int, default=None,
+                    help="S = n0 + myl of the random family; default: 2000 on one GPU (BASELINE configs[1]), 4000 on several "
+                         "(BASELINE configs[2]: 512 blocks x 10k, Schur dim 4k, 64 blocks per GPU on 8 GPUs)")
     ap.add_argument("--rho", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,7 +246,14 @@ def main():
                          "(configs[3]; --schur-dim and --rho are ignored: S = 95 + 31 (blocks - 1))")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as child processes BEFORE anything here touches the GPU
+        raise SystemExit(launch_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); the line reports n_gpus = {world}\n")
+    if a.schur_dim is None:
+        a.schur_dim = 2000 if world == 1 else 4000
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -310,7 +341,17 @@ def main():
                 comm = pa.ExternalComm.torch_distributed()
                 comm_kind = "rccl (torch.distributed callback)"
 
-    bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank,
+    ranks_seen = None
+    if comm is not None:
+        # "did the communicator the factorisation uses see N ranks": a sum of ones through pips_hip_allreduce_sum
+        one = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+        comm.allreduce_sum(one)
+        torch.cuda.synchronize()
+        ranks_seen = int(round(float(one.item())))
+        if ranks_seen != world:
+            raise SystemExit(f"[rank {rank}] the communicator sums over {ranks_seen} rank(s), the launch has {world}")
+
+    bt, diag_h = build_rank_problem(pa, a.seed, blocks, n_i, my_i, n0, myl, a.rho, local_rank, threads=max(1, min(16, (os.cpu_count() or 8) // world)),
                                     block_data=(lambda b: fam_blocks[b]) if fam_blocks is not None else None)
     if fam_blocks is not None:
         F0 = fam_F0
@@ -441,7 +482,7 @@ def main():
         payload = 8.0 * kkt.schur_sparse_nnz() if sparse_root else 8.0 * S * (S + 1) / 2
         P = max(world, 1)
         tot = tk["reduce_panels"][0] if tk["reduce_panels"][1] > 0 else tk["reduce"][0]
-        collective = {"schur_reduce_exposed_ms": round(tk["reduce"][0], 3), "schur_reduce_total_ms": round(tot, 3),
+        collective = {"ranks_seen": ranks_seen, "schur_reduce_exposed_ms": round(tk["reduce"][0], 3), "schur_reduce_total_ms": round(tot, 3),
                       "schur_panels": tk["reduce_panels"][1] or 1,
                       "overlapped_fraction": (round(1.0 - tk["reduce"][0] / tot, 3) if tk["reduce_panels"][1] > 0 and tot > 0 else 0.0),
                       "b0_reduce_ms_in": "phase_ms.step.lsolve_border_reduce (border product + all-reduce of S doubles, x4)",
@@ -456,12 +497,16 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
-                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else ""))
+                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else
+                                                           " [BASELINE configs[2]]" if world == 8 and bpg == 64 and n_i == 10000 and S == 4000 else
+                                                           f" [BASELINE configs[2] shape (Schur dim 4k, 64 blocks/GPU) on {world} of its 8 GPUs]"
+                                                           if world > 1 and bpg == 64 and n_i == 10000 and S == 4000 else ""))
                        if a.family == "random" else
                        (f"time-coupled family: {n_blocks_total} blocks x {n_i} vars ({my_i} banded eq rows, 10 nnz/row), 95 first-stage variables, "
                         f"31 two-link rows per neighbouring pair, Schur dim {S}, {bpg} blocks/GPU"
                         + (" [per-GPU share of BASELINE configs[3]]" if bpg == 256 and n_i == 50000 else "")),
-                       "family": a.family, "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
+                       "family": (a.family if a.family == "random" else "time-coupled (surrogate for SURVEY 8d config 4 = BASELINE configs[3]: "
+                                  "the random generator's fill at n_i = 50 000 gives dense factors, BASELINE.md)"), "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
                                                     if sparse_root else "dense LDL^T"), "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed and the "

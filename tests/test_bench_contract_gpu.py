@@ -50,7 +50,7 @@ def test_time_coupled_family_small(root):
     d = _run(["--family", "time-coupled", "--blocks-per-gpu", "8", "--n", "2000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
               "--root", root])
     _check_line(d, 1)
-    assert d["config"]["family"] == "time-coupled"
+    assert d["config"]["family"].startswith("time-coupled (surrogate")
     assert d["config"]["root"].startswith("sparse" if root == "auto" else "dense")
     ipm = d["ipm_end_to_end"]            # the harness on the same family (and the same root)
     assert ipm["status"] == 0 and ipm["rel_residual"] < 1e-7
@@ -65,3 +65,24 @@ def test_two_processes_share_the_gpu():
     c = d["collective"]
     assert c is not None and c["payload_bytes_per_step"] > 0
     assert d["config"]["root"].startswith("sparse") and "gloo" in d["config"]["collective"]
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts one process per rank before it touches the GPU, the line says n_gpus = 2
+    and the communicator the factorisation reduces through counted two ranks (here both on device 0: validation, not a measurement).
+    Without --schur-dim the N > 1 default is BASELINE configs[2]'s Schur dimension."""
+    d = _run(["--gpus", "2", "--blocks-per-gpu", "2", "--n", "1000", "--rho", "0.01", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-ipm"],
+             env={"PIPS_BENCH_SHARE_GPU": "1"})
+    _check_line(d, 2)
+    assert d["collective"]["ranks_seen"] == 2
+    assert "Schur dim 4000" in d["config"]["workload"]
+
+
+def test_gpus_flag_refuses_more_ranks_than_devices():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = dict(os.environ)
+    env.pop("PIPS_BENCH_SHARE_GPU", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 2 and "device(s)" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
