@@ -204,8 +204,10 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, bloc
 
 def launch_ranks(n):
     """One process per GPU (the reference maps blocks to MPI ranks the same way: Readers/Distributed/DistributedTree.C:62-89).
-    Children are started through torch.distributed.run with this script's own arguments; the parent never initialises HIP
-    (torch.cuda.device_count() does not) and only forwards the children's exit code; rank 0's JSON line goes to the inherited stdout."""
+    The children are this script with the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) and its own
+    arguments; the parent never initialises HIP (torch.cuda.device_count() does not) and only hands on the children's exit code; rank 0's
+    JSON line goes to the inherited stdout.  (torch.distributed.run is not used here: its argument parser trips over script options such
+    as --n; a launch through it works as before because WORLD_SIZE is then set.)"""
     import socket
     import subprocess
     have = torch.cuda.device_count()
@@ -216,12 +218,33 @@ def launch_ranks(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    return subprocess.call(cmd, env=env)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:       # a rank failed: the others would wait for it in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():

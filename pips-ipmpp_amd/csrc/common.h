@@ -101,6 +101,8 @@ struct BlockSym {
    // ---- multifrontal head (symbolic.cpp "multifrontal metadata"): every head supernode that is not a simple leaf is a front
    //      (w + r) x (w + r) whose update matrix (r x r, packed lower) goes to its parent front instead of being scattered
    bool mf_ok = false;                  // every front fits the LDS budget (AnalyzeOptions::mf_lds_doubles)
+   bool mf_split = false;               // border split (symbolic.cpp): update matrices keep only the columns of K rows, the border x border
+                                        // part of the Schur contribution comes from the finished panels (k_border_schur)
    int mf_max_front = 0;                // largest w + r among the fronts
    int64_t mf_U_total = 0;              // doubles of update-matrix storage of this block
    std::vector<int> sn_parent;          // per head supernode: the head supernode that holds its first below-row, else -1
@@ -126,7 +128,8 @@ struct BlockSym {
 //   [7]                    offset of the leaves' values (d_c, l_c: 1 + r_c doubles per leaf, leaves ascending) inside the block's
 //                          leaf-value region: the leaf kernel writes them there, the front reads them as one piece
 //   [8 ..)                 child table, 3 ints per child front, children ascending:
-//                             { offset of its update matrix minus this front's, r_c, offset of its update VECTOR (solves) minus this front's }
+//                             { offset of its update matrix minus this front's, r_c | uc_c << 16 (uc_c: update columns it hands over),
+//                               offset of its update VECTOR (solves) minus this front's }
 //   then                   per child, in the same order, the position of each of its r_c below-rows inside THIS front (0 .. w + r)
 //   then                   the leaf part
 //   leaf part              colptr[w + r + 1] | items (2 ints each) | leaf table (4 ints per leaf) | position lists
@@ -162,6 +165,8 @@ struct AnalyzeOptions {
    int64_t mf_lds_doubles = 19200;   // LDS budget of one front (150 KB of the 160 KB): the packed front if it fits, else its w panel
                                      // columns (the update matrix then stays in device memory); neither, or more than
                                      // MF_MAX_FRONT rows: the block is not multifrontal
+   int mf_split_nb_max = 176;   // border split of the update matrices where the block has at most this many non-empty border columns
+                                // (k_border_schur keeps the packed nb x nb triangle in LDS: 176 -> 122 KB); 0 = never
    double relax_zeros = 0.4;  // supernode amalgamation: admissible share of explicit zeros in a panel (0 = fundamental)
    int min_tail = 256;        // do not open a dense tail smaller than this
    int force_n_head = -1;     // >=0: override the cost model (tests)

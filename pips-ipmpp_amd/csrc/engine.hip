@@ -549,9 +549,14 @@ struct LevelRange {
 
 // Multifrontal head: one launch per (level, front class); class = (workgroup size, width bound) of k_front.
 struct MfLaunch { int level, cls, begin, cnt, lds_doubles, lds_fwd = 0, lds_bwd = 0; };
-static inline int mf_class(int w, long long nf, long long lds_budget) {
+// doubles of the update matrix a front keeps: all r columns, or (border split) those of its rb rows of K
+static inline long long mf_unp(const BlockSym& bs, const HeadSupernode& s) {
+   const long long uc = bs.mf_split ? s.rb : s.r;
+   return uc * s.r - uc * (uc - 1) / 2;
+}
+static inline int mf_class(int w, long long nf, long long unp, long long lds_budget) {
    const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
-   if (pw + r * (r + 1) / 2 + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
+   if (pw + unp + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
    return (nf <= 64 ? 0 : 2) + 3 * (w <= 16 ? 0 : 1);   // more than one wave: 256 threads - the phases around the pivots are spread over them
 }
 
@@ -570,6 +575,7 @@ static void apply_tuning(AnalyzeOptions& opt) {
    if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);       // seconds per scattered update
    if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
    if (const char* ml = getenv("PIPS_HIP_MF_LDS")) opt.mf_lds_doubles = atoll(ml);   // LDS budget of a front in doubles (tests: small values force the device-memory variant)
+   if (const char* sp = getenv("PIPS_HIP_MF_SPLIT")) opt.mf_split_nb_max = atoi(sp) == 0 ? 0 : std::min(176, std::max(atoi(sp), 2));   // border split: 0 = off, else the largest nb
 }
 
 struct Engine {
@@ -577,6 +583,7 @@ struct Engine {
    hipStream_t stream = nullptr;
    int nblk = 0, S = 0;
    bool analyzed = false, factored = false;
+   long long analysis_gen = 0;   // bumped by every analyze(): device buffers of the previous analysis are gone (captured graphs are stale)
    int refine_steps = 1;       // maximum number of iterative-refinement steps per solve
    double refine_tol = 0.0;    // > 0: adaptive refinement, stop as soon as the error measure of every block is <= tol
    int refine_mode = 0;        // 0: ||r_b||inf / ||rhs_b||inf ; 1: normwise backward error ||r_b||inf / (max|K_b| ||x_b||inf + ||rhs_b||inf)
@@ -616,6 +623,14 @@ struct Engine {
    double* d_mfLV = nullptr;   // d and l of the simple leaves below fronts, front by front
    double* d_mfV = nullptr;    // update vectors of the fronts (multifrontal solves)
    int *d_roots = nullptr, *d_root_off = nullptr;   // fronts without a head parent, per block (k_root_assemble)
+   BbBatch* d_bb_batches = nullptr;                 // border split (k_border_schur): batches of supernodes with border rows, block after block
+   BbMeta* d_bb_meta = nullptr;
+   int *d_bb_off = nullptr, *d_bb_pos = nullptr;    // batches of block b: [d_bb_off[b], d_bb_off[b + 1]); compressed border ids of the staged rows
+   double* d_bbarena = nullptr;                     // the border rows of those supernodes in the staging layout
+   std::vector<int> h_bb_off_keep;
+   int n_bb = 0, bb_stage = 3072, bb_nbmax = 0, bb_poscap = 0;
+   int* d_bb_round_blk = nullptr;                   // deterministic mode: the blocks of round k of k_border_schur
+   std::vector<int> bb_round_off;
    std::vector<int> h_root_off_keep;
    int n_roots = 0;
    int* d_round_blk = nullptr;                       // deterministic mode: the blocks of round k at [round_off[k], round_off[k + 1])
@@ -679,6 +694,9 @@ struct Engine {
       if (d_mfLV) (void)hipFree(d_mfLV);
       if (d_mfV) (void)hipFree(d_mfV);
       d_mfV = nullptr;
+      for (void* q : {(void*)d_bb_batches, (void*)d_bb_meta, (void*)d_bb_off, (void*)d_bb_pos, (void*)d_bbarena, (void*)d_bb_round_blk})
+         if (q) (void)hipFree(q);
+      d_bb_batches = nullptr; d_bb_meta = nullptr; d_bb_off = nullptr; d_bb_pos = nullptr; d_bbarena = nullptr; d_bb_round_blk = nullptr; n_bb = 0;
       for (void* q : {(void*)d_roots, (void*)d_root_off, (void*)d_round_blk})
          if (q) (void)hipFree(q);
       d_roots = d_root_off = d_round_blk = nullptr;
@@ -797,6 +815,17 @@ struct Engine {
          if (rb.empty()) rb.push_back(0);
          int rcb = dev_upload(&d_round_blk, rb, stream);
          if (rcb) return rcb;
+         // ... and the same rounds over the blocks whose border x border part k_border_schur forms
+         std::vector<int> bbr;
+         bb_round_off.assign(1, 0);
+         for (int k = 0; k < gs; ++k) {
+            for (int b = k; b < nblk; b += gs)
+               if (n_bb > 0 && h_bb_off_keep[b + 1] > h_bb_off_keep[b]) bbr.push_back(b);
+            bb_round_off.push_back((int)bbr.size());
+         }
+         if (d_bb_round_blk) { (void)hipFree(d_bb_round_blk); d_bb_round_blk = nullptr; }
+         if (bbr.empty()) bbr.push_back(0);
+         if ((rcb = dev_upload(&d_bb_round_blk, bbr, stream))) return rcb;
       }
       det_rounds.clear();
       std::vector<TileTask> all;
@@ -979,7 +1008,7 @@ struct Engine {
                const HeadSupernode& s = sym[b].sn[l];
                const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
                const long long nf = s.w + s.r, pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));
-               const long long packed = pw + (long long)s.r * (s.r + 1) / 2 + 8, panel = pw + 8;
+               const long long packed = pw + mf_unp(sym[b], s) + 8, panel = pw + 8;
                const long long extra = H[5] + (H[6] + H[3] + 1) / 2 + 2;
                if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) mf = false;   // 159 KB of the 160
             }
@@ -1008,7 +1037,7 @@ struct Engine {
          d.n = s.n; d.n_head = s.n_head; d.m = s.m; d.m_pad = s.m_pad; d.nb = s.nb; d.nb_pad = s.nb_pad; d.ldT = s.ldT;
          d.ntc = s.m_pad / TILE;
          d.ntr = s.m > 0 ? s.ldT / TILE : 0;
-         d.pad0 = 0;
+         d.mf_split = (mf && s.mf_split) ? 1 : 0;
          d.U = uar;
          uar += (long long)s.m_pad * s.m_pad;
          d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
@@ -1053,7 +1082,7 @@ struct Engine {
             for (const HeadSupernode& s : sym[b].sn) {
                if (is_simple(s)) continue;
                if ((int)lev_cnt.size() <= s.level) { lev_cnt.resize(s.level + 1, 0); lev_b.resize(s.level + 1, 0); lev_w.resize(s.level + 1, 0); }
-               const int c = mf_class(s.w, s.w + s.r, opt.mf_lds_doubles);
+               const int c = mf_class(s.w, s.w + s.r, mf_unp(sym[b], s), opt.mf_lds_doubles);
                ++lev_cnt[s.level];
                if (c < 6) { lev_b[s.level] = std::max(lev_b[s.level], c % 3); lev_w[s.level] = std::max(lev_w[s.level], c / 3); }
             }
@@ -1064,7 +1093,7 @@ struct Engine {
             // class 1: small (one wave); class 2: large (256 threads)
             int cls = (s.w <= 8 && s.r <= 64) ? 1 : 2, lds = 0;
             if (mf && !is_simple(s)) {
-               int c = mf_class(s.w, s.w + s.r, opt.mf_lds_doubles);
+               int c = mf_class(s.w, s.w + s.r, mf_unp(sym[b], s), opt.mf_lds_doubles);
                if (c < 6 && lev_cnt[s.level] <= MF_MERGE_MAX) c = lev_b[s.level] + 3 * lev_w[s.level];
                cls = 1 + c;
                // LDS of a front: the packed front (or its panel columns) + 8 doubles of slack, the leaves' values, and as ints the
@@ -1072,7 +1101,7 @@ struct Engine {
                const long long nf = s.w + s.r;
                const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
                const long long pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));   // packed panel / aligned L21 copy
-               lds = (int)(pw + (c >= 6 ? 0 : (long long)s.r * (s.r + 1) / 2) + 8 + H[5] + (H[6] + H[3] + 1) / 2 + 2);
+               lds = (int)(pw + (c >= 6 ? 0 : mf_unp(sym[b], s)) + 8 + H[5] + (H[6] + H[3] + 1) / 2 + 2);
             }
             if (is_simple(s)) cls = 0;
             keys.push_back({s.level, cls, lds, b, l});
@@ -1123,7 +1152,7 @@ struct Engine {
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          head_wcap = std::max(head_wcap, s.w);
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
-                           s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1};
+                           s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1, -1};
          if (mf && k.cls > 0 && s.r > 0 && sym[k.blk].sn_parent[k.loc] < 0) roots_of[k.blk].push_back(i);
          if (mf) {
             const BlockSym& bs = sym[k.blk];
@@ -1181,6 +1210,51 @@ struct Engine {
          n_roots = (int)h_roots.size();
          h_root_off_keep = h_root_off;
          if ((rc = dev_upload(&d_roots, h_roots, stream)) || (rc = dev_upload(&d_root_off, h_root_off, stream))) return rc;
+         // border split: the supernodes whose border rows k_border_schur multiplies out - the fronts, and the simple leaves below a front
+         // (a leaf without a front above it scatters its whole rank-one update itself), ascending; their border rows live a second
+         // time in the border-row arena (per supernode w x rp doubles + w pivots, padded to even), cut into batches of up to BB_GMAX
+         // supernodes / bb_stage doubles that the kernel stages as one contiguous piece
+         std::vector<BbMeta> h_meta;
+         std::vector<BbBatch> h_batch;
+         std::vector<int> h_bbpos;
+         h_bb_off_keep.assign(nblk + 1, 0);
+         bb_stage = 3072; bb_nbmax = 0; bb_poscap = 0;
+         long long bb_total = 0;
+         for (int b = 0; b < nblk; ++b) {
+            const BlockSym& bs = sym[b];
+            if (!bs.mf_split) continue;
+            for (const HeadSupernode& hs : bs.sn)
+               if (hs.rb < hs.r) bb_stage = std::max<int>(bb_stage, hs.w * ((hs.r - hs.rb + 3) / 4 * 4) + ((hs.w + 1) & ~1));
+         }
+         for (int b = 0; b < nblk; ++b) {
+            const BlockSym& bs = sym[b];
+            if (bs.mf_split) {
+               bb_nbmax = std::max(bb_nbmax, bs.nb);
+               BbBatch cur{0, 0, 0, 0, 0, 0, 0, 0};
+               auto flush = [&]() { if (cur.cnt > 0) { h_batch.push_back(cur); bb_poscap = std::max(bb_poscap, cur.npos); } cur = BbBatch{0, 0, 0, 0, 0, 0, 0, 0}; };
+               for (int l = 0; l < (int)bs.sn.size(); ++l) {
+                  const HeadSupernode& hs = bs.sn[l];
+                  if (hs.rb >= hs.r || (is_simple(hs) && bs.sn_parent[l] < 0)) continue;
+                  const int nbj = hs.r - hs.rb, rp = (nbj + 3) & ~3, sz = hs.w * rp + ((hs.w + 1) & ~1), nt = rp / 4;
+                  if (cur.cnt == BB_GMAX || cur.ndoubles + sz > bb_stage) flush();
+                  if (cur.cnt == 0) { cur.src = bb_total; cur.pos = (long long)h_bbpos.size(); cur.first = (int)h_meta.size(); }
+                  h_meta.push_back(BbMeta{cur.ndoubles, cur.npos, hs.w, nbj, cur.ntiles, 0, 0, 0});
+                  h_sns[sorted_id[b][l]].bb = bb_total;
+                  for (int a = hs.rb; a < hs.r; ++a) h_bbpos.push_back(bs.rowidx[hs.rows + a] - bs.n);
+                  ++cur.cnt; cur.ndoubles += sz; cur.ntiles += nt * (nt + 1) / 2; cur.npos += nbj;
+                  bb_total += sz;
+               }
+               flush();
+            }
+            h_bb_off_keep[b + 1] = (int)h_batch.size();
+         }
+         n_bb = (int)h_batch.size();
+         if (n_bb > 0) {
+            if ((rc = dev_upload(&d_bb_batches, h_batch, stream)) || (rc = dev_upload(&d_bb_meta, h_meta, stream)) ||
+                (rc = dev_upload(&d_bb_pos, h_bbpos, stream)) || (rc = dev_upload(&d_bb_off, h_bb_off_keep, stream))) return rc;
+            HIP_TRY(hipMalloc((void**)&d_bbarena, (size_t)std::max<long long>(bb_total, 2) * sizeof(double)));
+            HIP_TRY(hipMemsetAsync(d_bbarena, 0, (size_t)std::max<long long>(bb_total, 2) * sizeof(double), stream));   // (the padding rows stay zero)
+         }
       }
       // spine lists: per block, ascending local index = postorder (children before parents)
       std::vector<int> h_spine, h_spine_off(nblk + 1, 0);
@@ -1462,6 +1536,7 @@ struct Engine {
       slots_total = slots_acc; vslots_total = vslots_acc;
       h_sns_keep = h_sns;
       analyzed = true;
+      ++analysis_gen;
       factored = false;
       head_slots = false;
       const char* hs_env = getenv("PIPS_HIP_HEAD_SLOTS");
@@ -1481,7 +1556,7 @@ struct Engine {
       if (L.simple_cnt > 0)
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
                             L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
-                            mf ? 1 : 0, d_mfLV, d_lf_pos, d_lf_val);
+                            mf ? 1 : 0, d_mfLV, d_lf_pos, d_lf_val, d_bbarena);
       if (mf) return;
       if (L.small_cnt > 0)
          hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), (size_t)std::max(L.small_lds, 1) * sizeof(double), stream, d_sns,
@@ -1497,8 +1572,37 @@ struct Engine {
       const size_t lds = (size_t)m.lds_doubles * sizeof(double);
       if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front<BLOCK, WMAX, UG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_front<BLOCK, WMAX, UG>), dim3(m.cnt), dim3(BLOCK), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_psign,
-                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval, deterministic ? 1 : 0);
+                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval, deterministic ? 1 : 0, d_bbarena);
       return PIPS_OK;
+   }
+   int launch_border_schur(double* SC, int ldSC) {
+      // LDS: packed nb x nb triangle + one staged batch + its rows' positions + the batch's supernode records
+      constexpr int BLK = 512;
+      const long long ncp = ((long long)bb_nbmax * (bb_nbmax + 1) / 2 + 1) & ~1LL;
+      const size_t lds = (size_t)(ncp + bb_stage) * sizeof(double) + (size_t)((bb_poscap + 3) & ~3) * sizeof(int) + BB_GMAX * sizeof(BbMeta);
+      if (lds > 160 * 1024 || bb_poscap > 4 * BLK || bb_stage > 2 * 6 * BLK)
+         PIPS_FAIL(PIPS_ERR_STATE, "k_border_schur: %zu bytes of LDS for nb = %d (batch of %d doubles, %d rows)", lds, bb_nbmax, bb_stage, bb_poscap);
+      // a block's batches are walked by `split` workgroups (each with its own accumulator): enough of them to fill the chip
+      const int split = getenv("PIPS_HIP_BB_SPLIT") ? std::max(1, atoi(getenv("PIPS_HIP_BB_SPLIT"))) : std::max(1, std::min(16, 256 / std::max(nblk, 1)));
+      auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered) -> int {
+         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         hipLaunchKernelGGL(kern, dim3(cnt, sp), dim3(BLK), lds, stream, list, d_bb_off, d_bb_batches, d_bb_meta, d_bb_pos, d_blks, d_bmap, d_bbarena, SC, ldSC,
+                            d_sctab, gb, gs, grp, bb_stage, bb_poscap, ordered);
+         return PIPS_OK;
+      };
+      const bool small = bb_stage <= 2 * 3 * BLK;
+      int rc = PIPS_OK;
+      if (deterministic && d_gbuf && d_bb_round_blk) {
+         for (size_t k = 0; k + 1 < bb_round_off.size() && !rc; ++k) {
+            const int cnt = bb_round_off[k + 1] - bb_round_off[k];
+            if (cnt <= 0) continue;
+            rc = small ? go(k_border_schur<BLK, 3>, cnt, d_bb_round_blk + bb_round_off[k], d_gbuf, (long long)S * S, d_blk_group, 1, 1)
+                       : go(k_border_schur<BLK, 6>, cnt, d_bb_round_blk + bb_round_off[k], d_gbuf, (long long)S * S, d_blk_group, 1, 1);
+         }
+      } else
+         rc = small ? go(k_border_schur<BLK, 3>, nblk, (const int*)nullptr, (double*)nullptr, 0LL, (const int*)nullptr, split, deterministic ? 1 : 0)
+                    : go(k_border_schur<BLK, 6>, nblk, (const int*)nullptr, (double*)nullptr, 0LL, (const int*)nullptr, split, deterministic ? 1 : 0);
+      return rc;
    }
    long long* d_mfdbg = nullptr;   // PIPS_HIP_MF_CLOCKS: phase stamps of every front (8 per supernode), dumped after the factorisation
    int dump_front_clocks() {
@@ -1762,6 +1866,12 @@ struct Engine {
          } else
             hipLaunchKernelGGL(k_root_assemble, dim3(nblk, 2 * asm_half), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
                                d_arena, d_mfU, SC, ldSC, d_sctab, (double*)nullptr, 0LL, (const int*)nullptr, asm_half, asm_half);
+         if (timer.on) timer.end(stream);
+      }
+      if (mf && n_bb > 0 && SC) {   // border split: the border x border part of every block's Schur contribution, from the finished panels
+         if (timer.on) timer.begin(stream, 1);
+         const int rc_bb = launch_border_schur(SC, ldSC);
+         if (rc_bb) return rc_bb;
          if (timer.on) timer.end(stream);
       }
       if (spine_total > 0) {
@@ -2425,8 +2535,18 @@ struct KktSystem {
    bool solve_graph = false;                // pips_hip_kkt_set_solve_graph
    hipGraphExec_t graph_exec = nullptr;
    hipStream_t graph_stream = nullptr;
-   double *graph_b0 = nullptr, *graph_bl = nullptr;
-   bool graph_from_factor = false;
+   // everything a captured launch sequence has baked in: buffer addresses, the Ltsolve path, the number of refinement launches, the
+   // elimination of root inequality rows (zdiag0, C0), the root's pivoting mode, the analysis the leaf buffers belong to
+   struct GraphKey {
+      const void *b0 = nullptr, *bl = nullptr, *zdiag0 = nullptr, *c0_val = nullptr, *c0_rp = nullptr, *c0_ci = nullptr;
+      int from_factor = 0, refine_steps = 0, refine_mode = 0, mz0 = 0, pivoting = 0;
+      long long analysis_gen = 0;
+      bool operator==(const GraphKey& o) const {
+         return b0 == o.b0 && bl == o.bl && zdiag0 == o.zdiag0 && c0_val == o.c0_val && c0_rp == o.c0_rp && c0_ci == o.c0_ci &&
+                from_factor == o.from_factor && refine_steps == o.refine_steps && refine_mode == o.refine_mode && mz0 == o.mz0 &&
+                pivoting == o.pivoting && analysis_gen == o.analysis_gen;
+      }
+   } graph_key;
    long long graph_captures = 0, graph_replays = 0;
    bool last_ltsolve_from_factor = false;   // which Ltsolve the last solveCompressed took (reported per solve, not only at analyze time)
    bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
@@ -3681,7 +3801,11 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    int pert = 1;
    if (e->border_backward_ok && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
    k->last_ltsolve_from_factor = e->border_backward_ok && pert == 0;
-   if (k->graph_exec && (k->graph_b0 != b0_dev || k->graph_bl != b_leaf_dev || k->graph_from_factor != k->last_ltsolve_from_factor)) {
+   KktSystem::GraphKey key;
+   key.b0 = b0_dev; key.bl = b_leaf_dev; key.zdiag0 = k->d_zdiag0; key.c0_val = k->d_c0_val; key.c0_rp = k->d_c0_rp; key.c0_ci = k->d_c0_ci;
+   key.from_factor = k->last_ltsolve_from_factor ? 1 : 0; key.refine_steps = e->refine_steps; key.refine_mode = e->refine_mode; key.mz0 = k->mz0;
+   key.pivoting = k->root ? k->root->pivoting : 0; key.analysis_gen = e->analysis_gen;
+   if (k->graph_exec && !(k->graph_key == key)) {
       (void)hipGraphExecDestroy(k->graph_exec);
       k->graph_exec = nullptr;
    }
@@ -3702,7 +3826,7 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
       const hipError_t ei = hipGraphInstantiate(&k->graph_exec, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (ei != hipSuccess) { k->graph_exec = nullptr; PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_kkt_solve_compressed: hipGraphInstantiate: %s", hipGetErrorString(ei)); }
-      k->graph_b0 = b0_dev; k->graph_bl = b_leaf_dev; k->graph_from_factor = k->last_ltsolve_from_factor;
+      k->graph_key = key;
       ++k->graph_captures;
    }
    HIP_TRY(hipGraphLaunch(k->graph_exec, e->stream));

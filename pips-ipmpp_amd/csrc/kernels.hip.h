@@ -36,6 +36,7 @@ struct SnDesc {
    long long vslot;  // ... and of the forward-substitution scatter (r slots)
    long long U;      // multifrontal head: offset of the packed r x r update matrix inside the update arena, -1 if none
    long long mf;     // multifrontal head: offset of the front record inside mfint (common.h "Front record"), -1 for simple leaves
+   long long bb;     // border split: offset of the supernode's border rows inside the border-row arena (k_border_schur), -1 if none
 };
 
 
@@ -50,7 +51,7 @@ struct BlkDesc {
    long long dt_off;     // offset into dtail (m_pad)
    long long sctab_off;  // offset of this block's nb x nb position table inside sctab (sparse Schur complement), else 0
    int n, n_head, m, m_pad, nb, nb_pad, ldT, ntc, ntr;
-   int pad0;
+   int mf_split;         // multifrontal head with the border split (BlockSym::mf_split)
    long long U;          // offset of the block's scaled tail copy U = L D (m_pad x m_pad, ld = m_pad) inside the U arena
    double thr_rel, repl_rel;  // pivot threshold / replacement relative to the pivot's reference magnitude pref[k]
    double repl_abs;           // replacement when no reference magnitude exists (structurally zero diagonal)
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
                                                            const int* __restrict__ sctab,
                                                            ScatterCtx sx = ScatterCtx{0, nullptr, nullptr, nullptr, nullptr}, int mf = 0,
                                                            double* __restrict__ lvals = nullptr, const int* __restrict__ lfpos = nullptr,
-                                                           double* __restrict__ lfval = nullptr) {
+                                                           double* __restrict__ lfval = nullptr, double* __restrict__ bbarena = nullptr) {
    __shared__ int cnt_s[3];
    __shared__ int blk_s;
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -527,6 +528,13 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
 #pragma unroll
          for (int a = 0; a < SIMPLE_RMAX; ++a)
             if (a < r) lv[1 + a] = l[a];
+         if (sn.bb >= 0) {   // border split: the leaf's border rows for k_border_schur (w = 1: Lt[a], then the pivot)
+            double* Q = bbarena + sn.bb;
+#pragma unroll
+            for (int a = 0; a < SIMPLE_RMAX; ++a)
+               if (a < r && a >= sn.rb) Q[a - sn.rb] = l[a];
+            Q[(r - sn.rb + 3) & ~3] = d;
+         }
       }
       // target columns inside the head (time-coupled blocks: the rows of a primal column are dual rows the dissection keeps in the
       // head): positions from the precomputed segment tables, as in head_factor_body; l is re-read from the panel (L1 hits)
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
                                                 int* __restrict__ inertia, const double* __restrict__ pref,
                                                 const int* __restrict__ sctab, long long* __restrict__ dbg,
                                                 const double* __restrict__ lvals, const double* __restrict__ kval,
-                                                const double* __restrict__ bval, int ordered) {
+                                                const double* __restrict__ bval, int ordered, double* __restrict__ bbarena) {
    extern __shared__ __attribute__((aligned(16))) double mf_F[];
    __shared__ double dk[WMAX];
    // development aid (PIPS_HIP_MF_CLOCKS): thread 0 stamps the phase boundaries, 8 stamps per front
@@ -641,7 +649,10 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    const int w = sn.w, r = sn.r, nf = w + r, tid = threadIdx.x, lane = tid & 63, i = tid;
    const int* H = mfint + sn.mf;
    const int n_child = H[0], n_leaf = H[1], n_ent = H[2] >> 1, n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
-   const int np = r * (r + 1) / 2;
+   // update columns the front keeps and hands on: all r, or (border split, BlkDesc::mf_split) only those of its rb rows of K - the
+   // border x border part is formed by k_border_schur from the finished panels
+   const int uc = bd.mf_split ? sn.rb : r;
+   const int np = uc * r - uc * (uc - 1) / 2;
    auto co = [nf](int j) { return j * nf - j * (j - 1) / 2; };
    const int cw = co(w);                                       // packed size of the panel columns
    const int rp = (r + 3) & ~3;                                // row stride of the aligned L21 copy (step 3)
@@ -699,14 +710,16 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
       // A wave takes a PAIR of columns (b, rc - 1 - b) of a child's packed update matrix - together rc + 1 entries whatever b is -
       // and walks down it 64 rows at a time: coalesced reads, the target column is wave-uniform, one LDS read (the row's position)
       // and one fire-and-forget add per entry.  (pair, 64-row piece) items go round-robin over the waves, NB loads in flight each.
+      // A child that hands over only its first ucc columns (border split): a wave per (column, 64-row piece), the columns are long.
       constexpr int NW = BLOCK / 64, NB = 12;
       const int wave = tid >> 6;
       int off = 0;
       for (int c = 0; c < n_child; ++c) {
-         const int rc = H[MF_HDR + 3 * c + 1];
+         const int rcw = H[MF_HDR + 3 * c + 1], rc = rcw & 0xffff, ucc = rcw >> 16;
          const double* Uc = uarena + sn.U + H[MF_HDR + 3 * c];
          const int* rel = relbuf + off;
-         const int npairs = (rc + 1) >> 1, pieces = (rc + 1 + 63) >> 6, nitems = npairs * pieces;
+         const bool whole = ucc == rc;
+         const int npairs = (rc + 1) >> 1, pieces = ((whole ? rc + 1 : rc) + 63) >> 6, nitems = (whole ? npairs : ucc) * pieces;
          for (int s0 = wave; s0 < nitems; s0 += NW * NB) {
             double v[NB];
             int ea[NB], eb[NB];
@@ -716,10 +729,12 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
                ea[u] = -1; eb[u] = 0; v[u] = 0.0;
                if (item < nitems) {
                   const int pr = item / pieces, e = (item - pr * pieces) * 64 + lane;   // pr, pieces: wave-uniform
-                  const int b1 = pr, b2 = rc - 1 - pr, n1 = rc - b1;
-                  int a = -1, b = b1;
-                  if (e < n1) a = b1 + e;
-                  else if (b2 != b1 && e - n1 <= pr) { b = b2; a = b2 + (e - n1); }
+                  int a = -1, b = pr;
+                  if (whole) {
+                     const int b1 = pr, b2 = rc - 1 - pr, n1 = rc - b1;
+                     if (e < n1) a = b1 + e;
+                     else if (b2 != b1 && e - n1 <= pr) { b = b2; a = b2 + (e - n1); }
+                  } else if (pr + e < rc) a = pr + e;
                   if (a >= 0) { ea[u] = a; eb[u] = b; v[u] = Uc[b * rc - b * (b - 1) / 2 + (a - b)]; }
                }
             }
@@ -817,9 +832,17 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 #pragma unroll
       for (int k = 0; k < WMAX; ++k)
          if (k < w && k <= i) P[i + (long long)k * nf] = y[k];    // l_ik, d_k on the diagonal: what the solves read
+      if (sn.bb >= 0 && i >= w + sn.rb) {   // border split: the border rows once more, in the layout k_border_schur stages
+         const int nbj = r - sn.rb, rpb = (nbj + 3) & ~3;
+         double* Q = bbarena + sn.bb + (i - w - sn.rb);
+#pragma unroll
+         for (int k = 0; k < WMAX; ++k)
+            if (k < w) Q[k * rpb] = y[k];
+      }
    }
    }
    __syncthreads();   // every wave has taken its rows out of the packed panel: the region becomes the L21 copy Lt[k * rp + a]
+   if (sn.bb >= 0 && tid < w) { const int rpb = (r - sn.rb + 3) & ~3; bbarena[sn.bb + w * rpb + tid] = dk[tid]; }
    if (i >= w && i < nf) {
 #pragma unroll
       for (int k = 0; k < WMAX; ++k)
@@ -832,7 +855,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    MF_STAMP(5);
    if (r > 0) {
       typedef double double2_t __attribute__((ext_vector_type(2)));
-      const int nt = rp >> 2, ntiles = nt * (nt + 1) / 2;
+      const int nt = rp >> 2, ntb = (uc + 3) >> 2, ntiles = ntb * nt - ntb * (ntb - 1) / 2;   // column tiles tb < ntb only
       for (int t = tid; t < ntiles; t += BLOCK) {
          const int tb = packed_col(t, nt), ta = tb + (t - (tb * nt - tb * (tb - 1) / 2));
          const int a0 = 4 * ta, b0 = 4 * tb;
@@ -857,7 +880,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 #pragma unroll
          for (int z = 0; z < 4; ++z) {
             const int b = b0 + z;
-            if (b < r) {
+            if (b < uc) {
                double* ub = FU + cu(b) - b;
 #pragma unroll
                for (int x = 0; x < 4; ++x) {
@@ -872,7 +895,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
 
    // ---- 4. the update matrix leaves
    MF_STAMP(6);
-   if (r == 0) { MF_STAMP(7); return; }
+   if (np == 0) { MF_STAMP(7); return; }
    // the update matrix goes to the update arena: the parent front picks it up there; for a front without a head parent (parent
    // column in the dense tail) k_root_assemble adds it to the tail / Schur complement after the last level, front by front in a
    // fixed order - no atomics on targets that several fronts of a block share
@@ -912,7 +935,7 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
    const int n = bd.n, n_head = bd.n_head, c = blockIdx.y;
    double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
    const bool tail_chunk = c < nt;
-   if (!tail_chunk && !S_) return;
+   if (!tail_chunk && (!S_ || bd.mf_split)) return;   // (border split: the update matrices hold no border x border part, k_border_schur forms it)
    // block-local row ids [lo, hi) whose columns this workgroup owns
    int lo, hi;
    if (tail_chunk) {
@@ -963,6 +986,157 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
          }
          __syncthreads();   // the next front may reach the same entries from other threads
       }
+   }
+}
+
+// Border split (BlockSym::mf_split): the border x border part of a block's Schur contribution, formed from the finished head panels,
+//    C(i, j) = - sum_J sum_k L_J(i, k) d_k L_J(j, k),   i >= j compressed border ids,
+// over the head supernodes J of the block that hold border rows and take part in the multifrontal scheme (fronts, simple leaves
+// below a front) - what the update matrices would otherwise carry from front to front up to the root fronts.
+// The border rows of those supernodes are kept a second time, in the layout this kernel stages (k_front / k_head_factor_simple write
+// them as they write the panel): per supernode Lt[k * rp + a] (rp = nbj rounded up to 4, the padding stays zero from the analysis) and
+// its w pivots, supernode after supernode - a BATCH of up to BB_GMAX supernodes is one contiguous piece of that arena.
+// One workgroup per (block, share of the block's batches): C (packed lower triangle, nb (nb + 1) / 2 doubles) stays in LDS for the
+// whole walk; per batch the piece is copied to LDS (requested into registers one batch ahead), every thread forms 4 x 4 tiles of
+// L_b D L_b^T of the batch's supernodes in registers and adds them at the rows' border positions with LDS atomics (ds_add_f64: no
+// return value, no wait).  ordered != 0 (deterministic mode): the supernodes of a batch one after the other with a barrier between
+// them - inside a supernode the targets are distinct, so every sum has a fixed order.  At the end C is added to the Schur complement:
+// FP64 atomics (targets shared between blocks and shares), or - gbuf != nullptr - plain adds into the group's buffer by launches that
+// hold at most one block of every group.
+constexpr int BB_GMAX = 8;
+struct BbMeta { int lt_off, pos_off, w, nbj, tile0, pad0, pad1, pad2; };   // staging offset of Lt (doubles; the pivots follow at + w * rp),
+                                                                          // offset of the rows' positions inside the batch's list, tiles before it
+struct BbBatch {
+   long long src;     // offset of the batch inside the border-row arena
+   long long pos;     // offset of its rows' positions (compressed border ids) inside bbpos
+   int first, cnt;    // its supernodes inside the BbMeta array
+   int ndoubles, ntiles, npos, pad;
+};
+
+template <int BLOCK, int NPF>
+__global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ blk_list, const int* __restrict__ batch_off,
+                                                       const BbBatch* __restrict__ batches, const BbMeta* __restrict__ metas,
+                                                       const int* __restrict__ bbpos, const BlkDesc* __restrict__ blks,
+                                                       const int* __restrict__ bmap, const double* __restrict__ bbarena,
+                                                       double* __restrict__ SC, int ldSC, const int* __restrict__ sctab,
+                                                       double* __restrict__ gbuf, long long gstride, const int* __restrict__ blk_group,
+                                                       int stg_doubles, int pos_cap, int ordered) {
+   extern __shared__ __attribute__((aligned(16))) double bs_C[];
+   typedef double double2_t __attribute__((ext_vector_type(2)));
+   const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
+   const BlkDesc bd = blks[blk];
+   const int nb = bd.nb, tid = threadIdx.x;
+   const int q_begin = batch_off[blk], q_end = batch_off[blk + 1];
+   double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
+   if (q_begin >= q_end || !S_) return;
+   const int ncp = (nb * (nb + 1) / 2 + 1) & ~1;
+   double* C = bs_C;
+   double* stage = C + ncp;                              // stg_doubles
+   int* spos = (int*)(stage + stg_doubles);              // pos_cap
+   BbMeta* smeta = (BbMeta*)(spos + ((pos_cap + 3) & ~3));   // BB_GMAX
+   for (int idx = tid; idx < ncp; idx += BLOCK) C[idx] = 0.0;
+   constexpr int NPP = 4;   // positions per thread (pos_cap <= NPP * BLOCK, checked by the host)
+   double2_t pv[NPF];
+   int pp[NPP];
+   auto request = [&](const BbBatch& bt) {
+      const double2_t* src = (const double2_t*)(bbarena + bt.src);
+      const int n2 = bt.ndoubles >> 1;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+         const int e = tid + u * BLOCK;
+         if (e < n2) pv[u] = src[e];
+      }
+      const int* ps = bbpos + bt.pos;
+#pragma unroll
+      for (int u = 0; u < NPP; ++u) {
+         const int e = tid + u * BLOCK;
+         if (e < bt.npos) pp[u] = ps[e];
+      }
+   };
+   int q = q_begin + blockIdx.y;
+   if (q < q_end) request(batches[q]);
+   for (; q < q_end; q += gridDim.y) {
+      const BbBatch bt = batches[q];
+      __syncthreads();   // the tiles of the previous batch are done with the staging area (first pass: C is zeroed)
+      {
+         double2_t* st2 = (double2_t*)stage;
+         const int n2 = bt.ndoubles >> 1;
+#pragma unroll
+         for (int u = 0; u < NPF; ++u) {
+            const int e = tid + u * BLOCK;
+            if (e < n2) st2[e] = pv[u];
+         }
+#pragma unroll
+         for (int u = 0; u < NPP; ++u) {
+            const int e = tid + u * BLOCK;
+            if (e < bt.npos) spos[e] = pp[u];
+         }
+         if (tid < bt.cnt * 8) ((int*)smeta)[tid] = ((const int*)(metas + bt.first))[tid];
+      }
+      __syncthreads();
+      if (q + (int)gridDim.y < q_end) request(batches[q + gridDim.y]);
+      auto do_tile = [&](const BbMeta& m, int t) {
+         const int w = m.w, nbj = m.nbj, rp = (nbj + 3) & ~3, nt = rp >> 2;
+         const double* Lt = stage + m.lt_off;
+         const double* dk = Lt + w * rp;
+         const int* pos = spos + m.pos_off;
+         const int tb = packed_col(t, nt), ta = tb + (t - (tb * nt - tb * (tb - 1) / 2));
+         const int a0 = 4 * ta, b0 = 4 * tb;
+         double acc[4][4];
+#pragma unroll
+         for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int z = 0; z < 4; ++z) acc[x][z] = 0.0;
+#pragma unroll 4
+         for (int k = 0; k < w; ++k) {
+            const double2_t* ca = (const double2_t*)(Lt + k * rp + a0);
+            const double2_t* cb = (const double2_t*)(Lt + k * rp + b0);
+            const double2_t a01 = ca[0], a23 = ca[1], b01 = cb[0], b23 = cb[1];
+            const double d = dk[k];
+            const double la[4] = {a01.x, a01.y, a23.x, a23.y};
+            const double lb[4] = {b01.x * d, b01.y * d, b23.x * d, b23.y * d};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+               for (int z = 0; z < 4; ++z) acc[x][z] += la[x] * lb[z];
+         }
+#pragma unroll
+         for (int z = 0; z < 4; ++z) {
+            const int b = b0 + z;
+            if (b < nbj) {
+               const int j = pos[b];
+               double* cj = C + (j * nb - j * (j - 1) / 2) - j;
+#pragma unroll
+               for (int x = 0; x < 4; ++x) {
+                  const int a = a0 + x;
+                  if (a < nbj && a >= b) lds_add(cj + pos[a], -acc[x][z]);
+               }
+            }
+         }
+      };
+      if (!ordered) {
+         for (int t = tid; t < bt.ntiles; t += BLOCK) {
+            int g = 0;
+#pragma unroll
+            for (int h = 1; h < BB_GMAX; ++h) g += (h < bt.cnt && smeta[h].tile0 <= t) ? 1 : 0;
+            do_tile(smeta[g], t - smeta[g].tile0);
+         }
+      } else {
+         for (int g = 0; g < bt.cnt; ++g) {
+            const int t_end = (g + 1 < bt.cnt ? smeta[g + 1].tile0 : bt.ntiles) - smeta[g].tile0;
+            for (int t = tid; t < t_end; t += BLOCK) do_tile(smeta[g], t);
+            __syncthreads();
+         }
+      }
+   }
+   __syncthreads();
+   const int* bm = bmap + bd.bmap_off;
+   for (int idx = tid; idx < nb * (nb + 1) / 2; idx += BLOCK) {
+      const double v = C[idx];
+      if (v == 0.0) continue;   // (never touched)
+      const int j = packed_col(idx, nb), i = j + (idx - (j * nb - j * (j - 1) / 2));
+      double* tgt = sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, nb, i, j);
+      if (gbuf) *tgt += v; else atomic_add_f64(tgt, v);
    }
 }
 
@@ -1017,7 +1191,7 @@ __global__ __launch_bounds__(64) void k_front_fwd(const SnDesc* __restrict__ sns
    {
       int off = 0;
       for (int c = 0; c < n_child; ++c) {
-         const int rc = H[MF_HDR + 3 * c + 1];
+         const int rc = H[MF_HDR + 3 * c + 1] & 0xffff;
          const double* Vc = varena + sn.vslot + H[MF_HDR + 3 * c + 2];
          for (int a = lane; a < rc; a += 64) t[relbuf[off + a]] += Vc[a];   // distinct positions inside a child
          off += rc;

@@ -323,6 +323,13 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       out.mf_max_front = 0;
       out.mf_ok = true;
       auto is_simple = [&](const HeadSupernode& sn) { return sn.w == 1 && sn.r <= opt.simple_rmax && sn.level == 0; };
+      // Border split: the border x border part of an update matrix is needed by no front above - it is a partial sum of the block's
+      // Schur contribution that would only travel from front to front (time-coupled blocks: 64 % of the update-matrix volume, fronts of
+      // ~17 rows of K carrying ~100 border rows).  With the split a front keeps only the update columns that belong to rows of K
+      // (uc = rb of them, each with all r rows below: K x K and border x K); the border x border part is formed once per block from the
+      // finished panels, -sum_J L_b(J) D_J L_b(J)^T (k_border_schur).  Taken where that kernel's accumulator fits the LDS.
+      out.mf_split = out.nb > 0 && out.nb <= opt.mf_split_nb_max;
+      auto ucols = [&](const HeadSupernode& sn) { return out.mf_split ? sn.rb : sn.r; };
       std::vector<std::vector<int>> kids(nsn), leaves(nsn);
       for (int s = 0; s < nsn; ++s) {
          const HeadSupernode& sn = out.sn[s];
@@ -360,7 +367,8 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          const HeadSupernode& sn = out.sn[s];
          if (is_simple(sn)) continue;
          out.mf_U[s] = out.mf_U_total;
-         out.mf_U_total += (int64_t)sn.r * (sn.r + 1) / 2;
+         const int64_t uc = ucols(sn);
+         out.mf_U_total += uc * sn.r - uc * (uc - 1) / 2;   // update columns 0 .. uc - 1, packed: column b holds rows b .. r - 1
          out.mf_V[s] = out.mf_V_total;
          out.mf_V_total += sn.r;
       }
@@ -409,7 +417,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_int.insert(out.mf_int.end(), hdr, hdr + MF_HDR);
          for (int c : kids[s]) {
             out.mf_int.push_back((int)(out.mf_U[c] - out.mf_U[s]));
-            out.mf_int.push_back(out.sn[c].r);
+            out.mf_int.push_back(out.sn[c].r | (ucols(out.sn[c]) << 16));   // r_c, and the number of update columns the child hands over
             out.mf_int.push_back((int)(out.mf_V[c] - out.mf_V[s]));
          }
          for (int c : kids[s]) {
@@ -429,7 +437,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          // leaf part: colptr | items | leaf table | position lists
          std::vector<int> lists, item_col, item_a, item_b, tab;
          int n_vals = 0, n_items = 0;
-         for (int c : leaves[s]) n_items += out.sn[c].r;
+         for (int c : leaves[s]) n_items += ucols(out.sn[c]);   // (a leaf's border rows are no front columns under the border split)
          const int list_base = (nf + 1) + 2 * n_items + 4 * n_leaf;   // offset of the first position list inside the leaf part
          out.mf_int[hpos + 7] = (int)out.mf_LV_total;
          for (int c : leaves[s]) {
@@ -444,7 +452,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             tab.push_back(lf.r);
             tab.push_back(loff);
             lists.insert(lists.end(), pos.begin(), pos.end());
-            for (int b = 0; b < lf.r; ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (lf.r << 4) | b); item_b.push_back(loff); }
+            for (int b = 0; b < ucols(lf); ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (lf.r << 4) | b); item_b.push_back(loff); }
             n_vals += 1 + lf.r;
          }
          out.mf_LV_total += n_vals;

@@ -377,10 +377,16 @@ def test_time_coupled_blocks_match_oracle(cut, n_i, head, monkeypatch):
     if head == "multifrontal_devmem":
         # an LDS budget one double short of the largest packed front: its panel columns still fit, its update matrix is
         # worked on in device memory (the variant fronts beyond ~200 rows take at the default budget)
-        bt.close()
-        monkeypatch.setenv("PIPS_HIP_MF_LDS", str(info["max_front"] * (info["max_front"] + 1) // 2 + 7))
-        bt = analysed()
-        info = bt.info()
+        # (with the border split a front keeps fewer update columns than its packed triangle has: shrink the budget until one no longer fits)
+        budget = info["max_front"] * (info["max_front"] + 1) // 2 + 7
+        for _ in range(8):
+            bt.close()
+            monkeypatch.setenv("PIPS_HIP_MF_LDS", str(budget))
+            bt = analysed()
+            info = bt.info()
+            if info["fronts_in_device_memory"] > 0 or not info["multifrontal_head"]:
+                break
+            budget = int(budget * 0.75)
         assert info["fronts_in_device_memory"] > 0, info
     assert bt.schur_mode() in (1, 2)
     assert info["multifrontal_head"] == (0 if head == "scatter" else 1), info

@@ -72,3 +72,43 @@ def test_adaptive_refinement_keeps_the_direct_path():
     bt.sync()
     assert kkt.solve_graph_stats() == (0, 0)
     kkt.close(); bt.close()
+
+
+def test_settings_changed_after_a_capture_force_a_new_capture():
+    """The captured launch sequence bakes in the number of refinement launches and the root's pivoting mode (and the zdiag0 / C0 buffers of
+    eliminated root inequality rows): changing one of them after a capture must not replay the stale sequence."""
+    prob = Problem(5, 3, 200, 100, 12, 10, 0.05)
+    bt, kkt = _system(prob)
+    bt.set_refinement(0, 0.0)
+    kkt.set_solve_graph(True)
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    rng = np.random.default_rng(1)
+    b0h, blh = rng.standard_normal(prob.S), rng.standard_normal(prob.N * prob.n_leaf)
+    b0, bl = torch.empty(prob.S, dtype=torch.float64, device="cuda"), torch.empty(prob.N * prob.n_leaf, dtype=torch.float64, device="cuda")
+
+    def solve():
+        b0.copy_(torch.tensor(b0h)); bl.copy_(torch.tensor(blh))
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        return b0.cpu().numpy().copy(), bl.cpu().numpy().copy()
+
+    solve()
+    assert kkt.solve_graph_stats() == (1, 1)
+    bt.set_refinement(2, 0.0)                       # two refinement steps per leaf solve: another launch sequence
+    g0, gl = solve()
+    assert kkt.solve_graph_stats() == (2, 2)
+    kkt.set_solve_graph(False)
+    d0, dl = solve()
+    assert np.linalg.norm(g0 - d0) <= 1e-12 * np.linalg.norm(d0) and np.linalg.norm(gl - dl) <= 1e-12 * np.linalg.norm(dl)
+    kkt.set_solve_graph(True)
+    solve()
+    n_cap = kkt.solve_graph_stats()[0]
+    kkt.set_root_pivoting(1)                        # Bunch-Kaufman root: other kernels in the Dsolve
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    g0, gl = solve()
+    assert kkt.solve_graph_stats()[0] == n_cap + 1
+    kkt.set_solve_graph(False)
+    d0, dl = solve()
+    assert np.linalg.norm(g0 - d0) <= 1e-10 * np.linalg.norm(d0) and np.linalg.norm(gl - dl) <= 1e-10 * np.linalg.norm(dl)
+    kkt.close(); bt.close()
