@@ -429,7 +429,9 @@ def main():
     # ---- phase table + rooflines: ONE instrumented step (1 factorize + 4 solveCompressed) after the timed region, HIP events on
     #      the streams the work runs on (pips_hip_batch_get_timing / pips_hip_kkt_get_timing)
     bt.set_timing(True)
+    aug0 = bt.info().get("augmented_passes", 0)
     step()
+    aug_passes = bt.info().get("augmented_passes", 0) - aug0    # passes of this step that swept the augmented factor (border rows included)
     tm = bt.get_timing()
     tk = kkt.get_timing()
     bt.set_timing(False)
@@ -469,9 +471,13 @@ def main():
               "8 (nnz K + nnz L_head) + 4 (nnz K + row indices of the head supernodes): read K once, write L once"),
     ] + ([group("dense root", "k_tile_gemm<3> + k_tile_diag + k_tile_gemm<1>", "mfma", tk["root_factor"][0], 1, S ** 3 / 3.0, "S^3 / 3")]
          if not sparse_root else []) + [
+        # a solve with K_i reads the rows of K of the factor twice (16 bytes per entry and pass); a pass over the AUGMENTED factor also its
+        # border rows (head panels / border-row arena, the tails' border rows)
         group("leaf solve sweeps", "k_leaf_fwd_gather / k_head_fwd_chain / k_tail_rows_fwd / k_tail_rows_bwd / k_head_bwd_chain / k_leaf_bwd", "hbm",
-              tm["solve_head_fwd"][0] + tm["solve_tail"][0] + tm["solve_head_bwd"][0], n_solve_once, n_solve_once * 16.0 * info["nnzL"],
-              "every entry of L read once per sweep, forward and backward: 16 nnz(L) bytes per leaf solve pass"),
+              tm["solve_head_fwd"][0] + tm["solve_tail"][0] + tm["solve_head_bwd"][0], n_solve_once,
+              16.0 * (n_solve_once * (info["nnzL"] - info.get("nnzL_border", 0)) + aug_passes * info.get("nnzL_border", 0)),
+              "16 bytes per entry of L and pass (forward + backward): the rows of K in every pass, the border rows in the passes over the augmented factor "
+              f"({aug_passes} of {n_solve_once})"),
     ]
     dominant = max(groups, key=lambda g: g["ms_per_step"])
     roofline = dict(dominant)
@@ -498,7 +504,7 @@ def main():
     phase_ms = {"step": top, "root_factor_exposed": round(root_exposed, 3), "accounted": round(accounted, 3),
                 "leaf_factor": {k: round(tm[k][0], 3) for k in ("scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur")},
                 "leaf_solves": {k: round(tm[k][0], 3) for k in ("solve_permute", "solve_head_fwd", "solve_tail", "solve_head_bwd", "solve_refine")},
-                "leaf_solve_passes": n_solve_once}
+                "leaf_solve_passes": n_solve_once, "leaf_solve_passes_augmented": aug_passes}
     collective = None
     if use_dist:
         # bytes of the Schur reduction: the packed triangle of the dense root, or the value array of the sparse root's pattern
@@ -532,9 +538,10 @@ def main():
                                   "the random generator's fill at n_i = 50 000 gives dense factors, BASELINE.md)"), "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
                                                     if sparse_root else "dense LDL^T"), "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
-                       "ltsolve": ("one backward sweep of the augmented factor, u = L^-T (L21^T x0), unrefined; taken while no pivot is perturbed and the "
-                                   "refined Lsolve of the same call needed no step (DESIGN.md 2)"
-                                   if kkt.last_ltsolve_from_factor() else "border product + refined leaf solve"),
+                       "solve_path": {0: "every solveCompressed: two leaf solves with adaptive refinement + the two sparse border products",
+                                      1: "refined Lsolve; Ltsolve by one backward sweep of the augmented factor (no pivot perturbed, the refined Lsolve needed no step)",
+                                      2: "first solveCompressed after a factorisation: two refined leaf solves (the witness: no pivot perturbed, no refinement "
+                                         "step needed); the others: one forward + one backward sweep of the augmented factor [L 0; L_b I] (DESIGN.md 2)"}[kkt.last_solve_path()],
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},

@@ -231,6 +231,16 @@ int pips_hip_kkt_solve_graph_stats(void* handle, int64_t* captures, int64_t* rep
 /* 1 if the last pips_hip_kkt_solve_compressed took its Ltsolve from the augmented factor (one unrefined backward sweep: only while no
  * pivot is perturbed and the refined leaf solve of the same call needed no refinement step), 0 if by border product + refined solve */
 int pips_hip_kkt_last_ltsolve_from_factor(void* handle, int* flag);
+/* Which way the last pips_hip_kkt_solve_compressed went (Lsolve / Ltsolve of sLinsysRootAug.C:323-365 with addLniziLinkCons and
+ * LniTransMult, DistributedLeafLinearSystem.C:171-212, DistributedLinearSystem.C:430-483):
+ *   0  two leaf solves with adaptive refinement (K_i^-1 b_i, then K_i^-1 Br_i x0) and the two sparse border products;
+ *   1  refined Lsolve, Ltsolve by one backward sweep of the augmented factor;
+ *   2  one forward and one backward sweep of the augmented factor [L 0; L_b I]: the forward sweep leaves -Br_i^T K_i^-1 b_i in the
+ *      border rows, the backward sweep started from D^-1 y with the border rows at x0 gives K_i^-1 (b_i - Br_i x0).
+ * 1 and 2 carry no refinement; they are taken only while no pivot of the factorisation is perturbed, and 2 only after a
+ * solveCompressed on the same factors went way 0 / 1 and its refined solves met the backward-error tolerance without a step (the
+ * first solveCompressed after every factorisation is that witness; needs adaptive refinement, pips_hip_batch_set_refinement*). */
+int pips_hip_kkt_last_solve_path(void* handle, int* path);
 void pips_hip_kkt_destroy(void* handle);
 
 /* plain device buffers for hosts that do not bring their own allocator */

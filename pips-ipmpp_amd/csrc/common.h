@@ -62,11 +62,13 @@ struct HeadSupernode {
    int w;           // width
    int r;           // number of rows below the diagonal block
    int level;       // elimination-tree level among head supernodes (0 = leaves)
-   int64_t panel;   // offset (doubles) of the (w+r) x w column-major panel inside the block arena
+   int64_t panel;   // offset (doubles) of the ld x w column-major panel inside the block arena
    int64_t rows;    // offset (ints) of the r row indices inside BlockSym::rowidx
    int64_t upd;     // offset (ints) of this supernode's head-to-head update segments inside BlockSym::upd
    int n_useg;      // number of such segments (distinct head supernodes among the below-rows)
    int rb;          // index of the first border row among the below-rows (== r when there is none)
+   int ld;          // leading dimension of the stored panel: w + r, or - a front under the border split - w + rb: its border rows live
+                    // only in the border-row arena (the solve sweeps then read a compact panel of rows of K)
 };
 
 struct BlockSym {

@@ -509,6 +509,7 @@ static int tail_fwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_str
 
 static int tail_bwd(const TailCtx& c, double* xw, int nrhs = 1, long long xw_stride = 0, int border = 0) {
    const TailPlan& p = *c.plan;
+   if (p.ntc_max == 0) return PIPS_OK;   // no block has a dense tail
    if (border && !(c.sweep && c.sweep->enabled)) PIPS_FAIL(PIPS_ERR_STATE, "border-backward sweep needs the single-launch tail sweeps");
    if (c.sweep && c.sweep->enabled && nrhs <= SWEEP_NRHS_MAX) {
       hipLaunchKernelGGL(k_tail_rows_bwd, dim3(c.sweep->n_tasks, nrhs), dim3(256), 0, c.stream, c.sweep->args(xw_stride, c.stream), c.d_blks, c.d_arena, c.d_dtail,
@@ -557,7 +558,10 @@ static inline long long mf_unp(const BlockSym& bs, const HeadSupernode& s) {
 static inline int mf_class(int w, long long nf, long long unp, long long lds_budget) {
    const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
    if (pw + unp + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
-   return (nf <= 64 ? 0 : 2) + 3 * (w <= 16 ? 0 : 1);   // more than one wave: 256 threads - the phases around the pivots are spread over them
+   // more than one wave: 256 threads - the phases around the pivots are spread over them; PIPS_HIP_MF_128=1: 128 threads up to 128 rows
+   // (twice the fronts per compute unit where the registers, not the LDS, set the limit)
+   static const bool mid = getenv("PIPS_HIP_MF_128") && atoi(getenv("PIPS_HIP_MF_128")) != 0;
+   return (nf <= 64 ? 0 : (mid && nf <= 128) ? 1 : 2) + 3 * (w <= 16 ? 0 : 1);
 }
 
 // Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
@@ -626,7 +630,7 @@ struct Engine {
    BbBatch* d_bb_batches = nullptr;                 // border split (k_border_schur): batches of supernodes with border rows, block after block
    BbMeta* d_bb_meta = nullptr;
    int *d_bb_off = nullptr, *d_bb_pos = nullptr;    // batches of block b: [d_bb_off[b], d_bb_off[b + 1]); compressed border ids of the staged rows
-   double* d_bbarena = nullptr;                     // the border rows of those supernodes in the staging layout
+   long long bb_doubles = 0;                        // doubles of the border-row arena (behind the panels inside d_arena)
    std::vector<int> h_bb_off_keep;
    int n_bb = 0, bb_stage = 3072, bb_nbmax = 0, bb_poscap = 0;
    int* d_bb_round_blk = nullptr;                   // deterministic mode: the blocks of round k of k_border_schur
@@ -659,6 +663,8 @@ struct Engine {
    double* d_lf_val = nullptr;
    long long lf_rows = 0, lf_entries = 0;
    LeafDesc* d_leafdesc = nullptr;   // compact records of the level-0 simple leaves, in the order of d_sns (k_leaf_bwd)
+   int* d_lb_list = nullptr;         // the simple leaves that own border rows (k_leaf_border)
+   int n_lb = 0, nb_pad_max = 0;
    int head_wcap = HEAD_WMAX;   // widest head supernode of this analysis (picks the register-lean variants of the chain kernels)
    int *d_rowidx = nullptr, *d_upd = nullptr, *d_sncol = nullptr, *d_bmap = nullptr, *d_perm = nullptr, *d_inertia = nullptr, *d_nprimal = nullptr;
    int *d_br_rowptr = nullptr, *d_br_sc = nullptr, *d_br_src = nullptr;   // the border by leaf row (k_border_mult_rows)
@@ -694,9 +700,9 @@ struct Engine {
       if (d_mfLV) (void)hipFree(d_mfLV);
       if (d_mfV) (void)hipFree(d_mfV);
       d_mfV = nullptr;
-      for (void* q : {(void*)d_bb_batches, (void*)d_bb_meta, (void*)d_bb_off, (void*)d_bb_pos, (void*)d_bbarena, (void*)d_bb_round_blk})
+      for (void* q : {(void*)d_bb_batches, (void*)d_bb_meta, (void*)d_bb_off, (void*)d_bb_pos, (void*)d_bb_round_blk})
          if (q) (void)hipFree(q);
-      d_bb_batches = nullptr; d_bb_meta = nullptr; d_bb_off = nullptr; d_bb_pos = nullptr; d_bbarena = nullptr; d_bb_round_blk = nullptr; n_bb = 0;
+      d_bb_batches = nullptr; d_bb_meta = nullptr; d_bb_off = nullptr; d_bb_pos = nullptr; d_bb_round_blk = nullptr; n_bb = 0; bb_doubles = 0;
       for (void* q : {(void*)d_roots, (void*)d_root_off, (void*)d_round_blk})
          if (q) (void)hipFree(q);
       d_roots = d_root_off = d_round_blk = nullptr;
@@ -985,6 +991,11 @@ struct Engine {
       if (const char* bg = getenv("PIPS_HIP_BALANCED_GEMM")) balanced_gemm = atoi(bg) != 0;
       bool any_border = false;
       for (int b = 0; b < nblk; ++b) any_border = any_border || !in[b].btrow.empty();
+      {  // the border split (compact front panels) only exists with the multifrontal head
+         const char* env = getenv("PIPS_HIP_MF");
+         const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
+         if ((env && atoi(env) == 0) || (hs && atoi(hs) != 0 && !deterministic)) opt.mf_split_nb_max = 0;
+      }
       int rc = analyze_host(n_threads, schur_mode != 2);
       if (rc) return rc;
       schur_mode_eff = (schur_mode == 2 && any_border) ? 2 : 1;
@@ -1014,6 +1025,12 @@ struct Engine {
             }
          }
          mf_solves = mf_solves && mf && !deterministic;   // (deterministic mode keeps its slot-based forward substitution)
+         bool any_split = false;
+         for (int b = 0; b < nblk; ++b) any_split = any_split || sym[b].mf_split;
+         if (!mf && any_split) {   // some block cannot take the multifrontal head: every block back to full panels
+            opt.mf_split_nb_max = 0;
+            if ((rc = analyze_host(n_threads, schur_mode_eff != 2))) return rc;
+         }
       }
 
       // ---- offsets
@@ -1152,7 +1169,7 @@ struct Engine {
          const HeadSupernode& s = sym[k.blk].sn[k.loc];
          head_wcap = std::max(head_wcap, s.w);
          h_sns[i] = SnDesc{h_blks[k.blk].arena_off + s.panel, rows_base[k.blk] + s.rows, upd_base[k.blk] + s.upd, s.w, s.r, s.c0, k.blk,
-                           s.n_useg, s.rb, slots_acc, vslots_acc, -1, -1, -1};
+                           s.n_useg, s.rb, s.ld, 0, slots_acc, vslots_acc, -1, -1, -1};
          if (mf && k.cls > 0 && s.r > 0 && sym[k.blk].sn_parent[k.loc] < 0) roots_of[k.blk].push_back(i);
          if (mf) {
             const BlockSym& bs = sym[k.blk];
@@ -1181,7 +1198,7 @@ struct Engine {
                   // waves per SIMD - four workgroups of 256 threads, sixteen of 64); a bucket = one such class, since inside a class a
                   // smaller front gains nothing from a launch of its own and across a boundary every front of the launch loses a slot
                   auto cls_of = [&](int lds_doubles) {
-                     const int c = k.cls - 1, kmax = c == 0 ? 16 : c == 3 ? 12 : c == 2 ? 4 : 3;   // (154 VGPRs for the 32-wide variants)
+                     const int c = k.cls - 1, kmax = c == 0 ? 16 : c == 3 ? 12 : c == 1 ? 8 : c == 4 ? 6 : c == 2 ? 4 : 3;   // (154 VGPRs for the 32-wide variants)
                      return std::min(kmax, (int)(163840 / ((long long)lds_doubles * 8 + 1024)));
                   };
                   if (m.cnt >= 256 && cls_of(k.lds) < cls_of(first_lds)) open = true;
@@ -1219,7 +1236,7 @@ struct Engine {
          std::vector<int> h_bbpos;
          h_bb_off_keep.assign(nblk + 1, 0);
          bb_stage = 3072; bb_nbmax = 0; bb_poscap = 0;
-         long long bb_total = 0;
+         long long bb_total = arena_total;   // the border-row arena lives behind the panels in the same allocation (offsets like SnDesc::panel)
          for (int b = 0; b < nblk; ++b) {
             const BlockSym& bs = sym[b];
             if (!bs.mf_split) continue;
@@ -1252,9 +1269,8 @@ struct Engine {
          if (n_bb > 0) {
             if ((rc = dev_upload(&d_bb_batches, h_batch, stream)) || (rc = dev_upload(&d_bb_meta, h_meta, stream)) ||
                 (rc = dev_upload(&d_bb_pos, h_bbpos, stream)) || (rc = dev_upload(&d_bb_off, h_bb_off_keep, stream))) return rc;
-            HIP_TRY(hipMalloc((void**)&d_bbarena, (size_t)std::max<long long>(bb_total, 2) * sizeof(double)));
-            HIP_TRY(hipMemsetAsync(d_bbarena, 0, (size_t)std::max<long long>(bb_total, 2) * sizeof(double), stream));   // (the padding rows stay zero)
          }
+         bb_doubles = bb_total - arena_total;
       }
       // spine lists: per block, ascending local index = postorder (children before parents)
       std::vector<int> h_spine, h_spine_off(nblk + 1, 0);
@@ -1386,7 +1402,8 @@ struct Engine {
       }
 
       // ---- device allocation / upload
-      HIP_TRY(hipMalloc((void**)&d_arena, std::max<long long>(arena_total, 1) * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_arena, std::max<long long>(arena_total + bb_doubles, 1) * sizeof(double)));
+      if (bb_doubles > 0) HIP_TRY(hipMemsetAsync(d_arena + arena_total, 0, (size_t)bb_doubles * sizeof(double), stream));   // (the padding rows of the border-row arena stay zero)
       HIP_TRY(hipMalloc((void**)&d_uarena, std::max<long long>(uarena_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_kval, std::max<long long>(nnzK_total, 1) * sizeof(double)));
       HIP_TRY(hipMemset(d_kval, 0, std::max<long long>(nnzK_total, 1) * sizeof(double)));
@@ -1413,6 +1430,17 @@ struct Engine {
       if ((rc = dev_upload(&d_sns, h_sns, stream))) return rc;
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
       if ((rc = dev_upload(&d_rowidx, h_rowidx, stream))) return rc;
+      {  // simple leaves that own border rows (sweeps of the augmented factor: k_leaf_border), and the widest padded border
+         std::vector<int> lb;
+         if (!levels.empty())
+            for (int i = levels[0].simple_begin; i < levels[0].simple_begin + levels[0].simple_cnt; ++i)
+               if (h_sns[i].rb < h_sns[i].r) lb.push_back(i);
+         n_lb = (int)lb.size();
+         if (d_lb_list) { (void)hipFree(d_lb_list); d_lb_list = nullptr; }
+         if (n_lb > 0 && (rc = dev_upload(&d_lb_list, lb, stream))) return rc;
+         nb_pad_max = 0;
+         for (int b = 0; b < nblk; ++b) nb_pad_max = std::max(nb_pad_max, h_blks[b].nb_pad);
+      }
       // ---- the simple leaves' L entries by target row (forward substitution as a gather, see d_lf_rows)
       {
          const char* env = getenv("PIPS_HIP_LEAF_GATHER");
@@ -1523,6 +1551,13 @@ struct Engine {
          border_backward_ok = schur_mode_eff == 1 && nnzB_total > 0 && sweep.enabled && !deterministic && border_entries <= 1.25 * fwd_entries;
          if (const char* bb = getenv("PIPS_HIP_BORDER_BACKWARD"))
             border_backward_ok = atoi(bb) != 0 && schur_mode_eff == 1 && nnzB_total > 0 && sweep.enabled && !deterministic;
+         // Both halves of solveCompressed from the augmented factor (forward_augmented / backward_augmented): one forward and one backward
+         // sweep that also read the border rows, instead of two full solves (two sweeps each, a residual check each, two border
+         // products) - pays as long as the border rows are not several times what a sweep reads anyway
+         const bool aug_paths = schur_mode_eff == 1 && nnzB_total > 0 && (sweep.enabled || plan.ntc_max == 0) && !deterministic && !mf_solves && spine_total == 0 &&
+                                !head_slots && CHAIN_LAUNCH_MAX >= (1LL << 40);
+         aug_sweeps_ok = aug_paths && border_entries <= 3.0 * fwd_entries;
+         if (const char* as = getenv("PIPS_HIP_AUG_SWEEPS")) aug_sweeps_ok = atoi(as) != 0 && aug_paths;
       }
       if (diag_ahead && !side) {
          // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
@@ -1556,7 +1591,7 @@ struct Engine {
       if (L.simple_cnt > 0)
          hipLaunchKernelGGL(k_head_factor_simple, dim3((L.simple_cnt + 255) / 256), dim3(256), 0, stream, d_sns, L.simple_begin,
                             L.simple_cnt, d_blks, d_rowidx, d_upd, d_psign, d_psign_off, d_bmap, d_arena, SC, ldSC, d_inertia, d_pref, d_sctab, sx,
-                            mf ? 1 : 0, d_mfLV, d_lf_pos, d_lf_val, d_bbarena);
+                            mf ? 1 : 0, d_mfLV, d_lf_pos, d_lf_val, d_arena);
       if (mf) return;
       if (L.small_cnt > 0)
          hipLaunchKernelGGL((k_head_factor<64, 8, 640>), dim3(L.small_cnt), dim3(64), (size_t)std::max(L.small_lds, 1) * sizeof(double), stream, d_sns,
@@ -1572,7 +1607,7 @@ struct Engine {
       const size_t lds = (size_t)m.lds_doubles * sizeof(double);
       if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front<BLOCK, WMAX, UG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_front<BLOCK, WMAX, UG>), dim3(m.cnt), dim3(BLOCK), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_psign,
-                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval, deterministic ? 1 : 0, d_bbarena);
+                         d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval, deterministic ? 1 : 0, d_arena);
       return PIPS_OK;
    }
    int launch_border_schur(double* SC, int ldSC) {
@@ -1586,7 +1621,7 @@ struct Engine {
       const int split = getenv("PIPS_HIP_BB_SPLIT") ? std::max(1, atoi(getenv("PIPS_HIP_BB_SPLIT"))) : std::max(1, std::min(16, 256 / std::max(nblk, 1)));
       auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered) -> int {
          if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         hipLaunchKernelGGL(kern, dim3(cnt, sp), dim3(BLK), lds, stream, list, d_bb_off, d_bb_batches, d_bb_meta, d_bb_pos, d_blks, d_bmap, d_bbarena, SC, ldSC,
+         hipLaunchKernelGGL(kern, dim3(cnt, sp), dim3(BLK), lds, stream, list, d_bb_off, d_bb_batches, d_bb_meta, d_bb_pos, d_blks, d_bmap, d_arena, SC, ldSC,
                             d_sctab, gb, gs, grp, bb_stage, bb_poscap, ordered);
          return PIPS_OK;
       };
@@ -1981,7 +2016,7 @@ struct Engine {
          // few supernodes in the launch: a chain-like tree, take the latency-lean kernel; many: the high-occupancy one
          if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX)
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_fwd_chain<16> : k_head_fwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
-                               d_blks, d_rowidx, d_arena, xw, xws);
+                               d_blks, d_rowidx, d_arena, xw, xws, 0);
          else if (cnt > 0)
             hipLaunchKernelGGL(k_head_fwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
@@ -2228,6 +2263,8 @@ struct Engine {
    // forward sweep reads (decided at analyze time, border_backward_ok); needs Schur mode 1 and the single-launch tail sweeps.
    // There is no refinement in it: the caller uses it only while the factorisation has no perturbed pivot (perturbed_leaf_pivots).
    bool border_backward_ok = false;
+   bool aug_sweeps_ok = false;   // solveCompressed by one forward + one backward sweep of the augmented factor (decided at analyze time)
+   long long aug_passes = 0;     // passes (forward + backward) of those sweeps so far
    int perturbed_cache = -1;   // perturbed pivots of the current factorisation over all blocks; -1 = not fetched yet
    int perturbed_leaf_pivots(int* out) {
       if (perturbed_cache < 0) {
@@ -2238,6 +2275,78 @@ struct Engine {
          perturbed_cache = z;
       }
       *out = perturbed_cache;
+      return PIPS_OK;
+   }
+   // Forward sweep of the augmented factor [L 0; L_b I] on [b; 0]: the work vector keeps y = L^-1 P b (tail rows D^-1-scaled, as the tail
+   // sweep leaves them) for backward_augmented, and red += -L_b y = -Br^T K^-1 b, block by block (what Lsolve adds to b0,
+   // sLinsysRootAug.C:323-344, without the backward sweep, the residual check and the sparse border product of a full solve).
+   int forward_augmented(const double* b_dev, double* red) {
+      if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
+      HIP_TRY(hipSetDevice(device));
+      timer.begin(stream, 7);
+      hipLaunchKernelGGL(k_border_fill, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_bmap, (const double*)nullptr, d_xw, 0.0);
+      hipLaunchKernelGGL(k_permute_in, dim3(64, nblk, 1), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, b_dev, 0LL, d_xw, 0LL);
+      timer.end(stream);
+      timer.begin(stream, 8);
+      for (const LevelRange& L : levels) {
+         if (L.simple_cnt > 0 && lf_rows > 0)
+            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
+                               0LL, (int)lf_rows);
+         else if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt, d_blks,
+                               d_rowidx, d_arena, d_xw, 0LL, 0);
+         if (L.simple_cnt > 0 && n_lb > 0)
+            hipLaunchKernelGGL(k_leaf_border, dim3((n_lb + 255) / 256), dim3(256), 0, stream, d_lb_list, n_lb, d_sns, d_blks, d_rowidx, d_arena, d_xw, 0);
+         const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+         const int cnt = L.small_cnt + L.large_cnt;
+         if (cnt > 0)
+            hipLaunchKernelGGL(head_wcap <= 16 ? k_head_fwd_chain<16> : k_head_fwd_chain<HEAD_WMAX>, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks,
+                               d_rowidx, d_arena, d_xw, 0LL, 1);
+      }
+      timer.end(stream);
+      timer.begin(stream, 9);   // (one record of this phase per pass: the backward half books its tail sweep with the head's)
+      TailCtx c = ctx();
+      c.timer = nullptr;
+      int rc = tail_fwd(c, d_xw);
+      if (rc) return rc;
+      if (nb_pad_max > 0)
+         hipLaunchKernelGGL(k_tail_border_fwd, dim3(nb_pad_max / TILE, nblk), dim3(256), 0, stream, d_blks, d_arena, d_dtail, d_xw);
+      hipLaunchKernelGGL(k_border_collect, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_bmap, d_xw, red);
+      timer.end(stream);
+      ++aug_passes;
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
+   // ... and the backward sweep from where forward_augmented stopped: border slots = x0, x = L^-T (D^-1 y - L_b^T x0) = K^-1 (b - Br x0)
+   // in original order at out_dev (Ltsolve, sLinsysRootAug.C:346-365 / LniTransMult, with nothing left to combine)
+   int backward_augmented(const double* x0_dev, double* out_dev) {
+      HIP_TRY(hipSetDevice(device));
+      timer.begin(stream, 10);
+      hipLaunchKernelGGL(k_border_fill, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_bmap, x0_dev, d_xw, 1.0);
+      TailCtx c = ctx();
+      c.timer = nullptr;
+      int rc = tail_bwd(c, d_xw, 1, 0, 1);
+      if (rc) return rc;
+      for (int l = (int)levels.size() - 1; l >= 0; --l) {
+         const LevelRange& L = levels[l];
+         const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+         const int cnt = L.small_cnt + L.large_cnt;
+         if (cnt > 0)
+            hipLaunchKernelGGL(head_wcap <= 16 ? k_head_bwd_chain<16> : k_head_bwd_chain<HEAD_WMAX>, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks,
+                               d_rowidx, d_arena, d_xw, 0LL, 1, 1);
+         if (L.simple_cnt > 0 && d_leafdesc)
+            hipLaunchKernelGGL(k_leaf_bwd, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_leafdesc, L.simple_cnt, d_rowidx, d_arena, d_xw, 0LL, 1);
+         else if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt, d_blks,
+                               d_rowidx, d_arena, d_xw, 0LL, 1, sx_atomic(), 0, 0, 1);
+         if (L.simple_cnt > 0 && n_lb > 0)
+            hipLaunchKernelGGL(k_leaf_border, dim3((n_lb + 255) / 256), dim3(256), 0, stream, d_lb_list, n_lb, d_sns, d_blks, d_rowidx, d_arena, d_xw, 1);
+      }
+      timer.end(stream);
+      timer.begin(stream, 7);
+      hipLaunchKernelGGL(k_permute_out, dim3(64, nblk, 1), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, out_dev, 0LL, d_xw, 0LL);
+      timer.end(stream);
+      HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
    int solve_border_backward(const double* x0_dev, double* out_dev) {
@@ -2549,6 +2658,12 @@ struct KktSystem {
    } graph_key;
    long long graph_captures = 0, graph_replays = 0;
    bool last_ltsolve_from_factor = false;   // which Ltsolve the last solveCompressed took (reported per solve, not only at analyze time)
+   // Sweeps of the augmented factor for both halves of solveCompressed (Engine::forward_augmented / backward_augmented).  They carry no
+   // refinement, so they are taken only on evidence that this factorisation is accurate: no perturbed pivot, and an earlier
+   // solveCompressed on the SAME factors went the refined way and every refined leaf solve in it met the backward-error tolerance
+   // without a step (aug_validated_gen == factor_gen).  The first solveCompressed after every factorisation is that witness.
+   long long factor_gen = 0, aug_validated_gen = -1;
+   int last_solve_path = 0;   // 0: two refined leaf solves, 1: refined Lsolve + Ltsolve from the factor, 2: augmented sweeps
    bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
    // 0 diagonals + zero SC, 1 leaf factorisation, 2 Schur reduction, 3 finalize, 4 root factorisation (its own stream),
@@ -2937,6 +3052,16 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
          what[18] += s.nnzL - (int64_t)s.m * (s.m + 1) / 2;
          what[19] += (int64_t)s.rowidx.size();
       }
+   }
+   if (n_what > 21) {   // entries of L in border rows (head panels / border-row arena + the tails' border rows): read by the sweeps of the
+                        // augmented factor, not by a solve with K_i; and whether those sweeps may serve solveCompressed
+      what[20] = 0;
+      for (const BlockSym& s : e->sym) {
+         for (const HeadSupernode& hs : s.sn) what[20] += (int64_t)hs.w * (hs.r - hs.rb);
+         what[20] += (int64_t)s.nb * s.m;
+      }
+      what[21] = e->aug_sweeps_ok ? 1 : 0;
+      if (n_what > 22) what[22] = e->aug_passes;
    }
    return PIPS_OK;
 }
@@ -3563,6 +3688,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    Engine* e = k->leaves;
    HIP_TRY(hipSetDevice(e->device));
+   ++k->factor_gen;
    if (k->sparse) return kkt_factorize_sparse(k, leaf_diag_dev, xdiag0_dev, zdiag_link_dev);
    int rc;
    PhaseTimer& tm = k->timer;
@@ -3693,6 +3819,8 @@ int pips_hip_kkt_set_root_regularization(void* handle, double primal, double dua
 static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_leaf_dev, bool capturing) {
    Engine* e = k->leaves;
    int rc;
+   bool use_aug = false;
+   int lsolve_steps = 0;
    // with mz0 > 0 the caller's vector is [x0 | y0 | z0 | ylink | zlink]; the Schur system lives on the reduced vector
    // [x0 | y0 | ylink | zlink] (solveReducedLinkCons, sLinsysRootAug.C:397-433)
    double* red = b0_dev;
@@ -3722,11 +3850,20 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
+   if (!capturing && e->aug_sweeps_ok && e->refine_tol > 0.0 && k->aug_validated_gen == k->factor_gen) {
+      int pert = 1;
+      if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
+      use_aug = pert == 0;
+   }
    k->timer.begin(e->stream, 5);
-   if ((rc = e->solve(b_leaf_dev))) return rc;
+   if (use_aug) { if ((rc = e->forward_augmented(b_leaf_dev, red))) return rc; }
+   else {
+      if ((rc = e->solve(b_leaf_dev))) return rc;
+      lsolve_steps = e->last_refine_steps;
+   }
    k->timer.end(e->stream);
    k->timer.begin(e->stream, 6);
-   if ((rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
+   if (!use_aug && (rc = pips_hip_batch_border_tmult_dev(e, b_leaf_dev, red, -1.0))) return rc;
    if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, red, (size_t)k->S, e->stream)))
       return rc;
    k->timer.end(e->stream);
@@ -3757,23 +3894,35 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    // counters reached pinned memory with the factorisation: no wait for the solves queued behind it) AND, with adaptive refinement,
    // the refined leaf solve of this call's Lsolve - same factors - was satisfied by its first solve (backward error below the
    // tolerance without a step).  A pivot that kept its sign but is rounding noise passes the first test, not the second.
+   if (use_aug) {
+      if ((rc = e->backward_augmented(red, b_leaf_dev))) return rc;
+      k->last_ltsolve_from_factor = true;
+      k->last_solve_path = 2;
+      k->timer.end(e->stream);
+   } else {
    if (!capturing) {
       int pert = 1;
-      if (e->border_backward_ok && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
+      if ((e->border_backward_ok || e->aug_sweeps_ok) && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
       const bool lsolve_clean = e->refine_tol > 0.0 ? e->last_refine_steps == 0 : true;
       k->last_ltsolve_from_factor = e->border_backward_ok && !k->sparse && pert == 0 && lsolve_clean;
    }
+   int ltsolve_steps = 0;
    if (k->last_ltsolve_from_factor) {
       if ((rc = e->solve_border_backward(red, k->d_t))) return rc;
    } else {
       HIP_TRY(hipMemsetAsync(k->d_t, 0, (size_t)e->n_total * sizeof(double), e->stream));
       if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, 1.0))) return rc;
       if ((rc = e->solve(k->d_t))) return rc;
+      ltsolve_steps = e->last_refine_steps;
    }
+   k->last_solve_path = k->last_ltsolve_from_factor ? 1 : 0;
+   // this refined pass is the witness for the factors it ran on (see KktSystem::aug_validated_gen)
+   if (!capturing && e->aug_sweeps_ok && e->refine_tol > 0.0 && lsolve_steps == 0 && ltsolve_steps == 0) k->aug_validated_gen = k->factor_gen;
    k->timer.end(e->stream);
    k->timer.begin(e->stream, 9);
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    k->timer.end(e->stream);
+   }
    HIP_TRY(hipGetLastError());
    return PIPS_OK;
 }
@@ -3847,6 +3996,13 @@ int pips_hip_kkt_solve_graph_stats(void* handle, int64_t* captures, int64_t* rep
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    if (captures) *captures = k->graph_captures;
    if (replays) *replays = k->graph_replays;
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_last_solve_path(void* handle, int* path) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || !path) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_last_solve_path: bad arguments");
+   *path = k->last_solve_path;
    return PIPS_OK;
 }
 

@@ -26,11 +26,13 @@ constexpr int LDS_PAD = 16;     // LDS row padding (doubles): 144*8 B = 1152 B -
 constexpr int LDSW = TILE + LDS_PAD;
 
 struct SnDesc {
-   long long panel;  // global arena offset of the (w+r) x w panel
+   long long panel;  // global arena offset of the ld x w panel
    long long rows;   // global offset into rowidx
    long long upd;    // global offset into upd (head-to-head update segments)
    int w, r, c0, blk;
    int n_useg, rb;   // number of update segments; index of the first border row among the r below-rows
+   int ld, pad_;     // leading dimension of the stored panel: w + r, or w + rb for a front under the border split (its border rows live
+                     // only in the border-row arena at bb: Lt[k * rpb + a - rb], rpb = r - rb rounded up to 4)
    long long slot;   // deterministic mode: first contribution slot of the factorisation scatter (r (r + 1) / 2 slots: pair (a, b),
                      // a >= b, has slot + b r - b (b - 1) / 2 + a - b)
    long long vslot;  // ... and of the forward-substitution scatter (r slots)
@@ -62,6 +64,14 @@ struct BlkDesc {
 struct TileTask { int blk, ti, tj, pad; };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// Column pointer and stride of below-row a of a head supernode: rows of K sit in the panel; the border rows of a front under the border
+// split only in the border-row arena (which lives behind the panels in the same allocation: sn.bb is an arena offset like sn.panel)
+struct BelowRow { const double* p; long long stride; };
+__device__ __forceinline__ BelowRow below_row(const double* __restrict__ arena, const SnDesc& sn, int a) {
+   if (a < sn.ld - sn.w) return BelowRow{arena + sn.panel + sn.w + a, (long long)sn.ld};
+   return BelowRow{arena + sn.bb + (a - sn.rb), (long long)((sn.r - sn.rb + 3) & ~3)};
+}
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -292,7 +302,7 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
    __shared__ double prf[WMAX];
    __shared__ int sgn[WMAX];
 
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const int w = sn.w, r = sn.r, ld = sn.ld, tid = threadIdx.x;
    double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
 
@@ -831,8 +841,8 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    if (i < nf) {
 #pragma unroll
       for (int k = 0; k < WMAX; ++k)
-         if (k < w && k <= i) P[i + (long long)k * nf] = y[k];    // l_ik, d_k on the diagonal: what the solves read
-      if (sn.bb >= 0 && i >= w + sn.rb) {   // border split: the border rows once more, in the layout k_border_schur stages
+         if (k < w && k <= i && i < sn.ld) P[i + (long long)k * sn.ld] = y[k];    // l_ik, d_k on the diagonal: what the solves read
+      if (sn.bb >= 0 && i >= w + sn.rb) {   // border split: the border rows go to the border-row arena, in the layout k_border_schur stages
          const int nbj = r - sn.rb, rpb = (nbj + 3) & ~3;
          double* Q = bbarena + sn.bb + (i - w - sn.rb);
 #pragma unroll
@@ -1182,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_front_fwd(const SnDesc* __restrict__ sns
    // row `lane` of the pivot block, on its way while the front is assembled
    double row[WMAX];
 #pragma unroll
-   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k < lane) ? P[lane + (long long)k * nf] : 0.0;
+   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k < lane) ? P[lane + (long long)k * sn.ld] : 0.0;
    __syncthreads();
    if (n_leaf) {   // y_c of the leaves goes where their d sits (the forward sweep has no use for d)
       const int* tab = leafpart + (nf + 1) + 2 * n_items;
@@ -1228,8 +1238,10 @@ __global__ __launch_bounds__(64) void k_front_fwd(const SnDesc* __restrict__ sns
    const int* rows = rowidx + sn.rows;
    for (int i = w + lane; i < nf; i += 64) {
       double acc = t[i];
+      if (i < sn.ld) {   // (the border entries of an update vector are never used)
 #pragma unroll
-      for (int k = 0; k < WMAX; ++k) if (k < w) acc -= P[i + (long long)k * nf] * t[k];
+         for (int k = 0; k < WMAX; ++k) if (k < w) acc -= P[i + (long long)k * sn.ld] * t[k];
+      }
       if (has_parent) varena[sn.vslot + (i - w)] = acc;
       else {
          const int ra = rows[i - w];
@@ -1269,7 +1281,7 @@ __global__ __launch_bounds__(64) void k_front_bwd(const SnDesc* __restrict__ sns
    }
    double row[WMAX];
 #pragma unroll
-   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k <= lane) ? P[lane + (long long)k * nf] : 0.0;
+   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k <= lane) ? P[lane + (long long)k * sn.ld] : 0.0;
    double v;
    {
       // d_i sits at row[i]: pick it without a dynamic register index
@@ -1284,10 +1296,11 @@ __global__ __launch_bounds__(64) void k_front_bwd(const SnDesc* __restrict__ sns
       double p[WMAX];
 #pragma unroll
       for (int k = 0; k < WMAX; ++k) p[k] = 0.0;
-      for (int i = w + lane; i < nf; i += 64) {
+      for (int i = w + lane; i < (border ? nf : sn.ld); i += 64) {
          const double xi = xf[i];
+         const BelowRow br = below_row(arena, sn, i - w);
 #pragma unroll
-         for (int k = 0; k < WMAX; ++k) if (k < w) p[k] += P[i + (long long)k * nf] * xi;
+         for (int k = 0; k < WMAX; ++k) if (k < w) p[k] += br.p[k * br.stride] * xi;
       }
 #pragma unroll
       for (int k = 0; k < WMAX; ++k) if (k < w) part[k * 64 + lane] = p[k];
@@ -2194,7 +2207,7 @@ __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns,
    __shared__ double y[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const int w = sn.w, r = sn.r, ld = sn.ld, tid = threadIdx.x;
    const double* P = arena + sn.panel;
    double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;   // blockIdx.y = right-hand side
    if (tid < w) y[tid] = xb[sn.c0 + tid];
@@ -2223,7 +2236,7 @@ __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns,
    __shared__ double y[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x;
+   const int w = sn.w, r = sn.r, ld = sn.ld, tid = threadIdx.x;
    const double* P = arena + sn.panel;
    double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
    const int* rows = rowidx + sn.rows;
@@ -2231,7 +2244,7 @@ __global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns,
       double s = 0.0;
       for (int a = tid; a < r; a += 64) {
          const int ra = rows[a];
-         if (ra < bd.n || border) s += P[w + a + (long long)k * ld] * xb[xw_row(bd, ra)];
+         if (ra < bd.n || border) { const BelowRow br = below_row(arena, sn, a); s += br.p[k * br.stride] * xb[xw_row(bd, ra)]; }
       }
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
       if (tid == 0) y[k] = xb[sn.c0 + k] - s;
@@ -2257,9 +2270,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 template <int WB>   // WB: compile-time bound of the supernode width (register arrays, unrolled substitution)
 __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xb, double* ys) {
+                                              const double* __restrict__ arena, double* __restrict__ xb, double* ys, int border = 0) {
    // one wave; xb = the permuted work vector of this block and right-hand side; ys = HEAD_WMAX doubles of LDS of this wave
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
+   const int w = sn.w, r = sn.r, ld = sn.ld, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
    const int a0 = tid;
@@ -2275,10 +2288,12 @@ __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& b
    wave_lds_sync();
    for (int a = a0; a < r; a += 64) {
       const int ra = a == a0 ? ra0 : rows[a];
-      if (ra >= bd.n) break;  // border rows do not take part in solves with K_i
+      if (ra >= bd.n && !border) break;  // border rows do not take part in solves with K_i (border != 0: forward sweep of the augmented
+                                         // factor - the border slots of the work vector collect -L_b y)
+      const BelowRow br = below_row(arena, sn, a);
       double s = 0.0;
-      for (int k = 0; k < w; ++k) s += P[w + a + (long long)k * ld] * ys[k];
-      atomic_add_f64(xb + ra, -s);
+      for (int k = 0; k < w; ++k) s += br.p[k * br.stride] * ys[k];
+      atomic_add_f64(xb + xw_row(bd, ra), -s);
    }
    wave_lds_sync();   // ys is reused by the caller's next supernode / right-hand side
 }
@@ -2287,21 +2302,21 @@ __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& b
 // of its widest variant, and it decides how many waves share a SIMD
 template <int WCAP = HEAD_WMAX>
 __device__ __forceinline__ void head_fwd_any(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                             const double* __restrict__ arena, double* __restrict__ xb, double* ys) {
-   if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xb, ys);
-   else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xb, ys);
-   else if (sn.w <= 16 || WCAP <= 16) head_fwd_body<16>(sn, bd, rowidx, arena, xb, ys);
-   else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, ys);
+                                             const double* __restrict__ arena, double* __restrict__ xb, double* ys, int border = 0) {
+   if (sn.w == 1) head_fwd_body<1>(sn, bd, rowidx, arena, xb, ys, border);
+   else if (sn.w <= 8) head_fwd_body<8>(sn, bd, rowidx, arena, xb, ys, border);
+   else if (sn.w <= 16 || WCAP <= 16) head_fwd_body<16>(sn, bd, rowidx, arena, xb, ys, border);
+   else head_fwd_body<HEAD_WMAX>(sn, bd, rowidx, arena, xb, ys, border);
 }
 
 template <int WCAP>
 __global__ __launch_bounds__(64) void k_head_fwd_chain(const SnDesc* __restrict__ sns, int sn_begin,
                                                 const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride) {
+                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride, int border = 0) {
    __shared__ double ys[HEAD_WMAX];
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   head_fwd_any<WCAP>(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, ys);   // blockIdx.y = right-hand side
+   head_fwd_any<WCAP>(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, ys, border);   // blockIdx.y = right-hand side
 }
 
 // head diagonal scaling: z = D^-1 y for the head columns
@@ -2312,7 +2327,7 @@ __global__ void k_head_dscale(const SnDesc* __restrict__ sns, int nsn, const Blk
       const SnDesc sn = sns[s];
       if (mf && (sn.mf >= 0 || sn.n_useg > 0)) continue;   // fused into k_front_bwd
       const BlkDesc bd = blks[sn.blk];
-      const int ld = sn.w + sn.r;
+      const int ld = sn.ld;
       for (int k = 0; k < sn.w; ++k) xw[bd.xw_off + sn.c0 + k] /= arena[sn.panel + k + (long long)k * ld];
    }
 }
@@ -2326,7 +2341,7 @@ template <int WB>
 __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
                                               const double* __restrict__ arena, double* __restrict__ xb, double (*red)[65], int border = 0,
                                               int dscale = 0) {
-   const int w = sn.w, r = sn.r, ld = w + r, tid = threadIdx.x & 63;
+   const int w = sn.w, r = sn.r, ld = sn.ld, tid = threadIdx.x & 63;
    const double* P = arena + sn.panel;
    const int* rows = rowidx + sn.rows;
    double y = tid < w ? xb[sn.c0 + tid] : 0.0;
@@ -2338,9 +2353,10 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
       const int ra = rows[a];
       if (ra >= bd.n && !border) break;
       const double xa = xb[xw_row(bd, ra)];
+      const BelowRow br = below_row(arena, sn, a);   // (border rows - border-backward sweep only - may live in the border-row arena)
 #pragma unroll
       for (int k = 0; k < WB; ++k)
-         if (k < w) part[k] += P[w + a + (long long)k * ld] * xa;
+         if (k < w) part[k] += br.p[k * br.stride] * xa;
    }
    if (WB == 1) {   // a single sum: plain wave reduction
       double s = part[0];
@@ -2772,11 +2788,72 @@ __global__ __launch_bounds__(256) void k_tail_rows_bwd(SweepArgs a, const BlkDes
 
 // border part of the work vectors for the border-backward sweep: minus the root solution at the block's border rows, zero padding
 __global__ void k_border_fill(const BlkDesc* __restrict__ blks, const int* __restrict__ bmap, const double* __restrict__ x0,
-                              double* __restrict__ xw) {
+                              double* __restrict__ xw, double sign = -1.0) {
    const BlkDesc bd = blks[blockIdx.y];
    double* xbd = xw + bd.xw_off + bd.n_head + bd.m_pad;
    const int* bm = bmap + bd.bmap_off;
-   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < bd.nb_pad; r += gridDim.x * blockDim.x) xbd[r] = r < bd.nb ? -x0[bm[r]] : 0.0;
+   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < bd.nb_pad; r += gridDim.x * blockDim.x) xbd[r] = (r < bd.nb && x0) ? sign * x0[bm[r]] : 0.0;
+}
+
+// Sweeps of the AUGMENTED factor [L 0; L_b I] (Engine::forward_augmented / backward_augmented): with the border slots of the work vector
+// as targets the forward sweep leaves -L_b y = -Br^T K^-1 b there (L_b = Br^T L^-T D^-1), and the backward sweep started from
+// D^-1 y with the border slots holding x0 gives K^-1 (b - Br x0): one forward and one backward sweep per solveCompressed instead of two
+// full solves.  The pieces the level kernels do not cover:
+// ... the simple leaves that own border rows (thread per leaf): forward x_border -= l_b y_c, backward x_c -= l_b^T x_border
+__global__ __launch_bounds__(256) void k_leaf_border(const int* __restrict__ list, int cnt, const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
+                                                     const int* __restrict__ rowidx, const double* __restrict__ arena, double* __restrict__ xw, int backward) {
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= cnt) return;
+   const SnDesc sn = sns[list[t]];
+   const BlkDesc bd = blks[sn.blk];
+   const double* P = arena + sn.panel;
+   const int* rows = rowidx + sn.rows;
+   double* xb = xw + bd.xw_off;
+   if (!backward) {
+      const double y = xb[sn.c0];
+      for (int a = sn.rb; a < sn.r; ++a) atomic_add_f64(xb + xw_row(bd, rows[a]), -P[1 + a] * y);
+   } else {
+      double s = 0.0;
+      for (int a = sn.rb; a < sn.r; ++a) s += P[1 + a] * xb[xw_row(bd, rows[a])];
+      xb[sn.c0] -= s;
+   }
+}
+
+// ... the border rows of the dense tail, forward: x_border(ib) -= sum_j T(border tile row ib, tile column j) (d_j z_j), z = what
+// k_tail_rows_fwd left (its rows are D^-1-scaled).  grid (border tile rows, blocks), 256 threads: thread = (row, half of the columns)
+__global__ __launch_bounds__(256) void k_tail_border_fwd(const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+                                                         const double* __restrict__ dtail, double* __restrict__ xw) {
+   __shared__ double v[TILE];
+   __shared__ double part[TILE];
+   const BlkDesc bd = blks[blockIdx.y];
+   if (bd.m <= 0 || (int)blockIdx.x * TILE >= bd.nb_pad) return;
+   const int tid = threadIdx.x, row = tid & 127, half = tid >> 7, ld = bd.ldT;
+   const double* xt = xw + bd.xw_off + bd.n_head;
+   const double* Trow = arena + bd.T + bd.m_pad + (long long)blockIdx.x * TILE + row;
+   double acc = 0.0;
+   for (int j = 0; j < bd.m_pad; j += TILE) {
+      __syncthreads();
+      if (tid < TILE) v[tid] = xt[j + tid] * dtail[bd.dt_off + j + tid];
+      __syncthreads();
+      const double* Tc = Trow + (long long)(j + half * 64) * ld;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) acc += Tc[(long long)c * ld] * v[half * 64 + c];
+   }
+   if (half == 1) part[row] = acc;
+   __syncthreads();
+   if (half == 0) {
+      double* xbd = xw + bd.xw_off + bd.n_head + bd.m_pad;
+      xbd[blockIdx.x * TILE + row] -= acc + part[row];
+   }
+}
+
+// ... and the border slots of every block added to the root right-hand side: b0[bmap[r]] += x_border[r]
+__global__ void k_border_collect(const BlkDesc* __restrict__ blks, const int* __restrict__ bmap, const double* __restrict__ xw,
+                                 double* __restrict__ b0) {
+   const BlkDesc bd = blks[blockIdx.y];
+   const double* xbd = xw + bd.xw_off + bd.n_head + bd.m_pad;
+   const int* bm = bmap + bd.bmap_off;
+   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < bd.nb; r += gridDim.x * blockDim.x) atomic_add_f64(b0 + bm[r], xbd[r]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2806,7 +2883,7 @@ __global__ void k_mpermute(const BlkDesc* __restrict__ blks, const int* __restri
 template <int WB>
 __device__ __forceinline__ void mhead_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
                                            const double* __restrict__ arena, double* __restrict__ xm, int backward) {
-   const int w = sn.w, r = sn.r, ld = w + r, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
+   const int w = sn.w, r = sn.r, ld = sn.ld, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
    const double* P = arena + sn.panel;
    double* xb = xm + bd.xw_off * MQ;
    const int* rows = rowidx + sn.rows;
@@ -2885,7 +2962,7 @@ __global__ void k_mhead_dscale(const SnDesc* __restrict__ sns, int nsn, const Bl
    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (long long)nsn * MQ; idx += (long long)gridDim.x * blockDim.x) {
       const SnDesc sn = sns[idx / MQ];
       const BlkDesc bd = blks[sn.blk];
-      const int q = (int)(idx % MQ), ld = sn.w + sn.r;
+      const int q = (int)(idx % MQ), ld = sn.ld;
       for (int k = 0; k < sn.w; ++k) xm[(bd.xw_off + sn.c0 + k) * MQ + q] /= arena[sn.panel + k + (long long)k * ld];
    }
 }

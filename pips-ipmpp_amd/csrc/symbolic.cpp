@@ -253,9 +253,16 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    int64_t off = 0;
    double fl = 0;
    int64_t nnzL = 0;
+   // border split (see "multifrontal metadata" below): a front keeps its border rows only in the border-row arena, its panel holds
+   // the w + rb rows of K - compact, so that the solve sweeps do not drag the border rows' cache lines along
+   out.mf_split = nb > 0 && nb <= opt.mf_split_nb_max;
    for (auto& sn : out.sn) {
+      const int* rows = out.rowidx.data() + sn.rows;
+      sn.rb = (int)(std::lower_bound(rows, rows + sn.r, n) - rows);
+      const bool simple = sn.w == 1 && sn.r <= opt.simple_rmax && sn.level == 0;
+      sn.ld = sn.w + ((out.mf_split && !simple) ? sn.rb : sn.r);
       sn.panel = off;
-      off += (int64_t)(sn.w + sn.r) * sn.w;
+      off += (int64_t)sn.ld * sn.w;
       const double w = sn.w, r = sn.r;
       fl += w * w * w / 3.0 + w * w * r + w * r * r;
       nnzL += (int64_t)sn.w * (sn.w + 1) / 2 + (int64_t)sn.r * sn.w;
@@ -289,7 +296,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          int b1 = b0 + 1;
          while (b1 < sn.r && rows[b1] < tg.c0 + tg.w) ++b1;
          const int npos = sn.r - b0;
-         const int hdr[8] = {b0, b1, tg.c0, tg.w + tg.r, (int)(uint32_t)(tg.panel & 0xffffffffLL), (int)(tg.panel >> 32), npos, 0};
+         const int hdr[8] = {b0, b1, tg.c0, tg.ld, (int)(uint32_t)(tg.panel & 0xffffffffLL), (int)(tg.panel >> 32), npos, 0};
          out.upd.insert(out.upd.end(), hdr, hdr + 8);
          const int* trows = out.rowidx.data() + tg.rows;
          int q = 0;
@@ -328,7 +335,6 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       // ~17 rows of K carrying ~100 border rows).  With the split a front keeps only the update columns that belong to rows of K
       // (uc = rb of them, each with all r rows below: K x K and border x K); the border x border part is formed once per block from the
       // finished panels, -sum_J L_b(J) D_J L_b(J)^T (k_border_schur).  Taken where that kernel's accumulator fits the LDS.
-      out.mf_split = out.nb > 0 && out.nb <= opt.mf_split_nb_max;
       auto ucols = [&](const HeadSupernode& sn) { return out.mf_split ? sn.rb : sn.r; };
       std::vector<std::vector<int>> kids(nsn), leaves(nsn);
       for (int s = 0; s < nsn; ++s) {
@@ -475,6 +481,12 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_int[hpos + 5] = n_vals;
          append_entries();
       }
+      if (!out.mf_ok && out.mf_split) {   // compact panels need the multifrontal head: analyse again with full panels
+         AnalyzeOptions full = opt;
+         full.mf_split_nb_max = 0;
+         out = BlockSym();
+         return analyze_block(K, border, n_primal, full, out);
+      }
       if (!out.mf_ok) {
          std::vector<int>().swap(out.mf_int);
          std::vector<int64_t>().swap(out.mf_fix);
@@ -489,7 +501,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    // ---- scatter maps
    auto head_dst = [&](int c, int r) -> int64_t {
       const HeadSupernode& sn = out.sn[out.sn_of_col[c]];
-      const int ld = sn.w + sn.r;
+      const int ld = sn.ld;   // (entries of a front are taken from the value arrays by k_front: their offsets here are never used)
       int pos;
       if (r < sn.c0 + sn.w) {
          pos = r - sn.c0;

@@ -1,0 +1,113 @@
+"""solveCompressed by one forward and one backward sweep of the augmented factor [L 0; L_b I] (pips_hip_kkt_last_solve_path == 2;
+Engine::forward_augmented / backward_augmented) against the oracle's solve_compressed (sLinsysRootAug.C:323-365 restated) and against the
+refined two-solve path on the same factors: dense-tail blocks whose simple leaves own border rows, time-coupled blocks with compact front
+panels (border rows only in the border-row arena), all-head blocks without a tail.  The path is taken only after a refined pass on the
+same factors needed no refinement step, and never while a pivot is perturbed."""
+import numpy as np
+import pytest
+import torch
+
+import pips_ipmpp_amd as pa
+from oracle import oracle as orc
+from tests.util import Problem
+from tests.test_leaf_gpu import _TimeCoupledProblem
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(prob, force_head=False):
+    bt = pa.LeafBatch(prob.N, prob.S)
+    for b in range(prob.N):
+        bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    if force_head:
+        bt.set_options(force_n_head=prob.n_leaf)
+    bt.analyze(2)
+    bt.set_refinement_backward_error(2, 1e-15)
+    for b in range(prob.N):
+        bt.set_values(b, prob.blocks[b]["K"].val)
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0)
+    return bt, kkt
+
+
+def _oracle(prob, b0, bl):
+    S, N = prob.S, prob.N
+    SCo = np.tril(prob.oracle_finalize(prob.oracle_schur()))
+    root = orc.DenseRootSolver(S)
+    root.matrixChanged(SCo)
+    b0_o = b0.copy()
+    bs_o = [bl.reshape(N, -1)[b].copy() for b in range(N)]
+    orc.solve_compressed(b0_o, bs_o, [prob.oracle_leaf(b) for b in range(N)], [prob.Bt_scipy(b) for b in range(N)], root, prob.n0, 0, 0, prob.myl, 0)
+    return b0_o, np.concatenate(bs_o)
+
+
+@pytest.mark.parametrize("shape", ["dense_tail", "small", "time_coupled", "time_coupled_all_head"])
+def test_augmented_sweeps_match_oracle_and_refined_path(shape, monkeypatch):
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")     # (the cost model would pick it or not by the shape; here it is under test)
+    if shape == "dense_tail":
+        prob = Problem(3, 4, 1000, 500, 100, 100, 0.01)
+    elif shape == "small":
+        prob = Problem(5, 3, 200, 100, 12, 10, 0.05)
+    else:
+        prob = _TimeCoupledProblem(5, 3, 3000, 1500, 10, 8, 6)
+    bt, kkt = _system(prob, force_head=shape == "time_coupled_all_head")
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
+    xd0 = torch.tensor(prob.x_diag0, device="cuda")
+    kkt.factorize(diag, xd0)
+    rng = np.random.default_rng(11)
+    paths, sols = [], []
+    for rep in range(3):
+        b0h, blh = rng.standard_normal(prob.S), rng.standard_normal(prob.N * prob.n_leaf)
+        b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        paths.append(kkt.last_solve_path())
+        want0, wantl = _oracle(prob, b0h, blh)
+        g0, gl = b0.cpu().numpy(), bl.cpu().numpy()
+        assert np.linalg.norm(g0 - want0) <= 1e-8 * np.linalg.norm(want0), (rep, paths)
+        assert np.linalg.norm(gl - wantl) <= 1e-8 * np.linalg.norm(wantl), (rep, paths)
+        sols.append((b0h, blh, g0, gl))
+    # the first call after the factorisation is the refined witness, the others ride on it
+    assert paths[0] in (0, 1) and paths[1] == 2 and paths[2] == 2, paths
+    # the same right-hand side through the refined path on the same factors
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "0")
+    bt2, kkt2 = _system(prob, force_head=shape == "time_coupled_all_head")
+    kkt2.factorize(diag, xd0)
+    b0h, blh, g0, gl = sols[2]
+    b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+    kkt2.solve_compressed(b0, bl)
+    bt2.sync()
+    assert kkt2.last_solve_path() in (0, 1)
+    assert np.linalg.norm(g0 - b0.cpu().numpy()) <= 1e-10 * np.linalg.norm(g0)
+    assert np.linalg.norm(gl - bl.cpu().numpy()) <= 1e-10 * np.linalg.norm(gl)
+    # a new factorisation needs a new witness
+    kkt.factorize(diag * 1.3, xd0)
+    b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+    kkt.solve_compressed(b0, bl)
+    assert kkt.last_solve_path() in (0, 1)
+    for h in (kkt, bt, kkt2, bt2):
+        h.close()
+
+
+def test_perturbed_pivots_keep_the_refined_path(monkeypatch):
+    """A block with a structurally singular pivot (zero primal diagonal on an unconstrained variable) gets a replaced pivot: the factors are
+    not trusted, every solveCompressed goes the refined way."""
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")
+    prob = Problem(5, 3, 200, 100, 12, 10, 0.05)
+    d = prob.blocks[1]["diag"].copy()
+    blk = prob.blocks[1]
+    # a primal variable that no constraint row touches would do; simplest: make one primal diagonal tiny relative to its scale
+    d[:prob.n_i] = np.maximum(d[:prob.n_i], 1e-3)
+    d[0] = 0.0
+    blk["K"].val[blk["dpos"]] = d
+    blk["diag"] = d
+    bt, kkt = _system(prob)
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    pert = sum(bt.inertia(b)[2] for b in range(prob.N))
+    rng = np.random.default_rng(2)
+    for rep in range(3):
+        b0, bl = torch.tensor(rng.standard_normal(prob.S), device="cuda"), torch.tensor(rng.standard_normal(prob.N * prob.n_leaf), device="cuda")
+        kkt.solve_compressed(b0, bl)
+        if pert > 0:
+            assert kkt.last_solve_path() in (0, 1)
+    kkt.close(); bt.close()
