@@ -5,6 +5,7 @@
 #define HIP_LDL_SOLVER_H
 #include <cstdio>
 #include <tuple>
+#include <vector>
 #include "DenseMatrix.h"
 #include "DoubleLinearSolver.h"
 #include "SparseSymmetricMatrix.h"
@@ -25,7 +26,8 @@ public:
       const auto& st = K.getStorage();                  // lower-triangular CSR, krowM/jcolM/M (SparseStorage.h:45-50)
       check(pips_hip_ldl_create(&h, st.n, st.krowM, st.jcolM, device, 0), "create");
       check(pips_hip_ldl_set_inertia_hint(h, n_primal), "hint");   // expected inertia (locnx, locmy+locmz)
-      check(pips_hip_ldl_analyze(h), "analyze");        // once: the pattern never changes (DistributedLeafLinearSystem.C:10-42)
+      // the symbolic phase runs once, with the first factorisation (the pattern never changes, DistributedLeafLinearSystem.C:10-42): a
+      // border declared before that (declare_border) becomes part of it
    }
    ~HipLdlSolver() override { pips_hip_ldl_destroy(h); }
    void diagonalChanged(int, int) override { matrixChanged(); }
@@ -34,8 +36,11 @@ public:
       auto& v = dynamic_cast<DenseVector<double>&>(x);
       check(pips_hip_ldl_solve(h, 1, v.elements(), v.length()), "solve");
    }
-   // nrhss contiguous right-hand sides, one per row of length n (PardisoSolver.C:276-352); empty ones are skipped by the library, colSparsity is not needed
-   void solve(int nrhss, double* rhss, int*) override { check(pips_hip_ldl_solve(h, nrhss, rhss, mat.size()), "solve(nrhs)"); }
+   // nrhss contiguous right-hand sides, one per row of length n (PardisoSolver.C:276-352); empty ones are skipped by the library, and of the
+   // others only the rows colSparsity marks travel to the device (the caller's border pattern, DistributedLinearSystem.C:903; may be null)
+   void solve(int nrhss, double* rhss, int* colSparsity) override {
+      check(pips_hip_ldl_solve_sparse(h, nrhss, rhss, mat.size(), colSparsity), "solve(nrhs)");
+   }
    void solve(GeneralMatrix& rhs_in) override {
       auto& rhs = dynamic_cast<DenseMatrix&>(rhs_in);
       const auto [nrows, ncols] = rhs.n_rows_columns();
@@ -52,6 +57,19 @@ public:
    // = matrixChanged() followed by addTermToSchurComplBlocked(): SC is the S x S DenseSymmetricMatrix storage (row-major, lower triangle)
    void matrixChanged_and_add_schur_term(double* SC, int ldSC) {
       check(pips_hip_ldl_factor_schur(h, mat.getStorage().M, border->getStorage().M, SC, ldSC), "factor_schur");
+   }
+   // ---- level 1.5b: the leaf solvers of a rank as ONE batch.  sLinsysRootAug::assembleLocalKKT (:210-227) hands its loop over the children
+   //      over: instead of children[it]->addTermToSchurComplBlocked(...) one after the other, collect the children's solvers and call this
+   //      once - all leaves run in every launch, one S x S term comes back.  Likewise Lsolve / Ltsolve (:323-365) for their per-child solves.
+   static void matrixChanged_and_add_schur_terms(const std::vector<HipLdlSolver*>& leaves, double* SC, int ldSC) {
+      std::vector<void*> hs; std::vector<const double*> kv, bv;
+      for (const HipLdlSolver* l : leaves) { hs.push_back(l->h); kv.push_back(l->mat.getStorage().M); bv.push_back(l->border ? l->border->getStorage().M : nullptr); }
+      check(pips_hip_ldl_factor_schur_batch(hs.data(), (int)hs.size(), kv.data(), bv.data(), SC, ldSC), "factor_schur_batch");
+   }
+   static void solve_all(const std::vector<HipLdlSolver*>& leaves, const std::vector<double*>& rhs /* one per leaf, nullptr: none */) {
+      std::vector<void*> hs;
+      for (const HipLdlSolver* l : leaves) hs.push_back(l->h);
+      check(pips_hip_ldl_solve_batch(hs.data(), (int)hs.size(), rhs.data()), "solve_batch");
    }
    [[nodiscard]] bool reports_inertia() const override { return true; }
    [[nodiscard]] std::tuple<unsigned, unsigned, unsigned> get_inertia() const override {

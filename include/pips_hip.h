@@ -55,6 +55,27 @@ int pips_hip_ldl_inertia(void* handle, int* pos, int* neg, int* zero);
  *                  solves and inertia queries work afterwards as after pips_hip_ldl_factor */
 int pips_hip_ldl_set_border(void* handle, int S, const int* Bt_rowptr, const int* Bt_colidx);
 int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const double* Bt_vals_host, double* SC_host, int ldSC);
+/* Variants of the solve.  solve_dev: the right-hand sides are device memory (nrhs vectors at distance ld >= n; no PCIe, asynchronous on
+ * the handle's stream).  solve_sparse = DoubleLinearSolver::solve(int nrhss, double* rhss, int* colSparsity) with the third argument
+ * honoured: col_sparsity[i] != 0 marks the rows that can be non-zero in any right-hand side (the border's row pattern the caller builds,
+ * DistributedLinearSystem.C:903); only those rows of the non-zero right-hand sides travel to the device.  NULL: same as pips_hip_ldl_solve. */
+int pips_hip_ldl_solve_dev(void* handle, int nrhs, double* rhs_inout_dev, long long ld);
+int pips_hip_ldl_solve_sparse(void* handle, int nrhs, double* rhs_inout_host, int ld, const int* col_sparsity);
+/* Array-of-handles entries (INTEGRATION.md level 1.5b): the leaf solvers of a rank run as ONE batch from the host's loop over its children
+ * (sLinsysRootAug::assembleLocalKKT :210-227; Lsolve / Ltsolve :323-365).  The first call binds the handles (created, borders set, same
+ * Schur dimension and device; the same array in the same order afterwards) into one batch engine analysed over all of them.
+ *   factor_schur_batch  = for every leaf matrixChanged() + addTermToSchurComplBlocked(): K_vals_host[i] / Bt_vals_host[i] are leaf i's
+ *                         values (CSR order); adds sum_i -Br_i^T K_i^-1 Br_i to SC_host (row-major, lower triangle, ldSC >= S) with one
+ *                         S x S buffer on the device and one transfer; SC_host == NULL: factorise only
+ *   solve_batch         one right-hand side per leaf (host pointers of length n_i, NULL = none for that leaf), overwritten
+ *   solve_batch_dev     the flat device vector of all leaves, block after block
+ *   inertia_batch       per leaf (positive, negative, zero / perturbed)
+ * pips_hip_ldl_inertia / pips_hip_ldl_solve on a bound handle go through the batch (a single-leaf solve then costs a batch solve). */
+int pips_hip_ldl_factor_schur_batch(void* const* handles, int n, const double* const* K_vals_host, const double* const* Bt_vals_host,
+                                    double* SC_host, int ldSC);
+int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_inout_host);
+int pips_hip_ldl_solve_batch_dev(void* const* handles, int n, double* x_dev);
+int pips_hip_ldl_inertia_batch(void* const* handles, int n, int* pos, int* neg, int* zero);
 /* diagnostics of the symbolic phase: what[0]=nnz(L) what[1]=n_head what[2]=tail m what[3]=#head supernodes
  * what[4]=#levels what[5]=factor flops (rounded) */
 int pips_hip_ldl_info(void* handle, int64_t* what, int n_what);

@@ -2225,7 +2225,8 @@ struct Engine {
             double worst = 0.0;
             for (int b = 0; b < nblk; ++b) {
                const double den = refine_mode == 1 ? h_amax[b] * h_norms[2 * nblk + b] + h_norms[nblk + b] : h_norms[nblk + b];
-               if (den > 0.0) worst = std::max(worst, h_norms[b] / den);
+               // (a non-finite norm - Inf, or Inf / Inf = NaN - must win the comparison: never "converged" on a poisoned iterate)
+               if (den > 0.0) { const double q = h_norms[b] / den; if (!(q <= worst)) worst = q; }
             }
             last_refine_measure = worst;
             if (worst <= refine_tol) break;
@@ -3097,12 +3098,27 @@ int pips_hip_batch_get_timing(void* handle, double* ms, int64_t* cnt, int n) {
 void pips_hip_batch_destroy(void* handle) { delete (Engine*)handle; }
 
 // ---- single leaf solver handle -------------------------------------------------------------------------------------
+struct LdlGroup;
 struct LdlHandle {
    Engine eng;
    bool have_perm = false;
    double* d_sc = nullptr;        // S x S Schur term of this leaf (pips_hip_ldl_factor_schur)
    std::vector<double> h_sc;
+   std::shared_ptr<LdlGroup> group;   // the leaves of a rank bound into one batch engine (pips_hip_ldl_factor_schur_batch)
+   int group_index = -1;
    ~LdlHandle() { if (d_sc) (void)hipFree(d_sc); }
+};
+// Array-of-handles entries (INTEGRATION.md level 1.5b): the reference keeps one DoubleLinearSolver per leaf and loops over its children
+// (sLinsysRootAug::assembleLocalKKT :210-227, Lsolve / Ltsolve :323-365).  One leaf alone is a latency chain on the device (64 leaves of
+// configs[1] one after the other: 1.17 s per factorisation against 0.1 s as one batch), so the handles of a rank can be bound into ONE batch
+// engine: the patterns and borders the handles were given, analysed together; factor_schur_batch / solve_batch then run all leaves in every
+// launch, one S x S Schur buffer on the device and one transfer of it per factorisation instead of one per leaf.
+struct LdlGroup {
+   Engine eng;
+   std::vector<LdlHandle*> members;
+   double *d_sc = nullptr, *d_x = nullptr;
+   std::vector<double> h_sc;
+   ~LdlGroup() { if (d_sc) (void)hipFree(d_sc); if (d_x) (void)hipFree(d_x); }
 };
 
 int pips_hip_ldl_create(void** handle, int n, const int* krow, const int* jcol, int device, int flags) {
@@ -3213,9 +3229,22 @@ int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const dou
    return e.sweep.take_error("pips_hip_ldl_factor_schur");
 }
 
+extern "C" int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_inout_host);
 int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || nrhs < 0 || !rhs || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve: bad arguments");
+   if (!h->eng.factored && h->group && h->group->eng.factored) {
+      // factorised as a member of a batch: the batch engine solves (every block in every launch - correct, and as long as a batch
+      // solve: hosts that loop over their leaves should hand the loop over, pips_hip_ldl_solve_batch)
+      std::vector<void*> hs(h->group->members.begin(), h->group->members.end());
+      std::vector<double*> ptrs(hs.size(), nullptr);
+      for (int r = 0; r < nrhs; ++r) {
+         ptrs[h->group_index] = rhs + (size_t)r * ld;
+         int rcb = pips_hip_ldl_solve_batch(hs.data(), (int)hs.size(), ptrs.data());
+         if (rcb) return rcb;
+      }
+      return PIPS_OK;
+   }
    Engine& e = h->eng;
    if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve: factor first");
    HIP_TRY(hipSetDevice(e.device));
@@ -3264,9 +3293,206 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    return PIPS_OK;
 }
 
+// ---- device-pointer and sparse-row variants of the per-leaf solve
+int pips_hip_ldl_solve_dev(void* handle, int nrhs, double* rhs_inout_dev, long long ld) {
+   LdlHandle* h = (LdlHandle*)handle;
+   if (!h || nrhs < 1 || !rhs_inout_dev || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_dev: bad arguments");
+   Engine& e = h->eng;
+   if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_dev: factor first (a handle factorised through pips_hip_ldl_factor_schur_batch is solved with pips_hip_ldl_solve_batch*)");
+   HIP_TRY(hipSetDevice(e.device));
+   return nrhs == 1 ? e.solve(rhs_inout_dev) : e.solve_multi(rhs_inout_dev, nrhs, ld);
+}
+
+// rows[i] = rhs row (0 <= row < n) of packed entry i: X[q * ld + rows[i]] = packed[q * n_rows + i]
+__global__ void k_expand_rows(const int* __restrict__ rows, int n_rows, const double* __restrict__ packed, double* __restrict__ X, long long ld, int nrhs) {
+   const long long total = (long long)n_rows * nrhs;
+   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+      const int q = (int)(idx / n_rows), i = (int)(idx - (long long)q * n_rows);
+      X[q * ld + rows[i]] = packed[idx];
+   }
+}
+
+// = DoubleLinearSolver::solve(int nrhss, double* rhss, int* colSparsity) with the third argument honoured: colSparsity[i] != 0 marks the rows
+// that can be non-zero in any of the right-hand sides (the caller's border_left_transp pattern, DistributedLinearSystem.C:903).  Only those
+// rows of the non-zero right-hand sides travel to the device (the solutions come back dense: K^-1 fills them).
+int pips_hip_ldl_solve_sparse(void* handle, int nrhs, double* rhs, int ld, const int* col_sparsity) {
+   if (!col_sparsity) return pips_hip_ldl_solve(handle, nrhs, rhs, ld);
+   LdlHandle* h = (LdlHandle*)handle;
+   if (!h || nrhs < 0 || !rhs || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_sparse: bad arguments");
+   Engine& e = h->eng;
+   if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_sparse: factor first");
+   HIP_TRY(hipSetDevice(e.device));
+   const int n = (int)e.n_total;
+   std::vector<int> rows, nz;
+   for (int i = 0; i < n; ++i) if (col_sparsity[i]) rows.push_back(i);
+   for (int r = 0; r < nrhs; ++r) {
+      const double* v = rhs + (size_t)r * ld;
+      bool any = false;
+      for (int i : rows) if (v[i] != 0.0) { any = true; break; }
+      if (any) nz.push_back(r);
+   }
+   const int nq = (int)nz.size(), nr = (int)rows.size();
+   if (nq == 0) return PIPS_OK;
+   std::vector<double> packed((size_t)nq * nr);
+   for (int q = 0; q < nq; ++q) {
+      const double* v = rhs + (size_t)nz[q] * ld;
+      for (int i = 0; i < nr; ++i) packed[(size_t)q * nr + i] = v[rows[i]];
+   }
+   double *d_X = nullptr, *d_packed = nullptr;
+   int* d_rows = nullptr;
+   const size_t row = (size_t)n * sizeof(double);
+   hipError_t err = hipMalloc((void**)&d_X, (size_t)nq * row);
+   if (err == hipSuccess) err = hipMalloc((void**)&d_packed, packed.size() * sizeof(double));
+   if (err == hipSuccess) err = hipMalloc((void**)&d_rows, (size_t)nr * sizeof(int));
+   if (err == hipSuccess) err = hipMemcpyAsync(d_packed, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, e.stream);
+   if (err == hipSuccess) err = hipMemcpyAsync(d_rows, rows.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice, e.stream);
+   if (err == hipSuccess) err = hipMemsetAsync(d_X, 0, (size_t)nq * row, e.stream);
+   int rc = PIPS_OK;
+   if (err == hipSuccess) {
+      hipLaunchKernelGGL(k_expand_rows, dim3(grid_for((long long)nq * nr, 256)), dim3(256), 0, e.stream, d_rows, nr, d_packed, d_X, (long long)n, nq);
+      rc = nq == 1 ? e.solve(d_X) : e.solve_multi(d_X, nq, n);
+      for (int q = 0; q < nq && !rc && err == hipSuccess; ++q)
+         err = hipMemcpyAsync(rhs + (size_t)nz[q] * ld, d_X + (size_t)q * n, row, hipMemcpyDeviceToHost, e.stream);
+      if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+   }
+   for (void* q : {(void*)d_X, (void*)d_packed, (void*)d_rows}) if (q) (void)hipFree(q);
+   if (rc) return rc;
+   if (err != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_ldl_solve_sparse: %s", hipGetErrorString(err));
+   return PIPS_OK;
+}
+
+// ---- array-of-handles entries
+static int ldl_group_of(void* const* handles, int n, std::shared_ptr<LdlGroup>& out) {
+   if (!handles || n <= 0) PIPS_FAIL(PIPS_ERR_ARG, "array of leaf handles: bad arguments");
+   LdlHandle* h0 = (LdlHandle*)handles[0];
+   if (!h0) PIPS_FAIL(PIPS_ERR_ARG, "array of leaf handles: null handle");
+   bool same = h0->group && (int)h0->group->members.size() == n;
+   for (int i = 0; i < n && same; ++i) same = handles[i] && h0->group->members[i] == (LdlHandle*)handles[i];
+   if (same) { out = h0->group; return PIPS_OK; }
+   // bind: one batch engine over the patterns (and borders) the handles hold
+   auto g = std::make_shared<LdlGroup>();
+   Engine& e = g->eng;
+   e.nblk = n;
+   e.S = h0->eng.S;
+   e.device = h0->eng.device;
+   e.thr_rel = h0->eng.thr_rel; e.repl_rel = h0->eng.repl_rel;
+   e.refine_steps = h0->eng.refine_steps; e.refine_tol = h0->eng.refine_tol; e.refine_mode = h0->eng.refine_mode;
+   e.in.resize(n);
+   for (int i = 0; i < n; ++i) {
+      LdlHandle* h = (LdlHandle*)handles[i];
+      if (!h) PIPS_FAIL(PIPS_ERR_ARG, "array of leaf handles: null handle at %d", i);
+      if (h->eng.S != e.S) PIPS_FAIL(PIPS_ERR_ARG, "array of leaf handles: handle %d declares Schur dimension %d, handle 0 %d", i, h->eng.S, e.S);
+      if (h->eng.device != e.device) PIPS_FAIL(PIPS_ERR_ARG, "array of leaf handles: handles on different devices");
+      e.in[i] = h->eng.in[0];
+      g->members.push_back(h);
+   }
+   int rc = pips_hip_batch_analyze(&e, std::min(n, 16));
+   if (rc) return rc;
+   for (int i = 0; i < n; ++i) { ((LdlHandle*)handles[i])->group = g; ((LdlHandle*)handles[i])->group_index = i; }
+   out = g;
+   return PIPS_OK;
+}
+
+int pips_hip_ldl_factor_schur_batch(void* const* handles, int n, const double* const* K_vals_host, const double* const* Bt_vals_host, double* SC_host,
+                                    int ldSC) {
+   std::shared_ptr<LdlGroup> g;
+   int rc = ldl_group_of(handles, n, g);
+   if (rc) return rc;
+   if (!K_vals_host) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_factor_schur_batch: no values");
+   Engine& e = g->eng;
+   const int S = e.S;
+   const bool schur = SC_host != nullptr;
+   if (schur && (S <= 0 || ldSC < S || !Bt_vals_host)) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_factor_schur_batch: Schur term asked for without border / ldSC %d < S %d", ldSC, S);
+   HIP_TRY(hipSetDevice(e.device));
+   for (int i = 0; i < n; ++i) {
+      if (!K_vals_host[i]) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_factor_schur_batch: no values for leaf %d", i);
+      HIP_TRY(hipMemcpyAsync(e.d_kval + e.kptr[i], K_vals_host[i], (size_t)(e.kptr[i + 1] - e.kptr[i]) * sizeof(double), hipMemcpyHostToDevice, e.stream));
+   }
+   if (schur && e.nnzB_total > 0) {
+      long long off = 0;
+      for (int i = 0; i < n; ++i) {
+         const size_t cnt = e.in[i].btcol.size();
+         if (cnt > 0) {
+            if (!Bt_vals_host[i]) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_factor_schur_batch: no border values for leaf %d", i);
+            HIP_TRY(hipMemcpyAsync(e.d_bval + off, Bt_vals_host[i], cnt * sizeof(double), hipMemcpyHostToDevice, e.stream));
+         }
+         off += (long long)cnt;
+      }
+   }
+   if (schur) {
+      if (!g->d_sc) HIP_TRY(hipMalloc((void**)&g->d_sc, (size_t)S * S * sizeof(double)));
+      HIP_TRY(hipMemsetAsync(g->d_sc, 0, (size_t)S * S * sizeof(double), e.stream));
+   }
+   if ((rc = e.factor(schur ? g->d_sc : nullptr, S))) return rc;
+   if (schur) {
+      g->h_sc.resize((size_t)S * S);
+      HIP_TRY(hipMemcpyAsync(g->h_sc.data(), g->d_sc, (size_t)S * S * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+      HIP_TRY(hipStreamSynchronize(e.stream));
+      // device: column-major, lower triangle valid; caller: row-major DenseSymmetricMatrix (DenseStorage.C:64-83), lower triangle meaningful
+      std::vector<char> used(S, 0);
+      for (const BlockSym& bs : e.sym) for (int c : bs.bmap) used[c] = 1;
+      std::vector<int> cols;
+      for (int c = 0; c < S; ++c) if (used[c]) cols.push_back(c);
+      for (int cb : cols)
+         for (int ra : cols)
+            if (ra >= cb) SC_host[(size_t)ra * ldSC + cb] += g->h_sc[(size_t)ra + (size_t)cb * S];
+   } else
+      HIP_TRY(hipStreamSynchronize(e.stream));
+   return e.sweep.take_error("pips_hip_ldl_factor_schur_batch");
+}
+
+int pips_hip_ldl_solve_batch_dev(void* const* handles, int n, double* x_dev) {
+   std::shared_ptr<LdlGroup> g;
+   int rc = ldl_group_of(handles, n, g);
+   if (rc) return rc;
+   if (!x_dev) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_batch_dev: null vector");
+   if (!g->eng.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_batch_dev: pips_hip_ldl_factor_schur_batch first");
+   HIP_TRY(hipSetDevice(g->eng.device));
+   return g->eng.solve(x_dev);
+}
+
+int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_inout_host) {
+   std::shared_ptr<LdlGroup> g;
+   int rc = ldl_group_of(handles, n, g);
+   if (rc) return rc;
+   if (!rhs_inout_host) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_batch: null array");
+   Engine& e = g->eng;
+   if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_batch: pips_hip_ldl_factor_schur_batch first");
+   HIP_TRY(hipSetDevice(e.device));
+   if (!g->d_x) HIP_TRY(hipMalloc((void**)&g->d_x, (size_t)std::max<long long>(e.n_total, 1) * sizeof(double)));
+   // a leaf without a right-hand side this time (NULL) is solved with zeros: the batch runs every block in every launch
+   HIP_TRY(hipMemsetAsync(g->d_x, 0, (size_t)e.n_total * sizeof(double), e.stream));
+   for (int i = 0; i < n; ++i)
+      if (rhs_inout_host[i])
+         HIP_TRY(hipMemcpyAsync(g->d_x + e.x_off[i], rhs_inout_host[i], (size_t)(e.x_off[i + 1] - e.x_off[i]) * sizeof(double), hipMemcpyHostToDevice, e.stream));
+   if ((rc = e.solve(g->d_x))) return rc;
+   for (int i = 0; i < n; ++i)
+      if (rhs_inout_host[i])
+         HIP_TRY(hipMemcpyAsync(rhs_inout_host[i], g->d_x + e.x_off[i], (size_t)(e.x_off[i + 1] - e.x_off[i]) * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+   HIP_TRY(hipStreamSynchronize(e.stream));
+   return e.sweep.take_error("pips_hip_ldl_solve_batch");
+}
+
+int pips_hip_ldl_inertia_batch(void* const* handles, int n, int* pos, int* neg, int* zero) {
+   std::shared_ptr<LdlGroup> g;
+   int rc = ldl_group_of(handles, n, g);
+   if (rc) return rc;
+   if (!g->eng.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_inertia_batch: factor first");
+   for (int i = 0; i < n; ++i) {
+      int p = 0, q = 0, z = 0;
+      if ((rc = pips_hip_batch_inertia(&g->eng, i, &p, &q, &z))) return rc;
+      if (pos) pos[i] = p;
+      if (neg) neg[i] = q;
+      if (zero) zero[i] = z;
+   }
+   return PIPS_OK;
+}
+
 int pips_hip_ldl_inertia(void* handle, int* pos, int* neg, int* zero) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (!h->eng.factored && h->group && h->group->eng.factored)   // factorised as a member of a batch (pips_hip_ldl_factor_schur_batch)
+      return pips_hip_batch_inertia(&h->group->eng, h->group_index, pos, neg, zero);
    return pips_hip_batch_inertia(&h->eng, 0, pos, neg, zero);
 }
 
@@ -3596,12 +3822,14 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
          // head = the dissected rows as long as their fronts stay LDS-resident in k_front (ROOT_ND_MAX_COLCOUNT); the cost model is no
          // guide here (it prices a scattering head against MFMA throughput, and the band's cost is the latency of its chain of diagonal tiles)
          int cut = 0;
-         if (hub_dissected_order(S, ap, ai, hubs, 48, nd_perm, k->root_colcount)) {
+         const bool dissected = hub_dissected_order(S, ap, ai, hubs, 48, nd_perm, k->root_colcount) && (int)nd_perm.size() == S;
+         if (dissected) {
             const int n_rest = S - (int)hubs.size();
             while (cut < n_rest && k->root_colcount[cut] <= ROOT_ND_MAX_COLCOUNT) ++cut;
          }
-         if (cut >= (S - (int)hubs.size()) / 2) { k->root_perm = nd_perm; r->opt.force_n_head = cut; r->sn_width = HEAD_WMAX; }
-         else mode = 1;
+         // (without separators - one linking row or none, say - nd_perm is empty: never take it, whatever the threshold says)
+         if (dissected && cut > 0 && cut >= (S - (int)hubs.size()) / 2) { k->root_perm = nd_perm; r->opt.force_n_head = cut; r->sn_width = HEAD_WMAX; }
+         else mode = banded ? 1 : 0;   // a forced mode on a pattern that is no band: minimum degree
       }
       if (mode == 2) {
          r->opt.user_perm = k->root_perm.data();

@@ -228,7 +228,11 @@ __global__ void k_pref_tail(const BlkDesc* __restrict__ blks, const double* __re
 __global__ void k_vec_block_absmax(const double* __restrict__ v, const BlkDesc* __restrict__ blks, double* __restrict__ out) {
    const BlkDesc bd = blks[blockIdx.y];
    double mx = 0.0;
-   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bd.n; i += gridDim.x * blockDim.x) mx = fmax(mx, fabs(v[bd.x_off + i]));
+   // a NaN entry counts as +Inf (fmax would drop it and the refinement check would see a clean residual on a poisoned iterate)
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bd.n; i += gridDim.x * blockDim.x) {
+      const double a = fabs(v[bd.x_off + i]);
+      mx = fmax(mx, a <= 1.7976931348623157e308 ? a : __longlong_as_double(0x7ff0000000000000LL));
+   }
    __shared__ double red[256];
    red[threadIdx.x] = mx;
    __syncthreads();
@@ -3103,11 +3107,13 @@ __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __re
          const int p = p0[u] + l;
          const bool in = mine[u] && p < p1[u];
          const int q = in ? fsrc[p] : 0;
-         c[u] = in ? fcol[p] : 0;
+         c[u] = in ? fcol[p] : -1;
          v[u] = in ? val[q] : 0.0;
       }
+      // (inactive lanes contribute an exact zero, not 0 * x[...]: a non-finite entry at the head of a block's x must not leak into the
+      // residual of every short row of the block)
 #pragma unroll
-      for (int u = 0; u < RU; ++u) s[u] = v[u] * x[base[u] + c[u]];
+      for (int u = 0; u < RU; ++u) s[u] = c[u] >= 0 ? v[u] * x[base[u] + c[u]] : 0.0;
 #pragma unroll
       for (int u = 0; u < RU; ++u)
          if (mine[u])

@@ -48,6 +48,8 @@ SYMBOLS = [
     "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement",
     "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
     "pips_hip_ldl_get_perm", "pips_hip_ldl_set_border", "pips_hip_ldl_factor_schur", "pips_hip_ldl_destroy",
+    "pips_hip_ldl_solve_dev", "pips_hip_ldl_solve_sparse", "pips_hip_ldl_factor_schur_batch", "pips_hip_ldl_solve_batch", "pips_hip_ldl_solve_batch_dev",
+    "pips_hip_ldl_inertia_batch",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
     "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_set_distributed", "pips_hip_dense_ldl_destroy",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
@@ -288,6 +290,53 @@ class HipLdlSolver:
         ld = x.shape[-1]
         _check(lib.pips_hip_ldl_solve(self._h, C.c_int(nrhs), _ptr(x), C.c_int(ld)), "pips_hip_ldl_solve")
         return x
+
+    def solve_sparse(self, x, col_sparsity):
+        """DoubleLinearSolver::solve(int nrhss, double* rhss, int* colSparsity): only the rows flagged in col_sparsity (int32, length n) travel."""
+        assert x.dtype == np.float64 and x.flags.c_contiguous
+        nrhs = 1 if x.ndim == 1 else x.shape[0]
+        cs = None if col_sparsity is None else _i32(col_sparsity)
+        _check(lib.pips_hip_ldl_solve_sparse(self._h, C.c_int(nrhs), _ptr(x), C.c_int(x.shape[-1]), _ptr(cs) if cs is not None else None),
+               "pips_hip_ldl_solve_sparse")
+        return x
+
+    def solve_dev(self, x_dev, nrhs=1, ld=None):
+        """right-hand sides in device memory (a torch tensor), overwritten"""
+        _check(lib.pips_hip_ldl_solve_dev(self._h, C.c_int(nrhs), _ptr(x_dev), C.c_longlong(self.n if ld is None else ld)), "pips_hip_ldl_solve_dev")
+        return x_dev
+
+    @staticmethod
+    def _handle_array(solvers):
+        return (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+
+    @staticmethod
+    def factor_schur_batch(solvers, SC=None):
+        """All leaf solvers of a rank as one batch (the host's loop over its children handed over): every K_i factorised, SC (S x S row-major,
+        lower triangle) += sum_i -Br_i^T K_i^-1 Br_i.  The solvers' K.val / Bt.val are read."""
+        hs = HipLdlSolver._handle_array(solvers)
+        n = len(solvers)
+        kv = (C.c_void_p * n)(*[s.K.val.ctypes.data for s in solvers])
+        bv = (C.c_void_p * n)(*[(s.Bt.val.ctypes.data if getattr(s, "Bt", None) is not None else None) for s in solvers])
+        _check(lib.pips_hip_ldl_factor_schur_batch(hs, C.c_int(n), kv, bv, _ptr(SC) if SC is not None else None,
+                                                   C.c_int(SC.shape[1] if SC is not None else 0)), "pips_hip_ldl_factor_schur_batch")
+
+    @staticmethod
+    def solve_batch(solvers, rhs_list):
+        """one right-hand side per leaf (numpy arrays of length n_i, or None), overwritten by the solutions"""
+        hs = HipLdlSolver._handle_array(solvers)
+        ptrs = (C.c_void_p * len(solvers))(*[(r.ctypes.data if r is not None else None) for r in rhs_list])
+        _check(lib.pips_hip_ldl_solve_batch(hs, C.c_int(len(solvers)), ptrs), "pips_hip_ldl_solve_batch")
+
+    @staticmethod
+    def solve_batch_dev(solvers, x_dev):
+        _check(lib.pips_hip_ldl_solve_batch_dev(HipLdlSolver._handle_array(solvers), C.c_int(len(solvers)), _ptr(x_dev)), "pips_hip_ldl_solve_batch_dev")
+
+    @staticmethod
+    def inertia_batch(solvers):
+        n = len(solvers)
+        p, q, z = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        _check(lib.pips_hip_ldl_inertia_batch(HipLdlSolver._handle_array(solvers), C.c_int(n), _ptr(p), _ptr(q), _ptr(z)), "pips_hip_ldl_inertia_batch")
+        return [(int(p[i]), int(q[i]), int(z[i])) for i in range(n)]
 
     def reports_inertia(self):
         return True

@@ -12,8 +12,9 @@ import pips_ipmpp_amd as pa
 ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=4)
 ap.add_argument("--chunk", type=int, default=160, help="border columns per multi-RHS solve (the reference: 20 x OMP threads)")
-ap.add_argument("--level", choices=["1", "1.5"], default="1", help="1: adapters only, the host's K4-K6 loop ships dense border columns; "
-                "1.5: pips_hip_ldl_set_border + pips_hip_ldl_factor_schur - CSR border up, S x S term down")
+ap.add_argument("--level", choices=["1", "1.5", "1.5b"], default="1", help="1: adapters only, the host's K4-K6 loop ships dense border columns; "
+                "1.5: pips_hip_ldl_set_border + pips_hip_ldl_factor_schur - CSR border up, S x S term down; "
+                "1.5b: the same through the array-of-handles entries (pips_hip_ldl_factor_schur_batch / pips_hip_ldl_solve_batch): the leaves of the rank as one batch")
 a = ap.parse_args()
 seed, N_total, n_i, S, rho = 20261002, 64, 10000, 2000, 1e-3
 my_i, n0, myl = n_i // 2, S // 2, S // 2
@@ -26,8 +27,11 @@ for b in range(a.blocks):
     K.val[dpos] = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
     Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F).to_scipy()
     s = pa.HipLdlSolver(K, n_primal=n_i, refine_steps=1)
-    if a.level == "1.5":
+    if a.level in ("1.5", "1.5b"):
         s.set_border(pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F))
+    if a.level == "1.5b":
+        solvers.append(s); Bts.append(Bt)
+        continue
     t0 = time.perf_counter(); s.analyze(); t_an += time.perf_counter() - t0
     if a.level == "1.5":
         s.matrixChanged_with_schur_term(np.zeros((S, S)))   # warm-up (first-touch allocations)
@@ -45,6 +49,9 @@ for b in range(a.blocks):
         t_schur += time.perf_counter() - t0
     solvers.append(s); Bts.append(Bt)
     print(f"block {b}: factor {t_fac / (b + 1) * 1e3:.1f} ms, Schur term {t_schur / (b + 1):.2f} s (running means)", file=sys.stderr, flush=True)
+if a.level == "1.5b":
+    t0 = time.perf_counter(); pa.HipLdlSolver.factor_schur_batch(solvers, np.zeros((S, S))); t_an = time.perf_counter() - t0   # binds + analyses + warm-up
+    t0 = time.perf_counter(); pa.HipLdlSolver.factor_schur_batch(solvers, SC); t_schur = time.perf_counter() - t0
 F0, c0, x0s = pa.gen_root(seed, n0, myl)
 from oracle import oracle as orc   # only finalize_kkt_dense: host-side assembly of the root rows, as the reference's host does
 SCf = orc.finalize_kkt_dense(np.tril(SC) * (N_total / a.blocks), n0, 0, myl, 0, pa.gen_diagonal(seed, 0, n0), F0=F0.to_scipy())
@@ -57,16 +64,25 @@ t_sc = []
 for r in range(4):
     b0 = rng.standard_normal(S); bs = [rng.standard_normal(n_i + my_i) for _ in range(a.blocks)]
     t0 = time.perf_counter()
-    for bi, sol, Bt in zip(bs, solvers, Bts):
-        sol.solve(bi); b0 -= Bt @ bi
-    root.solve(b0)
-    for bi, sol, Bt in zip(bs, solvers, Bts):
-        t = Bt.T @ b0; sol.solve(t); bi -= t
+    if a.level == "1.5b":      # the host's loops over the children handed over: one batch solve per half
+        pa.HipLdlSolver.solve_batch(solvers, bs)
+        for bi, Bt in zip(bs, Bts): b0 -= Bt @ bi
+        root.solve(b0)
+        ts = [Bt.T @ b0 for Bt in Bts]
+        pa.HipLdlSolver.solve_batch(solvers, ts)
+        for bi, t in zip(bs, ts): bi -= t
+    else:
+        for bi, sol, Bt in zip(bs, solvers, Bts):
+            sol.solve(bi); b0 -= Bt @ bi
+        root.solve(b0)
+        for bi, sol, Bt in zip(bs, solvers, Bts):
+            t = Bt.T @ b0; sol.solve(t); bi -= t
     t_sc.append(time.perf_counter() - t0)
 scale = N_total / a.blocks
 unit = (t_fac + t_schur) * scale + t_root + 4 * np.median(t_sc) * scale
 print(json.dumps({"path": "drop-in DoubleLinearSolver adapters only (host pointers, reference K4-K6 host loop)" if a.level == "1" else
-                          "level 1.5: adapters + pips_hip_ldl_factor_schur (CSR border up, S x S Schur term down; solves through host pointers)", "blocks_run": a.blocks, "chunk_columns": a.chunk,
+                          "level 1.5: adapters + pips_hip_ldl_factor_schur (CSR border up, S x S Schur term down; solves through host pointers)" if a.level == "1.5" else
+                          "level 1.5b: array-of-handles entries - all leaves of the rank as one batch (pips_hip_ldl_factor_schur_batch, pips_hip_ldl_solve_batch; host pointers)", "blocks_run": a.blocks, "chunk_columns": a.chunk,
                   "seconds_per_block": {"analyze_once": t_an / a.blocks, "factor": t_fac / a.blocks, "schur_term": t_schur / a.blocks},
                   "seconds_per_unit": {"leaf_factor": t_fac * scale, "leaf_schur": t_schur * scale, "root_factor": t_root, "solve_compressed_x4": 4 * float(np.median(t_sc)) * scale,
                                        "total": unit}, "units_per_s": 1.0 / unit}))
