@@ -100,32 +100,72 @@ __device__ __forceinline__ double spmv_epilogue(const SpmvArgs& a, int r, double
    }
 }
 
-template <int MODE>
+// Eight lanes per row (rows of the constraint Jacobian and of its transpose hold a handful of entries: a thread per row left seven
+// of eight lanes' worth of every 64-byte request unused and serialised a row's gathers): a wave reads the entries of eight consecutive
+// rows as one contiguous piece; two rows per lane group are in flight.  Bandwidth: profiles/r4_harness_spmv.txt.
+template <int MODE, int LPR = 8>   // LPR lanes per row: 8, or 4 where the rows average fewer than six entries (J^T of an LP)
 __global__ __launch_bounds__(256) void k_spmv(SpmvArgs a) {
    if (a.pred && *a.pred == 0) return;
-   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += gridDim.x * blockDim.x) {
-      const int b = a.rp[r], e = a.rp[r + 1];
-      if (e - b > CSR_LONG_ROW) continue;
-      double s = 0.0;
-      for (int p = b; p < e; ++p) s += a.v[p] * a.in[a.ci[p]];
-      a.out[r] = spmv_epilogue<MODE>(a, r, s);
+   constexpr int RU = 2, SH = LPR == 8 ? 3 : 2;
+   const int l = threadIdx.x & (LPR - 1);
+   const long long step = ((long long)gridDim.x * blockDim.x) >> SH, chunk = step * RU;
+   const long long i_end = (a.nrows + chunk - 1) / chunk * chunk;   // every lane of a wave makes the same trips (shuffles below)
+   for (long long r0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> SH; r0 < i_end; r0 += chunk) {
+      int b[RU], e[RU];
+      double s[RU];
+      bool mine[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+         const long long r = r0 + u * step;
+         mine[u] = r < a.nrows;
+         b[u] = mine[u] ? a.rp[r] : 0;
+         e[u] = mine[u] ? a.rp[r + 1] : 0;
+         mine[u] = mine[u] && e[u] - b[u] <= CSR_LONG_ROW;          // the others: k_spmv_long
+         s[u] = 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+         if (mine[u])
+            for (int p = b[u] + l; p < e[u]; p += LPR) s[u] += a.v[p] * a.in[a.ci[p]];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+         s[u] += __shfl_xor(s[u], 1);
+         s[u] += __shfl_xor(s[u], 2);
+         if (LPR == 8) s[u] += __shfl_xor(s[u], 4);
+         if (mine[u] && l == 0) { const int r = (int)(r0 + u * step); a.out[r] = spmv_epilogue<MODE>(a, r, s[u]); }
+      }
    }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_spmv_long(SpmvArgs a, const int* __restrict__ long_rows) {
+// Long rows (the columns of the first-stage variables in J^T: ~135 000 entries each on the time-coupled share, 95 of them): a row is cut
+// into LONG_PARTS pieces, one workgroup each (a workgroup per ROW left all but 95 compute units idle: 425 us, as long as the rest of the
+// product); the pieces' sums go to a scratch array and are added in a fixed order by the finishing kernel, which applies the epilogue.
+constexpr int LONG_PARTS = 32;
+__global__ __launch_bounds__(256) void k_spmv_long_part(SpmvArgs a, const int* __restrict__ long_rows, double* __restrict__ scratch) {
    if (a.pred && *a.pred == 0) return;
    __shared__ double red[256];
    const int r = long_rows[blockIdx.x];
+   const long long b = a.rp[r], e = a.rp[r + 1], len = (e - b + LONG_PARTS - 1) / LONG_PARTS;
+   const long long p0 = b + len * blockIdx.y, p1 = p0 + len < e ? p0 + len : e;
    double s = 0.0;
-   for (int p = a.rp[r] + threadIdx.x; p < a.rp[r + 1]; p += 256) s += a.v[p] * a.in[a.ci[p]];
+   for (long long p = p0 + threadIdx.x; p < p1; p += 256) s += a.v[p] * a.in[a.ci[p]];
    red[threadIdx.x] = s;
    __syncthreads();
    for (int k = 128; k > 0; k >>= 1) {
       if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
       __syncthreads();
    }
-   if (threadIdx.x == 0) a.out[r] = spmv_epilogue<MODE>(a, r, red[0]);
+   if (threadIdx.x == 0) scratch[(long long)blockIdx.x * LONG_PARTS + blockIdx.y] = red[0];
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_spmv_long_finish(SpmvArgs a, const int* __restrict__ long_rows, int n_long, const double* __restrict__ scratch) {
+   if (a.pred && *a.pred == 0) return;
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_long) return;
+   double s = 0.0;
+   for (int k = 0; k < LONG_PARTS; ++k) s += scratch[(long long)i * LONG_PARTS + k];
+   const int r = long_rows[i];
+   a.out[r] = spmv_epilogue<MODE>(a, r, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -567,6 +607,8 @@ struct Ipm {
    int *J_rp = nullptr, *J_ci = nullptr, *Jt_rp = nullptr, *Jt_ci = nullptr, *J_long = nullptr, *Jt_long = nullptr;
    double *J_v = nullptr, *Jt_v = nullptr;
    int nJ_long = 0, nJt_long = 0;
+   double* long_scratch = nullptr;   // LONG_PARTS partial sums per long row (k_spmv_long_part)
+   long long J_nnz = 0, Jt_nnz = 0;
    // data
    double *c = nullptr, *bA = nullptr, *M = nullptr, *Bd = nullptr, *wG = nullptr, *wXYZ = nullptr, *wX = nullptr, *wY = nullptr;
    long long *d_pack = nullptr, *d_code = nullptr;
@@ -683,9 +725,15 @@ struct Ipm {
       // product goes to a scratch vector and is copied over under the predicate afterwards
       const bool staged = n_ranks > 1 && pred != nullptr;
       if (staged) a.out = transposed ? w_tmp : w_tmp + nx;
-      if (a.nrows > 0) hipLaunchKernelGGL(k_spmv<MODE>, dim3(egrid(a.nrows)), dim3(256), 0, stream, a);
+      // eight lanes per row (four where the rows are short), two rows per lane group
+      const long long nnz_m = transposed ? Jt_nnz : J_nnz;
+      if (a.nrows > 0 && nnz_m < 6LL * a.nrows) hipLaunchKernelGGL((k_spmv<MODE, 4>), dim3(egrid(2LL * a.nrows)), dim3(256), 0, stream, a);
+      else if (a.nrows > 0) hipLaunchKernelGGL((k_spmv<MODE, 8>), dim3(egrid(4LL * a.nrows)), dim3(256), 0, stream, a);
       const int nl = transposed ? nJt_long : nJ_long;
-      if (nl > 0) hipLaunchKernelGGL(k_spmv_long<MODE>, dim3(nl), dim3(256), 0, stream, a, transposed ? Jt_long : J_long);
+      if (nl > 0) {
+         hipLaunchKernelGGL(k_spmv_long_part, dim3(nl, LONG_PARTS), dim3(256), 0, stream, a, transposed ? Jt_long : J_long, long_scratch);
+         hipLaunchKernelGGL(k_spmv_long_finish<MODE>, dim3((nl + 255) / 256), dim3(256), 0, stream, a, transposed ? Jt_long : J_long, nl, long_scratch);
+      }
       HIP_TRYH(hipGetLastError());
       if (n_ranks > 1) {   // replicated rows: sum of the ranks' contributions
          if (transposed) TRY(root_sum(a.out, n0));
@@ -1491,8 +1539,10 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
       for (int r = 0; r < my + mz; ++r) if (Jrp[r + 1] - Jrp[r] > CSR_LONG_ROW) la.push_back(r);
       for (int r = 0; r < nx; ++r) if (Jtrp[r + 1] - Jtrp[r] > CSR_LONG_ROW) lat.push_back(r);
       p->nJ_long = (int)la.size(); p->nJt_long = (int)lat.size();
+      p->J_nnz = Jrp[my + mz]; p->Jt_nnz = Jtrp[nx];
       la.push_back(0); lat.push_back(0);
       if ((rc = p->up(&p->J_long, la)) || (rc = p->up(&p->Jt_long, lat))) return rc;
+      if ((rc = p->alloc(&p->long_scratch, (long long)std::max<size_t>(std::max(la.size(), lat.size()), 1) * LONG_PARTS))) return rc;
    }
    if ((rc = p->up(&p->J_rp, Jrp)) || (rc = p->up(&p->J_ci, Jci)) || (rc = p->up(&p->J_v, Jv)) || (rc = p->up(&p->Jt_rp, Jtrp)) ||
        (rc = p->up(&p->Jt_ci, Jtci)) || (rc = p->up(&p->Jt_v, Jtv)))

@@ -1015,7 +1015,7 @@ class GeneralIpmSolver(IpmSolver):
     def mult(self, vec, transposed=False):
         """J vec ([A x | C x]) or J^T vec for J = [A; C] in the harness' row / column order (DistributedMatrix::mult / transpose_mult)."""
         vec = _f64(vec)
-        out = np.zeros(self.nx if transposed else self.ny + self.nzr)
+        out = np.zeros(self.nx if transposed else self.ny + getattr(self, "nzr", 0))
         _check(lib.pips_ipm_mult(self._h, C.c_int(1 if transposed else 0), _ptr(vec), _ptr(out)), "pips_ipm_mult")
         return out
 
