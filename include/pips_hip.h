@@ -294,6 +294,15 @@ int pips_hip_comm_create_external(void** comm, pips_hip_allreduce_cb allreduce, 
 typedef int (*pips_hip_reduce_scatter_cb)(void* user, double* buf_dev, size_t chunk);
 typedef int (*pips_hip_all_gather_cb)(void* user, double* buf_dev, size_t chunk);
 int pips_hip_comm_set_external_rsag(void* comm, int n_ranks, int rank, pips_hip_reduce_scatter_cb reduce_scatter, pips_hip_all_gather_cb all_gather);
+/* Broadcast of n device doubles from rank `root` (the panel of the distributed root factorisation, pips_hip_dense_ldl_set_distributed;
+ * the reference has every rank factorise the same matrix instead, DistributedRootLinearSystem.C:1436-1464).  The library's RCCL
+ * communicator uses ncclBroadcast; a host-supplied communicator its broadcast callback (MPI_Bcast on device pointers) when one was
+ * registered, else an all-reduce in which the other ranks contribute zeros - exact, twice the bytes on the wire; the caller clears the
+ * buffer on those ranks first (pips_hip_comm_has_broadcast tells which way it goes). */
+typedef int (*pips_hip_broadcast_cb)(void* user, double* buf_dev, size_t n, int root);
+int pips_hip_comm_set_external_broadcast(void* comm, int n_ranks, int rank, pips_hip_broadcast_cb broadcast);
+int pips_hip_broadcast(void* comm, double* buf_dev, size_t n, int root, void* stream);
+int pips_hip_comm_has_broadcast(void* comm);
 int pips_hip_allreduce_sum_rsag(void* comm, double* buf_dev, size_t n, void* stream);
 int pips_hip_comm_size(void* comm);
 

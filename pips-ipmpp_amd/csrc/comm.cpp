@@ -18,6 +18,7 @@ typedef int (*fn_init_rank)(nccl_comm_t*, int, nccl_id_t, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_reduce_scatter)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef const char* (*fn_errstr)(int);
 
@@ -28,6 +29,7 @@ struct Rccl {
    fn_allreduce allreduce = nullptr;
    fn_reduce_scatter reduce_scatter = nullptr;
    fn_all_gather all_gather = nullptr;
+   fn_broadcast broadcast = nullptr;
    fn_destroy destroy = nullptr;
    fn_errstr errstr = nullptr;
    bool load() {
@@ -43,6 +45,7 @@ struct Rccl {
       allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce");
       reduce_scatter = (fn_reduce_scatter)dlsym(lib, "ncclReduceScatter");
       all_gather = (fn_all_gather)dlsym(lib, "ncclAllGather");
+      broadcast = (fn_broadcast)dlsym(lib, "ncclBroadcast");
       destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
       errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
       return get_id && init_rank && allreduce && destroy;
@@ -57,6 +60,7 @@ struct Comm {
    int n_ranks = 1, rank = 0;
    pips_hip_reduce_scatter_cb ext_reduce_scatter = nullptr;   // optional: MPI_Reduce_scatter_block / MPI_Allgather of the host
    pips_hip_all_gather_cb ext_all_gather = nullptr;
+   pips_hip_broadcast_cb ext_broadcast = nullptr;             // optional: MPI_Bcast of the host
 };
 constexpr int kNcclDouble = 8;  // ncclFloat64
 constexpr int kNcclSum = 0;
@@ -150,6 +154,43 @@ int pips_hip_allreduce_sum_rsag(void* comm, double* buf_dev, size_t n, void* str
    rc = g_rccl.all_gather(mine, buf_dev, chunk, kNcclDouble, c->comm, (hipStream_t)stream);
    if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclAllGather failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
    return 0;
+}
+
+int pips_hip_comm_set_external_broadcast(void* comm, int n_ranks, int rank, pips_hip_broadcast_cb broadcast) {
+   Comm* c = (Comm*)comm;
+   if (!c || !c->external || n_ranks < 1 || rank < 0 || rank >= n_ranks || !broadcast) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_comm_set_external_broadcast: bad arguments");
+   c->n_ranks = n_ranks; c->rank = rank;
+   c->ext_broadcast = broadcast;
+   return 0;
+}
+
+/* buf_dev of rank `root` goes to every rank (the panel of the distributed root factorisation).  RCCL: ncclBroadcast; a host-supplied
+ * communicator: its broadcast callback, or - it has none - an all-reduce in which the other ranks contribute zeros (exact, twice the
+ * bytes on the wire: the caller's buffer on the other ranks is cleared for that). */
+int pips_hip_broadcast(void* comm, double* buf_dev, size_t n, int root, void* stream) {
+   Comm* c = (Comm*)comm;
+   if (!c || !buf_dev || root < 0) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_broadcast: bad arguments");
+   if (c->external) {
+      if (c->ext_broadcast) {
+         if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) PIPS_FAIL(pips::PIPS_ERR_HIP, "stream sync before the external broadcast failed");
+         const int rc = c->ext_broadcast(c->user, buf_dev, n, root);
+         if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "external broadcast callback returned %d", rc);
+         return 0;
+      }
+      return pips_hip_allreduce_sum(comm, buf_dev, n, stream);   // (the caller cleared the buffer on the other ranks: pips_hip_comm_has_broadcast == 0)
+   }
+   if (!g_rccl.broadcast) return pips_hip_allreduce_sum(comm, buf_dev, n, stream);
+   const int rc = g_rccl.broadcast(buf_dev, buf_dev, n, kNcclDouble, root, c->comm, (hipStream_t)stream);
+   if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclBroadcast failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
+   return 0;
+}
+
+/* 1: pips_hip_broadcast moves the root's bytes only (RCCL, or an external broadcast callback); 0: it falls back to the all-reduce of zeros,
+ * and the non-root ranks must clear their buffer before the call */
+int pips_hip_comm_has_broadcast(void* comm) {
+   Comm* c = (Comm*)comm;
+   if (!c) return 0;
+   return c->external ? (c->ext_broadcast ? 1 : 0) : (g_rccl.broadcast ? 1 : 0);
 }
 
 int pips_hip_comm_size(void* comm) { return comm ? ((Comm*)comm)->n_ranks : 1; }

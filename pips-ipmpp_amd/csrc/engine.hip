@@ -331,6 +331,11 @@ struct TailCtx {
    int n_groups = 0, first_slot = 0;
    SweepRt* sweep = nullptr;            // single-launch solve sweeps
    bool bunch_kaufman = false;          // diagonal tiles with 1 x 1 / 2 x 2 pivoting (k_tile_diag_bk) instead of the static pivot order
+   int *d_pert_cnt = nullptr, *d_pert_list = nullptr;   // ... and where they record the indices no pivot was found for inside the tile
+   const double* bk_orig = nullptr;                     // the matrix being factorised as the caller holds it (partner search), its layout, the order
+   int bk_orig_ld = 0, bk_orig_rowmajor = 0;
+   const int* d_bk_perm = nullptr;
+   int bk_isolate = 0;
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
 constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
@@ -403,7 +408,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          gemm_diag_tiles(p.upd_diag[j], c.side);
          if (c.bunch_kaufman)
             hipLaunchKernelGGL(k_tile_diag_bk, dim3(p.diag[j].cnt), dim3(256), 0, c.side, p.d_tasks + p.diag[j].off, c.d_blks, c.d_arena, c.d_dtail,
-                               c.d_winv, c.d_inertia);
+                               c.d_winv, c.d_inertia, c.d_pert_cnt, c.d_pert_list, c.bk_orig, c.bk_orig_ld, c.bk_orig_rowmajor, c.d_bk_perm, c.bk_isolate);
          else
          hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.side, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
@@ -422,7 +427,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          if (c.timer) c.timer->begin(c.stream, 3);
          if (c.bunch_kaufman)
             hipLaunchKernelGGL(k_tile_diag_bk, dim3(p.diag[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.diag[j].off, c.d_blks, c.d_arena, c.d_dtail,
-                               c.d_winv, c.d_inertia);
+                               c.d_winv, c.d_inertia, c.d_pert_cnt, c.d_pert_list, c.bk_orig, c.bk_orig_ld, c.bk_orig_rowmajor, c.d_bk_perm, c.bk_isolate);
          else
          hipLaunchKernelGGL(k_tile_diag, dim3(p.diag[j].cnt), dim3(256), 0, c.stream, p.d_tasks + p.diag[j].off,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
@@ -433,6 +438,9 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          hipLaunchKernelGGL(k_tile_gemm<1>, dim3((p.trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.trsm[j].off, p.trsm[j].cnt,
                             c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
          if (c.timer) c.timer->end(c.stream);
+         // Bunch-Kaufman root that will be looked at (DenseLdl::check_pivots): multipliers beyond what a whole-column search allows?
+         if (c.bunch_kaufman && c.is_root && c.d_pert_cnt)
+            hipLaunchKernelGGL(k_bk_growth, dim3(TILE), dim3(256), 0, c.stream, c.d_blks, c.d_arena, j, 1e8, c.d_pert_cnt, c.d_pert_list);
       }
       // right-looking modes: trailing update with the panel that ends at column j.  With a side stream the bulk of it
       // (tile columns >= j+2) runs there, so that the main stream can finish column j+1 and go on with its diagonal tile
@@ -2393,6 +2401,8 @@ struct Engine {
 // dense root solver (DeSymIndefSolver replacement) on the same tile kernels
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
+extern "C" int pips_hip_broadcast(void* comm, double* buf_dev, size_t n, int root, void* stream);
+extern "C" int pips_hip_comm_has_broadcast(void* comm);
 
 __global__ void k_inertia_to_double(const int* __restrict__ in, double* __restrict__ out, int back, int* __restrict__ in_out) {
    if (threadIdx.x < 3) { if (!back) out[threadIdx.x] = (double)in[threadIdx.x]; else in_out[threadIdx.x] = (int)(out[threadIdx.x] + 0.5); }
@@ -2429,7 +2439,7 @@ struct DenseLdl {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -2480,16 +2490,135 @@ struct DenseLdl {
       TailCtx c{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
       c.sweep = &sweep;
       c.bunch_kaufman = pivoting == 1;
+      if (pivoting == 1 && dist_P <= 1) {
+         c.d_pert_cnt = d_pert_cnt; c.d_pert_list = d_pert_list;
+         c.bk_orig = last_A; c.bk_orig_ld = last_lda; c.bk_orig_rowmajor = last_rowmajor; c.d_bk_perm = perm.empty() ? nullptr : d_perm;
+         c.bk_isolate = bk_isolate;
+      }
       return c;
+   }
+   // ---- Bunch-Kaufman beyond the tile.  k_tile_diag_bk searches its 128 x 128 tile; dsytrf searches the whole column
+   // (DeSymIndefSolver.C:78).  Where a tile finds no pivot for an index (a zero leading block coupled only to later rows: [[0 A^T]; [A 0]])
+   // the kernel records the row of the column's largest entry in the panel below.  check_pivots() - at the next host synchronisation
+   // point: the end of the host-pointer factor call, or the join with the root's stream before the first Dsolve - then moves every such
+   // row next to its column (a symmetric permutation P kept for the following factorisations: the structure that needed it comes back
+   // every iteration), factorises P A P^T again and goes on until no index is left without a pivot (at most BK_RETRIES times).  The
+   // pair then sits inside one tile, where the 2 x 2 pivot is found.  Solves permute their right-hand side in and out.
+   static constexpr int BK_RETRIES = 8;
+   static constexpr int BK_MAX_COLUMNS = 2048;   // columns per round whose original entries travel to the host for the partner choice
+   std::vector<int> perm;              // perm[i] = original index at position i (empty: identity)
+   int* d_perm = nullptr;
+   int *d_pert_cnt = nullptr, *d_pert_list = nullptr;
+   const double* last_A = nullptr;     // the matrix of the last factor_dev (the caller keeps it until the next factorisation)
+   int last_lda = 0, last_rowmajor = 0;
+   bool check_pending = false;
+   int bk_isolate = 1;                 // factorisations check_pivots will look at take an index without a pivot OUT of the matrix (k_tile_diag_bk)
+   int bk_refactorizations = 0;        // how often check_pivots had to factorise again (diagnostics / tests)
+   int check_pivots() {
+      if (!check_pending) return PIPS_OK;
+      check_pending = false;
+      if (pivoting != 1 || dist_P > 1 || !d_pert_cnt) return PIPS_OK;
+      HIP_TRY(hipSetDevice(device));
+      for (int attempt = 0; attempt < BK_RETRIES; ++attempt) {
+         int cnt = 0;
+         HIP_TRY(hipMemcpyAsync(&cnt, d_pert_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+         HIP_TRY(hipStreamSynchronize(stream));
+         if (cnt <= 0) return PIPS_OK;
+         std::vector<int> rec((size_t)2 * cnt);
+         HIP_TRY(hipMemcpy(rec.data(), d_pert_list, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
+         // positions (in the current order) -> partner positions.  For every index without a pivot the column of the ORIGINAL matrix comes
+         // to the host; in the order the tiles reported them each takes the row with its largest entry that is still free (not itself
+         // without a pivot, not taken by an earlier column): the row a 2 x 2 pivot with this column needs ([[0 A^T]; [A 0]]: a row of A).
+         const int n_use = std::min(cnt, BK_MAX_COLUMNS);
+         std::vector<double> cols((size_t)n_use * n);
+         {
+            double* d_cols = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_cols, cols.size() * sizeof(double)));
+            hipLaunchKernelGGL(k_bk_gather_columns, dim3(std::max(1, std::min(64, (n + 255) / 256)), n_use), dim3(256), 0, stream, last_A, last_lda, last_rowmajor,
+                               perm.empty() ? (const int*)nullptr : (const int*)d_perm, n, d_pert_list, n_use, d_cols);
+            const hipError_t ec = hipMemcpy(cols.data(), d_cols, cols.size() * sizeof(double), hipMemcpyDeviceToHost);
+            (void)hipFree(d_cols);
+            if (ec != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "dense root: %s", hipGetErrorString(ec));
+         }
+         std::vector<int> partner(n, -1);
+         std::vector<char> taken(n, 0), flagged(n, 0);
+         for (int q = 0; q < cnt; ++q) if (rec[2 * q] >= 0 && rec[2 * q] < n) flagged[rec[2 * q]] = 1;
+         bool any = false;
+         for (int q = 0; q < n_use; ++q) {
+            const int c = rec[2 * q];
+            if (c < 0 || c >= n || partner[c] >= 0) continue;
+            const double* col = cols.data() + (size_t)q * n;
+            int best = -1;
+            for (int i = 0; i < n; ++i)
+               if (!flagged[i] && !taken[i] && col[i] > 0.0 && (best < 0 || col[i] > col[best])) best = i;
+            if (best < 0) continue;
+            partner[c] = best; taken[best] = 1; any = true;
+         }
+         if (getenv("PIPS_HIP_BK_DEBUG")) {
+            int np_ = 0; for (int i = 0; i < n; ++i) np_ += partner[i] >= 0;
+            fprintf(stderr, "[pips_hip] dense root, attempt %d: %d indices without a pivot in their tile, %d paired with a row below; first: %d -> %d\n", attempt, cnt, np_, rec[0], rec[1]);
+            {
+               std::vector<double> dt(npad);
+               (void)hipMemcpy(dt.data(), d_dtail, (size_t)npad * sizeof(double), hipMemcpyDeviceToHost);
+               int bad = -1; double amin = 1e300, amax = 0;
+               for (int i = 0; i < n; ++i) { if (!(std::fabs(dt[i]) < 1e299) && bad < 0 && std::fabs(dt[i]) != 1e300) bad = i; if (std::fabs(dt[i]) < 1e299) { amin = std::min(amin, std::fabs(dt[i])); amax = std::max(amax, std::fabs(dt[i])); } }
+               fprintf(stderr, "   pivots: first non-finite at %d, |d| in [%.3e, %.3e]; d[380..388] = %.3e %.3e %.3e %.3e %.3e %.3e %.3e %.3e\n", bad, amin, amax, dt[380], dt[381], dt[382], dt[383], dt[384], dt[385], dt[386], dt[387]);
+            }
+            for (int q = 0; q < std::min(cnt, 4); ++q)
+               fprintf(stderr, "   pos %d (orig %d) -> pos %d (orig %d)\n", rec[2 * q], perm.empty() ? rec[2 * q] : perm[rec[2 * q]], rec[2 * q + 1],
+                       rec[2 * q + 1] < 0 ? -1 : (perm.empty() ? rec[2 * q + 1] : perm[rec[2 * q + 1]]));
+         }
+         if (!any) break;               // nothing below to pair with
+         std::vector<int> cur(n);
+         for (int i = 0; i < n; ++i) cur[i] = perm.empty() ? i : perm[i];
+         std::vector<int> next;
+         next.reserve(n);
+         std::vector<int> deferred;     // a pair must not straddle a tile boundary: an unpaired index goes in between
+         for (int i = 0; i < n; ++i) {
+            if (taken[i]) continue;      // emitted right behind its column (wherever it stood)
+            if (partner[i] >= 0) {
+               if ((int)next.size() % TILE == TILE - 1) {
+                  int filler = -1;
+                  for (int t = i + 1; t < n && filler < 0; ++t) if (!taken[t] && partner[t] < 0 && t != i && !flagged[t] && std::find(deferred.begin(), deferred.end(), t) == deferred.end()) filler = t;
+                  if (filler >= 0) { next.push_back(cur[filler]); deferred.push_back(filler); }
+               }
+               next.push_back(cur[i]);
+               next.push_back(cur[partner[i]]);
+            } else if (std::find(deferred.begin(), deferred.end(), i) == deferred.end())
+               next.push_back(cur[i]);
+         }
+         if ((int)next.size() != n) PIPS_FAIL(PIPS_ERR_STATE, "dense root: internal error building the pivot order (%zu of %d)", next.size(), n);
+         perm.swap(next);
+         if (!d_perm) HIP_TRY(hipMalloc((void**)&d_perm, (size_t)std::max(n, 1) * sizeof(int)));
+         HIP_TRY(hipMemcpy(d_perm, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+         ++bk_refactorizations;
+         int rc = factor_enqueue();
+         if (rc) return rc;
+      }
+      // indices without a pivot are left: they get the usual small replacement (and are reported as perturbed pivots - what the
+      // regularisation loop of the caller reacts to) instead of being taken out of the matrix
+      {
+         int cnt = 0;
+         HIP_TRY(hipMemcpyAsync(&cnt, d_pert_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+         HIP_TRY(hipStreamSynchronize(stream));
+         if (cnt > 0) {
+            bk_isolate = 0;
+            const int rc = factor_enqueue();
+            bk_isolate = 1;
+            if (rc) return rc;
+         }
+      }
+      return PIPS_OK;
    }
 
    // ---- distributed factorisation (several ranks, each with the whole reduced Schur complement): tile column j belongs to rank
    // j mod P (1-D column-cyclic).  The owner factorises the diagonal tile and solves the column's panel, the panel (Winv_j, d_j, L(:, j),
    // U(:, j)) goes to every rank, and every rank applies it to the tile columns it owns - 1 / P of the S^3 / 3 flops per rank instead
    // of all of them on every rank (DistributedRootLinearSystem.C:1436-1464 has every rank call dsytrf on the same matrix).  At the
-   // end every rank holds the complete factor, so the solves stay local and replicated.  The panel travels as an all-reduce in which
-   // the other ranks contribute zeros (exact: x + 0): the communicator abstraction has no broadcast yet, which doubles the bytes on
-   // the wire.  NOT TIMED: the GPU box has one device; correctness with 2 and 4 processes sharing it (tests/test_dist_root_gpu.py).
+   // end every rank holds the complete factor, so the solves stay local and replicated.  The panel travels by pips_hip_broadcast
+   // (ncclBroadcast / the host's broadcast callback; a host communicator without one: as an all-reduce in which the other ranks
+   // contribute zeros - exact, twice the bytes).  NOT TIMED: the GPU box has one device; correctness with 2 and 4 processes sharing it
+   // (tests/test_dist_root_gpu.py).
    void* dist_comm = nullptr;
    int dist_rank = 0, dist_P = 1;
    std::vector<TaskList> dist_diag, dist_trsm, dist_upd;
@@ -2549,9 +2678,9 @@ struct DenseLdl {
                HIP_TRY(hipMemcpy2DAsync(Lp, rows * sizeof(double), d_R + col0, ld_bytes, rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
                HIP_TRY(hipMemcpy2DAsync(Up, rows * sizeof(double), d_U + col0, ld_bytes, rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
             }
-         } else
-            HIP_TRY(hipMemsetAsync(d_panel, 0, count * sizeof(double), stream));
-         int rc = pips_hip_allreduce_sum(dist_comm, d_panel, count, stream);
+         } else if (!pips_hip_comm_has_broadcast(dist_comm))
+            HIP_TRY(hipMemsetAsync(d_panel, 0, count * sizeof(double), stream));   // (no broadcast primitive: the panel travels as an all-reduce of zeros)
+         int rc = pips_hip_broadcast(dist_comm, d_panel, count, owner, stream);
          if (rc) return rc;
          if (owner != dist_rank) {
             HIP_TRY(hipMemcpyAsync(d_winv + (size_t)j * TILE * TILE, d_panel, (size_t)TILE * TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -2578,9 +2707,24 @@ struct DenseLdl {
    // A_dev: n x n, symmetric, column-major with the lower triangle authoritative (== row-major with the upper one)
    // rowmajor = 1: A_dev is row-major (the reference's DenseStorage), 0: column-major; lower triangle authoritative
    int factor_dev(const double* A_dev, int lda, int rowmajor) {
+      last_A = A_dev; last_lda = lda; last_rowmajor = rowmajor;
+      int rc = factor_enqueue();
+      check_pending = pivoting == 1 && dist_P <= 1;
+      return rc;
+   }
+   int factor_enqueue() {
+      const double* A_dev = last_A;
+      const int lda = last_lda, rowmajor = last_rowmajor;
       HIP_TRY(hipSetDevice(device));
+      if (pivoting == 1 && dist_P <= 1) {
+         if (!d_pert_cnt) {
+            HIP_TRY(hipMalloc((void**)&d_pert_cnt, sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&d_pert_list, (size_t)2 * std::max(npad, 1) * sizeof(int)));
+         }
+         HIP_TRY(hipMemsetAsync(d_pert_cnt, 0, sizeof(int), stream));
+      }
       hipLaunchKernelGGL(k_copy_lower_to_padded, dim3(grid_for((long long)npad * npad, 256)), dim3(256), 0, stream, A_dev,
-                         lda, n, d_R, npad, npad, rowmajor);
+                         lda, n, d_R, npad, npad, rowmajor, perm.empty() ? (const int*)nullptr : (const int*)d_perm);
       hipLaunchKernelGGL(k_pref_tail, dim3(8, 1), dim3(256), 0, stream, d_blks, d_R, d_pref, 1);
       hipLaunchKernelGGL(k_block_absmax_init, dim3(1), dim3(256), 0, stream, d_blks, 1);
       hipLaunchKernelGGL(k_block_absmax, dim3(8, 1), dim3(256), 0, stream, d_pref, d_kptr, d_blks);
@@ -2594,13 +2738,17 @@ struct DenseLdl {
    int solve_dev(double* x_dev) {
       if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "dense solve called before factor");
       HIP_TRY(hipSetDevice(device));
+      int rc = check_pivots();     // (a factorisation whose pivots were not looked at yet: host-pointer callers come here first)
+      if (rc) return rc;
       HIP_TRY(hipMemsetAsync(d_xw, 0, (size_t)npad * sizeof(double), stream));
-      HIP_TRY(hipMemcpyAsync(d_xw, x_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-      int rc = tail_fwd(ctx(), d_xw);
+      if (perm.empty()) HIP_TRY(hipMemcpyAsync(d_xw, x_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      else hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_perm, n, x_dev, d_xw, 0, (double*)nullptr);
+      rc = tail_fwd(ctx(), d_xw);
       if (rc) return rc;
       rc = tail_bwd(ctx(), d_xw);
       if (rc) return rc;
-      HIP_TRY(hipMemcpyAsync(x_dev, d_xw, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      if (perm.empty()) HIP_TRY(hipMemcpyAsync(x_dev, d_xw, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      else hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(n, 256)), dim3(256), 0, stream, d_perm, n, (const double*)nullptr, d_xw, 1, x_dev);
       return PIPS_OK;
    }
 };
@@ -2635,6 +2783,15 @@ struct KktSystem {
    bool root_pending = false;
    int root_wait() {
       if (root_pending) {
+         if (root && root->check_pending) {   // Bunch-Kaufman root: were there indices without a pivot inside their tile?  (host wait for the
+                                              // root's stream - the work queued on the main stream meanwhile keeps the device busy)
+            hipStream_t keep = root->stream;
+            root->stream = root_stream;
+            const int rc = root->check_pivots();
+            root->stream = keep;
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev_root_done, root_stream));
+         }
          HIP_TRY(hipStreamWaitEvent(leaves->stream, ev_root_done, 0));
          root_pending = false;
       }
@@ -2649,12 +2806,12 @@ struct KktSystem {
    // elimination of root inequality rows (zdiag0, C0), the root's pivoting mode, the analysis the leaf buffers belong to
    struct GraphKey {
       const void *b0 = nullptr, *bl = nullptr, *zdiag0 = nullptr, *c0_val = nullptr, *c0_rp = nullptr, *c0_ci = nullptr;
-      int from_factor = 0, refine_steps = 0, refine_mode = 0, mz0 = 0, pivoting = 0;
+      int from_factor = 0, refine_steps = 0, refine_mode = 0, mz0 = 0, pivoting = 0, bk_gen = 0;
       long long analysis_gen = 0;
       bool operator==(const GraphKey& o) const {
          return b0 == o.b0 && bl == o.bl && zdiag0 == o.zdiag0 && c0_val == o.c0_val && c0_rp == o.c0_rp && c0_ci == o.c0_ci &&
                 from_factor == o.from_factor && refine_steps == o.refine_steps && refine_mode == o.refine_mode && mz0 == o.mz0 &&
-                pivoting == o.pivoting && analysis_gen == o.analysis_gen;
+                pivoting == o.pivoting && bk_gen == o.bk_gen && analysis_gen == o.analysis_gen;
       }
    } graph_key;
    long long graph_captures = 0, graph_replays = 0;
@@ -3559,6 +3716,7 @@ int pips_hip_dense_ldl_factor(void* handle, const double* A_host, int lda) {
                             (size_t)d->n * sizeof(double), (size_t)d->n, hipMemcpyHostToDevice, d->stream));
    int rc = d->factor_dev(d->d_in, d->n, 1);
    if (rc) return rc;
+   if ((rc = d->check_pivots())) return rc;     // (the staged copy d_in stays valid: a new pivot order factorises from it again)
    HIP_TRY(hipStreamSynchronize(d->stream));
    return PIPS_OK;
 }
@@ -3595,6 +3753,7 @@ int pips_hip_dense_ldl_inertia(void* handle, int* pos, int* neg, int* zero) {
    DenseLdl* d = (DenseLdl*)handle;
    if (!d || !d->factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_dense_ldl_inertia: factor first");
    HIP_TRY(hipSetDevice(d->device));
+   { const int rcp = d->check_pivots(); if (rcp) return rcp; }
    HIP_TRY(hipMemcpyAsync(d->h_inertia, d->d_inertia, 3 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
    HIP_TRY(hipStreamSynchronize(d->stream));
    { const int rce = d->sweep.take_error("pips_hip_dense_ldl_inertia"); if (rce) return rce; }
@@ -4182,6 +4341,7 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    key.b0 = b0_dev; key.bl = b_leaf_dev; key.zdiag0 = k->d_zdiag0; key.c0_val = k->d_c0_val; key.c0_rp = k->d_c0_rp; key.c0_ci = k->d_c0_ci;
    key.from_factor = k->last_ltsolve_from_factor ? 1 : 0; key.refine_steps = e->refine_steps; key.refine_mode = e->refine_mode; key.mz0 = k->mz0;
    key.pivoting = k->root ? k->root->pivoting : 0; key.analysis_gen = e->analysis_gen;
+   key.bk_gen = k->root ? k->root->bk_refactorizations : 0;   // (a new pivot order: the solve permutes its right-hand side)
    if (k->graph_exec && !(k->graph_key == key)) {
       (void)hipGraphExecDestroy(k->graph_exec);
       k->graph_exec = nullptr;

@@ -2016,8 +2016,13 @@ __device__ __forceinline__ void bk_publish_any(const double (&A)[36], const doub
 
 __global__ __launch_bounds__(256) void k_tile_diag_bk(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                      double* __restrict__ arena, double* __restrict__ dtail,
-                                                     double* __restrict__ winv, int* __restrict__ inertia) {
+                                                     double* __restrict__ winv, int* __restrict__ inertia,
+                                                     int* __restrict__ pert_cnt = nullptr, int* __restrict__ pert_list = nullptr,
+                                                     const double* __restrict__ orig = nullptr, int orig_ld = 0, int orig_rowmajor = 0,
+                                                     const int* __restrict__ perm = nullptr, int isolate = 0) {
    __shared__ DiagBkShared sh;
+   __shared__ double s_best[256];
+   __shared__ int s_idx[256];
    __builtin_amdgcn_s_setprio(3);
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
@@ -2088,7 +2093,39 @@ __global__ __launch_bounds__(256) void k_tile_diag_bk(const TileTask* __restrict
          // ---- 1 x 1 pivot at index p
          double d = p == k ? akk : arr;
          const bool pert = !(fmax(fabs(d), p == k ? lam : 0.0) > 1e-290) || !(fabs(d) > 0.0);
-         if (pert) d = bd.repl_abs > 0.0 ? bd.repl_abs : 1.0;
+         if (pert && pert_cnt) {
+            // No acceptable pivot for this index inside the tile.  dsytrf would look down the whole column (DeSymIndefSolver.C:78): record
+            // the row of the largest entry of column p BELOW the tile - DenseLdl::check_pivots moves that row next to p and factorises
+            // again.  The entries are taken from the ORIGINAL matrix (orig, under the current order perm): what the factorisation holds in
+            // the panel below is polluted by the replaced pivots of earlier tiles, and the row that couples to p in A is the partner a
+            // 2 x 2 pivot needs ([[0 A^T]; [A 0]]); without orig: from the panel as it stands.
+            double best = 0.0;
+            int bi = -1;
+            const double* colp = arena + bd.T + (long long)(gk0 + p) * ld;
+            const int pc = perm ? perm[gk0 + p] : gk0 + p;
+            for (int i = gk0 + TILE + tid; i < bd.m; i += 256) {
+               double v;
+               if (orig) {
+                  const int pi = perm ? perm[i] : i, hi = pi > pc ? pi : pc, lo = pi > pc ? pc : pi;
+                  v = fabs(orig_rowmajor ? orig[(long long)hi * orig_ld + lo] : orig[hi + (long long)lo * orig_ld]);
+               } else v = fabs(colp[i]);
+               if (v > best) { best = v; bi = i; }
+            }
+            s_best[tid] = best; s_idx[tid] = bi;
+            __syncthreads();
+            for (int h = 128; h > 0; h >>= 1) {
+               if (tid < h && (s_best[tid + h] > s_best[tid] || (s_best[tid + h] == s_best[tid] && s_idx[tid + h] >= 0 && (s_idx[tid] < 0 || s_idx[tid + h] < s_idx[tid])))) {
+                  s_best[tid] = s_best[tid + h]; s_idx[tid] = s_idx[tid + h];
+               }
+               __syncthreads();
+            }
+            if (tid == 0 && gk0 + p < bd.m) { const int slot = atomicAdd(pert_cnt, 1); pert_list[2 * slot] = gk0 + p; pert_list[2 * slot + 1] = s_best[0] > 0.0 ? s_idx[0] : -1; }
+            __syncthreads();
+         }
+         // isolate != 0 (a factorisation DenseLdl::check_pivots will look at): an index without a pivot is taken out of the matrix - a pivot
+         // so large that its column vanishes from every update - instead of replaced by a small one, whose multipliers would flood the
+         // trailing matrix and make every later tile fail with it: the later tiles then report their own indices only
+         if (pert) d = isolate ? 1e300 : (bd.repl_abs > 0.0 ? bd.repl_abs : 1.0);
          count(p, d, pert);
          if (tid == 0) sh.dk[p] = d;
          const double dinv = 1.0 / d;
@@ -3268,16 +3305,67 @@ __global__ void k_border_tmult_chunk(const int* __restrict__ rowptr, const int* 
 
 // dense helpers for the root system
 __global__ void k_copy_lower_to_padded(const double* __restrict__ src, int lds, int n, double* __restrict__ dst, int ldd,
-                                       int npad, int rowmajor) {
+                                       int npad, int rowmajor, const int* __restrict__ perm = nullptr) {
    // dst (col-major, npad x npad) lower := src lower (col-major, symmetric storage with the lower triangle authoritative);
-   // identity on the padding
+   // identity on the padding.  perm != nullptr: dst = P src P^T, dst(r, c) = src(perm[r], perm[c])
    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (long long)npad * npad;
         idx += (long long)gridDim.x * blockDim.x) {
       const int r = (int)(idx % npad), c = (int)(idx / npad);
       double v = 0.0;
-      if (r < n && c < n) { if (r >= c) v = rowmajor ? src[(long long)r * lds + c] : src[r + (long long)c * lds]; }
+      if (r < n && c < n) {
+         if (r >= c) {
+            int sr = r, sc = c;
+            if (perm) { const int a = perm[r], b = perm[c]; sr = a > b ? a : b; sc = a > b ? b : a; }
+            v = rowmajor ? src[(long long)sr * lds + sc] : src[sr + (long long)sc * lds];
+         }
+      }
       else if (r == c) v = 1.0;
       dst[r + (long long)c * ldd] = v;
+   }
+}
+
+// Growth check of a tile column under tile-bounded Bunch-Kaufman pivoting (DenseLdl::check_pivots): with the search of dsytrf (the
+// whole column, DeSymIndefSolver.C:78) no multiplier exceeds 1 / alpha = 1.56 (2.57 around a 2 x 2 pivot); a pivot chosen inside the
+// tile while the column's weight lies below it - the rounding noise of a numerically rank-deficient leading block taken for a pivot -
+// shows as multipliers of 1e10 in the rows below.  One workgroup per column of tile column tj: max |L(i, p)| over the rows below the
+// tile; beyond `limit` the index p is recorded like one without a pivot, its partner the row of that largest multiplier.
+__global__ __launch_bounds__(256) void k_bk_growth(const BlkDesc* __restrict__ blks, const double* __restrict__ arena, int tj, double limit,
+                                                  int* __restrict__ pert_cnt, int* __restrict__ pert_list) {
+   __shared__ double s_best[256];
+   __shared__ int s_idx[256];
+   const BlkDesc bd = blks[0];
+   const int tid = threadIdx.x, p = tj * TILE + blockIdx.x;
+   if (p >= bd.m) return;
+   const double* col = arena + bd.T + (long long)p * bd.ldT;
+   double best = 0.0;
+   int bi = -1;
+   for (int i = (tj + 1) * TILE + tid; i < bd.m; i += 256) { const double v = fabs(col[i]); if (v > best || !(v == v)) { best = v == v ? v : 1e308; bi = i; } }
+   s_best[tid] = best; s_idx[tid] = bi;
+   __syncthreads();
+   for (int h = 128; h > 0; h >>= 1) {
+      if (tid < h && s_best[tid + h] > s_best[tid]) { s_best[tid] = s_best[tid + h]; s_idx[tid] = s_idx[tid + h]; }
+      __syncthreads();
+   }
+   if (tid == 0 && s_best[0] > limit) { const int slot = atomicAdd(pert_cnt, 1); pert_list[2 * slot] = p; pert_list[2 * slot + 1] = s_idx[0]; }
+}
+
+// |A(perm[i], perm[c_q])| for the columns c_q = list[2 q] DenseLdl::check_pivots looks for partners for (A: the caller's symmetric matrix,
+// lower triangle authoritative): out[q * n + i]
+__global__ void k_bk_gather_columns(const double* __restrict__ A, int lda, int rowmajor, const int* __restrict__ perm, int n, const int* __restrict__ list,
+                                    int n_cols, double* __restrict__ out) {
+   const int q = blockIdx.y;
+   if (q >= n_cols) return;
+   const int c = list[2 * q], pc = perm ? perm[c] : c;
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int pi = perm ? perm[i] : i, hi = pi > pc ? pi : pc, lo = pi > pc ? pc : pi;
+      out[(long long)q * n + i] = fabs(rowmajor ? A[(long long)hi * lda + lo] : A[hi + (long long)lo * lda]);
+   }
+}
+
+// work vector of a dense solve under the symmetric permutation of DenseLdl: xw[i] = x[perm[i]] / x[perm[i]] = xw[i]
+__global__ void k_perm_gather(const int* __restrict__ perm, int n, const double* __restrict__ x, double* __restrict__ xw, int back, double* __restrict__ xo) {
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      if (!back) xw[i] = x[perm[i]]; else xo[perm[i]] = xw[i];
    }
 }
 

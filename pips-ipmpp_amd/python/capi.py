@@ -63,7 +63,7 @@ SYMBOLS = [
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_last_ltsolve_from_factor", "pips_hip_kkt_last_solve_path", "pips_hip_kkt_set_solve_graph", "pips_hip_kkt_solve_graph_stats", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
-    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
+    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_comm_set_external_broadcast", "pips_hip_broadcast", "pips_hip_comm_has_broadcast", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
@@ -558,6 +558,13 @@ class Comm:
         n = t.numel() if n is None else n
         _check(lib.pips_hip_allreduce_sum(self._h, _ptr(t), C.c_size_t(n), _ptr(stream)), "pips_hip_allreduce_sum")
 
+    def broadcast(self, t, root, n=None, stream=None):
+        n = t.numel() if n is None else n
+        _check(lib.pips_hip_broadcast(self._h, _ptr(t), C.c_size_t(n), C.c_int(root), _ptr(stream)), "pips_hip_broadcast")
+
+    def has_broadcast(self):
+        return bool(lib.pips_hip_comm_has_broadcast(self._h))
+
     def close(self):
         if self._h:
             lib.pips_hip_comm_destroy(self._h)
@@ -605,6 +612,19 @@ class ExternalComm(Comm):
                 return _ALLREDUCE_CB(_f)
             self._rs, self._ag = _wrap(reduce_scatter, "reduce-scatter"), _wrap(all_gather, "all-gather")
             _check(lib.pips_hip_comm_set_external_rsag(self._h, C.c_int(n_ranks), C.c_int(rank), self._rs, self._ag), "pips_hip_comm_set_external_rsag")
+
+    def set_broadcast(self, broadcast, n_ranks, rank):
+        """broadcast(ptr, n, root): n device doubles at ptr go from rank root to every rank (MPI_Bcast on device pointers in a host program);
+        without one pips_hip_broadcast falls back to an all-reduce of zeros."""
+        def _f(_user, ptr, n, root):
+            try:
+                broadcast(int(ptr), int(n), int(root))
+                return 0
+            except Exception as e:
+                sys.stderr.write(f"external broadcast failed: {e}\n")
+                return 1
+        self._bc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)(_f)
+        _check(lib.pips_hip_comm_set_external_broadcast(self._h, C.c_int(n_ranks), C.c_int(rank), self._bc), "pips_hip_comm_set_external_broadcast")
 
     @classmethod
     def torch_distributed(cls, group=None):

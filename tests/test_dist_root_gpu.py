@@ -26,7 +26,7 @@ def _matrix(n0, m, seed):
     return M, rng.standard_normal((n0 + m, 2))
 
 
-def _worker(rank, world, port, out, n0, m, pivoting):
+def _worker(rank, world, port, out, n0, m, pivoting, bcast=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,6 +42,17 @@ def _worker(rank, world, port, out, n0, m, pivoting):
         calls.append(n)
 
     comm = pa.ExternalComm(allreduce, n_ranks=world, rank=rank)
+    bcalls = []
+    if bcast:      # the host's broadcast (MPI_Bcast in a PIPS-IPM++ process): the panel moves once instead of as an all-reduce of zeros
+        def broadcast(ptr, n, root):
+            t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+            h = t.cpu()
+            dist.broadcast(h, root)
+            t.copy_(h)
+            torch.cuda.synchronize()
+            bcalls.append(n)
+        comm.set_broadcast(broadcast, world, rank)
+        assert comm.has_broadcast()
     s = pa.HipDenseLdlSolver(n0 + m, n_primal=n0)
     s.set_pivoting(pivoting)
     s.set_distributed(comm, rank, world)
@@ -50,16 +61,17 @@ def _worker(rank, world, port, out, n0, m, pivoting):
         s.matrixChanged(np.ascontiguousarray(np.tril(M)))
     X = np.ascontiguousarray(B.T.copy())
     s.solve(X)
-    np.savez(os.path.join(out, f"rank{rank}.npz"), X=X.T, inertia=np.array(s.get_inertia()), n_calls=len(calls))
+    np.savez(os.path.join(out, f"rank{rank}.npz"), X=X.T, inertia=np.array(s.get_inertia()), n_calls=len(calls) + len(bcalls) // 2, n_bcast=len(bcalls) // 2)
     s.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n0,m,pivoting", [(2, 600, 400, 0), (2, 600, 400, 1), (4, 700, 330, 0), (4, 300, 90, 1)])
-def test_column_cyclic_root_matches_lapack_on_every_rank(tmp_path, world, n0, m, pivoting):
-    port = 29500 + (os.getpid() % 2000) + 57 + 11 * world + pivoting
-    mp.start_processes(_worker, args=(world, port, str(tmp_path), n0, m, pivoting), nprocs=world, join=True, start_method="spawn")
+@pytest.mark.parametrize("world,n0,m,pivoting,bcast", [(2, 600, 400, 0, False), (2, 600, 400, 1, False), (4, 700, 330, 0, False), (4, 300, 90, 1, False),
+                                                        (2, 600, 400, 0, True), (4, 300, 90, 1, True)])
+def test_column_cyclic_root_matches_lapack_on_every_rank(tmp_path, world, n0, m, pivoting, bcast):
+    port = 29500 + (os.getpid() % 2000) + 57 + 11 * world + pivoting + (5 if bcast else 0)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), n0, m, pivoting, bcast), nprocs=world, join=True, start_method="spawn")
     M, B = _matrix(n0, m, 17)
     ldu, ipiv, info = sla.lapack.dsytrf(M, lower=1)
     Xl, info = sla.lapack.dsytrs(ldu, ipiv, B, lower=1)
@@ -71,6 +83,7 @@ def test_column_cyclic_root_matches_lapack_on_every_rank(tmp_path, world, n0, m,
         assert np.linalg.norm(g["X"] - Xl) / np.linalg.norm(Xl) < 1e-8
         assert np.linalg.norm(M @ g["X"] - B) / np.linalg.norm(B) < 1e-10
         assert int(g["n_calls"]) == n_tiles + 1            # one panel per tile column + the inertia counts
+        assert int(g["n_bcast"]) == (n_tiles if bcast else 0)   # the panels by broadcast where the communicator has one
         if first is None:
             first = g["X"]
         else:

@@ -102,3 +102,39 @@ def test_static_order_still_default_with_hint():
     assert ins == inb == (n0, m, 0)
     assert np.linalg.norm(Xs - Xb) / np.linalg.norm(Xs) < 1e-10
     assert np.linalg.norm(M @ Xb - B) / np.linalg.norm(B) < 1e-11
+
+
+@pytest.mark.parametrize("case", ["zero_leading_tile", "zero_leading_two_tiles", "rank_deficient_leading_tile"])
+def test_pivots_beyond_the_diagonal_tile(case):
+    """dsytrf searches the whole column (DeSymIndefSolver.C:78); k_tile_diag_bk its 128 x 128 tile.  A leading tile that is singular on
+    its own while the matrix is regular ([[0 A^T]; [A 0]]: every pivot of the zero block needs a row of A) is what the tile search cannot
+    take: the indices it finds no pivot for are paired with the row of their column's largest entry below the tile, moved next to it
+    (a symmetric permutation kept for later factorisations) and the matrix is factorised again - solution, inertia and zero perturbed
+    pivots as LAPACK."""
+    rng = np.random.default_rng(7)
+    if case == "zero_leading_tile":
+        n0, m = 128, 160
+    elif case == "zero_leading_two_tiles":
+        n0, m = 256, 300
+    else:
+        n0, m = 128, 200
+    A = rng.standard_normal((m, n0)) * (rng.random((m, n0)) < 0.2)
+    A[rng.permutation(m)[:n0], np.arange(n0)] += 3.0            # full column rank
+    H = np.zeros((n0, n0))
+    if case == "rank_deficient_leading_tile":
+        V = rng.standard_normal((n0, 40))
+        H = V @ V.T                                              # rank 40 of 128
+    C = rng.standard_normal((m, m)) * 0.1
+    M = np.block([[H, A.T], [A, -(C @ C.T) - 1e-3 * np.eye(m)]])
+    B = rng.standard_normal((n0 + m, 3))
+    Xl, inl = lapack_solve_and_inertia(M, B)
+    s = pa.HipDenseLdlSolver(M.shape[0], n_primal=-1)
+    for rep in range(2):                                         # the second factorisation starts from the order the first one found
+        s.matrixChanged(np.ascontiguousarray(np.tril(M)))
+        X = np.ascontiguousarray(B.T.copy())
+        s.solve(X)
+        inh = s.get_inertia()
+        assert inh == (inl[0], inl[1], 0), (rep, inh, inl)
+        assert np.linalg.norm(M @ X.T - B) / np.linalg.norm(B) < 1e-10
+        assert np.linalg.norm(X.T - Xl) / np.linalg.norm(Xl) < 1e-8
+    s.close()
