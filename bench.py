@@ -57,9 +57,7 @@ def update_kernel_algorithmic_flops(m, nb):
 def update_kernel_traffic(n_blocks, n_i, S, world):
     """HBM bytes of the update kernel per factorize from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes over this very command, FETCH_SIZE doubled per MI355X_MICROARCH.md); only valid for the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r3_bench_update_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r2_bench_update_traffic.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_bench_update_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), "")
     if world != 1 or n_blocks != 64 or n_i != 10000 or S != 2000 or not os.path.exists(path):
         return None
     try:
@@ -71,7 +69,7 @@ def update_kernel_traffic(n_blocks, n_i, S, world):
 def head_traffic(family, n_blocks, n_i, key="hbm_bytes_per_factorize"):
     """HBM bytes of the sparse-head kernels per factorize (or, key = "solve_hbm_bytes_per_step", of the leaf solve sweeps per step)
     from the committed PMC summary (tools/profile_cfg3.sh); only valid for the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r3_cfg3_head_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r4_cfg3_head_traffic.json")   # (the round-3 file belongs to the head before the border split)
     if family != "time-coupled" or n_blocks != 256 or n_i != 50000 or not os.path.exists(path):
         return None
     try:
@@ -137,7 +135,7 @@ def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho, family_blocks=None, fam
             "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i)}
 
 
-def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, block0=None):
+def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, block0=None, whole_block=False):
     """Reference-style CPU path timed on a bounded sample and extrapolated linearly (all blocks are statistically
     identical and independent): per block PARDISO phase 12 (or the oracle LDL^T) + multi-RHS solves for the border
     columns (K5) + the sparse accumulation (K6) + 2*R single solves; plus the dense root dsytrf."""
@@ -156,7 +154,9 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, bloc
     Ks = sp.csr_matrix((K.val, K.colidx, K.rowptr), shape=(K.nrows, K.ncols))
     Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F).to_scipy()
     S = n0 + myl
-    n_rhs_sample = min(32, S)
+    # whole_block (runs of 20 steps or more: the driver's): EVERY non-empty border column of the block goes through K4-K6 in the reference's
+    # chunks (20 columns per thread, DistributedLinearSystem.C:766-1047) - no extrapolation over columns; else 32 columns, scaled
+    n_rhs_sample = S if whole_block else min(32, S)
     if pm.available() and mem_ok:
         kind_detail = f"MKL PARDISO mtype -2 with the reference's iparm (PardisoProjectSolver.C:68-77), {cores} threads"
         solver = pm.MklPardisoSolver(Ks, num_threads=cores)
@@ -172,15 +172,24 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, bloc
     nonempty = np.nonzero(np.diff(Bt.indptr) > 0)[0]
     cols = nonempty[:n_rhs_sample]
     n_border = len(nonempty)          # the reference skips empty border columns (DistributedLinearSystem.C:870-874)
-    dense = np.ascontiguousarray(Bt[cols].toarray())
-    # best of two / three repetitions: the first multi-RHS call pays thread start-up, and the host is shared
-    t_schur = float("inf")
-    for _ in range(2):
-        rhs = dense.copy()
+    if whole_block:
+        chunk = 20 * max(1, used)
         t0 = time.perf_counter()
-        solver.solve(rhs)
-        SCrows = (Bt @ rhs.T).T  # noqa: F841  (K6)
-        t_schur = min(t_schur, (time.perf_counter() - t0) * (n_border / max(1, len(cols))))
+        for k0 in range(0, len(cols), chunk):
+            rhs = np.ascontiguousarray(Bt[cols[k0:k0 + chunk]].toarray())   # K4: dense-ify
+            solver.solve(rhs)                                                # K5
+            SCrows = (Bt @ rhs.T).T  # noqa: F841                            # K6
+        t_schur = time.perf_counter() - t0
+    else:
+        dense = np.ascontiguousarray(Bt[cols].toarray())
+        # best of two / three repetitions: the first multi-RHS call pays thread start-up, and the host is shared
+        t_schur = float("inf")
+        for _ in range(2):
+            rhs = dense.copy()
+            t0 = time.perf_counter()
+            solver.solve(rhs)
+            SCrows = (Bt @ rhs.T).T  # noqa: F841  (K6)
+            t_schur = min(t_schur, (time.perf_counter() - t0) * (n_border / max(1, len(cols))))
     t_solve = float("inf")
     for rep in range(3):
         x = np.random.default_rng(rep).standard_normal(K.nrows)
@@ -197,7 +206,7 @@ def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, bloc
     return {
         "value": 1.0 / per_group, "unit": f"{bpg}-block work units/s", "cores": used, "kind": "port",
         "sample": (f"1 of {n_blocks_total} blocks: factor {t_factor:.2f}s, {len(cols)} of {n_border} non-empty border columns solved "
-                   f"(extrapolated {t_schur:.2f}s), 1 single solve {t_solve*1e3:.0f}ms, root dsytrf {t_root:.2f}s; "
+                   f"({'measured' if whole_block else 'extrapolated'} {t_schur:.2f}s), 1 single solve {t_solve*1e3:.0f}ms, root dsytrf {t_root:.2f}s; "
                    f"x{bpg} blocks per unit, {2*R_SOLVES} leaf solves per block; {kind_detail}"),
     }
 
@@ -554,7 +563,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(pa, a.seed, n_i, my_i, n0, myl, a.rho, n_blocks_total, bpg,
-                                                   fam_blocks[0] if fam_blocks is not None else None)
+                                                   fam_blocks[0] if fam_blocks is not None else None, whole_block=a.steps >= 20)
             except Exception as e:  # the baseline must never break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": f"{bpg}-block work units/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}

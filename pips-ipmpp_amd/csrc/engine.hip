@@ -329,6 +329,7 @@ struct TailCtx {
    long long gstride = 0;
    const int* d_blk_group = nullptr;
    int n_groups = 0, first_slot = 0;
+   bool det_defer_reduce = false;       // several ranks: the group buffers are added over ALL ranks' groups in one fixed tree by the caller
    SweepRt* sweep = nullptr;            // single-launch solve sweeps
    bool bunch_kaufman = false;          // diagonal tiles with 1 x 1 / 2 x 2 pivoting (k_tile_diag_bk) instead of the static pivot order
    int *d_pert_cnt = nullptr, *d_pert_list = nullptr;   // ... and where they record the indices no pivot was found for inside the tile
@@ -470,8 +471,9 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
             hipLaunchKernelGGL(k_tile_gemm<2>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, c.d_det_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
                                c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena, c.d_gbuf, c.gstride, c.d_blk_group);
       const int S_ = ldSC;
-      hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (S_ + 255) / 256)), S_), dim3(256), 0, c.stream, SC, ldSC, S_, c.d_gbuf,
-                         c.gstride, c.n_groups, c.first_slot);
+      if (!c.det_defer_reduce)
+         hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (S_ + 255) / 256)), S_), dim3(256), 0, c.stream, SC, ldSC, S_, c.d_gbuf,
+                            c.gstride, c.n_groups, c.first_slot);
       if (c.timer) c.timer->end(c.stream);
    } else if (SC && c.sc_groups && !c.d_sctab) {
       if (c.timer) c.timer->begin(c.stream, 5);
@@ -798,6 +800,11 @@ struct Engine {
    double* d_gbuf = nullptr;
    int* d_blk_group = nullptr;
    int det_n_groups = 0, det_first_slot = 0;
+   // Several ranks whose count divides eight: every rank's group buffers travel to every rank (an all-reduce in which the others hold
+   // zeros at these slots: exact) and ALL eight slots are added in the one fixed tree of k_reduce_groups on every rank - the sums
+   // associate the same way for 1, 2, 4 and 8 ranks (pips_hip_kkt_factorize / the deterministic Lsolve), at eight times the bytes of
+   // the plain reduction of the Schur complement
+   bool det_global = false;
    // groups for the deterministic Schur accumulation: the global problem has eight group slots; this rank (rank of n_ranks, blocks
    // sharded contiguously and evenly) fills 8 / n_ranks of them (all eight when n_ranks does not divide 8).  What holds across rank
    // counts: 1 and 2 ranks give equal bits; 4 and 8 ranks are reproducible run to run only - the all-reduce, not the fixed tree,
@@ -806,6 +813,7 @@ struct Engine {
       if (!analyzed || !deterministic) return PIPS_OK;
       const int slots = (n_ranks >= 1 && n_ranks <= 8 && 8 % n_ranks == 0) ? 8 / n_ranks : 8;
       det_first_slot = slots == 8 ? 0 : rank * slots;
+      det_global = n_ranks > 1 && slots < 8 && !getenv("PIPS_HIP_DET_LOCAL_TREE");
       const int gs = std::max(1, (nblk + slots - 1) / slots);     // blocks per group
       det_n_groups = (nblk + gs - 1) / gs;
       std::vector<int> grp(std::max(nblk, 1), 0);
@@ -930,6 +938,7 @@ struct Engine {
       if (deterministic && d_gbuf) {
          c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = (long long)S * S; c.d_blk_group = d_blk_group;
          c.n_groups = det_n_groups; c.first_slot = det_first_slot;
+         c.det_defer_reduce = det_global;
       }
       c.sweep = &sweep;
       return c;
@@ -2769,6 +2778,7 @@ struct KktSystem {
    double *d_SC = nullptr, *d_t = nullptr, *d_fin_val = nullptr, *d_c0_val = nullptr, *d_red = nullptr, *d_packed = nullptr;
    long long* d_fin_idx = nullptr;
    long long n_fin = 0;
+   double *d_gall = nullptr, *d_gvec_all = nullptr;   // deterministic mode over several ranks: all eight group slots (8 x S x S / 8 x S)
    int mz0 = 0;
    int *d_c0_rp = nullptr, *d_c0_ci = nullptr;
    const double* d_zdiag0 = nullptr;   // caller-owned, set per iteration
@@ -2844,7 +2854,7 @@ struct KktSystem {
       if (ev_root_done) (void)hipEventDestroy(ev_root_done);
       if (comm_stream) (void)hipStreamDestroy(comm_stream);
       if (ev_reduced) (void)hipEventDestroy(ev_reduced);
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr, d_gall, d_gvec_all};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
@@ -3988,7 +3998,7 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
          }
          // (without separators - one linking row or none, say - nd_perm is empty: never take it, whatever the threshold says)
          if (dissected && cut > 0 && cut >= (S - (int)hubs.size()) / 2) { k->root_perm = nd_perm; r->opt.force_n_head = cut; r->sn_width = HEAD_WMAX; }
-         else mode = banded ? 1 : 0;   // a forced mode on a pattern that is no band: minimum degree
+         else mode = 1;   // (the band order - linking rows, then x0 - is always built above: root_perm holds it)
       }
       if (mode == 2) {
          r->opt.user_perm = k->root_perm.data();
@@ -4093,7 +4103,18 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    // reduceKKT (:860-881).  PIPS_HIP_FORCE_REDUCE exercises the reduction path with a one-rank communicator (tests).
    const bool reduce = k->n_ranks > 1 || k->force_reduce;
    const int rec_reduce = tm.begin_i(e->stream, 2);   // what the main stream waits for the reduction: its exposed part
-   if (reduce) {
+   if (reduce && e->deterministic && e->det_global && e->d_gbuf) {
+      // deterministic mode over several ranks: every rank's group buffers to every rank, then ALL eight slots in the one fixed tree (the
+      // leaf engine left its groups unreduced, Engine::det_global) - equal bits for 1, 2, 4 and 8 ranks
+      if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
+      const size_t gs = (size_t)k->S * k->S;
+      if (!k->d_gall) HIP_TRY(hipMalloc((void**)&k->d_gall, 8 * gs * sizeof(double)));
+      HIP_TRY(hipMemsetAsync(k->d_gall, 0, 8 * gs * sizeof(double), e->stream));
+      HIP_TRY(hipMemcpyAsync(k->d_gall + (size_t)e->det_first_slot * gs, e->d_gbuf, (size_t)e->det_n_groups * gs * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_gall, 8 * gs, e->stream))) return rc;
+      hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (k->S + 255) / 256)), k->S), dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_gall,
+                         (long long)gs, 8, 0);
+   } else if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       // only the lower triangle is authoritative: reduce S(S+1)/2 packed doubles instead of S^2
       const size_t np = (size_t)k->S * (k->S + 1) / 2;
@@ -4230,9 +4251,18 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
                             e->d_bt_xoff, b_leaf_dev, e->d_bt_tmp, e->bt_rows_total, -1.0);
          e->gather(e->g_btm_grp, e->d_bt_tmp, e->d_gvec);
       }
+      if (e->det_global && k->n_ranks > 1) {   // all eight group slots on every rank, one tree (see pips_hip_kkt_factorize)
+         if (!k->d_gvec_all) HIP_TRY(hipMalloc((void**)&k->d_gvec_all, (size_t)8 * k->S * sizeof(double)));
+         HIP_TRY(hipMemsetAsync(k->d_gvec_all, 0, (size_t)8 * k->S * sizeof(double), e->stream));
+         HIP_TRY(hipMemcpyAsync(k->d_gvec_all + (size_t)e->det_first_slot * k->S, e->d_gvec, (size_t)e->det_n_groups * k->S * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+         if ((rc = pips_hip_allreduce_sum(k->comm, k->d_gvec_all, (size_t)8 * k->S, e->stream))) return rc;
+         hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (k->S + 255) / 256)), 1), dim3(256), 0, e->stream, e->d_tvec, k->S, k->S, k->d_gvec_all,
+                            (long long)k->S, 8, 0);
+      } else {
       hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (k->S + 255) / 256)), 1), dim3(256), 0, e->stream, e->d_tvec, k->S, k->S, e->d_gvec,
                          (long long)k->S, e->det_n_groups, e->det_first_slot);
       if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, e->d_tvec, (size_t)k->S, e->stream))) return rc;
+      }
       hipLaunchKernelGGL(k_axpy, dim3(grid_for(k->S, 256)), dim3(256), 0, e->stream, red, e->d_tvec, 1.0, (long long)k->S);
    } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)

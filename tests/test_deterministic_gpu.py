@@ -2,7 +2,7 @@
 forward substitution go through contribution slots gathered in a fixed order, the Schur accumulation over the blocks through
 group buffers added in a fixed tree, the border products through gather lists.  Asserted here: the Schur complement, every
 inertia count and the solveCompressed result are BIT-identical over repeated factorisations, over two separately analysed
-handles, and between one rank and two ranks (two processes sharing the GPU, gloo all-reduce of two operands).  The reference's
+handles, and between one rank and 2 / 4 / 8 ranks (processes sharing the GPU, gloo all-reduce behind the external communicator).  The reference's
 breakdown tests compare against 1e-40 (PIPSisZero, pipsdef.h:35,108; LinearSystem.C:640-785) - they are meaningful only when
 the numbers are reproducible."""
 import os
@@ -93,10 +93,11 @@ def _worker(rank, world, port, out, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["random", "banded"])
-def test_bit_identical_between_one_and_two_ranks(tmp_path, kind):
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + (41 if kind == "random" else 43)
+@pytest.mark.parametrize("kind,world", [("random", 2), ("banded", 2), ("random", 4), ("banded", 4), ("random", 8)])
+def test_bit_identical_between_one_and_several_ranks(tmp_path, kind, world):
+    """2, 4 and 8 processes sharing the GPU: every rank's group buffers reach every rank and all eight group slots are added in one fixed
+    tree (Engine::det_global), so the sums associate as on one rank - equal bits, not just reproducible ones."""
+    port = 29500 + (os.getpid() % 2000) + (41 if kind == "random" else 43) + 3 * world
     mp.start_processes(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True, start_method="spawn")
     prob = _problem(kind)
     one = _run(prob, list(range(prob.N)), True, reps=1)[0]

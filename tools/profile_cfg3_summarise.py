@@ -43,7 +43,8 @@ N_FACT = 2
 rows, head_bytes, solve_bytes = [], 0.0, 0.0
 # the kernels of a leaf solve pass (bench.py's "leaf solve sweeps" group)
 SOLVE_KERNELS = {"k_permute_in", "k_permute_out", "k_leaf_fwd_gather", "k_leaf_bwd", "k_head_fwd_chain", "k_head_bwd_chain", "k_head_fwd",
-                 "k_head_bwd", "k_head_solve_simple", "k_head_dscale", "k_tail_rows_fwd", "k_tail_rows_bwd", "k_tail_fwd", "k_tail_bwd"}
+                 "k_head_bwd", "k_head_solve_simple", "k_head_dscale", "k_tail_rows_fwd", "k_tail_rows_bwd", "k_tail_fwd", "k_tail_bwd",
+                 "k_leaf_border", "k_tail_border_fwd", "k_border_collect", "k_border_fill"}
 for k in sorted(set(fetch) | set(write)):
     fk, nd = fetch.get(k, (0.0, 0))
     wk, nw = write.get(k, (0.0, 0))
@@ -52,14 +53,14 @@ for k in sorted(set(fetch) | set(write)):
     n = max(nd, nw, 1)
     rows.append({"kernel": k, "dispatches_in_pmc_pass": n, "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
                  "avg_launch_us": avg_ns / 1e3, "achieved_TBps": ((rd + wr) / n) / (avg_ns * 1e-9) / 1e12 if avg_ns > 0 else None})
-    if k.startswith("k_front") or k.startswith("k_head_factor"):
+    if k.startswith("k_front") or k.startswith("k_head_factor") or k.startswith("k_border_schur") or k.startswith("k_root_assemble"):
         head_bytes += rd + wr
     if k.split("<")[0] in SOLVE_KERNELS:
         solve_bytes += rd + wr
 rows.sort(key=lambda r: -(r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]) * r["dispatches_in_pmc_pass"])
 json.dump({"note": "FETCH_SIZE x 2048, WRITE_SIZE x 1024 bytes per counter KiB (see docstring); separate --pmc passes", "kernels": rows},
           open(os.path.join(out, f"{tag}_cfg3_hbm_by_kernel.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_factorize": head_bytes / N_FACT, "kernels": "k_front<*> + k_head_factor_simple",
+json.dump({"hbm_bytes_per_factorize": head_bytes / N_FACT, "kernels": "k_front<*> + k_head_factor_simple + k_border_schur + k_root_assemble",
            "solve_hbm_bytes_per_step": solve_bytes / N_FACT, "solve_kernels": sorted(SOLVE_KERNELS),
            "source": f"{tag}_cfg3_hbm_by_kernel.json", "factorizations_in_pass": N_FACT},
           open(os.path.join(out, f"{tag}_cfg3_head_traffic.json"), "w"), indent=1)
