@@ -484,7 +484,7 @@ def main():
         # border rows (head panels / border-row arena, the tails' border rows)
         group("leaf solve sweeps", "k_leaf_fwd_gather / k_head_fwd_chain / k_tail_rows_fwd / k_tail_rows_bwd / k_head_bwd_chain / k_leaf_bwd", "hbm",
               tm["solve_head_fwd"][0] + tm["solve_tail"][0] + tm["solve_head_bwd"][0], n_solve_once,
-              16.0 * (n_solve_once * (info["nnzL"] - info.get("nnzL_border", 0)) + aug_passes * info.get("nnzL_border", 0)),
+              16.0 * (n_solve_once * (info["nnzL"] - info.get("nnzL_border", 0)) + aug_passes * (info.get("nnzL_border", 0) + info.get("tail_border_entries", 0))),
               "16 bytes per entry of L and pass (forward + backward): the rows of K in every pass, the border rows in the passes over the augmented factor "
               f"({aug_passes} of {n_solve_once})"),
     ]

@@ -641,6 +641,7 @@ struct Engine {
    BbMeta* d_bb_meta = nullptr;
    int *d_bb_off = nullptr, *d_bb_pos = nullptr;    // batches of block b: [d_bb_off[b], d_bb_off[b + 1]); compressed border ids of the staged rows
    long long bb_doubles = 0;                        // doubles of the border-row arena (behind the panels inside d_arena)
+   double* d_bb_out = nullptr;                      // deterministic mode: the blocks' border x border triangles before they join their groups
    std::vector<int> h_bb_off_keep;
    int n_bb = 0, bb_stage = 3072, bb_nbmax = 0, bb_poscap = 0;
    int* d_bb_round_blk = nullptr;                   // deterministic mode: the blocks of round k of k_border_schur
@@ -710,8 +711,9 @@ struct Engine {
       if (d_mfLV) (void)hipFree(d_mfLV);
       if (d_mfV) (void)hipFree(d_mfV);
       d_mfV = nullptr;
-      for (void* q : {(void*)d_bb_batches, (void*)d_bb_meta, (void*)d_bb_off, (void*)d_bb_pos, (void*)d_bb_round_blk})
+      for (void* q : {(void*)d_bb_batches, (void*)d_bb_meta, (void*)d_bb_off, (void*)d_bb_pos, (void*)d_bb_round_blk, (void*)d_bb_out})
          if (q) (void)hipFree(q);
+      d_bb_out = nullptr;
       d_bb_batches = nullptr; d_bb_meta = nullptr; d_bb_off = nullptr; d_bb_pos = nullptr; d_bb_round_blk = nullptr; n_bb = 0; bb_doubles = 0;
       for (void* q : {(void*)d_roots, (void*)d_root_off, (void*)d_round_blk})
          if (q) (void)hipFree(q);
@@ -1636,20 +1638,27 @@ struct Engine {
          PIPS_FAIL(PIPS_ERR_STATE, "k_border_schur: %zu bytes of LDS for nb = %d (batch of %d doubles, %d rows)", lds, bb_nbmax, bb_stage, bb_poscap);
       // a block's batches are walked by `split` workgroups (each with its own accumulator): enough of them to fill the chip
       const int split = getenv("PIPS_HIP_BB_SPLIT") ? std::max(1, atoi(getenv("PIPS_HIP_BB_SPLIT"))) : std::max(1, std::min(16, 256 / std::max(nblk, 1)));
-      auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered) -> int {
+      auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered, double* out = nullptr,
+                    long long out_stride = 0) -> int {
          if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
          hipLaunchKernelGGL(kern, dim3(cnt, sp), dim3(BLK), lds, stream, list, d_bb_off, d_bb_batches, d_bb_meta, d_bb_pos, d_blks, d_bmap, d_arena, SC, ldSC,
-                            d_sctab, gb, gs, grp, bb_stage, bb_poscap, ordered);
+                            d_sctab, gb, gs, grp, bb_stage, bb_poscap, ordered, out, out_stride);
          return PIPS_OK;
       };
       const bool small = bb_stage <= 2 * 3 * BLK;
       int rc = PIPS_OK;
       if (deterministic && d_gbuf && d_bb_round_blk) {
+         // every block at once (each supernode list in its fixed order) into a triangle of its own, then the blocks of a group in order: a walk
+         // takes as long for 8 workgroups as for 256, so one launch per round of blocks made the share's factorisation 230 ms
+         const long long tri = (long long)ncp;
+         if (!d_bb_out) HIP_TRY(hipMalloc((void**)&d_bb_out, (size_t)std::max(nblk, 1) * tri * sizeof(double)));
+         rc = small ? go(k_border_schur<BLK, 3>, nblk, (const int*)nullptr, (double*)nullptr, 0LL, (const int*)nullptr, 1, 1, d_bb_out, tri)
+                    : go(k_border_schur<BLK, 6>, nblk, (const int*)nullptr, (double*)nullptr, 0LL, (const int*)nullptr, 1, 1, d_bb_out, tri);
          for (size_t k = 0; k + 1 < bb_round_off.size() && !rc; ++k) {
             const int cnt = bb_round_off[k + 1] - bb_round_off[k];
-            if (cnt <= 0) continue;
-            rc = small ? go(k_border_schur<BLK, 3>, cnt, d_bb_round_blk + bb_round_off[k], d_gbuf, (long long)S * S, d_blk_group, 1, 1)
-                       : go(k_border_schur<BLK, 6>, cnt, d_bb_round_blk + bb_round_off[k], d_gbuf, (long long)S * S, d_blk_group, 1, 1);
+            if (cnt > 0)
+               hipLaunchKernelGGL(k_border_schur_add, dim3(cnt, 8), dim3(256), 0, stream, d_bb_round_blk + bb_round_off[k], d_blks, d_bmap, d_bb_out, tri, ldSC, d_sctab,
+                                  d_gbuf, (long long)S * S, d_blk_group);
          }
       } else
          rc = small ? go(k_border_schur<BLK, 3>, nblk, (const int*)nullptr, (double*)nullptr, 0LL, (const int*)nullptr, split, deterministic ? 1 : 0)
@@ -3224,12 +3233,14 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
    if (n_what > 21) {   // entries of L in border rows (head panels / border-row arena + the tails' border rows): read by the sweeps of the
                         // augmented factor, not by a solve with K_i; and whether those sweeps may serve solveCompressed
       what[20] = 0;
+      int64_t tail_border = 0;
       for (const BlockSym& s : e->sym) {
-         for (const HeadSupernode& hs : s.sn) what[20] += (int64_t)hs.w * (hs.r - hs.rb);
-         what[20] += (int64_t)s.nb * s.m;
+         for (const HeadSupernode& hs : s.sn) what[20] += (int64_t)hs.w * (hs.r - hs.rb);   // (counted in nnzL: stored with the head)
+         tail_border += (int64_t)s.nb * s.m;                                                   // (not counted in nnzL)
       }
       what[21] = e->aug_sweeps_ok ? 1 : 0;
       if (n_what > 22) what[22] = e->aug_passes;
+      if (n_what > 23) what[23] = tail_border;
    }
    return PIPS_OK;
 }

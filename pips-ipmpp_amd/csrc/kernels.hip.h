@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
                                                        const int* __restrict__ bmap, const double* __restrict__ bbarena,
                                                        double* __restrict__ SC, int ldSC, const int* __restrict__ sctab,
                                                        double* __restrict__ gbuf, long long gstride, const int* __restrict__ blk_group,
-                                                       int stg_doubles, int pos_cap, int ordered) {
+                                                       int stg_doubles, int pos_cap, int ordered, double* __restrict__ blk_out = nullptr,
+                                                       long long blk_stride = 0) {
    extern __shared__ __attribute__((aligned(16))) double bs_C[];
    typedef double double2_t __attribute__((ext_vector_type(2)));
    const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
    const int nb = bd.nb, tid = threadIdx.x;
    const int q_begin = batch_off[blk], q_end = batch_off[blk + 1];
    double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
-   if (q_begin >= q_end || !S_) return;
+   if (q_begin >= q_end || (!S_ && !blk_out)) return;
    const int ncp = (nb * (nb + 1) / 2 + 1) & ~1;
    double* C = bs_C;
    double* stage = C + ncp;                              // stg_doubles
@@ -1144,6 +1145,11 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
       }
    }
    __syncthreads();
+   if (blk_out) {   // deterministic mode: the block's triangle as it stands; k_border_schur_add puts the blocks of a group in order
+      double* out = blk_out + blk_stride * blk;
+      for (int idx = tid; idx < nb * (nb + 1) / 2; idx += BLOCK) out[idx] = C[idx];
+      return;
+   }
    const int* bm = bmap + bd.bmap_off;
    for (int idx = tid; idx < nb * (nb + 1) / 2; idx += BLOCK) {
       const double v = C[idx];
@@ -1151,6 +1157,26 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
       const int j = packed_col(idx, nb), i = j + (idx - (j * nb - j * (j - 1) / 2));
       double* tgt = sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, nb, i, j);
       if (gbuf) *tgt += v; else atomic_add_f64(tgt, v);
+   }
+}
+
+// deterministic mode: the triangles k_border_schur left per block go into their group's buffer - a launch holds at most one block of
+// every group (plain adds), the launches follow the blocks' order inside the groups
+__global__ __launch_bounds__(256) void k_border_schur_add(const int* __restrict__ blk_list, const BlkDesc* __restrict__ blks, const int* __restrict__ bmap,
+                                                         const double* __restrict__ blk_out, long long blk_stride, int ldSC,
+                                                         const int* __restrict__ sctab, double* __restrict__ gbuf, long long gstride,
+                                                         const int* __restrict__ blk_group) {
+   const int blk = blk_list[blockIdx.x];
+   const BlkDesc bd = blks[blk];
+   const int nb = bd.nb;
+   const double* in = blk_out + blk_stride * blk;
+   double* S_ = gbuf + gstride * blk_group[blk];
+   const int* bm = bmap + bd.bmap_off;
+   for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < nb * (nb + 1) / 2; idx += gridDim.y * blockDim.x) {
+      const double v = in[idx];
+      if (v == 0.0) continue;
+      const int j = packed_col(idx, nb), i = j + (idx - (j * nb - j * (j - 1) / 2));
+      *sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, nb, i, j) += v;
    }
 }
 

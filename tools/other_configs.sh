@@ -16,3 +16,13 @@ for l in open("$O"):
     d=json.loads(l); r=d["roofline"]; i=d.get("ipm_end_to_end") or {}
     print(d["config"]["workload"][:100], "|", d["ms_per_step"], d["value"], "|", r["group"], "frac", r["frac"], {k: v for k, v in d["phase_ms"]["step"].items()}, "| ipm", i.get("iterations"), round(i.get("seconds",0),2), i.get("status"))
 PY
+# round 4: the largest point of the SURVEY 8d random generator (10 non-zeros per row) that 256 blocks per GPU reach in 288 GB
+# (tools/config3_random_limit.py: n_i = 10 000 fits, 15 000 does not), S = 8000 as configs[3] has it
+python3 $R/bench.py --family random --blocks-per-gpu 256 --n 10000 --schur-dim 8000 --rho 0.001 --steps 2 --warmup 1 --no-cpu-baseline --no-ipm 2>$R/gpurun_out/other_random256.err | grep '^{' > $R/gpurun_out/other_random256.json
+python3 - <<PY
+import json
+try:
+    d=json.load(open("$R/gpurun_out/other_random256.json")); print("random 256 x 10000, S = 8000:", d["ms_per_step"], d["value"], d["roofline"]["group"], d["roofline"]["frac"], d["phase_ms"]["step"])
+except Exception as e:
+    print("random 256 x 10000 failed:", e); print(open("$R/gpurun_out/other_random256.err").read()[-800:])
+PY
