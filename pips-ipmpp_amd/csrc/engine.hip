@@ -1633,7 +1633,12 @@ struct Engine {
       // LDS: packed nb x nb triangle + one staged batch + its rows' positions + the batch's supernode records
       constexpr int BLK = 512;
       const long long ncp = ((long long)bb_nbmax * (bb_nbmax + 1) / 2 + 1) & ~1LL;
-      const size_t lds = (size_t)(ncp + bb_stage) * sizeof(double) + (size_t)((bb_poscap + 3) & ~3) * sizeof(int) + BB_GMAX * sizeof(BbMeta);
+      // the triangle shared by `parts` workgroups (column ranges of equal area: a slice is at most tri / parts + one column), so that two
+      // or more workgroups fit a compute unit - measured on the configs[3] share: head 14.94 / 14.97 / 17.7 / 18.3 ms with 1 / 2 / 3 / 4
+      // parts (every part stages every batch; the walk is bound by its LDS traffic, not by waiting): one part it stays
+      const int parts = getenv("PIPS_HIP_BB_PARTS") ? std::max(1, std::min(4, atoi(getenv("PIPS_HIP_BB_PARTS")))) : 1;
+      const long long c_cap = parts > 1 ? ((ncp / parts + bb_nbmax + 2) & ~1LL) : ncp;
+      const size_t lds = (size_t)(c_cap + bb_stage) * sizeof(double) + (size_t)((bb_poscap + 3) & ~3) * sizeof(int) + BB_GMAX * sizeof(BbMeta);
       if (lds > 160 * 1024 || bb_poscap > 4 * BLK || bb_stage > 2 * 6 * BLK)
          PIPS_FAIL(PIPS_ERR_STATE, "k_border_schur: %zu bytes of LDS for nb = %d (batch of %d doubles, %d rows)", lds, bb_nbmax, bb_stage, bb_poscap);
       // a block's batches are walked by `split` workgroups (each with its own accumulator): enough of them to fill the chip
@@ -1641,8 +1646,8 @@ struct Engine {
       auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered, double* out = nullptr,
                     long long out_stride = 0) -> int {
          if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         hipLaunchKernelGGL(kern, dim3(cnt, sp), dim3(BLK), lds, stream, list, d_bb_off, d_bb_batches, d_bb_meta, d_bb_pos, d_blks, d_bmap, d_arena, SC, ldSC,
-                            d_sctab, gb, gs, grp, bb_stage, bb_poscap, ordered, out, out_stride);
+         hipLaunchKernelGGL(kern, dim3(cnt, sp, parts), dim3(BLK), lds, stream, list, d_bb_off, d_bb_batches, d_bb_meta, d_bb_pos, d_blks, d_bmap, d_arena, SC, ldSC,
+                            d_sctab, gb, gs, grp, bb_stage, bb_poscap, ordered, out, out_stride, (int)c_cap);
          return PIPS_OK;
       };
       const bool small = bb_stage <= 2 * 3 * BLK;

@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
                                                        double* __restrict__ SC, int ldSC, const int* __restrict__ sctab,
                                                        double* __restrict__ gbuf, long long gstride, const int* __restrict__ blk_group,
                                                        int stg_doubles, int pos_cap, int ordered, double* __restrict__ blk_out = nullptr,
-                                                       long long blk_stride = 0) {
+                                                       long long blk_stride = 0, int c_cap = 0) {
    extern __shared__ __attribute__((aligned(16))) double bs_C[];
    typedef double double2_t __attribute__((ext_vector_type(2)));
    const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
@@ -1044,12 +1044,24 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
    const int q_begin = batch_off[blk], q_end = batch_off[blk + 1];
    double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
    if (q_begin >= q_end || (!S_ && !blk_out)) return;
-   const int ncp = (nb * (nb + 1) / 2 + 1) & ~1;
+   // gridDim.z workgroups share the triangle by column ranges of (about) equal area: part z keeps the packed columns [jlo, jhi) in its LDS
+   // and forms only the tiles that reach them - half the LDS lets two workgroups share a compute unit, which is what hides the barriers
+   // and the LDS latency of the walk (one workgroup per compute unit: waves 65 % waiting)
+   const int tri = nb * (nb + 1) / 2;
+   auto coff = [nb](int j) { return j * nb - j * (j - 1) / 2; };
+   int jlo = 0, jhi = nb;
+   if (gridDim.z > 1) {
+      const int want_lo = (int)((long long)tri * blockIdx.z / gridDim.z), want_hi = (int)((long long)tri * (blockIdx.z + 1) / gridDim.z);
+      jlo = blockIdx.z == 0 ? 0 : packed_col(want_lo, nb);
+      jhi = blockIdx.z + 1 == gridDim.z ? nb : packed_col(want_hi, nb);
+   }
+   const int cbase = coff(jlo), ncp = c_cap > 0 ? c_cap : ((tri + 1) & ~1);
    double* C = bs_C;
    double* stage = C + ncp;                              // stg_doubles
    int* spos = (int*)(stage + stg_doubles);              // pos_cap
    BbMeta* smeta = (BbMeta*)(spos + ((pos_cap + 3) & ~3));   // BB_GMAX
    for (int idx = tid; idx < ncp; idx += BLOCK) C[idx] = 0.0;
+   if (coff(jhi) - cbase > ncp) return;   // (the host sized the slice for the largest block: cannot happen)
    constexpr int NPP = 4;   // positions per thread (pos_cap <= NPP * BLOCK, checked by the host)
    double2_t pv[NPF];
    int pp[NPP];
@@ -1097,6 +1109,7 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
          const int* pos = spos + m.pos_off;
          const int tb = packed_col(t, nt), ta = tb + (t - (tb * nt - tb * (tb - 1) / 2));
          const int a0 = 4 * ta, b0 = 4 * tb;
+         if (pos[b0] >= jhi || pos[min(b0 + 3, nbj - 1)] < jlo) return;   // none of the tile's columns belongs to this part (positions ascend)
          double acc[4][4];
 #pragma unroll
          for (int x = 0; x < 4; ++x)
@@ -1118,9 +1131,9 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
 #pragma unroll
          for (int z = 0; z < 4; ++z) {
             const int b = b0 + z;
-            if (b < nbj) {
+            if (b < nbj && pos[b] >= jlo && pos[b] < jhi) {
                const int j = pos[b];
-               double* cj = C + (j * nb - j * (j - 1) / 2) - j;
+               double* cj = C + (j * nb - j * (j - 1) / 2) - j - cbase;
 #pragma unroll
                for (int x = 0; x < 4; ++x) {
                   const int a = a0 + x;
@@ -1145,15 +1158,17 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
       }
    }
    __syncthreads();
+   const int n_mine = coff(jhi) - cbase;
    if (blk_out) {   // deterministic mode: the block's triangle as it stands; k_border_schur_add puts the blocks of a group in order
-      double* out = blk_out + blk_stride * blk;
-      for (int idx = tid; idx < nb * (nb + 1) / 2; idx += BLOCK) out[idx] = C[idx];
+      double* out = blk_out + blk_stride * blk + cbase;
+      for (int idx = tid; idx < n_mine; idx += BLOCK) out[idx] = C[idx];
       return;
    }
    const int* bm = bmap + bd.bmap_off;
-   for (int idx = tid; idx < nb * (nb + 1) / 2; idx += BLOCK) {
-      const double v = C[idx];
+   for (int li = tid; li < n_mine; li += BLOCK) {
+      const double v = C[li];
       if (v == 0.0) continue;   // (never touched)
+      const int idx = li + cbase;
       const int j = packed_col(idx, nb), i = j + (idx - (j * nb - j * (j - 1) / 2));
       double* tgt = sc_entry(S_, ldSC, bm, sctab, bd.sctab_off, nb, i, j);
       if (gbuf) *tgt += v; else atomic_add_f64(tgt, v);
