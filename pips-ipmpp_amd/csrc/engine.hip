@@ -1255,6 +1255,15 @@ struct Engine {
          std::vector<int> h_bbpos;
          h_bb_off_keep.assign(nblk + 1, 0);
          bb_stage = 3072; bb_nbmax = 0; bb_poscap = 0;
+         {  // staging area: as much of the LDS as the packed triangle of the widest border leaves (a batch is one barrier pair and one
+            // request latency whatever it holds; the supernodes of the upper levels take 2000+ doubles each), at most 6144 doubles
+            int nbm = 0;
+            for (int b = 0; b < nblk; ++b) if (sym[b].mf_split) nbm = std::max(nbm, sym[b].nb);
+            const long long tri = ((long long)nbm * (nbm + 1) / 2 + 1) & ~1LL;
+            const long long room = 19200 - tri - 4 * 512 / 2 - 64;   // (positions: up to 4 * 512 ints; supernode records)
+            const long long want = getenv("PIPS_HIP_BB_STAGE") ? atoll(getenv("PIPS_HIP_BB_STAGE")) : 6144;
+            bb_stage = (int)std::max<long long>(3072, std::min<long long>(want, room)) & ~1;
+         }
          long long bb_total = arena_total;   // the border-row arena lives behind the panels in the same allocation (offsets like SnDesc::panel)
          for (int b = 0; b < nblk; ++b) {
             const BlockSym& bs = sym[b];
@@ -1567,7 +1576,9 @@ struct Engine {
                border_entries += (double)sn.w * nbord;
             }
          }
-         border_backward_ok = schur_mode_eff == 1 && nnzB_total > 0 && sweep.enabled && !deterministic && border_entries <= 1.25 * fwd_entries;
+         // (round 4: 3 x instead of 1.25 x - with compact front panels and the border-row arena the sweep reads the border rows as one piece per supernode;
+         //  on the configs[3] share, ratio 1.23, the witness pass of a factorisation drops from two refined solves to one + this sweep)
+         border_backward_ok = schur_mode_eff == 1 && nnzB_total > 0 && (sweep.enabled || plan.ntc_max == 0) && !deterministic && border_entries <= 3.0 * fwd_entries;
          if (const char* bb = getenv("PIPS_HIP_BORDER_BACKWARD"))
             border_backward_ok = atoi(bb) != 0 && schur_mode_eff == 1 && nnzB_total > 0 && sweep.enabled && !deterministic;
          // Both halves of solveCompressed from the augmented factor (forward_augmented / backward_augmented): one forward and one backward
@@ -4335,9 +4346,9 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    } else {
    if (!capturing) {
       int pert = 1;
-      if ((e->border_backward_ok || e->aug_sweeps_ok) && !k->sparse && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
+      if ((e->border_backward_ok || e->aug_sweeps_ok) && (rc = e->perturbed_leaf_pivots(&pert))) return rc;
       const bool lsolve_clean = e->refine_tol > 0.0 ? e->last_refine_steps == 0 : true;
-      k->last_ltsolve_from_factor = e->border_backward_ok && !k->sparse && pert == 0 && lsolve_clean;
+      k->last_ltsolve_from_factor = e->border_backward_ok && pert == 0 && lsolve_clean;   // (dense or sparse root: x0 comes in Schur numbering either way)
    }
    int ltsolve_steps = 0;
    if (k->last_ltsolve_from_factor) {
