@@ -337,6 +337,7 @@ struct TailCtx {
    int bk_orig_ld = 0, bk_orig_rowmajor = 0;
    const int* d_bk_perm = nullptr;
    int bk_isolate = 0;
+   int root_persist_wgs = 0;            // dense root: workgroups of the persistent trailing update (0: a workgroup per tile)
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
 constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
@@ -359,8 +360,10 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       }
       if (c.is_root) {
          if (persist)
-            hipLaunchKernelGGL(k_tile_gemm_persist<3>, dim3(512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
-                               c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
+            // fewer persistent workgroups than the chip holds (two per compute unit): the ones left with a single workgroup have room for
+            // the kernels of the diagonal-tile chain, which a launch of one workgroup per tile makes wait for its drain
+            hipLaunchKernelGGL(k_tile_gemm_persist<3>, dim3(c.root_persist_wgs > 0 ? c.root_persist_wgs : 512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks,
+                               c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
          else {
             // The bulk update of the trailing matrix runs on the side stream beside the diagonal-tile chain of the next column.
             // Stream priorities only order the launches the command processor has not started yet: once a launch of thousands of
@@ -2473,7 +2476,7 @@ struct DenseLdl {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list, d_ctr_pool};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -2524,6 +2527,7 @@ struct DenseLdl {
       TailCtx c{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
       c.sweep = &sweep;
       c.bunch_kaufman = pivoting == 1;
+      if (root_persist_wgs > 0 && d_ctr_pool) { c.d_ctr_pool = d_ctr_pool; c.ctr_cursor = &ctr_cursor; c.root_persist_wgs = root_persist_wgs; }
       if (pivoting == 1 && dist_P <= 1) {
          c.d_pert_cnt = d_pert_cnt; c.d_pert_list = d_pert_list;
          c.bk_orig = last_A; c.bk_orig_ld = last_lda; c.bk_orig_rowmajor = last_rowmajor; c.d_bk_perm = perm.empty() ? nullptr : d_perm;
@@ -2538,6 +2542,10 @@ struct DenseLdl {
    // row next to its column (a symmetric permutation P kept for the following factorisations: the structure that needed it comes back
    // every iteration), factorises P A P^T again and goes on until no index is left without a pivot (at most BK_RETRIES times).  The
    // pair then sits inside one tile, where the 2 x 2 pivot is found.  Solves permute their right-hand side in and out.
+   // persistent trailing update (PIPS_HIP_ROOT_PERSIST=<workgroups>): see tail_factor / k_tile_gemm_persist
+   int root_persist_wgs = getenv("PIPS_HIP_ROOT_PERSIST") ? atoi(getenv("PIPS_HIP_ROOT_PERSIST")) : 0;
+   int* d_ctr_pool = nullptr;
+   int ctr_cursor = 0;
    static constexpr int BK_RETRIES = 8;
    static constexpr int BK_MAX_COLUMNS = 2048;   // columns per round whose original entries travel to the host for the partner choice
    std::vector<int> perm;              // perm[i] = original index at position i (empty: identity)
@@ -2756,6 +2764,11 @@ struct DenseLdl {
             HIP_TRY(hipMalloc((void**)&d_pert_list, (size_t)2 * std::max(npad, 1) * sizeof(int)));
          }
          HIP_TRY(hipMemsetAsync(d_pert_cnt, 0, sizeof(int), stream));
+      }
+      if (root_persist_wgs > 0) {
+         if (!d_ctr_pool) HIP_TRY(hipMalloc((void**)&d_ctr_pool, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int)));
+         HIP_TRY(hipMemsetAsync(d_ctr_pool, 0, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int), stream));
+         ctr_cursor = 0;
       }
       hipLaunchKernelGGL(k_copy_lower_to_padded, dim3(grid_for((long long)npad * npad, 256)), dim3(256), 0, stream, A_dev,
                          lda, n, d_R, npad, npad, rowmajor, perm.empty() ? (const int*)nullptr : (const int*)d_perm);
