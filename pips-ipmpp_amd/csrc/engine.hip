@@ -4577,6 +4577,14 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
    int rc = analyze_block(K, B, n_primal, opt, sym[0]);
    if (rc) return rc;
    if (what) sym_info(sym, what, n_what);
+   if (what && n_what > 16) {   // multifrontal head: usable, border split taken, doubles of update matrices, doubles of border rows kept beside the panels
+      const BlockSym& bs = sym[0];
+      what[13] = bs.mf_ok ? 1 : 0;
+      what[14] = bs.mf_split ? 1 : 0;
+      what[15] = bs.mf_U_total;
+      what[16] = 0;
+      for (const HeadSupernode& hs : bs.sn) if (hs.ld < hs.w + hs.r) what[16] += (int64_t)hs.w * (hs.r - hs.rb);
+   }
    if (const char* dump = getenv("PIPS_HIP_DUMP_SN")) {   // development aid: one line per head supernode
       if (FILE* f = fopen(dump, "w")) {
          const BlockSym& bs = sym[0];

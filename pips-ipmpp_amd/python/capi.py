@@ -208,17 +208,18 @@ def map_children_to_ranks(n_children, n_ranks):
 
 
 def symbolic_probe(K, n_primal=-1, Bt=None, force_n_head=-1, want_perm=False):
-    what = np.zeros(11, np.int64)
+    what = np.zeros(17, np.int64)
     perm = np.zeros(K.nrows, np.int32) if want_perm else None
     cc = np.zeros(K.nrows, np.int32) if want_perm else None
     S = Bt.nrows if Bt is not None else 0
     _check(lib.pips_symbolic_probe(C.c_int(K.nrows), C.c_int(n_primal), _ptr(K.rowptr), _ptr(K.colidx), C.c_int(S),
                                    _ptr(Bt.rowptr) if Bt is not None else None,
                                    _ptr(Bt.colidx) if Bt is not None else None, C.c_int(force_n_head), _ptr(what),
-                                   C.c_int(11), _ptr(perm), _ptr(cc)), "pips_symbolic_probe")
+                                   C.c_int(17), _ptr(perm), _ptr(cc)), "pips_symbolic_probe")
     info = dict(nnzL=int(what[0]), n=int(what[1]), n_head=int(what[2]), m=int(what[3]), n_sn=int(what[4]),
                 n_levels=int(what[5]), flops_factor=int(what[6]), flops_border=int(what[7]), arena_bytes=int(what[8]),
-                ntc=int(what[9]), upd_bytes=int(what[10]))
+                ntc=int(what[9]), upd_bytes=int(what[10]), multifrontal=int(what[13]), border_split=int(what[14]),
+                update_matrix_doubles=int(what[15]), border_row_arena_doubles=int(what[16]))
     if want_perm:
         info["perm"] = perm
         info["colcount"] = cc

@@ -199,3 +199,28 @@ def test_sparse_root_order_reports_missing_separators():
     K = pa.Csr(S, S, A.indptr, A.indices, A.data)
     with pytest.raises(RuntimeError):
         pa.capi.symbolic_probe_hubs(K, np.arange(n0), n_primal=n0)
+
+
+def test_border_split_of_the_multifrontal_head(monkeypatch):
+    """Symbolic side of the border split: on a time-coupled block with few border columns the fronts keep only the update
+    columns of their rows of K - the update matrices shrink by more than half, the panels become compact (the border rows move to the
+    border-row arena), the stored factor is the same; a block with more border columns than the LDS triangle takes, or the switch off,
+    keeps whole update matrices and full panels."""
+    import pips_ipmpp_amd as pa
+    c3 = pa.CONFIG3_SHARE
+    blocks, F0, my_i, myl = pa.time_coupled_blocks(3, 6000, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], 5)
+    W, T, F = blocks[1]
+    K, dpos = pa.kkt_leaf_assemble(6000, W)
+    Bt = pa.border_assemble(6000, my_i, 0, c3["n0"], 0, A=T, F=F)
+    on = pa.symbolic_probe(K, 6000, Bt=Bt)
+    monkeypatch.setenv("PIPS_HIP_MF_SPLIT", "0")
+    off = pa.symbolic_probe(K, 6000, Bt=Bt)
+    assert on["multifrontal"] == 1 and on["border_split"] == 1 and off["border_split"] == 0
+    assert on["nnzL"] == off["nnzL"] and on["n_sn"] == off["n_sn"] and on["n_levels"] == off["n_levels"]
+    assert on["update_matrix_doubles"] < 0.5 * off["update_matrix_doubles"]
+    assert on["border_row_arena_doubles"] > 0 and off["border_row_arena_doubles"] == 0
+    assert on["arena_bytes"] < off["arena_bytes"]                       # compact panels
+    assert on["arena_bytes"] + 8 * on["border_row_arena_doubles"] <= off["arena_bytes"] + 8 * 16 * on["n_sn"]   # nothing stored twice
+    monkeypatch.setenv("PIPS_HIP_MF_SPLIT", "20")                       # fewer border columns allowed than the block has
+    few = pa.symbolic_probe(K, 6000, Bt=Bt)
+    assert few["border_split"] == 0 and few["update_matrix_doubles"] == off["update_matrix_doubles"]
