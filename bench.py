@@ -389,9 +389,8 @@ def main():
         F0 = fam_F0
     else:
         F0, c0, x0s = pa.gen_root(a.seed, n0, myl)
-    # time-coupled family: 2-link rows -> sparse root, as the reference does for this class (sLinsysRootAug.C:1629-1739); deterministic
-    # mode has no sparse root yet
-    sparse_root = a.root == "sparse" or (a.root == "auto" and fam_blocks is not None and not os.environ.get("PIPS_HIP_DETERMINISTIC"))
+    # time-coupled family: 2-link rows -> sparse root, as the reference does for this class (sLinsysRootAug.C:1629-1739)
+    sparse_root = a.root == "sparse" or (a.root == "auto" and fam_blocks is not None)
     all_cols = None
     if sparse_root:
         if fam_blocks is None:
@@ -549,8 +548,8 @@ def main():
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "solve_path": {0: "every solveCompressed: two leaf solves with adaptive refinement + the two sparse border products",
                                       1: "refined Lsolve; Ltsolve by one backward sweep of the augmented factor (no pivot perturbed, the refined Lsolve needed no step)",
-                                      2: "first solveCompressed after a factorisation: two refined leaf solves (the witness: no pivot perturbed, no refinement "
-                                         "step needed); the others: one forward + one backward sweep of the augmented factor [L 0; L_b I] (DESIGN.md 2)"}[kkt.last_solve_path()],
+                                      2: "first solveCompressed after a factorisation: refined leaf solve(s) - Lsolve, and Ltsolve too unless the border rows are thin enough for the "
+                                         "backward sweep of the factor (the witness: no pivot perturbed, no refinement step needed); the others: one forward + one backward sweep of the augmented factor [L 0; L_b I] (DESIGN.md 2)"}[kkt.last_solve_path()],
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},

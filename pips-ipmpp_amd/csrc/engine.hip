@@ -329,6 +329,7 @@ struct TailCtx {
    long long gstride = 0;
    const int* d_blk_group = nullptr;
    int n_groups = 0, first_slot = 0;
+   long long sc_len = 0;                // sparse Schur complement: length of its value array (one group buffer)
    bool det_defer_reduce = false;       // several ranks: the group buffers are added over ALL ranks' groups in one fixed tree by the caller
    SweepRt* sweep = nullptr;            // single-launch solve sweeps
    bool bunch_kaufman = false;          // diagonal tiles with 1 x 1 / 2 x 2 pivoting (k_tile_diag_bk) instead of the static pivot order
@@ -467,14 +468,18 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       }
    }
    if ((rc = main_writes(1 << 30))) return rc;   // join the side stream
-   if (SC && c.det_rounds && !c.d_sctab) {
+   if (SC && c.det_rounds) {
       if (c.timer) c.timer->begin(c.stream, 5);
       for (const TaskList& l : *c.det_rounds)   // the group buffers were zeroed (and took the head's contributions) in Engine::factor
          if (l.cnt > 0)
             hipLaunchKernelGGL(k_tile_gemm<2>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, c.stream, c.d_det_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
                                c.d_dtail, c.d_winv, c.d_bmap, SC, ldSC, c.d_sctab, c.d_uarena, c.d_gbuf, c.gstride, c.d_blk_group);
       const int S_ = ldSC;
-      if (!c.det_defer_reduce)
+      if (c.det_defer_reduce) {
+      } else if (c.d_sctab)   // sparse Schur complement: the value array as one column
+         hipLaunchKernelGGL(k_reduce_groups, dim3((unsigned)std::max(1LL, std::min(1024LL, (c.sc_len + 255) / 256)), 1), dim3(256), 0, c.stream, SC, 0, (int)c.sc_len,
+                            c.d_gbuf, c.gstride, c.n_groups, c.first_slot);
+      else
          hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (S_ + 255) / 256)), S_), dim3(256), 0, c.stream, SC, ldSC, S_, c.d_gbuf,
                             c.gstride, c.n_groups, c.first_slot);
       if (c.timer) c.timer->end(c.stream);
@@ -810,6 +815,9 @@ struct Engine {
    // associate the same way for 1, 2, 4 and 8 ranks (pips_hip_kkt_factorize / the deterministic Lsolve), at eight times the bytes of
    // the plain reduction of the Schur complement
    bool det_global = false;
+   // length of one group buffer: S x S (dense Schur complement) or the value array of the sparse one (set_sc_tables)
+   long long sc_len = 0;
+   long long det_gstride() const { return sc_len > 0 ? sc_len : (long long)S * S; }
    // groups for the deterministic Schur accumulation: the global problem has eight group slots; this rank (rank of n_ranks, blocks
    // sharded contiguously and evenly) fills 8 / n_ranks of them (all eight when n_ranks does not divide 8).  What holds across rank
    // counts: 1 and 2 ranks give equal bits; 4 and 8 ranks are reproducible run to run only - the all-reduce, not the fixed tree,
@@ -868,11 +876,11 @@ struct Engine {
       d_det_tasks = nullptr; d_gbuf = nullptr; d_blk_group = nullptr;
       int rc;
       if ((rc = dev_upload(&d_det_tasks, all, stream)) || (rc = dev_upload(&d_blk_group, grp, stream))) return rc;
-      if (S > 0) HIP_TRY(hipMalloc((void**)&d_gbuf, (size_t)det_n_groups * S * S * sizeof(double)));
+      if (S > 0) HIP_TRY(hipMalloc((void**)&d_gbuf, (size_t)det_n_groups * det_gstride() * sizeof(double)));
       {  // the head's own Schur contributions join their block's group buffer
          g_sc_grp.release();
          std::vector<SlotEntry> ent(sc_e_keep.size());
-         for (size_t i = 0; i < sc_e_keep.size(); ++i) ent[i] = {(long long)grp[sc_blk_keep[i]] * S * S + sc_e_keep[i].target, sc_e_keep[i].slot};
+         for (size_t i = 0; i < sc_e_keep.size(); ++i) ent[i] = {(long long)grp[sc_blk_keep[i]] * det_gstride() + sc_e_keep[i].target, sc_e_keep[i].slot};
          if ((rc = upload_gather(ent, g_sc_grp))) return rc;
       }
       // Br^T z in the same group order: rows of group g go to slot g of an 8 x S scratch matrix
@@ -941,7 +949,7 @@ struct Engine {
       if (!sc_groups.empty()) { c.sc_groups = &sc_groups; c.d_sc_tasks = d_sc_tasks; c.ev_sc = &ev_sc; }
       if (persistent_gemm || balanced_gemm) { c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor; c.balanced = balanced_gemm; }
       if (deterministic && d_gbuf) {
-         c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = (long long)S * S; c.d_blk_group = d_blk_group;
+         c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = det_gstride(); c.sc_len = sc_len; c.d_blk_group = d_blk_group;
          c.n_groups = det_n_groups; c.first_slot = det_first_slot;
          c.det_defer_reduce = det_global;
       }
@@ -1677,7 +1685,7 @@ struct Engine {
             const int cnt = bb_round_off[k + 1] - bb_round_off[k];
             if (cnt > 0)
                hipLaunchKernelGGL(k_border_schur_add, dim3(cnt, 8), dim3(256), 0, stream, d_bb_round_blk + bb_round_off[k], d_blks, d_bmap, d_bb_out, tri, ldSC, d_sctab,
-                                  d_gbuf, (long long)S * S, d_blk_group);
+                                  d_gbuf, det_gstride(), d_blk_group);
          }
       } else
          rc = small ? go(k_border_schur<BLK, 3>, nblk, (const int*)nullptr, (double*)nullptr, 0LL, (const int*)nullptr, split, deterministic ? 1 : 0)
@@ -1863,7 +1871,7 @@ struct Engine {
 
    // Sparse Schur complement: tab holds, block after block, the nb x nb table "position of entry (la, lb), la >= lb, of this
    // block's contribution inside the value array of SC's lower-triangular CSR"; factor(values, 0) then accumulates there.
-   int set_sc_tables(const std::vector<int>& tab, const std::vector<long long>& off) {
+   int set_sc_tables(const std::vector<int>& tab, const std::vector<long long>& off, long long sc_nnz) {
       if (!analyzed) PIPS_FAIL(PIPS_ERR_STATE, "set_sc_tables: analyze first");
       if (schur_mode_eff != 1) PIPS_FAIL(PIPS_ERR_STATE, "a sparse Schur complement needs Schur mode 1 (set it before analyze)");
       HIP_TRY(hipSetDevice(device));
@@ -1872,7 +1880,7 @@ struct Engine {
       if (rc) return rc;
       for (int b = 0; b < nblk; ++b) h_blks[b].sctab_off = off[b];
       HIP_TRY(hipMemcpy(d_blks, h_blks.data(), (size_t)nblk * sizeof(BlkDesc), hipMemcpyHostToDevice));
-      if (deterministic) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: not available with the sparse Schur complement");
+      sc_len = sc_nnz;
       if (head_slots) {   // the Schur targets of the head moved into the CSR value array: record again
          for (auto& g : g_levels) g.release();
          for (auto& g : gv_levels) g.release();
@@ -1926,7 +1934,7 @@ struct Engine {
          if (timer.on) timer.begin(stream, 1);
          gather(g_tail, d_slot_val, d_arena);
          if (SC && deterministic && d_gbuf) {
-            HIP_TRY(hipMemsetAsync(d_gbuf, 0, (size_t)det_n_groups * S * S * sizeof(double), stream));
+            HIP_TRY(hipMemsetAsync(d_gbuf, 0, (size_t)det_n_groups * det_gstride() * sizeof(double), stream));
             gather(g_sc_grp, d_slot_val, d_gbuf);
          } else if (SC) gather(g_sc, d_slot_val, SC);
          if (timer.on) timer.end(stream);
@@ -1941,7 +1949,7 @@ struct Engine {
                const int cnt = round_off[k + 1] - round_off[k];
                if (cnt > 0)
                   hipLaunchKernelGGL(k_root_assemble, dim3(cnt, 2 * asm_half), dim3(256), 0, stream, d_round_blk + round_off[k], d_root_off, d_roots, d_sns, d_blks, d_rowidx,
-                                     d_bmap, d_arena, d_mfU, SC, ldSC, d_sctab, d_gbuf, (long long)S * S, d_blk_group, asm_half, asm_half);
+                                     d_bmap, d_arena, d_mfU, SC, ldSC, d_sctab, d_gbuf, det_gstride(), d_blk_group, asm_half, asm_half);
             }
          } else
             hipLaunchKernelGGL(k_root_assemble, dim3(nblk, 2 * asm_half), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
@@ -3974,13 +3982,15 @@ int pips_hip_kkt_create_sparse(void** handle, void* batch, int n0, int my0, int 
       for (int la = 0; la < nb; ++la)
          for (int lb = 0; lb <= la; ++lb) tab[off[b] + (long long)la * nb + lb] = (int)pos_of(bm[la], bm[lb]);
    }
-   int rc = e->set_sc_tables(tab, off);
+   int rc = e->set_sc_tables(tab, off, (long long)k->sc_rowptr[S]);
    if (rc) return rc;
+   if (e->deterministic && (rc = e->set_det_groups(rank, n_ranks))) return rc;   // group buffers as long as the value array
    // ---- the root as a one-block sparse engine; its value array is the Schur complement
    k->root_sp = std::make_unique<Engine>();
    Engine* r = k->root_sp.get();
    r->nblk = 1; r->S = 0; r->device = e->device; r->stream = e->stream;
    r->thr_rel = e->thr_rel; r->repl_rel = e->repl_rel;
+   r->deterministic = e->deterministic;   // (the root's own factorisation and sweeps: slots and fixed-order gathers instead of atomics)
    r->in.assign(1, BlockInput());
    r->in[0].n = S; r->in[0].n_primal = n0;
    r->in[0].krow = k->sc_rowptr; r->in[0].kcol = k->sc_colidx;
@@ -4091,7 +4101,16 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    tm.end(e->stream);
    const bool reduce = k->n_ranks > 1 || k->force_reduce;
    tm.begin(e->stream, 2);
-   if (reduce) {
+   if (reduce && e->deterministic && e->det_global && e->d_gbuf) {
+      // deterministic mode over several ranks: all eight group slots of the value array on every rank, one fixed tree (as in pips_hip_kkt_factorize)
+      if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
+      if (!k->d_gall) HIP_TRY(hipMalloc((void**)&k->d_gall, 8 * nnz * sizeof(double)));
+      HIP_TRY(hipMemsetAsync(k->d_gall, 0, 8 * nnz * sizeof(double), e->stream));
+      HIP_TRY(hipMemcpyAsync(k->d_gall + (size_t)e->det_first_slot * nnz, e->d_gbuf, (size_t)e->det_n_groups * nnz * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_gall, 8 * nnz, e->stream))) return rc;
+      hipLaunchKernelGGL(k_reduce_groups, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(1024, (nnz + 255) / 256)), 1), dim3(256), 0, e->stream, r->d_kval, 0, (int)nnz,
+                         k->d_gall, (long long)nnz, 8, 0);
+   } else if (reduce) {
       if (!k->comm) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: n_ranks > 1 needs a communicator");
       if ((rc = pips_hip_allreduce_sum(k->comm, r->d_kval, nnz, e->stream))) return rc;
    }
@@ -4103,8 +4122,8 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
                          k->n_fin);
    if (k->mz0 > 0) {
       if (!k->d_zdiag0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_kkt_factorize: mz0 > 0 needs pips_hip_kkt_set_root_inequalities + a zdiag0 vector");
-      hipLaunchKernelGGL(k_ctdc, dim3(grid_for(k->mz0, 128)), dim3(128), 0, e->stream, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val, k->d_zdiag0,
-                         r->d_kval, 0, k->d_sc_rowptr);
+      hipLaunchKernelGGL(k_ctdc, e->deterministic ? dim3(1) : dim3(grid_for(k->mz0, 128)), e->deterministic ? dim3(1) : dim3(128), 0, e->stream, k->mz0, k->d_c0_rp,
+                         k->d_c0_ci, k->d_c0_val, k->d_zdiag0, r->d_kval, 0, k->d_sc_rowptr);
    }
    if (zdiag_link_dev && k->mzl > 0)
       hipLaunchKernelGGL(k_add_at, dim3(grid_for(k->mzl, 256)), dim3(256), 0, e->stream, r->d_kval, k->d_zlink_pos, zdiag_link_dev, k->mzl);
@@ -4278,7 +4297,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       HIP_TRY(hipMemcpyAsync(red, b0_dev, (size_t)head * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(red + head, b0_dev + head + k->mz0, (size_t)tailn * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
    }
-   if (e->deterministic && e->d_gvec && !k->sparse) {
+   if (e->deterministic && e->d_gvec) {
       // deterministic Lsolve: t = -sum_i Br_i^T K_i^-1 b_i is formed on its own - group-wise in block order, the (at most eight)
       // groups in the fixed tree of k_reduce_groups, the ranks' parts by the all-reduce - and added to b0 on every rank.  Guarantee:
       // run-to-run reproducibility for any rank count, and equal bits for 1 and 2 ranks (a two-operand all-reduce has one order);

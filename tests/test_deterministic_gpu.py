@@ -23,10 +23,13 @@ def _problem(kind):
     if kind == "banded":     # time-coupled blocks: three elimination-tree levels, head-to-head updates, 2-link borders
         from tests.test_sparse_root_gpu import TwoLinkProblem
         return TwoLinkProblem(93, 8, 2400, 1200, 5, 4, 5.0 / 2400)
+    if kind.startswith("sparse"):   # the same structure with the sparse root: 112 linking rows (enough for the dissected root order)
+        from tests.test_sparse_root_gpu import TwoLinkProblem
+        return TwoLinkProblem(94, 8, 600, 300, 5, 16, 5.0 / 600)
     return Problem(7, 8, 600, 300, 30, 20, 0.02)
 
 
-def _run(prob, mine, deterministic, comm=None, rank=0, world=1, reps=3):
+def _run(prob, mine, deterministic, comm=None, rank=0, world=1, reps=3, sparse=False):
     S = prob.S
     bt = pa.LeafBatch(len(mine), S)
     bt.set_deterministic(deterministic)
@@ -35,7 +38,10 @@ def _run(prob, mine, deterministic, comm=None, rank=0, world=1, reps=3):
     bt.analyze(4)
     for i, b in enumerate(mine):
         bt.set_values(i, prob.blocks[b]["K"].val)
-    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=world)
+    kw = {}
+    if sparse:   # every rank needs the border column sets of all blocks (one value array is reduced)
+        kw = dict(sparse_root=True, all_block_cols=[np.nonzero(np.diff(prob.blocks[b]["Bt"].rowptr) > 0)[0] for b in range(prob.N)])
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=world, **kw)
     diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in mine]), device="cuda")
     xd0 = torch.tensor(prob.x_diag0, device="cuda")
     rng = np.random.default_rng(0)
@@ -44,7 +50,7 @@ def _run(prob, mine, deterministic, comm=None, rank=0, world=1, reps=3):
     out = []
     for _ in range(reps):
         kkt.factorize(diag, xd0)
-        SC = kkt.schur_to_host().copy()
+        SC = kkt.schur_sparse_to_host().data.copy() if sparse else kkt.schur_to_host().copy()
         b0 = torch.tensor(b0_full, device="cuda")
         bl = torch.tensor(np.concatenate([bs_full[b] for b in mine]), device="cuda")
         kkt.solve_compressed(b0, bl)
@@ -54,21 +60,32 @@ def _run(prob, mine, deterministic, comm=None, rank=0, world=1, reps=3):
     return out
 
 
-@pytest.mark.parametrize("kind", ["random", "banded"])
-def test_bit_identical_over_runs_and_handles(kind):
+_ROOT_ORDER = {"sparse_band": "1", "sparse_amd": "0", "sparse_dissected": "2"}
+
+
+@pytest.mark.parametrize("kind", ["random", "banded", "sparse_band", "sparse_amd", "sparse_dissected"])
+def test_bit_identical_over_runs_and_handles(kind, monkeypatch):
+    """sparse_*: the Schur complement as a CSR value array (group buffers as long as that array), the root factorised by the leaf engine in
+    deterministic mode too - in each of its three elimination orders."""
+    sparse = kind.startswith("sparse")
+    if sparse:
+        monkeypatch.setenv("PIPS_HIP_SPARSE_ROOT_BAND", _ROOT_ORDER[kind])
+    def _run_here(*a, **kw):
+        return _run(*a, sparse=sparse, **kw)
+
     prob = _problem(kind)
     mine = list(range(prob.N))
-    runs = _run(prob, mine, True) + _run(prob, mine, True)
+    runs = _run_here(prob, mine, True) + _run_here(prob, mine, True)
     for r in runs[1:]:
         assert np.array_equal(r["SC"], runs[0]["SC"]) and np.array_equal(r["x0"], runs[0]["x0"]) and np.array_equal(r["xl"], runs[0]["xl"])
         assert r["inertia"] == runs[0]["inertia"]
     # ... and it is the same system the default (atomic) path solves
-    ref = _run(prob, mine, False, reps=1)[0]
+    ref = _run_here(prob, mine, False, reps=1)[0]
     assert np.abs(ref["SC"] - runs[0]["SC"]).max() <= 1e-9 * np.abs(ref["SC"]).max()
     assert np.linalg.norm(ref["xl"] - runs[0]["xl"]) <= 1e-8 * np.linalg.norm(ref["xl"])
     assert ref["inertia"] == runs[0]["inertia"]
     # the default path is NOT reproducible to the bit (that is what the mode is for); do not assert it - just report
-    two = _run(prob, mine, False, reps=2)
+    two = _run_here(prob, mine, False, reps=2)
     print(f"{kind}: default path, two factorisations: max |dSC| {np.abs(two[0]['SC'] - two[1]['SC']).max():.1e}")
 
 
@@ -86,21 +103,24 @@ def _worker(rank, world, port, out, kind):
         t.copy_(h)
         torch.cuda.synchronize()
 
-    r = _run(prob, mine, True, comm=pa.ExternalComm(allreduce), rank=rank, world=world, reps=2)
+    r = _run(prob, mine, True, comm=pa.ExternalComm(allreduce), rank=rank, world=world, reps=2, sparse=kind.startswith("sparse"))
     assert np.array_equal(r[0]["SC"], r[1]["SC"]) and np.array_equal(r[0]["xl"], r[1]["xl"])
     np.savez(os.path.join(out, f"det{rank}.npz"), SC=r[0]["SC"], x0=r[0]["x0"], xl=r[0]["xl"], mine=np.array(mine), inertia=np.array(r[0]["inertia"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("random", 2), ("banded", 2), ("random", 4), ("banded", 4), ("random", 8)])
-def test_bit_identical_between_one_and_several_ranks(tmp_path, kind, world):
+@pytest.mark.parametrize("kind,world", [("random", 2), ("banded", 2), ("random", 4), ("banded", 4), ("random", 8), ("sparse_dissected", 2), ("sparse_band", 4),
+                                        ("sparse_dissected", 8)])
+def test_bit_identical_between_one_and_several_ranks(tmp_path, kind, world, monkeypatch):
     """2, 4 and 8 processes sharing the GPU: every rank's group buffers reach every rank and all eight group slots are added in one fixed
     tree (Engine::det_global), so the sums associate as on one rank - equal bits, not just reproducible ones."""
-    port = 29500 + (os.getpid() % 2000) + (41 if kind == "random" else 43) + 3 * world
+    if kind.startswith("sparse"):
+        monkeypatch.setenv("PIPS_HIP_SPARSE_ROOT_BAND", _ROOT_ORDER[kind])   # (inherited by the spawned ranks)
+    port = 29500 + (os.getpid() % 2000) + {"random": 41, "banded": 43}.get(kind, 47) + 3 * world
     mp.start_processes(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True, start_method="spawn")
     prob = _problem(kind)
-    one = _run(prob, list(range(prob.N)), True, reps=1)[0]
+    one = _run(prob, list(range(prob.N)), True, reps=1, sparse=kind.startswith("sparse"))[0]
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), f"det{r}.npz"))
         assert np.array_equal(g["SC"], one["SC"])          # the reduced, finalised Schur complement: same bits on every rank
