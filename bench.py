@@ -409,12 +409,16 @@ def main():
     b_leaf = torch.empty_like(rhs_leaf)
     b0 = torch.empty_like(rhs0)
 
+    step_paths = []
+
     def step():
         kkt.factorize(diag, xd0)
+        step_paths.clear()
         for _ in range(R_SOLVES):
             b_leaf.copy_(rhs_leaf)
             b0.copy_(rhs0)
             kkt.solve_compressed(b0, b_leaf)
+            step_paths.append(kkt.last_solve_path())   # (a host-side field: no synchronisation)
 
     def barrier():
         if use_dist:
@@ -549,7 +553,11 @@ def main():
                        "solve_path": {0: "every solveCompressed: two leaf solves with adaptive refinement + the two sparse border products",
                                       1: "refined Lsolve; Ltsolve by one backward sweep of the augmented factor (no pivot perturbed, the refined Lsolve needed no step)",
                                       2: "first solveCompressed after a factorisation: refined leaf solve(s) - Lsolve, and Ltsolve too unless the border rows are thin enough for the "
-                                         "backward sweep of the factor (the witness: no pivot perturbed, no refinement step needed); the others: one forward + one backward sweep of the augmented factor [L 0; L_b I] (DESIGN.md 2)"}[kkt.last_solve_path()],
+                                         "backward sweep of the factor (the witness: no pivot perturbed, no refinement step needed); the others: one forward + one backward sweep of the augmented factor [L 0; L_b I] (DESIGN.md 2)",
+                                      3: "every solveCompressed: one forward + one backward sweep of the augmented factor [L 0; L_b I]; the first pair after a factorisation "
+                                         "is checked against the leaf rows (residual measure of the adaptive refinement within the tolerance, no pivot perturbed) "
+                                         "- the witness for the others (DESIGN.md 2)"}[3 if step_paths and step_paths[0] == 3 else kkt.last_solve_path()],
+                       "solve_paths_last_step": list(step_paths),
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},

@@ -257,10 +257,12 @@ int pips_hip_kkt_last_ltsolve_from_factor(void* handle, int* flag);
  *   0  two leaf solves with adaptive refinement (K_i^-1 b_i, then K_i^-1 Br_i x0) and the two sparse border products;
  *   1  refined Lsolve, Ltsolve by one backward sweep of the augmented factor;
  *   2  one forward and one backward sweep of the augmented factor [L 0; L_b I]: the forward sweep leaves -Br_i^T K_i^-1 b_i in the
- *      border rows, the backward sweep started from D^-1 y with the border rows at x0 gives K_i^-1 (b_i - Br_i x0).
- * 1 and 2 carry no refinement; they are taken only while no pivot of the factorisation is perturbed, and 2 only after a
- * solveCompressed on the same factors went way 0 / 1 and its refined solves met the backward-error tolerance without a step (the
- * first solveCompressed after every factorisation is that witness; needs adaptive refinement, pips_hip_batch_set_refinement*). */
+ *      border rows, the backward sweep started from D^-1 y with the border rows at x0 gives K_i^-1 (b_i - Br_i x0);
+ *   3  the sweeps of 2 with their result checked: r_i = (b_i - Br_i x0) - K_i x_i within the refinement tolerance, else the result is
+ *      discarded and the call is repeated the refined way (one rank only).
+ * 1 and 2 carry no refinement; they are taken only while no pivot of the factorisation is perturbed, and 2 only after a witness on
+ * the same factors: a solveCompressed that went way 3, or way 0 / 1 with its refined solves meeting the backward-error tolerance
+ * without a step (the first solveCompressed after every factorisation; needs adaptive refinement, pips_hip_batch_set_refinement*). */
 int pips_hip_kkt_last_solve_path(void* handle, int* path);
 void pips_hip_kkt_destroy(void* handle);
 

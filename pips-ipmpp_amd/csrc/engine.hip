@@ -2294,6 +2294,40 @@ struct Engine {
       return PIPS_OK;
    }
 
+   // The measure of the adaptive refinement for a solution somebody else produced: worst block of ||rhs - K x||inf over the denominator of
+   // refine_mode (normwise backward error, or ||rhs||inf) - one product with the CSR values, the norms, one small copy to the host.
+   int residual_measure(const double* rhs_dev, const double* x_dev, double* worst_out) {
+      if (refine_steps <= 0 || !d_res || !d_norms) PIPS_FAIL(PIPS_ERR_STATE, "residual_measure: refinement buffers missing");
+      const size_t bytes = (size_t)n_total * sizeof(double);
+      timer.begin(stream, 11);
+      HIP_TRY(hipMemsetAsync(d_norms, 0, (size_t)3 * nblk * sizeof(double), stream));
+      hipLaunchKernelGGL(k_vec_block_absmax, dim3(absmax_chunks(), nblk), dim3(256), 0, stream, rhs_dev, d_blks, d_norms + nblk);
+      if (n_flong > 0) HIP_TRY(hipMemcpyAsync(d_res, rhs_dev, bytes, hipMemcpyDeviceToDevice, stream));
+      hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total * 8, 256, 65536)), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev, d_res, n_total,
+                         d_rowbase, 0LL, n_flong > 0 ? (const double*)nullptr : rhs_dev);
+      if (n_flong > 0)
+         hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev, d_res, d_rowbase, 0LL);
+      hipLaunchKernelGGL(k_vec_block_absmax, dim3(absmax_chunks(), nblk), dim3(256), 0, stream, d_res, d_blks, d_norms);
+      if (refine_mode == 1) hipLaunchKernelGGL(k_vec_block_absmax, dim3(absmax_chunks(), nblk), dim3(256), 0, stream, x_dev, d_blks, d_norms + 2 * nblk);
+      HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)3 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
+      timer.end(stream);
+      if (refine_mode == 1 && h_amax.empty()) {
+         h_amax.resize(nblk);
+         std::vector<BlkDesc> tmp(nblk);
+         HIP_TRY(hipMemcpyAsync(tmp.data(), d_blks, (size_t)nblk * sizeof(BlkDesc), hipMemcpyDeviceToHost, stream));
+         HIP_TRY(hipStreamSynchronize(stream));
+         for (int b = 0; b < nblk; ++b) h_amax[b] = tmp[b].repl_abs / (repl_rel > 0 ? repl_rel : 1.0);
+      }
+      HIP_TRY(hipStreamSynchronize(stream));
+      double worst = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+         const double den = refine_mode == 1 ? h_amax[b] * h_norms[2 * nblk + b] + h_norms[nblk + b] : h_norms[nblk + b];
+         if (den > 0.0) { const double q = h_norms[b] / den; if (!(q <= worst)) worst = q; }
+      }
+      *worst_out = worst;
+      return PIPS_OK;
+   }
+
    // The inertia counters travel to pinned host memory at the end of every factorisation (factor()); a query only waits for that
    // copy - not for whatever was queued behind the factorisation (the leaf solves of an Lsolve, say).
    int* h_inertia_pin = nullptr;
@@ -2877,7 +2911,16 @@ struct KktSystem {
    // solveCompressed on the SAME factors went the refined way and every refined leaf solve in it met the backward-error tolerance
    // without a step (aug_validated_gen == factor_gen).  The first solveCompressed after every factorisation is that witness.
    long long factor_gen = 0, aug_validated_gen = -1;
-   int last_solve_path = 0;   // 0: two refined leaf solves, 1: refined Lsolve + Ltsolve from the factor, 2: augmented sweeps
+   int last_solve_path = 0;   // 0: two refined leaf solves, 1: refined Lsolve + Ltsolve from the factor, 2: augmented sweeps, 3: augmented sweeps
+                              // whose result was checked (below)
+   // One rank: the witness is the first sweep pair itself - its result x_i is put into the leaf rows, r_i = b_i - Br_i x0 - K_i x_i, and
+   // accepted where the measure of the adaptive refinement is within the tolerance (one product with K instead of a refined solve and
+   // its extra backward sweep); a result that fails is thrown away, the saved right-hand side goes the refined way and the sweeps stay
+   // off for these factors (aug_failed_gen).  Several ranks keep the refined witness: the decision to repeat a solveCompressed would
+   // have to be taken by all ranks together.  PIPS_HIP_AUG_WITNESS=0: the refined witness everywhere.
+   long long aug_failed_gen = -1;
+   bool checked_witness = !(getenv("PIPS_HIP_AUG_WITNESS") && atoi(getenv("PIPS_HIP_AUG_WITNESS")) == 0);
+   double *d_bsave = nullptr, *d_b0save = nullptr;
    bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
    // 0 diagonals + zero SC, 1 leaf factorisation, 2 Schur reduction, 3 finalize, 4 root factorisation (its own stream),
@@ -2900,7 +2943,7 @@ struct KktSystem {
       if (ev_root_done) (void)hipEventDestroy(ev_root_done);
       if (comm_stream) (void)hipStreamDestroy(comm_stream);
       if (ev_reduced) (void)hipEventDestroy(ev_reduced);
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr, d_gall, d_gvec_all};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr, d_gall, d_gvec_all, d_bsave, d_b0save};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
@@ -4286,7 +4329,7 @@ int pips_hip_kkt_set_root_regularization(void* handle, double primal, double dua
 static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_leaf_dev, bool capturing) {
    Engine* e = k->leaves;
    int rc;
-   bool use_aug = false;
+   bool use_aug = false, verify = false;
    int lsolve_steps = 0;
    // with mz0 > 0 the caller's vector is [x0 | y0 | z0 | ylink | zlink]; the Schur system lives on the reduced vector
    // [x0 | y0 | ylink | zlink] (solveReducedLinkCons, sLinsysRootAug.C:397-433)
@@ -4326,10 +4369,21 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
-   if (!capturing && e->aug_sweeps_ok && e->refine_tol > 0.0 && k->aug_validated_gen == k->factor_gen) {
-      int pert = 1;
-      if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
-      use_aug = pert == 0;
+   if (!capturing && e->aug_sweeps_ok && e->refine_tol > 0.0 && k->aug_failed_gen != k->factor_gen) {
+      const bool validated = k->aug_validated_gen == k->factor_gen;
+      const bool may_check = k->checked_witness && k->n_ranks <= 1 && !k->force_reduce && e->refine_steps > 0;
+      if (validated || may_check) {
+         int pert = 1;
+         if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
+         use_aug = pert == 0;
+         verify = use_aug && !validated;
+      }
+   }
+   if (verify) {   // the right-hand side as the caller gave it: needed for the check, and for the refined pass if the check fails
+      if (!k->d_bsave) HIP_TRY(hipMalloc((void**)&k->d_bsave, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
+      if (!k->d_b0save) HIP_TRY(hipMalloc((void**)&k->d_b0save, (size_t)(k->S + k->mz0 + 1) * sizeof(double)));
+      HIP_TRY(hipMemcpyAsync(k->d_bsave, b_leaf_dev, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(k->d_b0save, b0_dev, (size_t)(k->S + k->mz0) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
    }
    k->timer.begin(e->stream, 5);
    if (use_aug) { if ((rc = e->forward_augmented(b_leaf_dev, red))) return rc; }
@@ -4374,6 +4428,23 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       if ((rc = e->backward_augmented(red, b_leaf_dev))) return rc;
       k->last_ltsolve_from_factor = true;
       k->last_solve_path = 2;
+      if (verify) {
+         // r_i = (b_i - Br_i x0) - K_i x_i over the blocks, measured like a refinement step would measure it
+         HIP_TRY(hipMemcpyAsync(k->d_t, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+         if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, -1.0))) return rc;
+         double worst = 0.0;
+         if ((rc = e->residual_measure(k->d_t, b_leaf_dev, &worst))) return rc;
+         if (worst <= e->refine_tol) {
+            k->aug_validated_gen = k->factor_gen;
+            k->last_solve_path = 3;
+         } else {   // not good enough without refinement: the refined path on the saved right-hand side, no sweeps on these factors
+            k->timer.end(e->stream);
+            k->aug_failed_gen = k->factor_gen;
+            HIP_TRY(hipMemcpyAsync(b_leaf_dev, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(b0_dev, k->d_b0save, (size_t)(k->S + k->mz0) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            return kkt_solve_compressed_enqueue(k, b0_dev, b_leaf_dev, capturing);
+         }
+      }
       k->timer.end(e->stream);
    } else {
    if (!capturing) {

@@ -741,7 +741,8 @@ class KktSystem:
         return bool(f.value)
 
     def last_solve_path(self):
-        """0: two refined leaf solves; 1: refined Lsolve + Ltsolve from the factor; 2: one forward + one backward sweep of the augmented factor"""
+        """0: two refined leaf solves; 1: refined Lsolve + Ltsolve from the factor; 2: one forward + one backward sweep of the augmented factor;
+        3: the same sweeps, their result checked against the leaf rows (the witness of a factorisation on one rank)"""
         f = C.c_int()
         _check(lib.pips_hip_kkt_last_solve_path(self._h, C.byref(f)), "pips_hip_kkt_last_solve_path")
         return int(f.value)

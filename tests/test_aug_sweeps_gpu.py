@@ -2,7 +2,8 @@
 Engine::forward_augmented / backward_augmented) against the oracle's solve_compressed (sLinsysRootAug.C:323-365 restated) and against the
 refined two-solve path on the same factors: dense-tail blocks whose simple leaves own border rows, time-coupled blocks with compact front
 panels (border rows only in the border-row arena), all-head blocks without a tail.  The path is taken only after a refined pass on the
-same factors needed no refinement step, and never while a pivot is perturbed."""
+same factors needed no refinement step - or, on one rank, after the first sweep pair's own result passed the residual check of the leaf
+rows (path 3) - and never while a pivot is perturbed."""
 import numpy as np
 import pytest
 import torch
@@ -66,8 +67,8 @@ def test_augmented_sweeps_match_oracle_and_refined_path(shape, monkeypatch):
         assert np.linalg.norm(g0 - want0) <= 1e-8 * np.linalg.norm(want0), (rep, paths)
         assert np.linalg.norm(gl - wantl) <= 1e-8 * np.linalg.norm(wantl), (rep, paths)
         sols.append((b0h, blh, g0, gl))
-    # the first call after the factorisation is the refined witness, the others ride on it
-    assert paths[0] in (0, 1) and paths[1] == 2 and paths[2] == 2, paths
+    # the first call after the factorisation is the witness (its sweeps are checked against the leaf rows), the others ride on it
+    assert paths[0] == 3 and paths[1] == 2 and paths[2] == 2, paths
     # the same right-hand side through the refined path on the same factors
     monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "0")
     bt2, kkt2 = _system(prob, force_head=shape == "time_coupled_all_head")
@@ -83,9 +84,41 @@ def test_augmented_sweeps_match_oracle_and_refined_path(shape, monkeypatch):
     kkt.factorize(diag * 1.3, xd0)
     b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
     kkt.solve_compressed(b0, bl)
-    assert kkt.last_solve_path() in (0, 1)
+    assert kkt.last_solve_path() == 3
     for h in (kkt, bt, kkt2, bt2):
         h.close()
+
+
+@pytest.mark.parametrize("witness", ["refined", "failing_check"])
+def test_witness_variants(witness, monkeypatch):
+    """refined: PIPS_HIP_AUG_WITNESS=0 keeps the refined pass as the witness (what several ranks always do).  failing_check: with a
+    tolerance no double-precision result can meet the check of the first sweep pair fails - its result is discarded, the saved right-hand
+    side goes the refined way, and the sweeps stay off for these factors; the answer is the oracle's either way."""
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")
+    if witness == "refined":
+        monkeypatch.setenv("PIPS_HIP_AUG_WITNESS", "0")
+    prob = _TimeCoupledProblem(5, 3, 3000, 1500, 10, 8, 6)
+    bt, kkt = _system(prob)
+    if witness == "failing_check":
+        bt.set_refinement_backward_error(2, 1e-30)
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    rng = np.random.default_rng(5)
+    paths = []
+    for rep in range(3):
+        b0h, blh = rng.standard_normal(prob.S), rng.standard_normal(prob.N * prob.n_leaf)
+        b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        paths.append(kkt.last_solve_path())
+        want0, wantl = _oracle(prob, b0h, blh)
+        assert np.linalg.norm(b0.cpu().numpy() - want0) <= 1e-8 * np.linalg.norm(want0), (rep, paths)
+        assert np.linalg.norm(bl.cpu().numpy() - wantl) <= 1e-8 * np.linalg.norm(wantl), (rep, paths)
+    if witness == "refined":
+        assert paths[0] in (0, 1) and paths[1:] == [2, 2], paths
+    else:
+        assert all(q in (0, 1) for q in paths), paths
+    kkt.close(); bt.close()
 
 
 def test_perturbed_pivots_keep_the_refined_path(monkeypatch):

@@ -33,9 +33,11 @@ def _check_line(d, n_gpus):
     assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
     step = d["phase_ms"]["step"]
-    # 4 solveCompressed: two leaf-solve passes each, or one where the sweeps of the augmented factor serve (never the first after a factorisation)
+    # 4 solveCompressed: two leaf-solve passes each, or one where the sweeps of the augmented factor serve (one rank: all four, the first
+    # of them checked against the leaf rows; several ranks: never the first after a factorisation)
     passes, aug = d["phase_ms"]["leaf_solve_passes"], d["phase_ms"]["leaf_solve_passes_augmented"]
-    assert step["leaf_factor"] > 0 and step["lsolve_leaf"] > 0 and 4 <= passes <= 8 and aug <= 3
+    assert step["leaf_factor"] > 0 and step["lsolve_leaf"] > 0 and 4 <= passes <= 8 and aug <= (4 if n_gpus == 1 else 3)
+    assert len(d["config"]["solve_paths_last_step"]) == 4
 
 
 def test_default_family_small():
