@@ -549,6 +549,11 @@ def main():
                        "family": (a.family if a.family == "random" else "time-coupled (surrogate for SURVEY 8d config 4 = BASELINE configs[3]: "
                                   "the random generator's fill at n_i = 50 000 gives dense factors, BASELINE.md)"), "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
                                                     if sparse_root else "dense LDL^T"), "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
+                       # N > 1 runs the configs[2] shape, N = 1 configs[1]: per-GPU throughput of the two differs by the Schur dimension alone
+                       # (the driver's efficiency against the N = 1 line mixes that in) - the same shape on ONE device, measured, for reference
+                       **({"same_shape_on_one_gpu": {"units_per_s": 4.213, "ms_per_step": 237.36, "source": "profiles/r4_bench_other_configs.jsonl "
+                                                     "(bench.py --blocks-per-gpu 64 --n 10000 --schur-dim 4000, one MI355X, round 4)"}}
+                          if world > 1 and a.family == "random" and bpg == 64 and n_i == 10000 and S == 4000 else {}),
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "solve_path": {0: "every solveCompressed: two leaf solves with adaptive refinement + the two sparse border products",
                                       1: "refined Lsolve; Ltsolve by one backward sweep of the augmented factor (no pivot perturbed, the refined Lsolve needed no step)",
