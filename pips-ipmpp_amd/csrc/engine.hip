@@ -4138,6 +4138,7 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    PhaseTimer& tm = k->timer;
    tm.on = e->timer.on;
    tm.reset();
+   if ((rc = k->root_wait())) return rc;                                         // the previous root factorisation still reads the value array
    HIP_TRY(hipMemsetAsync(r->d_kval, 0, nnz * sizeof(double), e->stream));
    tm.begin(e->stream, 1);
    if ((rc = e->factor(r->d_kval, 0))) return rc;
@@ -4176,10 +4177,34 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
       hipLaunchKernelGGL(k_add_const_diag, dim3(grid_for(k->S - k->n0, 256)), dim3(256), 0, e->stream, r->d_kval, 0, k->d_sc_rowptr, k->n0,
                          k->S - k->n0, -k->root_reg_dual);
    HIP_TRY(hipGetLastError());
-   tm.begin(e->stream, 4);
+   // The root engine's factorisation is a chain of small launches (the dissected root: 26 levels of fronts + the hubs' tile): on a stream
+   // of its own it runs beside the leaf sweeps of the next solveCompressed's Lsolve, as the dense root does (root_wait() joins before
+   // Dsolve, the next factorisation, queries).  PIPS_HIP_ROOT_SYNC=1: on the main stream.
+   static const bool root_async = !getenv("PIPS_HIP_ROOT_SYNC");
+   if (!root_async) {
+      tm.begin(e->stream, 4);
+      rc = r->factor(nullptr, 0);
+      tm.end(e->stream);
+      return rc;
+   }
+   if (!k->root_stream) {
+      int prio_lo = 0, prio_hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      HIP_TRY(hipStreamCreateWithPriority(&k->root_stream, hipStreamNonBlocking, prio_hi));
+      HIP_TRY(hipEventCreateWithFlags(&k->ev_sc_final, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&k->ev_root_done, hipEventDisableTiming));
+   }
+   HIP_TRY(hipEventRecord(k->ev_sc_final, e->stream));
+   HIP_TRY(hipStreamWaitEvent(k->root_stream, k->ev_sc_final, 0));
+   r->stream = k->root_stream;
+   tm.begin(k->root_stream, 4);
    rc = r->factor(nullptr, 0);
-   tm.end(e->stream);
-   return rc;
+   tm.end(k->root_stream);
+   r->stream = e->stream;                                                         // solves and queries run on the main stream
+   if (rc) return rc;
+   HIP_TRY(hipEventRecord(k->ev_root_done, k->root_stream));
+   k->root_pending = true;
+   return PIPS_OK;
 }
 
 int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const double* xdiag0_dev, const double* zdiag_link_dev) {
@@ -4404,6 +4429,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       hipLaunchKernelGGL(k_z0_elim, e->deterministic ? dim3(1) : dim3(grid_for(k->mz0, 128)), e->deterministic ? dim3(1) : dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
    if (k->sparse) {
+      if (!capturing && (rc = k->root_wait())) return rc;
       if ((rc = k->root_sp->solve(red))) return rc;
    } else {
       if (!capturing && (rc = k->root_wait())) return rc;   // (a captured sequence: joined before the capture began)
@@ -4620,9 +4646,9 @@ int pips_hip_kkt_get_schur(void* handle, double** SC_dev, int* ld) {
 int pips_hip_kkt_root_inertia(void* handle, int* pos, int* neg, int* zero) {
    KktSystem* k = (KktSystem*)handle;
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
-   if (k->sparse) return pips_hip_batch_inertia(k->root_sp.get(), 0, pos, neg, zero);
    int rcw = k->root_wait();
    if (rcw) return rcw;
+   if (k->sparse) return pips_hip_batch_inertia(k->root_sp.get(), 0, pos, neg, zero);
    return pips_hip_dense_ldl_inertia(k->root.get(), pos, neg, zero);
 }
 
