@@ -197,16 +197,29 @@ __global__ __launch_bounds__(256) void k_multi_reduce(RedPack pk, double* __rest
    if (pred && *pred == 0) return;
    const RedTerm t = pk.t[blockIdx.y];
    double acc = red_id(t.kind);
-   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < t.n; i += (long long)gridDim.x * blockDim.x) {
-      double v;
-      switch (t.kind) {
-         case R_DOT: v = t.a[i] * t.b[i]; if (t.w) v *= t.w[i]; break;
-         case R_ABSMAX: v = fabs(t.a[i]); break;
-         case R_MIN_MASKED: v = t.c[i] != 0.0 ? t.a[i] : INFINITY; break;
-         case R_STEPBOUND: v = t.b[i] < 0.0 ? -t.a[i] / t.b[i] : INFINITY; break;
-         default: v = (t.a[i] + t.p * t.c[i]) * (t.b[i] + t.q * t.d[i]); if (t.w) v *= t.w[i]; break;
+   // the kind is uniform over the launch row: one loop per kind, four entries per thread and trip with all their loads issued before the
+   // first use (a scalar loop with the switch inside streamed 12.8 M-entry vectors at 2 TB/s)
+   const long long stride = (long long)gridDim.x * blockDim.x, i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+   auto sweep = [&](auto term) {
+      long long i = i0;
+      for (; i + 3 * stride < t.n; i += 4 * stride) {
+         const double v0 = term(i), v1 = term(i + stride), v2 = term(i + 2 * stride), v3 = term(i + 3 * stride);
+         acc = red_comb(t.kind, acc, red_comb(t.kind, red_comb(t.kind, v0, v1), red_comb(t.kind, v2, v3)));
       }
-      acc = red_comb(t.kind, acc, v);
+      for (; i < t.n; i += stride) acc = red_comb(t.kind, acc, term(i));
+   };
+   switch (t.kind) {
+      case R_DOT:
+         if (t.w) sweep([&](long long i) { return t.a[i] * t.b[i] * t.w[i]; });
+         else sweep([&](long long i) { return t.a[i] * t.b[i]; });
+         break;
+      case R_ABSMAX: sweep([&](long long i) { return fabs(t.a[i]); }); break;
+      case R_MIN_MASKED: sweep([&](long long i) { return t.c[i] != 0.0 ? t.a[i] : (double)INFINITY; }); break;
+      case R_STEPBOUND: sweep([&](long long i) { return t.b[i] < 0.0 ? -t.a[i] / t.b[i] : (double)INFINITY; }); break;
+      default:
+         if (t.w) sweep([&](long long i) { return (t.a[i] + t.p * t.c[i]) * (t.b[i] + t.q * t.d[i]) * t.w[i]; });
+         else sweep([&](long long i) { return (t.a[i] + t.p * t.c[i]) * (t.b[i] + t.q * t.d[i]); });
+         break;
    }
    __shared__ double red[256];
    red[threadIdx.x] = acc;
