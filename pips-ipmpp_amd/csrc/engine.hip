@@ -876,7 +876,8 @@ struct Engine {
       d_det_tasks = nullptr; d_gbuf = nullptr; d_blk_group = nullptr;
       int rc;
       if ((rc = dev_upload(&d_det_tasks, all, stream)) || (rc = dev_upload(&d_blk_group, grp, stream))) return rc;
-      if (S > 0) HIP_TRY(hipMalloc((void**)&d_gbuf, (size_t)det_n_groups * det_gstride() * sizeof(double)));
+      // (the group buffers themselves are allocated by the first factorisation that has a Schur complement to fill: a system with the
+      //  sparse root never needs the det_n_groups x S x S doubles of the dense layout this is first called with)
       {  // the head's own Schur contributions join their block's group buffer
          g_sc_grp.release();
          std::vector<SlotEntry> ent(sc_e_keep.size());
@@ -1896,6 +1897,8 @@ struct Engine {
    int factor(double* SC, int ldSC) {
       if (!analyzed) PIPS_FAIL(PIPS_ERR_STATE, "factor called before analyze");
       HIP_TRY(hipSetDevice(device));
+      if (deterministic && SC && S > 0 && !d_gbuf && d_blk_group)
+         HIP_TRY(hipMalloc((void**)&d_gbuf, (size_t)det_n_groups * det_gstride() * sizeof(double)));
       timer.reset();
       if (timer.on) timer.begin(stream, 6);
       if (timer.on) timer.begin(stream, 0);
