@@ -247,6 +247,10 @@ int pips_hip_kkt_get_timing(void* handle, double* ms, int64_t* cnt, int n);
  * inside the outer BiCGStab, whose preconditioner this call is (LinearSystem.C:550-798).  Only with a fixed number of refinement steps
  * (pips_hip_batch_set_refinement with tol = 0: the adaptive variant reads norms on the host between steps), one rank, the dense root;
  * otherwise the call is issued launch by launch as before.  stats: captures made / replays so far. */
+/* The dense root is factorised on a stream of its own so that the leaf solves of the next solveCompressed run beside it (default on;
+ * PIPS_HIP_ROOT_SYNC=1 switches it off for the process).  own_stream = 0: on the main stream - for callers that ask for the root's
+ * inertia right after every factorisation (the order of LinearSystem::factorize_with_correct_inertia), where nothing can overlap. */
+int pips_hip_kkt_set_root_stream(void* handle, int own_stream);
 int pips_hip_kkt_set_solve_graph(void* handle, int on);
 int pips_hip_kkt_solve_graph_stats(void* handle, int64_t* captures, int64_t* replays);
 /* 1 if the last pips_hip_kkt_solve_compressed took its Ltsolve from the augmented factor (one unrefined backward sweep: only while no

@@ -2874,6 +2874,8 @@ struct KktSystem {
    hipStream_t root_stream = nullptr;
    hipEvent_t ev_sc_final = nullptr, ev_root_done = nullptr;
    bool root_pending = false;
+   bool root_own_stream = true;   // pips_hip_kkt_set_root_stream: a caller that asks for the root's inertia after every factorisation (the IPM
+                                  // harness) has nothing to run beside the root - the second stream then only costs (measured: section 4.3b)
    int root_wait() {
       if (root_pending) {
          if (root && root->check_pending) {   // Bunch-Kaufman root: were there indices without a pivot inside their tile?  (host wait for the
@@ -4184,7 +4186,8 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    // of its own it runs beside the leaf sweeps of the next solveCompressed's Lsolve, as the dense root does (root_wait() joins before
    // Dsolve, the next factorisation, queries): 40.6 -> 39.9 ms per unit on the configs[3] share.  OPT-IN (PIPS_HIP_SPARSE_ROOT_ASYNC=1):
    // one bench run of about fifteen with it did not finish within its time limit on the GPU box and the cause has not been found.
-   static const bool root_async = getenv("PIPS_HIP_SPARSE_ROOT_ASYNC") && atoi(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC")) != 0 && !getenv("PIPS_HIP_ROOT_SYNC");
+   static const bool root_async_env = getenv("PIPS_HIP_SPARSE_ROOT_ASYNC") && atoi(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC")) != 0 && !getenv("PIPS_HIP_ROOT_SYNC");
+   const bool root_async = root_async_env && k->root_own_stream;
    if (!root_async) {
       tm.begin(e->stream, 4);
       rc = r->factor(nullptr, 0);
@@ -4319,7 +4322,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    HIP_TRY(hipGetLastError());
    tm.end(e->stream);
    static const bool root_async_env = !getenv("PIPS_HIP_ROOT_SYNC");
-   const bool root_async = root_async_env && k->root->dist_P <= 1;   // the distributed root issues collectives: main stream
+   const bool root_async = root_async_env && k->root_own_stream && k->root->dist_P <= 1;   // the distributed root issues collectives: main stream
    if (!root_async) {
       tm.begin(e->stream, 4);
       rc = k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)
@@ -4558,6 +4561,15 @@ int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_d
    }
    HIP_TRY(hipGraphLaunch(k->graph_exec, e->stream));
    ++k->graph_replays;
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_set_root_stream(void* handle, int own_stream) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   int rc = k->root_wait();
+   if (rc) return rc;
+   k->root_own_stream = own_stream != 0;
    return PIPS_OK;
 }
 

@@ -1515,6 +1515,8 @@ int build(Ipm* p, int n_blocks, const pips_ipm_block* blocks, int myl, int mzl, 
       rc = pips_hip_kkt_create(&p->kkt, p->batch, n0, my0, myl, e_mzl, rp(A0), A0.ci, A0.v, rp(F0), F0.ci, F0.v, rp(G0), G0.ci, G0.v, p->comm, p->rank,
                                p->n_ranks);
    if (rc) return rc;
+   // factorize() asks for every inertia right after the factorisation (the inertia loop): nothing would run beside a root on its own stream
+   if ((rc = pips_hip_kkt_set_root_stream(p->kkt, 0))) return rc;
    HIP_TRYH(hipGetDevice(&p->device));
    if ((rc = p->alloc(&p->d_red, 64 * (long long)p->n_ranks))) return rc;
    if (p->n_ranks > 1) {

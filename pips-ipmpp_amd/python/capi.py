@@ -61,7 +61,7 @@ SYMBOLS = [
     "pips_hip_batch_get_timing", "pips_hip_batch_destroy",
     "pips_hip_kkt_create", "pips_hip_kkt_create_sparse", "pips_hip_kkt_get_schur_sparse", "pips_hip_kkt_sparse_root_info", "pips_hip_kkt_factorize", "pips_hip_kkt_set_root_regularization", "pips_hip_kkt_solve_compressed", "pips_hip_kkt_get_schur",
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
-    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_last_ltsolve_from_factor", "pips_hip_kkt_last_solve_path", "pips_hip_kkt_set_solve_graph", "pips_hip_kkt_solve_graph_stats", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
+    "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_last_ltsolve_from_factor", "pips_hip_kkt_last_solve_path", "pips_hip_kkt_set_solve_graph", "pips_hip_kkt_set_root_stream", "pips_hip_kkt_solve_graph_stats", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
     "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_comm_set_external_broadcast", "pips_hip_broadcast", "pips_hip_comm_has_broadcast", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
@@ -750,6 +750,10 @@ class KktSystem:
     def set_solve_graph(self, on=True):
         """solveCompressed as a captured / replayed HIP graph (fixed refinement, one rank, dense root; else launch by launch)."""
         _check(lib.pips_hip_kkt_set_solve_graph(self._h, C.c_int(1 if on else 0)), "pips_hip_kkt_set_solve_graph")
+
+    def set_root_stream(self, own_stream):
+        """dense root on a stream of its own (default) or on the main stream (callers that query the inertia after every factorisation)"""
+        _check(lib.pips_hip_kkt_set_root_stream(self._h, C.c_int(1 if own_stream else 0)), "pips_hip_kkt_set_root_stream")
 
     def solve_graph_stats(self):
         c, r = C.c_int64(), C.c_int64()
