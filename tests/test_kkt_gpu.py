@@ -156,3 +156,30 @@ def test_reduction_path_with_host_supplied_allreduce(monkeypatch):
         inner.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_root_on_the_main_stream_gives_the_same_bits(monkeypatch):
+    """pips_hip_kkt_set_root_stream(0): the dense root factorised on the main stream instead of a stream of its own (what a caller does that
+    asks for the inertia after every factorisation) - same kernels in the same order, so the root's solution and inertia are identical
+    to the bit in deterministic mode (the leaves' atomics aside, which that mode removes)."""
+    import torch
+    monkeypatch.setenv("PIPS_HIP_DETERMINISTIC", "1")
+    prob = Problem(78, 4, 600, 300, 60, 40, 0.02)
+    diag = torch.tensor(np.concatenate([b["diag"] for b in prob.blocks]), device="cuda")
+    xd0 = torch.tensor(prob.x_diag0, device="cuda")
+    rng = np.random.default_rng(1)
+    b0h, blh = rng.standard_normal(prob.S), rng.standard_normal(prob.N * prob.n_leaf)
+    res = []
+    for own in (True, False, True):
+        bt, kkt = build_system(prob)
+        kkt.set_root_stream(own)
+        for rep in range(2):       # twice: the second factorisation has to wait for the first one's root before it clears the Schur complement
+            kkt.factorize(diag, xd0)
+            b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+            kkt.solve_compressed(b0, bl)
+            bt.sync()
+        res.append((b0.cpu().numpy(), bl.cpu().numpy(), kkt.root_inertia()))
+        kkt.close(); bt.close()
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and r[2] == res[0][2]
+    assert res[0][2] == (prob.n0, prob.myl, 0)
