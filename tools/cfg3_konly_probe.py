@@ -1,0 +1,30 @@
+"""Development aid: the configs[3] share's leaf factorisation with the border taken away (T_i = 0, no linking rows): what the head costs for the
+rows of K alone - the lower bound of any scheme that treats the border rows apart.  usage: python tools/cfg3_konly_probe.py [blocks n_i]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp, torch
+import pips_ipmpp_amd as pa
+import bench
+nb, n_i = (int(a) for a in sys.argv[1:3]) if len(sys.argv) >= 3 else (256, 50000)
+c3 = pa.CONFIG3_SHARE
+blocks, F0, my_i, myl = pa.time_coupled_blocks(nb, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
+for variant in ("with border", "K only"):
+    def data(b):
+        W, T, F = blocks[b]
+        if variant == "K only":
+            T = pa.Csr(T.nrows, T.ncols, np.zeros(T.nrows + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+            F = pa.Csr(F.nrows, F.ncols, np.zeros(F.nrows + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+        return W, T, F
+    bt, diag_h = bench.build_rank_problem(pa, 5, list(range(nb)), n_i, my_i, c3["n0"], myl, 0.0, 0, block_data=data)
+    diag = torch.tensor(diag_h, device="cuda")
+    S = c3["n0"] + myl
+    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
+    bt.set_diagonals(diag)
+    for rep in range(2): bt.factor(SC, S); bt.sync()
+    bt.set_timing(True); bt.factor(SC, S); bt.sync(); tm = bt.get_timing(); bt.set_timing(False)
+    torch.cuda.synchronize(); t0 = time.time()
+    for rep in range(3): bt.factor(SC, S)
+    bt.sync(); dt = (time.time() - t0) / 3 * 1e3
+    info = bt.info()
+    print(f"{variant}: factor {dt:.2f} ms, head {tm['head'][0]:.2f} ms, nnzL {info['nnzL']:,}, levels {info['n_levels']}, max front {info['max_front']}, nb {info['nb']}", flush=True)
+    bt.close()
