@@ -26,5 +26,14 @@ for variant in ("with border", "K only"):
     for rep in range(3): bt.factor(SC, S)
     bt.sync(); dt = (time.time() - t0) / 3 * 1e3
     info = bt.info()
+    if variant == "with border" and os.environ.get("PROBE_WIDE"):
+        # primal diagonals over sixteen decades, as late interior-point iterations have them: does the head's time depend on the values?
+        rngw = np.random.default_rng(3)
+        dw = diag_h.copy().reshape(nb, -1)
+        dw[:, :n_i] = 10.0 ** rngw.uniform(-8, 8, (nb, n_i))
+        bt.set_diagonals(torch.tensor(dw.reshape(-1), device="cuda"))
+        for rep in range(2): bt.factor(SC, S); bt.sync()
+        bt.set_timing(True); bt.factor(SC, S); bt.sync(); tw = bt.get_timing(); bt.set_timing(False)
+        print(f"   primal diagonals 1e-8 .. 1e8: head {tw['head'][0]:.2f} ms, perturbed pivots {sum(bt.inertia(b)[2] for b in range(nb))}", flush=True)
     print(f"{variant}: factor {dt:.2f} ms, head {tm['head'][0]:.2f} ms, nnzL {info['nnzL']:,}, levels {info['n_levels']}, max front {info['max_front']}, nb {info['nb']}", flush=True)
     bt.close()
