@@ -1292,13 +1292,13 @@ struct Engine {
                for (int l = 0; l < (int)bs.sn.size(); ++l) {
                   const HeadSupernode& hs = bs.sn[l];
                   if (hs.rb >= hs.r || (is_simple(hs) && bs.sn_parent[l] < 0)) continue;
-                  const int nbj = hs.r - hs.rb, rp = (nbj + 3) & ~3, sz = hs.w * rp + ((hs.w + 1) & ~1), nt = rp / 4;
+                  const int nbj = hs.r - hs.rb, rp = (nbj + 3) & ~3, sz = hs.w * rp + ((hs.w + 1) & ~1);
                   if (cur.cnt == BB_GMAX || cur.ndoubles + sz > bb_stage) flush();
                   if (cur.cnt == 0) { cur.src = bb_total; cur.pos = (long long)h_bbpos.size(); cur.first = (int)h_meta.size(); }
                   h_meta.push_back(BbMeta{cur.ndoubles, cur.npos, hs.w, nbj, cur.ntiles, 0, 0, 0});
                   h_sns[sorted_id[b][l]].bb = bb_total;
                   for (int a = hs.rb; a < hs.r; ++a) h_bbpos.push_back(bs.rowidx[hs.rows + a] - bs.n);
-                  ++cur.cnt; cur.ndoubles += sz; cur.ntiles += nt * (nt + 1) / 2; cur.npos += nbj;
+                  ++cur.cnt; cur.ndoubles += sz; cur.ntiles += bb_tile_count(rp); cur.npos += nbj;
                   bb_total += sz;
                }
                flush();

@@ -1018,6 +1018,21 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
 // FP64 atomics (targets shared between blocks and shares), or - gbuf != nullptr - plain adds into the group's buffer by launches that
 // hold at most one block of every group.
 constexpr int BB_GMAX = 8;
+// register tile of k_border_schur: BB_TR rows x 4 columns of L_b D L_b^T per thread and step (BB_TR = 4: square tiles over the lower triangle;
+// 8: two row groups per tile - six LDS reads per 32 multiply-adds instead of four per 16)
+#ifndef PIPS_BB_TR
+#define PIPS_BB_TR 4
+#endif
+constexpr int BB_TR = PIPS_BB_TR;
+// tiles of a supernode with rp (a multiple of 4) padded border rows; tile t -> (column group tb of 4, row group ta of BB_TR)
+__host__ __device__ inline int bb_tile_count(int rp) {
+   const int nt4 = rp >> 2;
+   if (BB_TR == 4) return nt4 * (nt4 + 1) / 2;
+   const int nt8 = (rp + 7) >> 3;
+   int cnt = 0;
+   for (int tb = 0; tb < nt4; ++tb) cnt += nt8 - (tb >> 1);
+   return cnt;
+}
 struct BbMeta { int lt_off, pos_off, w, nbj, tile0, pad0, pad1, pad2; };   // staging offset of Lt (doubles; the pivots follow at + w * rp),
                                                                           // offset of the rows' positions inside the batch's list, tiles before it
 struct BbBatch {
@@ -1107,24 +1122,38 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
          const double* Lt = stage + m.lt_off;
          const double* dk = Lt + w * rp;
          const int* pos = spos + m.pos_off;
-         const int tb = packed_col(t, nt), ta = tb + (t - (tb * nt - tb * (tb - 1) / 2));
-         const int a0 = 4 * ta, b0 = 4 * tb;
+         int tb, a0;
+         if (BB_TR == 4) {
+            tb = packed_col(t, nt);
+            a0 = 4 * (tb + (t - (tb * nt - tb * (tb - 1) / 2)));
+         } else {   // column groups 2 j and 2 j + 1 both start at row group j: nt8 - j tiles each
+            const int nt8 = (rp + 7) >> 3;
+            int j = packed_col(t >> 1, nt8);
+            while (j > 0 && 2 * (j * nt8 - j * (j - 1) / 2) > t) --j;
+            while (j + 1 < nt8 && 2 * ((j + 1) * nt8 - (j + 1) * j / 2) <= t) ++j;
+            const int rem = t - 2 * (j * nt8 - j * (j - 1) / 2), per = nt8 - j;
+            tb = 2 * j + (rem >= per ? 1 : 0);
+            a0 = 8 * (j + (rem >= per ? rem - per : rem));
+         }
+         const int b0 = 4 * tb;
          if (pos[b0] >= jhi || pos[min(b0 + 3, nbj - 1)] < jlo) return;   // none of the tile's columns belongs to this part (positions ascend)
-         double acc[4][4];
+         double acc[BB_TR][4];
 #pragma unroll
-         for (int x = 0; x < 4; ++x)
+         for (int x = 0; x < BB_TR; ++x)
 #pragma unroll
             for (int z = 0; z < 4; ++z) acc[x][z] = 0.0;
 #pragma unroll 4
          for (int k = 0; k < w; ++k) {
             const double2_t* ca = (const double2_t*)(Lt + k * rp + a0);
             const double2_t* cb = (const double2_t*)(Lt + k * rp + b0);
-            const double2_t a01 = ca[0], a23 = ca[1], b01 = cb[0], b23 = cb[1];
+            double la[BB_TR];
+#pragma unroll
+            for (int x = 0; x < BB_TR; x += 2) { const double2_t v = ca[x >> 1]; la[x] = v.x; la[x + 1] = v.y; }   // (rows beyond rp: the next column's first entries - their sums are never stored)
+            const double2_t b01 = cb[0], b23 = cb[1];
             const double d = dk[k];
-            const double la[4] = {a01.x, a01.y, a23.x, a23.y};
             const double lb[4] = {b01.x * d, b01.y * d, b23.x * d, b23.y * d};
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < BB_TR; ++x)
 #pragma unroll
                for (int z = 0; z < 4; ++z) acc[x][z] += la[x] * lb[z];
          }
@@ -1135,7 +1164,7 @@ __global__ __launch_bounds__(BLOCK) void k_border_schur(const int* __restrict__ 
                const int j = pos[b];
                double* cj = C + (j * nb - j * (j - 1) / 2) - j - cbase;
 #pragma unroll
-               for (int x = 0; x < 4; ++x) {
+               for (int x = 0; x < BB_TR; ++x) {
                   const int a = a0 + x;
                   if (a < nbj && a >= b) lds_add(cj + pos[a], -acc[x][z]);
                }
