@@ -10,7 +10,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -3362,10 +3364,30 @@ void pips_hip_batch_destroy(void* handle) { delete (Engine*)handle; }
 
 // ---- single leaf solver handle -------------------------------------------------------------------------------------
 struct LdlGroup;
+// pips_hip_ldl_factor_schur of single handles: the leaf kernels address the Schur complement as a dense S x S array, but a leaf only touches
+// the nb x nb entries of its non-empty border columns - one S x S scratch array per DEVICE serves every handle (a call leaves it with a
+// stream synchronisation; 64 handles with an array each were 32 GB at S = 8000), and only the compact nb x nb block travels to the host.
+struct SchurScratch {
+   std::mutex mu;
+   std::map<int, std::pair<double*, size_t>> per_device;   // device -> (array, doubles)
+};
+static SchurScratch g_schur_scratch;
+
+// C[i + j * nb] = SC[bm[i] + bm[j] * ld] (the block of a leaf's border columns, column-major; the lower triangle is what the caller reads) -
+// and SC is left zero on the whole block, whichever triangle a Schur mode wrote
+__global__ void k_schur_take_block(double* __restrict__ SC, int ld, const int* __restrict__ bm, int nb, double* __restrict__ C) {
+   const int j = blockIdx.y;
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+      double* p = SC + bm[i] + (long long)bm[j] * ld;
+      C[i + (long long)j * nb] = *p;
+      *p = 0.0;
+   }
+}
+
 struct LdlHandle {
    Engine eng;
    bool have_perm = false;
-   double* d_sc = nullptr;        // S x S Schur term of this leaf (pips_hip_ldl_factor_schur)
+   double* d_sc = nullptr;        // compact nb x nb Schur term of this leaf (pips_hip_ldl_factor_schur)
    std::vector<double> h_sc;
    std::shared_ptr<LdlGroup> group;   // the leaves of a rank bound into one batch engine (pips_hip_ldl_factor_schur_batch)
    int group_index = -1;
@@ -3475,20 +3497,38 @@ int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const dou
    HIP_TRY(hipSetDevice(e.device));
    if ((rc = pips_hip_batch_set_values(&e, 0, K_vals_host))) return rc;
    if (e.nnzB_total > 0) HIP_TRY(hipMemcpyAsync(e.d_bval, Bt_vals_host, (size_t)e.nnzB_total * sizeof(double), hipMemcpyHostToDevice, e.stream));
-   if (!h->d_sc) HIP_TRY(hipMalloc((void**)&h->d_sc, (size_t)S * S * sizeof(double)));
-   HIP_TRY(hipMemsetAsync(h->d_sc, 0, (size_t)S * S * sizeof(double), e.stream));
-   if ((rc = e.factor(h->d_sc, S))) return rc;
-   h->h_sc.resize((size_t)S * S);
-   HIP_TRY(hipMemcpyAsync(h->h_sc.data(), h->d_sc, (size_t)S * S * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+   const BlockSym& bs = e.sym[0];
+   const int nb = (int)bs.bmap.size();
+   // the device's shared S x S scratch array: zero on entry (allocated zeroed; every call takes its block out again and leaves zeros)
+   double* scratch = nullptr;
+   {
+      std::lock_guard<std::mutex> lock(g_schur_scratch.mu);
+      auto& slot = g_schur_scratch.per_device[e.device];
+      if (slot.second < (size_t)S * S) {
+         if (slot.first) (void)hipFree(slot.first);
+         slot = {nullptr, 0};
+         HIP_TRY(hipMalloc((void**)&slot.first, (size_t)S * S * sizeof(double)));
+         slot.second = (size_t)S * S;
+         HIP_TRY(hipMemset(slot.first, 0, (size_t)S * S * sizeof(double)));
+      }
+      scratch = slot.first;
+   }
+   if ((rc = e.factor(scratch, S))) {   // (whatever reached the scratch array must not meet the next handle)
+      (void)hipStreamSynchronize(e.stream);
+      (void)hipMemset(scratch, 0, (size_t)S * S * sizeof(double));
+      return rc;
+   }
+   if (nb > 0) {
+      if (!h->d_sc) HIP_TRY(hipMalloc((void**)&h->d_sc, (size_t)nb * nb * sizeof(double)));
+      hipLaunchKernelGGL(k_schur_take_block, dim3(std::max(1, std::min(16, (nb + 255) / 256)), nb), dim3(256), 0, e.stream, scratch, S, e.d_bmap, nb, h->d_sc);
+      h->h_sc.resize((size_t)nb * nb);
+      HIP_TRY(hipMemcpyAsync(h->h_sc.data(), h->d_sc, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+   }
    HIP_TRY(hipStreamSynchronize(e.stream));
    // device: column-major with the lower triangle valid; caller: row-major DenseSymmetricMatrix, lower triangle meaningful
    // (DenseStorage.C:64-83): entry [i][j], i >= j, takes the device's (i, j) - only the rows of this leaf's non-empty border columns differ from zero
-   const BlockSym& bs = e.sym[0];
-   for (int cb : bs.bmap)
-      for (int ra : bs.bmap) {
-         if (ra < cb) continue;
-         SC_host[(size_t)ra * ldSC + cb] += h->h_sc[(size_t)ra + (size_t)cb * S];
-      }
+   for (int j = 0; j < nb; ++j)
+      for (int i = j; i < nb; ++i) SC_host[(size_t)bs.bmap[i] * ldSC + bs.bmap[j]] += h->h_sc[(size_t)i + (size_t)j * nb];
    return e.sweep.take_error("pips_hip_ldl_factor_schur");
 }
 
