@@ -3500,9 +3500,10 @@ int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const dou
    const BlockSym& bs = e.sym[0];
    const int nb = (int)bs.bmap.size();
    // the device's shared S x S scratch array: zero on entry (allocated zeroed; every call takes its block out again and leaves zeros)
+   // (held to the end of the call: host threads that factorise their leaves side by side take turns on the scratch array)
+   std::lock_guard<std::mutex> scratch_lock(g_schur_scratch.mu);
    double* scratch = nullptr;
    {
-      std::lock_guard<std::mutex> lock(g_schur_scratch.mu);
       auto& slot = g_schur_scratch.per_device[e.device];
       if (slot.second < (size_t)S * S) {
          if (slot.first) (void)hipFree(slot.first);
