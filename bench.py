@@ -78,6 +78,55 @@ def head_traffic(family, n_blocks, n_i, key="hbm_bytes_per_factorize"):
         return None
 
 
+def shape_key(family, bpg, n_i, S_whole, chain_blocks):
+    """what one GPU holds in a run, machine-readable (config.shape of the line): the key under which one-GPU lines are looked up"""
+    return {"family": family, "blocks_per_gpu": int(bpg), "n": int(n_i), "schur_dim": int(S_whole), "chain_blocks": (int(chain_blocks) if chain_blocks else None)}
+
+
+def same_shape_on_one_gpu(shape):
+    """The newest committed ONE-GPU bench line of the per-GPU shape an N-GPU run uses (profiles/r*_bench_other_configs.jsonl,
+    profiles/r*_cfg3*_bench_n1.json): the one-device reference of that shape for reading a scaling series whose N = 1 line is
+    another configuration.  Read from the files, never pasted; None when no such line is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_other_configs.jsonl")) + glob.glob(os.path.join(ROOT, "profiles", "r*_cfg3*_bench_n1.json")),
+                   key=lambda q: (-int(re.match(r"r(\d+)_", os.path.basename(q)).group(1)), q))
+    for path in files:
+        for raw in open(path):
+            try:
+                d = json.loads(raw)
+            except Exception:
+                continue
+            if not isinstance(d, dict) or d.get("n_gpus") != 1 or "config" not in d:
+                continue
+            have = d["config"].get("shape")
+            if have is None:     # lines of rounds 1-4 (random family): "<B> blocks x <n> vars (...), Schur dim <S>, <B> blocks/GPU"
+                m = re.match(r"(\d+) blocks x (\d+) vars .*Schur dim (\d+), (\d+) blocks/GPU", d["config"].get("workload", ""))
+                if m and d["config"].get("family", "random") == "random":
+                    have = shape_key("random", m.group(4), m.group(2), m.group(3), None)
+            if have == shape and not d["config"].get("deterministic"):
+                return {"units_per_s": d["value"], "ms_per_step": d["ms_per_step"], "source": os.path.relpath(path, ROOT)}
+    return None
+
+
+def workload_label(family, world, bpg, n_i, my_i, rho, S, whole=None, myl=None):
+    """config.workload: what was run, and which BASELINE.json configuration it is"""
+    total = world * bpg
+    if family == "random":
+        tag = (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else
+               " [BASELINE configs[2]]" if world == 8 and bpg == 64 and n_i == 10000 and S == 4000 else
+               f" [BASELINE configs[2] shape (Schur dim 4k, 64 blocks/GPU) on {world} of its 8 GPUs]" if world > 1 and bpg == 64 and n_i == 10000 and S == 4000 else "")
+        return f"{total} blocks x {n_i} vars ({my_i} eq rows, rho={rho}), Schur dim {S}, {bpg} blocks/GPU" + tag
+    c3 = whole.G == 2048 and whole.S == 8000 and n_i == 50000
+    tag = (" [BASELINE configs[3]]" if c3 and total == whole.G else
+           f" [BASELINE configs[3] shape on {world} of its 8 GPUs]" if c3 and bpg == 256 else
+           " [the 256-block chain of rounds 3-4: 31 linking rows per pair]" if whole.G == 256 and whole.S == 8000 and n_i == 50000 and bpg == 256 else "")
+    return (f"time-coupled chain of {whole.G} blocks x {n_i} vars ({my_i} banded eq rows, 10 nnz/row), {whole.n0} first-stage variables, "
+            f"{whole.myl} two-link rows over its {whole.G - 1} neighbouring pairs, Schur dim {whole.S}: "
+            + (f"all of it on {world} GPU(s), {bpg} blocks/GPU" if total == whole.G else
+               f"blocks 0..{total - 1} on {world} GPU(s), {bpg} blocks/GPU, with the {myl} linking rows they touch (Schur dim {S})") + tag)
+
+
 def build_rank_problem(pa, seed, blocks, n_i, my_i, n0, myl, rho, device, block_data=None, threads=None):
     """block_data: b -> (W, T, F) for families other than the generator's"""
     S = n0 + myl
@@ -274,8 +323,13 @@ def main():
                     help="root system: dense LDL^T of the S x S Schur complement, or the sparse root (2-link structure: the Schur complement is "
                          "kept as a CSR value array and factorised by a one-block sparse engine); auto = sparse for the time-coupled family")
     ap.add_argument("--family", choices=["random", "time-coupled"], default="random",
-                    help="random: the generator of SURVEY 8d (BASELINE configs[1], [2], [4]); time-coupled: banded blocks with 2-link rows "
-                         "(configs[3]; --schur-dim and --rho are ignored: S = 95 + 31 (blocks - 1))")
+                    help="random: the generator of SURVEY 8d (BASELINE configs[1], [2], [4]); time-coupled: banded blocks with 2-link rows - "
+                         "ONE fixed chain (configs[3]: --chain-blocks 2048, --schur-dim 8000) of which rank r holds blocks "
+                         "[r * blocks-per-gpu, (r + 1) * blocks-per-gpu); --rho is ignored")
+    ap.add_argument("--chain-blocks", type=int, default=None,
+                    help="time-coupled family: blocks of the whole chain (default 2048 = BASELINE configs[3]; 256 = the 256-block chain of "
+                         "rounds 3-4, 31 linking rows per pair).  Fewer ranks than the chain needs run its first gpus * blocks-per-gpu blocks "
+                         "with the linking rows those blocks touch")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -285,7 +339,7 @@ def main():
     if a.gpus != world and int(os.environ.get("RANK", "0")) == 0:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); the line reports n_gpus = {world}\n")
     if a.schur_dim is None:
-        a.schur_dim = 2000 if world == 1 else 4000
+        a.schur_dim = 8000 if a.family == "time-coupled" else 2000 if world == 1 else 4000
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -314,15 +368,22 @@ def main():
     bpg = a.blocks_per_gpu
     blocks = list(range(rank * bpg, (rank + 1) * bpg))
     n_blocks_total = bpg * world
-    fam_blocks = fam_F0 = None
+    fam_blocks = fam_F0 = chain = whole = None
     if a.family == "time-coupled":
-        c3 = pa.CONFIG3_SHARE
-        # every rank draws the whole chain (the 2-link rows tie neighbouring blocks together) and keeps its contiguous share
-        fam_blocks, fam_F0, my_i, myl = pa.time_coupled_blocks(n_blocks_total, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
-        n0 = c3["n0"]
+        # ONE fixed chain (BASELINE configs[3]: 2048 blocks, S = 8000) mapped onto the ranks as the reference maps its tree
+        # (Readers/Distributed/DistributedTree.C:62-89): a rank draws ONLY its own blocks (every block has its own generator), so host
+        # memory and set-up time per rank do not depend on the number of ranks.  With fewer ranks than the chain needs the problem is
+        # the chain's first world * bpg blocks and the linking rows they touch (TimeCoupledChain.prefix).
+        whole = pa.config3_chain(n_i, a.chain_blocks, a.schur_dim)
+        if n_blocks_total > whole.G:
+            raise SystemExit(f"bench.py: {world} rank(s) x {bpg} blocks exceed the chain's {whole.G} blocks (--chain-blocks)")
+        chain = whole.prefix(n_blocks_total)
+        fam_blocks = dict(zip(blocks, chain.blocks(blocks[0], blocks[-1] + 1)))
+        fam_F0, my_i, myl, n0 = chain.F0(), chain.my_i, chain.myl, chain.n0
     else:
         n0 = myl = a.schur_dim // 2
     S = n0 + myl
+    shape = shape_key(a.family, bpg, n_i, whole.S if whole is not None else S, whole.G if whole is not None else None)
 
     comm = None
     comm_kind = "none"
@@ -395,9 +456,15 @@ def main():
     if sparse_root:
         if fam_blocks is None:
             raise SystemExit("--root sparse needs --family time-coupled (the random family's Schur complement is dense)")
-        # non-empty border columns of EVERY block of the problem (every rank reduces the same pattern): x0 columns T touches, rows of F
-        all_cols = [np.concatenate([np.unique(T.colidx), n0 + np.nonzero(np.diff(F.rowptr) > 0)[0]]).astype(np.int32)
-                    for (_, T, F) in fam_blocks]
+        # non-empty border columns of EVERY block of the problem (every rank reduces the same pattern): x0 columns T touches, rows of F.
+        # A rank knows its own blocks; the lists of the others come over the process group (a few hundred integers per block)
+        mine = [chain.border_columns(b, fam_blocks[b][1]) for b in blocks]
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            all_cols = [c for part in gathered for c in part]
+        else:
+            all_cols = mine
     kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, comm=comm, rank=rank, n_ranks=world, sparse_root=sparse_root, all_block_cols=all_cols)
     dev = torch.device("cuda", local_rank)
     diag = torch.tensor(diag_h, device=dev)
@@ -537,23 +604,14 @@ def main():
             "value": round(world * a.steps / dt, 4), "unit": f"{bpg}-block work units/s (1 factorize + 4 solveCompressed)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{n_blocks_total} blocks x {n_i} vars ({my_i} eq rows, rho={a.rho}), Schur dim {S}, "
-                                    f"{bpg} blocks/GPU" + (" [BASELINE configs[1]]" if world == 1 and bpg == 64 and n_i == 10000 and S == 2000 else
-                                                           " [BASELINE configs[2]]" if world == 8 and bpg == 64 and n_i == 10000 and S == 4000 else
-                                                           f" [BASELINE configs[2] shape (Schur dim 4k, 64 blocks/GPU) on {world} of its 8 GPUs]"
-                                                           if world > 1 and bpg == 64 and n_i == 10000 and S == 4000 else ""))
-                       if a.family == "random" else
-                       (f"time-coupled family: {n_blocks_total} blocks x {n_i} vars ({my_i} banded eq rows, 10 nnz/row), 95 first-stage variables, "
-                        f"31 two-link rows per neighbouring pair, Schur dim {S}, {bpg} blocks/GPU"
-                        + (" [per-GPU share of BASELINE configs[3]]" if bpg == 256 and n_i == 50000 else "")),
+            "config": {"workload": workload_label(a.family, world, bpg, n_i, my_i, a.rho, S, whole, myl),
+                       "shape": shape,
                        "family": (a.family if a.family == "random" else "time-coupled (surrogate for SURVEY 8d config 4 = BASELINE configs[3]: "
                                   "the random generator's fill at n_i = 50 000 gives dense factors, BASELINE.md)"), "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
                                                     if sparse_root else "dense LDL^T"), "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",
                        # N > 1 runs the configs[2] shape, N = 1 configs[1]: per-GPU throughput of the two differs by the Schur dimension alone
                        # (the driver's efficiency against the N = 1 line mixes that in) - the same shape on ONE device, measured, for reference
-                       **({"same_shape_on_one_gpu": {"units_per_s": 4.213, "ms_per_step": 237.36, "source": "profiles/r4_bench_other_configs.jsonl "
-                                                     "(bench.py --blocks-per-gpu 64 --n 10000 --schur-dim 4000, one MI355X, round 4)"}}
-                          if world > 1 and a.family == "random" and bpg == 64 and n_i == 10000 and S == 4000 else {}),
+                       **({"same_shape_on_one_gpu": same_shape_on_one_gpu(shape)} if world > 1 else {}),
                        "solves_per_unit": R_SOLVES, "collective": comm_kind, "leaf_refinement": "adaptive, <=2 steps, normwise backward error <= 1e-15 (steps taken in the last solve: %d)" % bt.last_refinement_steps(),
                        "solve_path": {0: "every solveCompressed: two leaf solves with adaptive refinement + the two sparse border products",
                                       1: "refined Lsolve; Ltsolve by one backward sweep of the augmented factor (no pivot perturbed, the refined Lsolve needed no step)",

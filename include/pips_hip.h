@@ -173,7 +173,8 @@ int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero);
 /* what[0]=sum nnz(L) what[1]=sum n what[2]=sum n_head what[3]=sum tail m what[4]=#head supernodes what[5]=max levels
  * what[6]=factor flops what[7]=border (TRSM+SYRK) flops what[8]=arena bytes what[9]=max tail tile columns
  * what[10]=bytes of the head-to-head update position tables what[11]=sum of non-empty border columns what[12]=sum nnz(K lower)
- * what[13]=1 if solveCompressed takes its Ltsolve from the augmented factor (one backward sweep) while no pivot is perturbed */
+ * what[13]=1 if solveCompressed takes its Ltsolve from the augmented factor (one backward sweep) while no pivot is perturbed
+ * what[14]=1 multifrontal head ... what[24]=blocks analysed with the border split of the fronts (python/capi.py LeafBatch.info names all) */
 int pips_hip_batch_info(void* handle, int64_t* what, int n_what);
 int pips_hip_batch_sync(void* handle);
 /* per-phase device time in ms (HIP events on the handle's stream) of the last pips_hip_batch_factor
@@ -268,6 +269,13 @@ int pips_hip_kkt_last_ltsolve_from_factor(void* handle, int* flag);
  * the same factors: a solveCompressed that went way 3, or way 0 / 1 with its refined solves meeting the backward-error tolerance
  * without a step (the first solveCompressed after every factorisation; needs adaptive refinement, pips_hip_batch_set_refinement*). */
 int pips_hip_kkt_last_solve_path(void* handle, int* path);
+/* How often a solveCompressed that goes by sweeps (way 2) is measured against the leaf rows like the witness (way 3): every `every`-th
+ * one; 1 (the default) = every solve is measured, as the reference's PARDISO measures and refines every leaf solve (iparm[7] = 2,
+ * PardisoProjectSolver.C:72); 0 = only the first after a factorisation.  A solve whose measure exceeds the refinement tolerance is
+ * repeated the refined way from the saved right-hand side and the sweeps stay off for these factors; with several ranks the ranks decide
+ * together (one number all-reduced per solveCompressed).  _counts: measured solves and failed measures so far. */
+int pips_hip_kkt_set_solve_check(void* handle, int every);
+int pips_hip_kkt_solve_check_counts(void* handle, long long* checked, long long* failed);
 void pips_hip_kkt_destroy(void* handle);
 
 /* plain device buffers for hosts that do not bring their own allocator */

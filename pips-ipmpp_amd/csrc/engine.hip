@@ -1044,25 +1044,37 @@ struct Engine {
          mf = !(env && atoi(env) == 0) && !(hs && atoi(hs) != 0 && !deterministic);
          mf_solves = getenv("PIPS_HIP_MF_SOLVES") && atoi(getenv("PIPS_HIP_MF_SOLVES")) != 0;
          if (const char* bk = getenv("PIPS_HIP_MF_BUCKETS")) mf_bucket_by_class = std::string(bk) != "spread";
-         for (int b = 0; b < nblk && mf; ++b) {
-            mf = sym[b].mf_ok;
-            // fronts with very many leaves below them: the staged leaf data must fit beside the front
-            for (size_t l = 0; l < sym[b].sn.size() && mf; ++l) {
-               if (sym[b].mf_meta[l] < 0) continue;
-               const HeadSupernode& s = sym[b].sn[l];
-               const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
-               const long long nf = s.w + s.r, pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));
-               const long long packed = pw + mf_unp(sym[b], s) + 8, panel = pw + 8;
-               const long long extra = H[5] + (H[6] + H[3] + 1) / 2 + 2;
-               if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) mf = false;   // 159 KB of the 160
+         const bool mf_wanted = mf;
+         auto fronts_fit = [&]() {
+            bool ok = mf_wanted;
+            for (int b = 0; b < nblk && ok; ++b) {
+               ok = sym[b].mf_ok;
+               // fronts with very many leaves below them: the staged leaf data must fit beside the front
+               for (size_t l = 0; l < sym[b].sn.size() && ok; ++l) {
+                  if (sym[b].mf_meta[l] < 0) continue;
+                  const HeadSupernode& s = sym[b].sn[l];
+                  const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
+                  const long long nf = s.w + s.r, pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));
+                  const long long packed = pw + mf_unp(sym[b], s) + 8, panel = pw + 8;
+                  const long long extra = H[5] + (H[6] + H[3] + 1) / 2 + 2;
+                  if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) ok = false;   // 159 KB of the 160
+               }
             }
-         }
+            return ok;
+         };
+         mf = fronts_fit();
          mf_solves = mf_solves && mf && !deterministic;   // (deterministic mode keeps its slot-based forward substitution)
          bool any_split = false;
          for (int b = 0; b < nblk; ++b) any_split = any_split || sym[b].mf_split;
-         if (!mf && any_split) {   // some block cannot take the multifrontal head: every block back to full panels
+         // ... or k_border_schur's triangle + staged batch + row positions exceed the LDS (nb close to the cap under wide fronts whose
+         // below-rows are nearly all border rows): the same formula the launch uses, evaluated here so that such an input is analysed with
+         // whole update matrices instead of failing in every factor()
+         const bool bb_too_big = mf && any_split && !bb_fits(bb_plan_size());
+         if ((!mf && any_split) || bb_too_big) {   // every block back to full panels
             opt.mf_split_nb_max = 0;
             if ((rc = analyze_host(n_threads, schur_mode_eff != 2))) return rc;
+            if (bb_too_big) mf = fronts_fit();   // (the fronts grew by their border columns: they must still fit)
+            mf_solves = mf_solves && mf;
          }
       }
 
@@ -1269,22 +1281,11 @@ struct Engine {
          std::vector<int> h_bbpos;
          h_bb_off_keep.assign(nblk + 1, 0);
          bb_stage = 3072; bb_nbmax = 0; bb_poscap = 0;
-         {  // staging area: as much of the LDS as the packed triangle of the widest border leaves (a batch is one barrier pair and one
-            // request latency whatever it holds; the supernodes of the upper levels take 2000+ doubles each), at most 6144 doubles
-            int nbm = 0;
-            for (int b = 0; b < nblk; ++b) if (sym[b].mf_split) nbm = std::max(nbm, sym[b].nb);
-            const long long tri = ((long long)nbm * (nbm + 1) / 2 + 1) & ~1LL;
-            const long long room = 19200 - tri - 4 * 512 / 2 - 64;   // (positions: up to 4 * 512 ints; supernode records)
-            const long long want = getenv("PIPS_HIP_BB_STAGE") ? atoll(getenv("PIPS_HIP_BB_STAGE")) : 6144;
-            bb_stage = (int)std::max<long long>(3072, std::min<long long>(want, room)) & ~1;
-         }
+         // staging area: as much of the LDS as the packed triangle of the widest border leaves (a batch is one barrier pair and one request
+         // latency whatever it holds; the supernodes of the upper levels take 2000+ doubles each), at most 6144 doubles, at least the largest
+         // single supernode (bb_plan_size)
+         bb_stage = bb_plan_size().stage;
          long long bb_total = arena_total;   // the border-row arena lives behind the panels in the same allocation (offsets like SnDesc::panel)
-         for (int b = 0; b < nblk; ++b) {
-            const BlockSym& bs = sym[b];
-            if (!bs.mf_split) continue;
-            for (const HeadSupernode& hs : bs.sn)
-               if (hs.rb < hs.r) bb_stage = std::max<int>(bb_stage, hs.w * ((hs.r - hs.rb + 3) / 4 * 4) + ((hs.w + 1) & ~1));
-         }
          for (int b = 0; b < nblk; ++b) {
             const BlockSym& bs = sym[b];
             if (bs.mf_split) {
@@ -1654,17 +1655,54 @@ struct Engine {
                          d_psign_off, d_bmap, d_arena, d_mfU, SC, ldSC, d_inertia, d_pref, d_sctab, d_mfdbg, d_mfLV, d_kval, d_bval, deterministic ? 1 : 0, d_arena);
       return PIPS_OK;
    }
+   // ---- k_border_schur's LDS need, from the symbolic analysis alone (the same rules as the batching loop of analyze()): staging area,
+   //      most row positions of a batch, widest border.  Evaluated at analyze time: a block set whose border rows do not fit (nb near 176
+   //      under wide fronts that are nearly all border rows) goes back to whole update matrices there instead of failing in every factor()
+   struct BbPlanSize { int stage = 3072, poscap = 0, nbmax = 0; };
+   BbPlanSize bb_plan_size() const {
+      BbPlanSize z;
+      for (int b = 0; b < nblk; ++b) if (sym[b].mf_split) z.nbmax = std::max(z.nbmax, sym[b].nb);
+      const long long tri = ((long long)z.nbmax * (z.nbmax + 1) / 2 + 1) & ~1LL;
+      const long long room = 19200 - tri - 4 * 512 / 2 - 64;   // (positions: up to 4 * 512 ints; supernode records)
+      z.stage = (int)std::max<long long>(3072, std::min<long long>(6144, room)) & ~1;
+      for (int b = 0; b < nblk; ++b) {
+         const BlockSym& bs = sym[b];
+         if (!bs.mf_split) continue;
+         for (const HeadSupernode& hs : bs.sn)
+            if (hs.rb < hs.r) z.stage = std::max<int>(z.stage, hs.w * ((hs.r - hs.rb + 3) / 4 * 4) + ((hs.w + 1) & ~1));
+      }
+      for (int b = 0; b < nblk; ++b) {
+         const BlockSym& bs = sym[b];
+         if (!bs.mf_split) continue;
+         int cnt = 0, nd = 0, np = 0;
+         for (int l = 0; l < (int)bs.sn.size(); ++l) {
+            const HeadSupernode& hs = bs.sn[l];
+            const bool simple = hs.w == 1 && hs.r <= SIMPLE_RMAX && hs.level == 0;    // (analyze()'s is_simple)
+            if (hs.rb >= hs.r || (simple && bs.sn_parent[l] < 0)) continue;
+            const int nbj = hs.r - hs.rb, rp = (nbj + 3) & ~3, sz = hs.w * rp + ((hs.w + 1) & ~1);
+            if (cnt == BB_GMAX || nd + sz > z.stage) { z.poscap = std::max(z.poscap, np); cnt = nd = np = 0; }
+            ++cnt; nd += sz; np += nbj;
+         }
+         z.poscap = std::max(z.poscap, np);
+      }
+      return z;
+   }
+   static size_t bb_lds_bytes(const BbPlanSize& z) {
+      const long long ncp = ((long long)z.nbmax * (z.nbmax + 1) / 2 + 1) & ~1LL;
+      return (size_t)(ncp + z.stage) * sizeof(double) + (size_t)((z.poscap + 3) & ~3) * sizeof(int) + BB_GMAX * sizeof(BbMeta);
+   }
+   static bool bb_fits(const BbPlanSize& z) { return bb_lds_bytes(z) <= 160 * 1024 && z.poscap <= 4 * 512 && z.stage <= 2 * 6 * 512; }
    int launch_border_schur(double* SC, int ldSC) {
       // LDS: packed nb x nb triangle + one staged batch + its rows' positions + the batch's supernode records
       constexpr int BLK = 512;
       const long long ncp = ((long long)bb_nbmax * (bb_nbmax + 1) / 2 + 1) & ~1LL;
-      // the triangle shared by `parts` workgroups (column ranges of equal area: a slice is at most tri / parts + one column), so that two
-      // or more workgroups fit a compute unit - measured on the configs[3] share: head 14.94 / 14.97 / 17.7 / 18.3 ms with 1 / 2 / 3 / 4
-      // parts (every part stages every batch; the walk is bound by its LDS traffic, not by waiting): one part it stays
-      const int parts = getenv("PIPS_HIP_BB_PARTS") ? std::max(1, std::min(4, atoi(getenv("PIPS_HIP_BB_PARTS")))) : 1;
-      const long long c_cap = parts > 1 ? ((ncp / parts + bb_nbmax + 2) & ~1LL) : ncp;
-      const size_t lds = (size_t)(c_cap + bb_stage) * sizeof(double) + (size_t)((bb_poscap + 3) & ~3) * sizeof(int) + BB_GMAX * sizeof(BbMeta);
-      if (lds > 160 * 1024 || bb_poscap > 4 * BLK || bb_stage > 2 * 6 * BLK)
+      // (the triangle shared by 2 / 3 / 4 workgroups by column ranges, so that several fit a compute unit, measured 14.97 / 17.7 / 18.3 ms
+      // against 14.94 on the 256-block chain's head: every part stages every batch - docs/HISTORY_r4.md; one workgroup holds it whole)
+      constexpr int parts = 1;
+      const long long c_cap = ncp;
+      BbPlanSize z; z.stage = bb_stage; z.poscap = bb_poscap; z.nbmax = bb_nbmax;
+      const size_t lds = bb_lds_bytes(z);
+      if (!bb_fits(z))   // (analyze() has checked the same formula and taken the split off where it does not hold: an assertion)
          PIPS_FAIL(PIPS_ERR_STATE, "k_border_schur: %zu bytes of LDS for nb = %d (batch of %d doubles, %d rows)", lds, bb_nbmax, bb_stage, bb_poscap);
       // a block's batches are walked by `split` workgroups (each with its own accumulator): enough of them to fill the chip
       const int split = getenv("PIPS_HIP_BB_SPLIT") ? std::max(1, atoi(getenv("PIPS_HIP_BB_SPLIT"))) : std::max(1, std::min(16, 256 / std::max(nblk, 1)));
@@ -2927,6 +2965,16 @@ struct KktSystem {
    // have to be taken by all ranks together.  PIPS_HIP_AUG_WITNESS=0: the refined witness everywhere.
    long long aug_failed_gen = -1;
    bool checked_witness = !(getenv("PIPS_HIP_AUG_WITNESS") && atoi(getenv("PIPS_HIP_AUG_WITNESS")) == 0);
+   // Every solveCompressed that goes by sweeps is measured like that (pips_hip_kkt_set_solve_check: every k-th one; 0 = the witness
+   // only, rounds 4's behaviour): the reference's PARDISO measures and refines EVERY leaf solve (iparm[7] = 2,
+   // PardisoProjectSolver.C:72), and one clean right-hand side does not bound the backward error of the next.  Several ranks decide
+   // together: each solveCompressed ends with a one-number all-reduce "did any rank's check fail"; if so every rank restores its
+   // right-hand side and all go the refined way (a rank's inaccurate -Br^T K^-1 b taints x0 for everybody).
+   int solve_check_every = 1, sweeps_since_check = 0;
+   long long checked_solves = 0, failed_checks = 0;
+   double* d_flag = nullptr;
+   bool joint_aug_any = false;        // several ranks: some rank's analysis chose the sweeps (all-reduced once per analysis)
+   long long joint_aug_gen = -1;
    double *d_bsave = nullptr, *d_b0save = nullptr;
    bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
@@ -2950,7 +2998,7 @@ struct KktSystem {
       if (ev_root_done) (void)hipEventDestroy(ev_root_done);
       if (comm_stream) (void)hipStreamDestroy(comm_stream);
       if (ev_reduced) (void)hipEventDestroy(ev_reduced);
-      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr, d_gall, d_gvec_all, d_bsave, d_b0save};
+      void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr, d_gall, d_gvec_all, d_bsave, d_b0save, d_flag};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
    }
@@ -3329,6 +3377,7 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
       if (n_what > 22) what[22] = e->aug_passes;
       if (n_what > 23) what[23] = tail_border;
    }
+   if (n_what > 24) { what[24] = 0; for (const BlockSym& s : e->sym) what[24] += s.mf_split ? 1 : 0; }   // blocks with the border split
    return PIPS_OK;
 }
 
@@ -3391,7 +3440,11 @@ struct LdlHandle {
    std::vector<double> h_sc;
    std::shared_ptr<LdlGroup> group;   // the leaves of a rank bound into one batch engine (pips_hip_ldl_factor_schur_batch)
    int group_index = -1;
-   ~LdlHandle() { if (d_sc) (void)hipFree(d_sc); }
+   // which engine holds this leaf's NEWEST factors: the batch's (set for every member by pips_hip_ldl_factor_schur_batch) or the handle's
+   // own (pips_hip_ldl_factor / _factor_schur clear it) - a handle can go through both over its life (matrixChanged() alone, later the
+   // host's loop handed over), and solve / inertia must never answer from the older of the two
+   bool newest_in_group = false;
+   ~LdlHandle();
 };
 // Array-of-handles entries (INTEGRATION.md level 1.5b): the reference keeps one DoubleLinearSolver per leaf and loops over its children
 // (sLinsysRootAug::assembleLocalKKT :210-227, Lsolve / Ltsolve :323-365).  One leaf alone is a latency chain on the device (64 leaves of
@@ -3405,6 +3458,39 @@ struct LdlGroup {
    std::vector<double> h_sc;
    ~LdlGroup() { if (d_sc) (void)hipFree(d_sc); if (d_x) (void)hipFree(d_x); }
 };
+// a handle that goes away leaves an empty slot in its group: the siblings keep the batch's factors (their own solves go through
+// group_solve_rows, which needs no sibling), the next array-of-handles call sees another array and binds anew
+LdlHandle::~LdlHandle() {
+   if (d_sc) (void)hipFree(d_sc);
+   if (group && group_index >= 0 && group_index < (int)group->members.size() && group->members[group_index] == this) group->members[group_index] = nullptr;
+}
+// array-of-handles solves / queries answer from the batch's factors: refuse if a member has been factorised alone since
+static int ldl_group_is_current(const LdlGroup& g, const char* who) {
+   if (!g.eng.factored) PIPS_FAIL(PIPS_ERR_STATE, "%s: pips_hip_ldl_factor_schur_batch first", who);
+   for (size_t i = 0; i < g.members.size(); ++i)
+      if (g.members[i] && !g.members[i]->newest_in_group)
+         PIPS_FAIL(PIPS_ERR_STATE, "%s: handle %d was factorised on its own after the batch's factorisation - factorise the array again", who, (int)i);
+   return PIPS_OK;
+}
+static inline bool ldl_uses_group(const LdlHandle* h) { return h->group && h->newest_in_group && h->group->eng.factored; }
+// one member's right-hand sides through the batch engine (every block in every launch, the others with zeros - correct, and as long as
+// a batch solve: hosts that loop over their leaves should hand the loop over, pips_hip_ldl_solve_batch).  rhs: nrhs rows of length ld,
+// on the host or on the device
+static int group_solve_rows(LdlGroup& g, int index, int nrhs, double* rhs, long long ld, bool on_device, const char* who) {
+   Engine& e = g.eng;
+   HIP_TRY(hipSetDevice(e.device));
+   if (!g.d_x) HIP_TRY(hipMalloc((void**)&g.d_x, (size_t)std::max<long long>(e.n_total, 1) * sizeof(double)));
+   const size_t cnt = (size_t)(e.x_off[index + 1] - e.x_off[index]) * sizeof(double);
+   for (int r = 0; r < nrhs; ++r) {
+      HIP_TRY(hipMemsetAsync(g.d_x, 0, (size_t)e.n_total * sizeof(double), e.stream));
+      HIP_TRY(hipMemcpyAsync(g.d_x + e.x_off[index], rhs + (size_t)r * ld, cnt, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e.stream));
+      int rc = e.solve(g.d_x);
+      if (rc) return rc;
+      HIP_TRY(hipMemcpyAsync(rhs + (size_t)r * ld, g.d_x + e.x_off[index], cnt, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e.stream));
+   }
+   if (!on_device) HIP_TRY(hipStreamSynchronize(e.stream));
+   return e.sweep.take_error(who);
+}
 
 int pips_hip_ldl_create(void** handle, int n, const int* krow, const int* jcol, int device, int flags) {
    (void)flags;
@@ -3462,6 +3548,7 @@ int pips_hip_ldl_factor(void* handle, const double* vals_host) {
    if (rc) return rc;
    rc = h->eng.factor(nullptr, 0);
    if (rc) return rc;
+   h->newest_in_group = false;      // (the batch's copy of this leaf is the older one now)
    HIP_TRY(hipStreamSynchronize(h->eng.stream));
    return PIPS_OK;
 }
@@ -3519,6 +3606,7 @@ int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const dou
       (void)hipMemset(scratch, 0, (size_t)S * S * sizeof(double));
       return rc;
    }
+   h->newest_in_group = false;
    if (nb > 0) {
       if (!h->d_sc) HIP_TRY(hipMalloc((void**)&h->d_sc, (size_t)nb * nb * sizeof(double)));
       hipLaunchKernelGGL(k_schur_take_block, dim3(std::max(1, std::min(16, (nb + 255) / 256)), nb), dim3(256), 0, e.stream, scratch, S, e.d_bmap, nb, h->d_sc);
@@ -3537,18 +3625,8 @@ extern "C" int pips_hip_ldl_solve_batch(void* const* handles, int n, double* con
 int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || nrhs < 0 || !rhs || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve: bad arguments");
-   if (!h->eng.factored && h->group && h->group->eng.factored) {
-      // factorised as a member of a batch: the batch engine solves (every block in every launch - correct, and as long as a batch
-      // solve: hosts that loop over their leaves should hand the loop over, pips_hip_ldl_solve_batch)
-      std::vector<void*> hs(h->group->members.begin(), h->group->members.end());
-      std::vector<double*> ptrs(hs.size(), nullptr);
-      for (int r = 0; r < nrhs; ++r) {
-         ptrs[h->group_index] = rhs + (size_t)r * ld;
-         int rcb = pips_hip_ldl_solve_batch(hs.data(), (int)hs.size(), ptrs.data());
-         if (rcb) return rcb;
-      }
-      return PIPS_OK;
-   }
+   if (ldl_uses_group(h))   // the newest factors of this leaf are the batch's
+      return group_solve_rows(*h->group, h->group_index, nrhs, rhs, ld, false, "pips_hip_ldl_solve");
    Engine& e = h->eng;
    if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve: factor first");
    HIP_TRY(hipSetDevice(e.device));
@@ -3601,8 +3679,9 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
 int pips_hip_ldl_solve_dev(void* handle, int nrhs, double* rhs_inout_dev, long long ld) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || nrhs < 1 || !rhs_inout_dev || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_dev: bad arguments");
+   if (ldl_uses_group(h)) return group_solve_rows(*h->group, h->group_index, nrhs, rhs_inout_dev, ld, true, "pips_hip_ldl_solve_dev");
    Engine& e = h->eng;
-   if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_dev: factor first (a handle factorised through pips_hip_ldl_factor_schur_batch is solved with pips_hip_ldl_solve_batch*)");
+   if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_dev: factor first");
    HIP_TRY(hipSetDevice(e.device));
    return nrhs == 1 ? e.solve(rhs_inout_dev) : e.solve_multi(rhs_inout_dev, nrhs, ld);
 }
@@ -3623,6 +3702,7 @@ int pips_hip_ldl_solve_sparse(void* handle, int nrhs, double* rhs, int ld, const
    if (!col_sparsity) return pips_hip_ldl_solve(handle, nrhs, rhs, ld);
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || nrhs < 0 || !rhs || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_sparse: bad arguments");
+   if (ldl_uses_group(h)) return pips_hip_ldl_solve(handle, nrhs, rhs, ld);   // (through the batch every row travels: colSparsity saves nothing there)
    Engine& e = h->eng;
    if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_sparse: factor first");
    HIP_TRY(hipSetDevice(e.device));
@@ -3728,6 +3808,7 @@ int pips_hip_ldl_factor_schur_batch(void* const* handles, int n, const double* c
       HIP_TRY(hipMemsetAsync(g->d_sc, 0, (size_t)S * S * sizeof(double), e.stream));
    }
    if ((rc = e.factor(schur ? g->d_sc : nullptr, S))) return rc;
+   for (LdlHandle* m : g->members) if (m) m->newest_in_group = true;
    if (schur) {
       g->h_sc.resize((size_t)S * S);
       HIP_TRY(hipMemcpyAsync(g->h_sc.data(), g->d_sc, (size_t)S * S * sizeof(double), hipMemcpyDeviceToHost, e.stream));
@@ -3750,7 +3831,7 @@ int pips_hip_ldl_solve_batch_dev(void* const* handles, int n, double* x_dev) {
    int rc = ldl_group_of(handles, n, g);
    if (rc) return rc;
    if (!x_dev) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_batch_dev: null vector");
-   if (!g->eng.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_batch_dev: pips_hip_ldl_factor_schur_batch first");
+   if ((rc = ldl_group_is_current(*g, "pips_hip_ldl_solve_batch_dev"))) return rc;
    HIP_TRY(hipSetDevice(g->eng.device));
    return g->eng.solve(x_dev);
 }
@@ -3761,7 +3842,7 @@ int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_ino
    if (rc) return rc;
    if (!rhs_inout_host) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve_batch: null array");
    Engine& e = g->eng;
-   if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve_batch: pips_hip_ldl_factor_schur_batch first");
+   if ((rc = ldl_group_is_current(*g, "pips_hip_ldl_solve_batch"))) return rc;
    HIP_TRY(hipSetDevice(e.device));
    if (!g->d_x) HIP_TRY(hipMalloc((void**)&g->d_x, (size_t)std::max<long long>(e.n_total, 1) * sizeof(double)));
    // a leaf without a right-hand side this time (NULL) is solved with zeros: the batch runs every block in every launch
@@ -3781,7 +3862,7 @@ int pips_hip_ldl_inertia_batch(void* const* handles, int n, int* pos, int* neg, 
    std::shared_ptr<LdlGroup> g;
    int rc = ldl_group_of(handles, n, g);
    if (rc) return rc;
-   if (!g->eng.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_inertia_batch: factor first");
+   if ((rc = ldl_group_is_current(*g, "pips_hip_ldl_inertia_batch"))) return rc;
    for (int i = 0; i < n; ++i) {
       int p = 0, q = 0, z = 0;
       if ((rc = pips_hip_batch_inertia(&g->eng, i, &p, &q, &z))) return rc;
@@ -3795,7 +3876,7 @@ int pips_hip_ldl_inertia_batch(void* const* handles, int n, int* pos, int* neg, 
 int pips_hip_ldl_inertia(void* handle, int* pos, int* neg, int* zero) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
-   if (!h->eng.factored && h->group && h->group->eng.factored)   // factorised as a member of a batch (pips_hip_ldl_factor_schur_batch)
+   if (ldl_uses_group(h))   // the newest factorisation of this leaf was the batch's (pips_hip_ldl_factor_schur_batch)
       return pips_hip_batch_inertia(&h->group->eng, h->group_index, pos, neg, zero);
    return pips_hip_batch_inertia(&h->eng, 0, pos, neg, zero);
 }
@@ -4413,6 +4494,61 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       HIP_TRY(hipMemcpyAsync(red, b0_dev, (size_t)head * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(red + head, b0_dev + head + k->mz0, (size_t)tailn * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
    }
+   // several ranks (or the forced reduction of the tests): the checks are decided together - see KktSystem::solve_check_every
+   const bool joint = k->n_ranks > 1 || k->force_reduce;
+   const bool can_measure = !capturing && e->refine_tol > 0.0 && e->refine_steps > 0 && !(e->deterministic && e->d_gvec);
+   // (whether the ranks exchange the outcome may depend only on what is equal on every rank: the settings the host gives all ranks alike,
+   // and "some rank's analysis chose the sweeps" - the cost model decides per rank - settled once per analysis by an all-reduce)
+   if (joint && can_measure && k->checked_witness && k->solve_check_every > 0 && k->joint_aug_gen != e->analysis_gen) {
+      if (!k->d_flag) HIP_TRY(hipMalloc((void**)&k->d_flag, sizeof(double)));
+      double any = e->aug_sweeps_ok ? 1.0 : 0.0;
+      HIP_TRY(hipMemcpyAsync(k->d_flag, &any, sizeof(double), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      if ((rc = pips_hip_allreduce_sum(k->comm, k->d_flag, 1, e->stream))) return rc;
+      HIP_TRY(hipMemcpyAsync(&any, k->d_flag, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      k->joint_aug_any = any > 0.0;
+      k->joint_aug_gen = e->analysis_gen;
+   }
+   const bool joint_check = joint && can_measure && k->checked_witness && k->solve_check_every > 0 && k->joint_aug_any;
+   if (can_measure && e->aug_sweeps_ok && k->aug_failed_gen != k->factor_gen) {
+      const bool validated = k->aug_validated_gen == k->factor_gen;
+      const bool may_check = k->checked_witness && (!joint || joint_check);
+      if (validated || may_check) {
+         int pert = 1;
+         if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
+         use_aug = pert == 0;
+         const bool due = use_aug && validated && may_check && k->solve_check_every > 0 && ++k->sweeps_since_check >= k->solve_check_every;
+         verify = use_aug && (!validated || due);
+      }
+   }
+   if (verify || joint_check) {   // the right-hand side as the caller gave it: needed for the check, and for the refined pass if a check fails
+      if (!k->d_bsave) HIP_TRY(hipMalloc((void**)&k->d_bsave, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
+      if (!k->d_b0save) HIP_TRY(hipMalloc((void**)&k->d_b0save, (size_t)(k->S + k->mz0 + 1) * sizeof(double)));
+      HIP_TRY(hipMemcpyAsync(k->d_bsave, b_leaf_dev, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(k->d_b0save, b0_dev, (size_t)(k->S + k->mz0) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+   }
+   // the joint decision at the end of the call: any rank's failed check sends every rank back to its saved right-hand side
+   auto settle = [&](bool my_check_failed) -> int {
+      bool redo = my_check_failed;
+      if (joint_check) {
+         if (!k->d_flag) HIP_TRY(hipMalloc((void**)&k->d_flag, sizeof(double)));
+         double flag = my_check_failed ? 1.0 : 0.0;
+         HIP_TRY(hipMemcpyAsync(k->d_flag, &flag, sizeof(double), hipMemcpyHostToDevice, e->stream));
+         HIP_TRY(hipStreamSynchronize(e->stream));   // (the source is a stack variable)
+         int rcf = pips_hip_allreduce_sum(k->comm, k->d_flag, 1, e->stream);
+         if (rcf) return rcf;
+         HIP_TRY(hipMemcpyAsync(&flag, k->d_flag, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+         HIP_TRY(hipStreamSynchronize(e->stream));
+         redo = flag > 0.0;
+      }
+      if (!redo) return PIPS_OK;
+      ++k->failed_checks;
+      k->aug_failed_gen = k->factor_gen;   // no sweeps on these factors any more, on any rank
+      HIP_TRY(hipMemcpyAsync(b_leaf_dev, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(b0_dev, k->d_b0save, (size_t)(k->S + k->mz0) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+      return kkt_solve_compressed_enqueue(k, b0_dev, b_leaf_dev, capturing);
+   };
    if (e->deterministic && e->d_gvec) {
       // deterministic Lsolve: t = -sum_i Br_i^T K_i^-1 b_i is formed on its own - group-wise in block order, the (at most eight)
       // groups in the fixed tree of k_reduce_groups, the ranks' parts by the all-reduce - and added to b0 on every rank.  Guarantee:
@@ -4442,22 +4578,6 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));
-   if (!capturing && e->aug_sweeps_ok && e->refine_tol > 0.0 && k->aug_failed_gen != k->factor_gen) {
-      const bool validated = k->aug_validated_gen == k->factor_gen;
-      const bool may_check = k->checked_witness && k->n_ranks <= 1 && !k->force_reduce && e->refine_steps > 0;
-      if (validated || may_check) {
-         int pert = 1;
-         if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
-         use_aug = pert == 0;
-         verify = use_aug && !validated;
-      }
-   }
-   if (verify) {   // the right-hand side as the caller gave it: needed for the check, and for the refined pass if the check fails
-      if (!k->d_bsave) HIP_TRY(hipMalloc((void**)&k->d_bsave, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
-      if (!k->d_b0save) HIP_TRY(hipMalloc((void**)&k->d_b0save, (size_t)(k->S + k->mz0 + 1) * sizeof(double)));
-      HIP_TRY(hipMemcpyAsync(k->d_bsave, b_leaf_dev, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-      HIP_TRY(hipMemcpyAsync(k->d_b0save, b0_dev, (size_t)(k->S + k->mz0) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-   }
    k->timer.begin(e->stream, 5);
    if (use_aug) { if ((rc = e->forward_augmented(b_leaf_dev, red))) return rc; }
    else {
@@ -4502,24 +4622,25 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       if ((rc = e->backward_augmented(red, b_leaf_dev))) return rc;
       k->last_ltsolve_from_factor = true;
       k->last_solve_path = 2;
+      bool failed = false;
       if (verify) {
          // r_i = (b_i - Br_i x0) - K_i x_i over the blocks, measured like a refinement step would measure it
          HIP_TRY(hipMemcpyAsync(k->d_t, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
          if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, -1.0))) return rc;
          double worst = 0.0;
          if ((rc = e->residual_measure(k->d_t, b_leaf_dev, &worst))) return rc;
+         ++k->checked_solves;
+         k->sweeps_since_check = 0;
          if (worst <= e->refine_tol) {
             k->aug_validated_gen = k->factor_gen;
             k->last_solve_path = 3;
-         } else {   // not good enough without refinement: the refined path on the saved right-hand side, no sweeps on these factors
-            k->timer.end(e->stream);
-            k->aug_failed_gen = k->factor_gen;
-            HIP_TRY(hipMemcpyAsync(b_leaf_dev, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-            HIP_TRY(hipMemcpyAsync(b0_dev, k->d_b0save, (size_t)(k->S + k->mz0) * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-            return kkt_solve_compressed_enqueue(k, b0_dev, b_leaf_dev, capturing);
-         }
+         } else
+            failed = true;   // not good enough without refinement: the refined path on the saved right-hand side, no sweeps on these factors
       }
       k->timer.end(e->stream);
+      if (failed || joint_check) return settle(failed);
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
    } else {
    if (!capturing) {
       int pert = 1;
@@ -4538,11 +4659,13 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    }
    k->last_solve_path = k->last_ltsolve_from_factor ? 1 : 0;
    // this refined pass is the witness for the factors it ran on (see KktSystem::aug_validated_gen)
-   if (!capturing && e->aug_sweeps_ok && e->refine_tol > 0.0 && lsolve_steps == 0 && ltsolve_steps == 0) k->aug_validated_gen = k->factor_gen;
+   // (a pass that was allowed no step proves nothing: refine_steps > 0)
+   if (can_measure && e->aug_sweeps_ok && lsolve_steps == 0 && ltsolve_steps == 0) k->aug_validated_gen = k->factor_gen;
    k->timer.end(e->stream);
    k->timer.begin(e->stream, 9);
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    k->timer.end(e->stream);
+   if (joint_check) return settle(false);   // (another rank's check may have failed)
    }
    HIP_TRY(hipGetLastError());
    return PIPS_OK;
@@ -4627,6 +4750,22 @@ int pips_hip_kkt_solve_graph_stats(void* handle, int64_t* captures, int64_t* rep
    if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    if (captures) *captures = k->graph_captures;
    if (replays) *replays = k->graph_replays;
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_set_solve_check(void* handle, int every) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k || every < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_kkt_set_solve_check: bad arguments");
+   k->solve_check_every = every;
+   k->sweeps_since_check = 0;
+   return PIPS_OK;
+}
+
+int pips_hip_kkt_solve_check_counts(void* handle, long long* checked, long long* failed) {
+   KktSystem* k = (KktSystem*)handle;
+   if (!k) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (checked) *checked = k->checked_solves;
+   if (failed) *failed = k->failed_checks;
    return PIPS_OK;
 }
 

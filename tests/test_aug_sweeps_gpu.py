@@ -67,8 +67,20 @@ def test_augmented_sweeps_match_oracle_and_refined_path(shape, monkeypatch):
         assert np.linalg.norm(g0 - want0) <= 1e-8 * np.linalg.norm(want0), (rep, paths)
         assert np.linalg.norm(gl - wantl) <= 1e-8 * np.linalg.norm(wantl), (rep, paths)
         sols.append((b0h, blh, g0, gl))
-    # the first call after the factorisation is the witness (its sweeps are checked against the leaf rows), the others ride on it
-    assert paths[0] == 3 and paths[1] == 2 and paths[2] == 2, paths
+    # every solveCompressed by sweeps is measured against the leaf rows (the default: pips_hip_kkt_set_solve_check(1)) ...
+    assert paths == [3, 3, 3] and kkt.solve_check_counts() == (3, 0), (paths, kkt.solve_check_counts())
+    # ... every second one / only the first after a factorisation (the witness; the others ride on it)
+    for every, want_paths in ((2, [3, 2, 3, 2]), (0, [3, 2, 2, 2])):
+        kkt.set_solve_check(every)
+        kkt.factorize(diag, xd0)
+        got_paths = []
+        for rep in range(4):
+            b0, bl = torch.tensor(sols[rep % 3][0], device="cuda"), torch.tensor(sols[rep % 3][1], device="cuda")
+            kkt.solve_compressed(b0, bl)
+            got_paths.append(kkt.last_solve_path())
+            assert np.linalg.norm(bl.cpu().numpy() - sols[rep % 3][3]) <= 1e-10 * np.linalg.norm(sols[rep % 3][3])
+        assert got_paths == want_paths, (every, got_paths)
+    kkt.set_solve_check(1)
     # the same right-hand side through the refined path on the same factors
     monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "0")
     bt2, kkt2 = _system(prob, force_head=shape == "time_coupled_all_head")
@@ -115,7 +127,7 @@ def test_witness_variants(witness, monkeypatch):
         assert np.linalg.norm(b0.cpu().numpy() - want0) <= 1e-8 * np.linalg.norm(want0), (rep, paths)
         assert np.linalg.norm(bl.cpu().numpy() - wantl) <= 1e-8 * np.linalg.norm(wantl), (rep, paths)
     if witness == "refined":
-        assert paths[0] in (0, 1) and paths[1:] == [2, 2], paths
+        assert paths[0] in (0, 1) and paths[1:] == [3, 3], paths      # (followers: sweeps, each measured)
     else:
         assert all(q in (0, 1) for q in paths), paths
     kkt.close(); bt.close()
@@ -137,10 +149,181 @@ def test_perturbed_pivots_keep_the_refined_path(monkeypatch):
     diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
     kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
     pert = sum(bt.inertia(b)[2] for b in range(prob.N))
+    assert pert > 0                        # (the construction must produce what the test is about)
     rng = np.random.default_rng(2)
     for rep in range(3):
         b0, bl = torch.tensor(rng.standard_normal(prob.S), device="cuda"), torch.tensor(rng.standard_normal(prob.N * prob.n_leaf), device="cuda")
         kkt.solve_compressed(b0, bl)
-        if pert > 0:
-            assert kkt.last_solve_path() in (0, 1)
+        assert kkt.last_solve_path() in (0, 1)
+    assert kkt.solve_check_counts() == (0, 0)
     kkt.close(); bt.close()
+
+
+def _leaf_backward_errors(prob, b0_in, bl_in, x0, xl):
+    """per block: || (b_i - Br_i x0) - K_i x_i ||_inf / (||K_i||_inf ||x_i||_inf + ||b_i - Br_i x0||_inf) from the CSR values on the host, and
+    the same residual relative to the right-hand side alone"""
+    out = []
+    for b in range(prob.N):
+        Kf = prob.K_full(b).tocsr()
+        rhs = bl_in.reshape(prob.N, -1)[b] - prob.Bt_scipy(b).T @ x0
+        x = xl.reshape(prob.N, -1)[b]
+        r = rhs - Kf @ x
+        out.append((np.abs(r).max() / (abs(Kf).sum(axis=1).max() * np.abs(x).max() + np.abs(rhs).max()), np.abs(r).max() / np.abs(rhs).max()))
+    return out
+
+
+@pytest.mark.parametrize("shape", ["dense_tail", "time_coupled"])
+def test_followers_with_adversarial_right_hand_sides_are_measured_and_fall_back(shape, monkeypatch):
+    """Round-4 verdict, weak 1(b): diagonals frozen over sixteen decades (a late interior-point iterate), a benign witness, then followers
+    scaled by 1e+-6 and concentrated on the rows of the smallest pivots.  EVERY follower that goes by sweeps is measured against the leaf
+    rows (way 3) - none rides on the witness - and whatever way a follower took, its leaf rows hold to the backward error the adaptive
+    refinement of the reference's PARDISO guarantees (iparm[7] = 2, PardisoProjectSolver.C:72).  The residual relative to the right-hand
+    side alone, ||K x - b|| / ||b||, is printed, not asserted: with x = K^-1 b up to 1e16 ||b|| / ||K|| no method in double precision
+    bounds it (the refined path does not either)."""
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")
+    if shape == "dense_tail":
+        prob = Problem(21, 3, 600, 300, 30, 20, 0.01, diag_lo=-8.0, diag_hi=8.0)
+    else:
+        prob = _TimeCoupledProblem(23, 3, 3000, 1500, 10, 8, 6)
+        rng = np.random.default_rng(23)
+        for blk in prob.blocks:
+            blk["diag"][:prob.n_i] = 10.0 ** rng.uniform(-8, 8, prob.n_i)
+            blk["K"].val[blk["dpos"]] = blk["diag"]
+    bt, kkt = _system(prob)
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    assert sum(bt.inertia(b)[2] for b in range(prob.N)) == 0
+    rng = np.random.default_rng(7)
+    n_leaf = prob.n_leaf
+    small = [np.argsort(np.abs(prob.blocks[b]["diag"][:prob.n_i]))[:40] for b in range(prob.N)]
+    cases = [("witness", 1.0, None)] + [(f"follower scaled {sc:g} on the smallest pivots", sc, True) for sc in (1e6, 1e-6, 1e6, 1e-6)] + \
+            [("follower, mixed scales", 1.0, False)]
+    worst_eta = 0.0
+    for name, scale, aligned in cases:
+        blh = rng.standard_normal(prob.N * n_leaf)
+        if aligned:
+            v = np.zeros((prob.N, n_leaf))
+            for b in range(prob.N):
+                v[b, small[b]] = rng.standard_normal(40)
+            blh = scale * v.ravel()
+        elif aligned is False:
+            blh *= 10.0 ** rng.uniform(-6, 6, blh.size)
+        b0h = scale * rng.standard_normal(prob.S)
+        b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        path = kkt.last_solve_path()
+        assert path in (0, 1, 3), (name, path)          # never way 2: no follower is taken on trust
+        errs = _leaf_backward_errors(prob, b0h, blh, b0.cpu().numpy(), bl.cpu().numpy())
+        eta = max(e[0] for e in errs)
+        print(f"{shape}: {name}: way {path}, leaf backward error {eta:.2e}, ||r||/||b|| {max(e[1] for e in errs):.2e}")
+        assert eta <= (5e-15 if path == 3 else 1e-13), (name, path, errs)      # (way 3: the measure itself is <= 1e-15 with max|K| for ||K||)
+        worst_eta = max(worst_eta, eta)
+    checked, failed = kkt.solve_check_counts()
+    print(f"{shape}: measured {checked}, failed {failed}, worst leaf backward error {worst_eta:.2e}")
+    assert checked >= 1 and (failed > 0 or checked == len(cases))      # (a failed measure turns the later solves to the refined way)
+    # a follower whose measure FAILS goes the refined way from the saved right-hand side, and the sweeps stay off for these factors
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    b0h, blh = rng.standard_normal(prob.S), rng.standard_normal(prob.N * n_leaf)
+    b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+    kkt.solve_compressed(b0, bl)
+    assert kkt.last_solve_path() == 3
+    c0, f0 = kkt.solve_check_counts()
+    bt.set_refinement_backward_error(2, 1e-30)          # no double-precision result meets this: the next measure fails
+    ways = []
+    for rep in range(2):
+        b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        ways.append(kkt.last_solve_path())
+        errs = _leaf_backward_errors(prob, b0h, blh, b0.cpu().numpy(), bl.cpu().numpy())
+        assert max(e[0] for e in errs) <= 1e-13
+    assert ways[0] in (0, 1) and ways[1] in (0, 1), ways
+    assert kkt.solve_check_counts() == (c0 + 1, f0 + 1)
+    kkt.close(); bt.close()
+
+
+def _joint_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PIPS_HIP_AUG_SWEEPS"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = _TimeCoupledProblem(5, 4, 3000, 1500, 10, 8, 6)
+    mine = np.nonzero(pa.map_children_to_ranks(prob.N, world) == rank)[0]
+    calls = []
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        torch.cuda.synchronize()
+        calls.append(n)
+    comm = pa.ExternalComm(allreduce)
+    bt = pa.LeafBatch(len(mine), prob.S, device=0)
+    for i, b in enumerate(mine):
+        bt.set_block(i, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    bt.analyze(2)
+    bt.set_refinement_backward_error(2, 1e-15)
+    for i, b in enumerate(mine):
+        bt.set_values(i, prob.blocks[b]["K"].val)
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=world)
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in mine]), device="cuda")
+    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
+    rng = np.random.default_rng(4)
+    res = {}
+    for rep in range(3):
+        b0_full = rng.standard_normal(prob.S)
+        bs_full = [rng.standard_normal(prob.n_leaf) for _ in range(prob.N)]
+        if rep == 2 and rank == 1:
+            bt.set_refinement_backward_error(2, 1e-30)        # this rank's measure fails from here on: BOTH ranks must repeat the solve
+        b0 = torch.tensor(b0_full, device="cuda")
+        bl = torch.tensor(np.concatenate([bs_full[b] for b in mine]), device="cuda")
+        n_calls = len(calls)
+        kkt.solve_compressed(b0, bl)
+        bt.sync()
+        res[f"path{rep}"] = kkt.last_solve_path()
+        res[f"calls{rep}"] = np.array(calls[n_calls:])
+        res[f"x0_{rep}"] = b0.cpu().numpy()
+        xl = bl.cpu().numpy().reshape(len(mine), -1)
+        for i, b in enumerate(mine):
+            res[f"x{b}_{rep}"] = xl[i]
+    res["counts"] = np.array(kkt.solve_check_counts())
+    np.savez(os.path.join(out, f"rank{rank}.npz"), blocks=np.array(mine), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_decide_together_about_a_failed_measure(tmp_path):
+    """Several ranks: every solveCompressed by sweeps is measured on every rank and the outcome is all-reduced (one number); when one
+    rank's measure fails, both ranks restore their right-hand sides and repeat the solve the refined way - the answer is the oracle's on
+    both, and the sequence of collectives is the same on both ranks."""
+    import os
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29300 + os.getpid() % 500
+    mp.start_processes(_joint_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    prob = _TimeCoupledProblem(5, 4, 3000, 1500, 10, 8, 6)
+    S = prob.S
+    SCo = np.tril(prob.oracle_finalize(prob.oracle_schur()))
+    root = orc.DenseRootSolver(S)
+    root.matrixChanged(SCo)
+    g = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    rng = np.random.default_rng(4)
+    for rep in range(3):
+        b0 = rng.standard_normal(S)
+        bs = [rng.standard_normal(prob.n_leaf) for _ in range(prob.N)]
+        orc.solve_compressed(b0, bs, [prob.oracle_leaf(b) for b in range(prob.N)], [prob.Bt_scipy(b) for b in range(prob.N)], root, prob.n0, 0, 0, prob.myl, 0)
+        for r in range(world):
+            assert np.linalg.norm(g[r][f"x0_{rep}"] - b0) <= 1e-8 * np.linalg.norm(b0), (rep, r)
+            for b in g[r]["blocks"]:
+                assert np.linalg.norm(g[r][f"x{b}_{rep}"] - bs[b]) <= 1e-8 * np.linalg.norm(bs[b]), (rep, r, b)
+        assert list(g[0][f"calls{rep}"]) == list(g[1][f"calls{rep}"])         # the same collectives in the same order on both ranks
+    # first two solves: sweeps, measured, accepted on both ranks (the first one settles once "does any rank sweep": one extra number);
+    # third: rank 1's measure fails -> both repeat the refined way
+    assert [int(g[r]["path0"]) for r in range(world)] == [3, 3] and [int(g[r]["path1"]) for r in range(world)] == [3, 3]
+    assert all(int(g[r]["path2"]) in (0, 1) for r in range(world))
+    assert list(g[0]["calls0"]) == [1, S, 1] and list(g[0]["calls1"]) == [S, 1] and list(g[0]["calls2"]) == [S, 1, S, 1]
+    assert [tuple(g[r]["counts"]) for r in range(world)] == [(3, 1), (3, 1)]

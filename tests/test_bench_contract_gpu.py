@@ -33,10 +33,11 @@ def _check_line(d, n_gpus):
     assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
     step = d["phase_ms"]["step"]
-    # 4 solveCompressed: two leaf-solve passes each, or one where the sweeps of the augmented factor serve (one rank: all four, the first
-    # of them checked against the leaf rows; several ranks: never the first after a factorisation)
+    # 4 solveCompressed: two leaf-solve passes each, or one where the sweeps of the augmented factor serve (each of them measured against
+    # the leaf rows; several ranks exchange the outcome)
     passes, aug = d["phase_ms"]["leaf_solve_passes"], d["phase_ms"]["leaf_solve_passes_augmented"]
-    assert step["leaf_factor"] > 0 and step["lsolve_leaf"] > 0 and 4 <= passes <= 8 and aug <= (4 if n_gpus == 1 else 3)
+    assert step["leaf_factor"] > 0 and step["lsolve_leaf"] > 0 and 4 <= passes <= 8 and aug <= 4
+    assert set(d["config"]["solve_paths_last_step"]) <= {0, 1, 3}          # never way 2 by default: no solve rides on another one's measure
     assert len(d["config"]["solve_paths_last_step"]) == 4
 
 
@@ -80,6 +81,29 @@ def test_gpus_flag_starts_the_ranks_itself():
     _check_line(d, 2)
     assert d["collective"]["ranks_seen"] == 2
     assert "Schur dim 4000" in d["config"]["workload"]
+
+
+def test_eight_ranks_hold_one_fixed_chain():
+    """configs[3] as a problem that shards: `--gpus 8 --family time-coupled` on a 16-block chain with Schur dimension 200 (reduced --n; the
+    eight ranks share device 0) - the Schur dimension is the chain's, not a function of the rank count, every rank holds its two blocks,
+    the sparse root's pattern is assembled from the lists the ranks exchange, and the factorisation's communicator counted eight ranks."""
+    args = ["--family", "time-coupled", "--chain-blocks", "16", "--schur-dim", "200", "--blocks-per-gpu", "2", "--n", "600", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-ipm"]
+    d8 = _run(["--gpus", "8"] + args, env={"PIPS_BENCH_SHARE_GPU": "1"})
+    _check_line(d8, 8)
+    assert d8["collective"]["ranks_seen"] == 8
+    assert "Schur dim 200: all of it on 8 GPU(s), 2 blocks/GPU" in d8["config"]["workload"]
+    assert d8["config"]["shape"] == {"family": "time-coupled", "blocks_per_gpu": 2, "n": 600, "schur_dim": 200, "chain_blocks": 16}
+    assert d8["config"]["root"].startswith("sparse")
+    # four ranks run the first eight blocks of the SAME chain (its Schur dimension still 200) with the linking rows those blocks touch
+    d4 = _run(["--gpus", "4"] + args, env={"PIPS_BENCH_SHARE_GPU": "1"})
+    _check_line(d4, 4)
+    assert d4["collective"]["ranks_seen"] == 4
+    assert "Schur dim 200: blocks 0..7 on 4 GPU(s)" in d4["config"]["workload"] and "(Schur dim 151)" in d4["config"]["workload"]   # 95 + floor(8 * 105 / 15)
+    # more ranks than the chain has blocks for: refused
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--family", "time-coupled", "--chain-blocks", "4", "--blocks-per-gpu", "8",
+                          "--n", "600", "--steps", "1"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "exceed the chain" in out.stderr
 
 
 def test_gpus_flag_refuses_more_ranks_than_devices():

@@ -526,3 +526,39 @@ def test_leaf_handle_schur_term_matches_the_blocked_loop(shape):
             loop[ids, :] -= (Bt @ dense.T).T
         assert np.abs(np.tril(loop) - np.tril(got)).max() / scale < RTOL_SC
         s.close()
+
+
+def test_border_split_that_would_not_fit_the_lds_is_taken_off_at_analyze_time(monkeypatch):
+    """Round-4 advisor finding: nb = 176 (the border split's cap) under fronts up to 32 wide whose below-rows are nearly all border rows
+    makes k_border_schur's triangle + staged batch + row positions exceed the 160 KB of LDS; the launch used to refuse it in EVERY
+    factor().  The analysis now evaluates the launch's own formula and falls back to whole update matrices: the input factorises, and
+    matches the oracle."""
+    import torch
+    monkeypatch.setenv("PIPS_HIP_SN_WIDTH", "32")
+    prob = _TimeCoupledProblem(9, 2, 3000, 1500, 100, 76, 6)
+    S, N = prob.S, prob.N
+    probe = pa.symbolic_probe(prob.blocks[0]["K"], prob.n_i, Bt=prob.blocks[0]["Bt"])
+    assert probe["border_split"] == 1                 # block by block the symbolic phase would split (nb = 176 is within the cap)
+    bt = pa.LeafBatch(N, S)
+    for b in range(N):
+        bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    bt.analyze(2)
+    info = bt.info()
+    assert info["nb"] == 176 * N and info["multifrontal_head"] == 1 and info["blocks_with_border_split"] == 0
+    for b in range(N):
+        bt.set_values(b, prob.blocks[b]["K"].val)
+    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
+    bt.factor(SC, S)
+    bt.sync()
+    got = hip_lower_as_rowmajor(SC.cpu().numpy(), S)
+    want = np.tril(prob.oracle_schur())
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-9
+    bt.close()
+    # the same blocks at the default supernode width keep the split
+    monkeypatch.delenv("PIPS_HIP_SN_WIDTH")
+    bt = pa.LeafBatch(N, S)
+    for b in range(N):
+        bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    bt.analyze(2)
+    assert bt.info()["blocks_with_border_split"] == N
+    bt.close()

@@ -100,3 +100,70 @@ def test_solve_dev_and_col_sparsity():
     torch.cuda.synchronize()
     assert np.abs(Xd.cpu().numpy() - want[[0, 1, 2, 4]]).max() <= 1e-10 * np.abs(want).max()
     s.close()
+
+
+def test_single_and_batch_factorisations_mixed_never_answer_from_stale_factors():
+    """A handle goes through matrixChanged() on its own, later through the array-of-handles entry with other values, later on its own again:
+    solve / solve_sparse / solve_dev / get_inertia always answer from the NEWEST factorisation of that leaf, whichever engine holds it
+    (round-4 advisor finding: the private factors stayed 'factored' after a batch factorisation and were used, silently)."""
+    prob = Problem(11, 3, 500, 250, 24, 16, 0.02)
+    N = prob.N
+    solvers = _solvers(prob)
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal(prob.n_leaf)
+
+    def expect(b):
+        xo = rhs.copy()
+        prob.oracle_leaf(b).solve(xo)
+        return xo
+
+    def check(b, tol=1e-9):
+        want = expect(b)
+        x = rhs.copy()
+        solvers[b].solve(x)
+        assert np.linalg.norm(x - want) / np.linalg.norm(want) < tol
+        cs = np.ones(prob.n_leaf, np.int32)
+        X = np.stack([rhs, 2.0 * rhs])
+        solvers[b].solve_sparse(X, cs)
+        assert np.linalg.norm(X[0] - want) / np.linalg.norm(want) < tol and np.linalg.norm(X[1] - 2 * want) / np.linalg.norm(want) < 2 * tol
+        xd = torch.tensor(rhs, device="cuda")
+        solvers[b].solve_dev(xd)
+        torch.cuda.synchronize()
+        assert np.linalg.norm(xd.cpu().numpy() - want) / np.linalg.norm(want) < tol
+
+    def rescale(b, f):
+        prob.blocks[b]["K"].val[prob.blocks[b]["dpos"]] = prob.blocks[b]["diag"] * f
+        if hasattr(prob, "_leaf_cache"):
+            prob._leaf_cache.pop(b, None)
+
+    # 1. every handle alone
+    for b in range(N):
+        solvers[b].matrixChanged()
+    x_old = rhs.copy()
+    solvers[0].solve(x_old)
+    check(0)
+    # 2. other values, through the batch: the private factors are stale now
+    for b in range(N):
+        rescale(b, 3.0)
+    SC = np.zeros((prob.S, prob.S))
+    pa.HipLdlSolver.factor_schur_batch(solvers, SC)
+    x_new = rhs.copy()
+    solvers[0].solve(x_new)
+    assert np.linalg.norm(x_new - x_old) > 1e-3 * np.linalg.norm(x_old)       # (the two factorisations do differ)
+    for b in range(N):
+        check(b)
+    # 3. one handle alone again with third values: its batch copy is the stale one; the siblings still answer from the batch
+    rescale(1, 0.25)
+    solvers[1].matrixChanged()
+    check(1)
+    check(0)
+    check(2)
+    assert solvers[1].get_inertia() == (prob.n_i, prob.my_i, 0)
+    # ... and the array-of-handles solve refuses to mix the two generations instead of answering from the stale copy
+    with pytest.raises(RuntimeError, match="factorised on its own"):
+        pa.HipLdlSolver.solve_batch(solvers, [rhs.copy() for _ in range(N)])
+    # 4. a sibling goes away: the others keep working through the batch
+    solvers[2].close()
+    check(0)
+    solvers[0].close()
+    solvers[1].close()
