@@ -330,6 +330,9 @@ def main():
                     help="time-coupled family: blocks of the whole chain (default 2048 = BASELINE configs[3]; 256 = the 256-block chain of "
                          "rounds 3-4, 31 linking rows per pair).  Fewer ranks than the chain needs run its first gpus * blocks-per-gpu blocks "
                          "with the linking rows those blocks touch")
+    ap.add_argument("--solve-check-every", type=int, default=None,
+                    help="measure every k-th solveCompressed that goes by sweeps of the augmented factor against the leaf rows "
+                         "(library default 1: every one; 0: only the first after a factorisation - rounds 4's behaviour)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -466,6 +469,8 @@ def main():
         else:
             all_cols = mine
     kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, comm=comm, rank=rank, n_ranks=world, sparse_root=sparse_root, all_block_cols=all_cols)
+    if a.solve_check_every is not None:
+        kkt.set_solve_check(a.solve_check_every)
     dev = torch.device("cuda", local_rank)
     diag = torch.tensor(diag_h, device=dev)
     xd0 = torch.tensor(pa.gen_diagonal(a.seed, 0, n0), device=dev)
@@ -617,10 +622,10 @@ def main():
                                       1: "refined Lsolve; Ltsolve by one backward sweep of the augmented factor (no pivot perturbed, the refined Lsolve needed no step)",
                                       2: "first solveCompressed after a factorisation: refined leaf solve(s) - Lsolve, and Ltsolve too unless the border rows are thin enough for the "
                                          "backward sweep of the factor (the witness: no pivot perturbed, no refinement step needed); the others: one forward + one backward sweep of the augmented factor [L 0; L_b I] (DESIGN.md 2)",
-                                      3: "every solveCompressed: one forward + one backward sweep of the augmented factor [L 0; L_b I]; the first pair after a factorisation "
-                                         "is checked against the leaf rows (residual measure of the adaptive refinement within the tolerance, no pivot perturbed) "
-                                         "- the witness for the others (DESIGN.md 2)"}[3 if step_paths and step_paths[0] == 3 else kkt.last_solve_path()],
-                       "solve_paths_last_step": list(step_paths),
+                                      3: "every solveCompressed: one forward + one backward sweep of the augmented factor [L 0; L_b I], its result measured against the "
+                                         "leaf rows (residual measure of the adaptive refinement within the tolerance, no pivot perturbed; a failed measure repeats the "
+                                         "solve the refined way) - ways 2 in solve_paths_last_step are sweeps riding on an earlier measure (--solve-check-every) (DESIGN.md 2)"}[3 if step_paths and step_paths[0] == 3 else kkt.last_solve_path()],
+                       "solve_paths_last_step": list(step_paths), "solve_checks": dict(zip(("measured", "failed"), kkt.solve_check_counts())),
                        "iter_per_s": round(a.steps / dt, 4),
                        "nnzL_per_gpu": info["nnzL"], "tail_dim_avg": round(m_avg, 1), "border_rows_avg": round(nb_avg, 1),
                        "factor_flops_per_gpu": info["flops_factor"] + info["flops_border"]},

@@ -108,7 +108,9 @@ def assemble(blocks):
 
 
 def solve_general(A, b, C, clow, iclow, cupp, icupp, c, xlow, ixlow, xupp, ixupp, max_iter=100, mutol=1e-6, artol=1e-4, trace=None,
-                  dual_reg=0.0, gondzio=2, free_diag=0.0):
+                  dual_reg=0.0, gondzio=2, free_diag=0.0, kkt_solver=None):
+    """kkt_solver: None = SuperLU on the assembled reduced KKT matrix; else a callable K (csc, symmetric) -> (rhs -> solution): how the
+    large fixtures plug MKL PARDISO in (tests/golden/make_ipm_configs1.py: the reference's leaf-solver class on the global matrix)."""
     A, C = sp.csr_matrix(A), sp.csr_matrix(C)
     my, nx = A.shape
     mz = C.shape[0]
@@ -154,7 +156,13 @@ def solve_general(A, b, C, clow, iclow, cupp, icupp, c, xlow, ixlow, xupp, ixupp
         K = sp.bmat([[sp.diags(dd + free_diag * free), A.T, C.T],
                      [A, -dual_reg * sp.identity(my) if dual_reg else None, None],
                      [C, None, sp.diags(nom)]], format="csc")
-        sol = spl.splu(K).solve(np.concatenate([rx, rA, rzz]))
+        if kkt_solver is not None:
+            key = (dd.tobytes(), nom.tobytes())           # (one factorisation per iterate: predictor, corrector and Gondzio steps share it)
+            if solve.key != key:
+                solve.key, solve.fn = key, kkt_solver(K)
+            sol = solve.fn(np.concatenate([rx, rA, rzz]))
+        else:
+            sol = spl.splu(K).solve(np.concatenate([rx, rA, rzz]))
         dx, dy, dz = sol[:nx], -sol[nx:nx + my], -sol[nx + my:]
         ds = -(nom * (rs - dz))
         dG = np.concatenate([ds - rG[:oU], rG[oU:oV] - ds, dx - rG[oV:oW], rG[oW:] - dx]) * M
@@ -162,6 +170,7 @@ def solve_general(A, b, C, clow, iclow, cupp, icupp, c, xlow, ixlow, xupp, ixupp
         dL[on] = (rL[on] - L[on] * dG[on]) / G[on]
         return -dx, -ds, -dy, -dz, -dG, -dL
 
+    solve.key = solve.fn = None
     zero_res = (np.zeros(nx), np.zeros(my), np.zeros(mz), np.zeros(mz), np.zeros(ncp))
     dx, ds, dy, dz, dG, dL = solve(residuals(), G * L)
     x += dx; s += ds; y += dy; z += dz; G = G + dG; L = L + dL
@@ -232,7 +241,7 @@ def solve_blocks(blocks, **kw):
                          d["ixupp"], **kw)
 
 
-def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0, gondzio=2, bounded=None, free_diag=0.0):
+def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg=0.0, gondzio=2, bounded=None, free_diag=0.0, kkt_solver=None):
     """The generator's class  min c^T x, A x = b, x >= 0  (bounded: optional 0/1 mask, 0 = free variable: ixlow = ixupp = 0, no
     complementarity pair, dd_j = 0, LinearSystem.C:262-294) through the general routine.  free_diag: primal regularisation on the
     free entries of the KKT matrix (a free column without any coefficient makes the unregularised matrix exactly singular)."""
@@ -241,7 +250,7 @@ def solve_lp(A, b, c, max_iter=100, mutol=1e-6, artol=1e-4, trace=None, dual_reg
     ixlow = np.ones(nx) if bounded is None else np.asarray(bounded, dtype=float)
     z0 = np.zeros(0)
     return solve_general(A, b, sp.csr_matrix((0, nx)), z0, z0, z0, z0, c, np.zeros(nx), ixlow, np.zeros(nx), np.zeros(nx), max_iter=max_iter,
-                         mutol=mutol, artol=artol, trace=trace, dual_reg=dual_reg, gondzio=gondzio, free_diag=free_diag)
+                         mutol=mutol, artol=artol, trace=trace, dual_reg=dual_reg, gondzio=gondzio, free_diag=free_diag, kkt_solver=kkt_solver)
 
 
 # ----------------------------------------------------------------------------------------------------------------------------

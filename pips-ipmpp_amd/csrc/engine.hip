@@ -817,6 +817,8 @@ struct Engine {
    // associate the same way for 1, 2, 4 and 8 ranks (pips_hip_kkt_factorize / the deterministic Lsolve), at eight times the bytes of
    // the plain reduction of the Schur complement
    bool det_global = false;
+   bool defer_group_reduce = false;   // set by pips_hip_kkt_factorize around its factor() call: it adds the groups of ALL ranks in one tree itself;
+                                      // a direct pips_hip_batch_factor on the same batch reduces its own groups as on one rank
    // length of one group buffer: S x S (dense Schur complement) or the value array of the sparse one (set_sc_tables)
    long long sc_len = 0;
    long long det_gstride() const { return sc_len > 0 ? sc_len : (long long)S * S; }
@@ -954,7 +956,7 @@ struct Engine {
       if (deterministic && d_gbuf) {
          c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = det_gstride(); c.sc_len = sc_len; c.d_blk_group = d_blk_group;
          c.n_groups = det_n_groups; c.first_slot = det_first_slot;
-         c.det_defer_reduce = det_global;
+         c.det_defer_reduce = det_global && defer_group_reduce;   // (only the kkt paths finish the reduction themselves)
       }
       c.sweep = &sweep;
       return c;
@@ -2929,6 +2931,11 @@ struct KktSystem {
          }
          HIP_TRY(hipStreamWaitEvent(leaves->stream, ev_root_done, 0));
          root_pending = false;
+      } else if (root && root->check_pending) {
+         // the root was factorised on the main stream (pips_hip_kkt_set_root_stream(0)): the pivot check is still owed, and it reads from the
+         // device and waits - it must happen here, before a capture of the solve sequence begins, not inside DenseLdl::solve_dev
+         const int rc = root->check_pivots();
+         if (rc) return rc;
       }
       return PIPS_OK;
    }
@@ -4268,7 +4275,10 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    if ((rc = k->root_wait())) return rc;                                         // the previous root factorisation still reads the value array
    HIP_TRY(hipMemsetAsync(r->d_kval, 0, nnz * sizeof(double), e->stream));
    tm.begin(e->stream, 1);
-   if ((rc = e->factor(r->d_kval, 0))) return rc;
+   e->defer_group_reduce = (k->n_ranks > 1 || k->force_reduce) && e->deterministic && e->det_global;
+   rc = e->factor(r->d_kval, 0);
+   e->defer_group_reduce = false;
+   if (rc) return rc;
    tm.end(e->stream);
    const bool reduce = k->n_ranks > 1 || k->force_reduce;
    tm.begin(e->stream, 2);
@@ -4354,7 +4364,10 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    HIP_TRY(hipMemsetAsync(k->d_SC, 0, n * sizeof(double), e->stream));            // initializeKKT (:840-847)
    tm.end(e->stream);
    tm.begin(e->stream, 1);
-   if ((rc = e->factor(k->d_SC, k->S))) return rc;                               // children factor2 + assembleLocalKKT
+   e->defer_group_reduce = (k->n_ranks > 1 || k->force_reduce) && e->deterministic && e->det_global;
+   rc = e->factor(k->d_SC, k->S);                                                // children factor2 + assembleLocalKKT
+   e->defer_group_reduce = false;
+   if (rc) return rc;
    tm.end(e->stream);
    // reduceKKT (:860-881).  PIPS_HIP_FORCE_REDUCE exercises the reduction path with a one-rank communicator (tests).
    const bool reduce = k->n_ranks > 1 || k->force_reduce;
@@ -4499,7 +4512,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    const bool can_measure = !capturing && e->refine_tol > 0.0 && e->refine_steps > 0 && !(e->deterministic && e->d_gvec);
    // (whether the ranks exchange the outcome may depend only on what is equal on every rank: the settings the host gives all ranks alike,
    // and "some rank's analysis chose the sweeps" - the cost model decides per rank - settled once per analysis by an all-reduce)
-   if (joint && can_measure && k->checked_witness && k->solve_check_every > 0 && k->joint_aug_gen != e->analysis_gen) {
+   if (joint && can_measure && k->solve_check_every > 0 && k->joint_aug_gen != e->analysis_gen) {
       if (!k->d_flag) HIP_TRY(hipMalloc((void**)&k->d_flag, sizeof(double)));
       double any = e->aug_sweeps_ok ? 1.0 : 0.0;
       HIP_TRY(hipMemcpyAsync(k->d_flag, &any, sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -4510,11 +4523,11 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       k->joint_aug_any = any > 0.0;
       k->joint_aug_gen = e->analysis_gen;
    }
-   const bool joint_check = joint && can_measure && k->checked_witness && k->solve_check_every > 0 && k->joint_aug_any;
+   const bool joint_check = joint && can_measure && k->solve_check_every > 0 && k->joint_aug_any;
    if (can_measure && e->aug_sweeps_ok && k->aug_failed_gen != k->factor_gen) {
       const bool validated = k->aug_validated_gen == k->factor_gen;
-      const bool may_check = k->checked_witness && (!joint || joint_check);
-      if (validated || may_check) {
+      const bool may_check = !joint || joint_check;      // (a measure may fail: several ranks must be able to act on it together)
+      if (validated || (k->checked_witness && may_check)) {   // the first solve after a factorisation: a checked sweep pair, or the refined pass
          int pert = 1;
          if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
          use_aug = pert == 0;

@@ -286,7 +286,7 @@ def _joint_worker(rank, world, port, out):
         bt.sync()
         res[f"path{rep}"] = kkt.last_solve_path()
         res[f"calls{rep}"] = np.array(calls[n_calls:])
-        res[f"x0_{rep}"] = b0.cpu().numpy()
+        res[f"xroot_{rep}"] = b0.cpu().numpy()
         xl = bl.cpu().numpy().reshape(len(mine), -1)
         for i, b in enumerate(mine):
             res[f"x{b}_{rep}"] = xl[i]
@@ -317,7 +317,7 @@ def test_two_ranks_decide_together_about_a_failed_measure(tmp_path):
         bs = [rng.standard_normal(prob.n_leaf) for _ in range(prob.N)]
         orc.solve_compressed(b0, bs, [prob.oracle_leaf(b) for b in range(prob.N)], [prob.Bt_scipy(b) for b in range(prob.N)], root, prob.n0, 0, 0, prob.myl, 0)
         for r in range(world):
-            assert np.linalg.norm(g[r][f"x0_{rep}"] - b0) <= 1e-8 * np.linalg.norm(b0), (rep, r)
+            assert np.linalg.norm(g[r][f"xroot_{rep}"] - b0) <= 1e-8 * np.linalg.norm(b0), (rep, r)
             for b in g[r]["blocks"]:
                 assert np.linalg.norm(g[r][f"x{b}_{rep}"] - bs[b]) <= 1e-8 * np.linalg.norm(bs[b]), (rep, r, b)
         assert list(g[0][f"calls{rep}"]) == list(g[1][f"calls{rep}"])         # the same collectives in the same order on both ranks

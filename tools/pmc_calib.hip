@@ -33,6 +33,21 @@ __global__ void calib_atomic8(double* __restrict__ p, long long n) {
       __hip_atomic_fetch_add(p + i, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the access pattern of the solve sweeps (k_head_fwd_chain / k_head_bwd_chain / k_leaf_fwd_gather): a wave reads ONE contiguous piece of a few
+// kilobytes (a compact panel of ~33 x 16 doubles = 4224 bytes; a row of the border-row arena) at 8 bytes per lane, the pieces themselves
+// at unrelated places of a large arena.  start[] in doubles: multiples of 16 (128-byte aligned) or of 2 (16-byte aligned: what the arena
+// offsets guarantee).  Round-4 verdict, weak 3: does the x 2 of streaming reads apply to these kernels?
+template <int CHUNK>
+__global__ void calib_chunk8(const double* __restrict__ p, const int* __restrict__ start, long long nchunks, double* out) {
+   double s = 0;
+   const int lane = threadIdx.x & 63;
+   for (long long c = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6; c < nchunks; c += ((long long)gridDim.x * blockDim.x) >> 6) {
+      const double* q = p + (long long)start[c] * 2;
+      for (int i = lane; i < CHUNK; i += 64) s += q[i];
+   }
+   if (s == 1.2345e300) out[0] = s;
+}
+
 int main() {
    const long long n = 1LL << 28;   // 2 GiB of doubles
    double *p, *out; int* idx;
@@ -50,7 +65,21 @@ int main() {
    hipLaunchKernelGGL(calib_write8, dim3(4096), dim3(256), 0, 0, p, n);
    hipLaunchKernelGGL(calib_write16, dim3(4096), dim3(256), 0, 0, (double2_t*)p, n / 2);
    hipLaunchKernelGGL(calib_atomic8, dim3(4096), dim3(256), 0, 0, p, n);
+   {  // 2^19 pieces of 528 doubles (2.2 GB read) out of the 2 GiB buffer, starts drawn by a multiplicative hash
+      const long long nch = 1LL << 19;
+      int *h = (int*)malloc(nch * 4), *st;
+      CK(hipMalloc(&st, nch * 4));
+      for (int align : {8, 1}) {      // units of 2 doubles: 8 -> 128-byte aligned starts, 1 -> 16-byte aligned
+         for (long long i = 0; i < nch; ++i) h[i] = (int)(((unsigned long long)(i * 2654435761ULL) % (unsigned long long)((n - 1024) / 2 / align)) * align);
+         CK(hipMemcpy(st, h, nch * 4, hipMemcpyHostToDevice));
+         if (align == 8) hipLaunchKernelGGL(calib_chunk8<528>, dim3(4096), dim3(256), 0, 0, p, st, nch, out);
+         else hipLaunchKernelGGL(calib_chunk8<529>, dim3(4096), dim3(256), 0, 0, p, st, nch, out);     // (another instantiation = another kernel name in the counter file)
+         CK(hipDeviceSynchronize());
+      }
+      free(h);
+   }
    CK(hipDeviceSynchronize());
+   printf("calib_chunk8<528>: %lld bytes in 128-byte aligned pieces of 4224; calib_chunk8<529>: %lld bytes in 16-byte aligned pieces of 4232\n", (1LL << 19) * 528 * 8, (1LL << 19) * 529 * 8);
    printf("bytes moved per kernel: read8 %lld read16 %lld gather8 %lld (+ %lld index bytes; 64-byte sectors touched: %lld bytes) write8 %lld write16 %lld atomic8 %lld\n",
           n * 8, n * 8, n / 8 * 8, n / 8 * 4, n / 8 * 64, n * 8, n * 8, n * 8);
    return 0;
