@@ -66,16 +66,23 @@ def update_kernel_traffic(n_blocks, n_i, S, world):
         return None
 
 
-def head_traffic(family, n_blocks, n_i, key="hbm_bytes_per_factorize"):
+def head_traffic(shape, key="hbm_bytes_per_factorize"):
     """HBM bytes of the sparse-head kernels per factorize (or, key = "solve_hbm_bytes_per_step", of the leaf solve sweeps per step)
-    from the committed PMC summary (tools/profile_cfg3.sh); only valid for the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r4_cfg3_head_traffic.json")   # (the round-3 file belongs to the head before the border split)
-    if family != "time-coupled" or n_blocks != 256 or n_i != 50000 or not os.path.exists(path):
-        return None
-    try:
-        return json.load(open(path)).get(key)
-    except Exception:
-        return None
+    from the newest committed PMC summary of this very shape (tools/profile_cfg3.sh writes the shape into the file; the round-4 file
+    is the 256-block chain); None for a workload that was not profiled."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg3*_head_traffic.json")),
+                   key=lambda q: (-int(re.match(r"r(\d+)_", os.path.basename(q)).group(1)), q))
+    for path in files:
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        have = d.get("shape") or shape_key("time-coupled", 256, 50000, 8000, 256)
+        if have == shape and int(re.match(r"r(\d+)_", os.path.basename(path)).group(1)) >= 4:   # (round 3: the head before the border split)
+            return d.get(key)
+    return None
 
 
 def shape_key(family, bpg, n_i, S_whole, chain_blocks):
@@ -514,7 +521,12 @@ def main():
     #      the streams the work runs on (pips_hip_batch_get_timing / pips_hip_kkt_get_timing)
     bt.set_timing(True)
     aug0 = bt.info().get("augmented_passes", 0)
+    barrier()
+    t_instr = time.perf_counter()
     step()
+    torch.cuda.synchronize()
+    bt.sync()
+    t_instr = (time.perf_counter() - t_instr) * 1e3
     aug_passes = bt.info().get("augmented_passes", 0) - aug0    # passes of this step that swept the augmented factor (border rows included)
     tm = bt.get_timing()
     tk = kkt.get_timing()
@@ -568,9 +580,9 @@ def main():
     if dominant["group"] == "tail update":
         traffic = update_kernel_traffic(n_blocks_total, n_i, S, world)
     elif dominant["group"] == "sparse head":
-        traffic = head_traffic(a.family, n_blocks_total, n_i)
+        traffic = head_traffic(shape)
     elif dominant["group"] == "leaf solve sweeps":
-        traffic = head_traffic(a.family, n_blocks_total, n_i, "solve_hbm_bytes_per_step")
+        traffic = head_traffic(shape, "solve_hbm_bytes_per_step")
     else:
         traffic = None
     # per launch, like `achieved` (the rocprofv3 average duration of the kernel is ms_per_step / launches_per_step)
@@ -580,12 +592,13 @@ def main():
     # below it what the leaf engine reports for its own part.  The root factorisation runs on a stream of its own beside the first
     # Lsolve's leaf solve; only what exceeds that solve is on the critical path.
     top = {k: round(v[0], 3) for k, v in tk.items()}
-    lsolve_first = tk["lsolve_leaf"][0] / max(tk["lsolve_leaf"][1], 1)
-    root_exposed = (max(0.0, tk["root_factor"][0] - lsolve_first) if not (os.environ.get("PIPS_HIP_ROOT_SYNC") or sparse_root)
-                    else tk["root_factor"][0])   # (the sparse root is factorised on the main stream)
-    accounted = sum(tk[k][0] for k in ("diag_zero", "leaf_factor", "reduce", "finalize", "lsolve_leaf", "lsolve_border_reduce", "dsolve",
-                                       "ltsolve", "combine")) + root_exposed
+    # what the main stream waited for the root: the join before the first Dsolve where the root has a stream of its own (measured by
+    # events around the join, phase root_wait), the whole factorisation where it sits on the main stream
+    root_exposed = tk["root_wait"][0] + tk["root_factor_main_stream"][0]
+    accounted = sum(tk[k][0] for k in ("diag_zero", "leaf_factor", "reduce", "finalize", "root_factor_main_stream", "lsolve_leaf", "lsolve_border_reduce",
+                                       "root_wait", "dsolve", "ltsolve", "solve_check", "combine"))
     phase_ms = {"step": top, "root_factor_exposed": round(root_exposed, 3), "accounted": round(accounted, 3),
+                "instrumented_step_wall": round(t_instr, 3),   # the one step the phases were taken from, host clock around it (events and two extra waits inside)
                 "leaf_factor": {k: round(tm[k][0], 3) for k in ("scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur")},
                 "leaf_solves": {k: round(tm[k][0], 3) for k in ("solve_permute", "solve_head_fwd", "solve_tail", "solve_head_bwd", "solve_refine")},
                 "leaf_solve_passes": n_solve_once, "leaf_solve_passes_augmented": aug_passes}

@@ -46,7 +46,10 @@ def set_threads(n):
 class MklPardisoSolver:
     """DoubleLinearSolver-shaped wrapper: matrixChanged() / solve(x or (nrhs,n)) / get_inertia()."""
 
-    def __init__(self, K_lower_csr, num_threads=1):
+    def __init__(self, K_lower_csr, num_threads=1, matching=True, reuse_analysis=False):
+        """matching=False: iparm[12] = 0 (scaling stays) - on a whole arrowhead KKT matrix MKL's matching triples the fill (8 blocks of
+        configs[1]: 364 M against 166 M factor entries); the analysis then does not depend on the values and reuse_analysis=True runs
+        phase 11 once and phase 22 per matrixChanged()."""
         if not available():
             raise RuntimeError("libmkl_rt.so not found")
         self.K = K_lower_csr
@@ -72,12 +75,13 @@ class MklPardisoSolver:
         ip[7] = 2      # max iterative refinement steps
         ip[9] = 8      # pivot perturbation 1e-8 (default for mtype -2)
         ip[10] = 1     # scaling
-        ip[12] = 1     # matching (MKL supports 0/1; the reference asks Schenk-PARDISO for 2)
+        ip[12] = 1 if matching else 0     # matching (MKL supports 0/1; the reference asks Schenk-PARDISO for 2)
         ip[17] = -1
         ip[20] = 1     # Bunch-Kaufman 1x1/2x2 pivoting (default for mtype -2)
         ip[34] = 0     # fortran indexing, like the reference
         set_threads(num_threads)
         self.first = True
+        self.reuse_analysis = bool(reuse_analysis) and not matching
 
     def _call(self, phase, nrhs, b, x):
         err = C.c_int(0)
@@ -96,7 +100,13 @@ class MklPardisoSolver:
 
     def matrixChanged(self):
         self.a[:] = np.asarray(self.K.data)[self.map]
-        self._call(12, 1, None, None)    # analysis + numerical factorisation every time, as the reference does
+        if self.reuse_analysis:
+            if self.first:
+                self._call(11, 1, None, None)
+            self._call(22, 1, None, None)
+        else:
+            self._call(12, 1, None, None)    # analysis + numerical factorisation every time, as the reference does
+        self.first = False
 
     def solve(self, x):
         X = x.reshape(-1, self.n)

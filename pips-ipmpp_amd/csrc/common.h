@@ -111,8 +111,6 @@ struct BlockSym {
    std::vector<int64_t> mf_U;           // per head supernode: offset of its packed update matrix; simple leaf below a front: offset of
                                         // its 1 + r values inside the block's leaf-value region; -1: neither
    int64_t mf_LV_total = 0;             // doubles of leaf values of this block
-   std::vector<int64_t> mf_V;           // per front: offset of its update vector (r doubles; the multifrontal solves), -1 for simple leaves
-   int64_t mf_V_total = 0;
    std::vector<int64_t> mf_meta;        // per head supernode: offset of its front record inside mf_int, -1 for simple leaves
    std::vector<int> mf_int;             // front records
    std::vector<int64_t> mf_fix;         // positions inside mf_int that hold LOCAL supernode ids (the engine renumbers them)

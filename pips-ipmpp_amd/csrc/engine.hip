@@ -317,11 +317,10 @@ struct TailCtx {
    const std::vector<TaskList>* sc_groups = nullptr;
    const TileTask* d_sc_tasks = nullptr;
    const std::vector<hipEvent_t>* ev_sc = nullptr;
-   // persistent update kernel (k_tile_gemm_persist): pool of 8-counter slots, zeroed at the start of a factorisation; every
-   // update launch takes the next slot
+   // k_tile_gemm_bal (tasks drawn from per-XCD counters, an eighth more workgroups than tasks): pool of 8-counter slots, zeroed at the
+   // start of a factorisation; every such launch takes the next slot
    int* d_ctr_pool = nullptr;
    int* ctr_cursor = nullptr;
-   bool balanced = false;               // k_tile_gemm_bal: tasks drawn from per-XCD counters, an eighth more workgroups than tasks
    // deterministic Schur accumulation (Engine::set_det_groups): the blocks are cut into at most eight contiguous groups with a
    // buffer each; round k of the SYRK handles the k-th block of every group, so a launch never has two workgroups on the same
    // entry of a buffer and the blocks of a group arrive in their order; k_reduce_groups then adds the buffers in a fixed tree
@@ -340,57 +339,37 @@ struct TailCtx {
    int bk_orig_ld = 0, bk_orig_rowmajor = 0;
    const int* d_bk_perm = nullptr;
    int bk_isolate = 0;
-   int root_persist_wgs = 0;            // dense root: workgroups of the persistent trailing update (0: a workgroup per tile)
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
-constexpr int GEMM_PERSIST_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
+constexpr int GEMM_BAL_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
 
 static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
    const TailPlan& p = *c.plan;
-   static const int root_chunk = getenv("PIPS_HIP_ROOT_CHUNK") ? atoi(getenv("PIPS_HIP_ROOT_CHUNK")) : 0;
    auto gemm_diag_tiles = [&](const TaskList& l, hipStream_t st) {
       hipLaunchKernelGGL(k_tile_gemm<4>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
                          c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
    };
    auto gemm0 = [&](const TaskList& l, hipStream_t st) {
-      const bool persist = c.d_ctr_pool && l.cnt >= GEMM_PERSIST_MIN_TASKS && *c.ctr_cursor < GEMM_CTR_SLOTS;
-      int* ctr = persist ? c.d_ctr_pool + 8 * (*c.ctr_cursor)++ : nullptr;
-      if (persist && c.balanced && !c.is_root) {
+      // leaf tails: launches of two rounds of the chip or more draw their tiles from per-XCD counters with an eighth more workgroups than
+      // tiles (k_tile_gemm_bal); smaller ones one tile per workgroup.  (A persistent work-stealing variant, static shares, the root's bulk
+      // in chunks or as a persistent launch with fewer workgroups than the chip holds: measured, no gain - docs/HISTORY_r4.md.)
+      if (!c.is_root && c.d_ctr_pool && l.cnt >= GEMM_BAL_MIN_TASKS && *c.ctr_cursor < GEMM_CTR_SLOTS) {
+         int* ctr = c.d_ctr_pool + 8 * (*c.ctr_cursor)++;
          const int wgs = ((l.cnt + 7) / 8 * 8) / 8 * 9;
          hipLaunchKernelGGL(k_tile_gemm_bal<0>, dim3((wgs + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail,
                             c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
          return;
       }
-      if (c.is_root) {
-         if (persist)
-            // fewer persistent workgroups than the chip holds (two per compute unit): the ones left with a single workgroup have room for
-            // the kernels of the diagonal-tile chain, which a launch of one workgroup per tile makes wait for its drain
-            hipLaunchKernelGGL(k_tile_gemm_persist<3>, dim3(c.root_persist_wgs > 0 ? c.root_persist_wgs : 512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks,
-                               c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
-         else {
-            // The bulk update of the trailing matrix runs on the side stream beside the diagonal-tile chain of the next column.
-            // Stream priorities only order the launches the command processor has not started yet: once a launch of thousands of
-            // workgroups is running, the single workgroup of k_tile_diag gets no slot until that launch drains (rocprofv3 trace at
-            // S = 16000, tools/root_trace_summary.py: the diagonal kernel "takes" 270 - 1140 us beside the bulk and 70 us alone - it
-            // is waiting, and so do the trsm and the column update behind it: the lookahead overlaps only the drain).
-            // PIPS_HIP_ROOT_CHUNK=n sends the bulk in chunks of n workgroups so that the waiting kernels get in between two
-            // chunks - measured: the gaps between the chunks cost more than the overlap gains (S = 16000: 38.7 ms unchunked,
-            // 39.5 / 41.5 / 46.1 ms with 1024 / 512 / 256), so it is off by default.
-            const int chunk = st == c.side && root_chunk > 0 ? root_chunk : l.cnt;
-            for (int o = 0; o < l.cnt; o += chunk) {
-               const int n = std::min(chunk, l.cnt - o);
-               hipLaunchKernelGGL(k_tile_gemm<3>, dim3((n + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off + o, n, c.d_blks, c.d_arena,
-                                  c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
-            }
-         }
-      } else {
-         if (persist)
-            hipLaunchKernelGGL(k_tile_gemm_persist<0>, dim3(512), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
-                               c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena, ctr);
-         else
-            hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
-                               c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
-      }
+      if (c.is_root)
+         // The bulk update of the trailing matrix runs on the side stream beside the diagonal-tile chain of the next column.  Stream
+         // priorities only order the launches the command processor has not started yet: once a launch of thousands of workgroups is
+         // running, the single workgroup of k_tile_diag gets no slot until that launch drains (rocprofv3 trace at S = 16000: the diagonal
+         // kernel "takes" 270 - 1140 us beside the bulk and 70 us alone - it is waiting): the lookahead overlaps only the drain.
+         hipLaunchKernelGGL(k_tile_gemm<3>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+      else
+         hipLaunchKernelGGL(k_tile_gemm<0>, dim3((l.cnt + 7) / 8 * 8), dim3(512), 0, st, p.d_tasks + l.off, l.cnt, c.d_blks, c.d_arena,
+                            c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
    };
    // Lookahead bookkeeping (right-looking modes with a side stream): while the side stream applies a finished panel to
    // the tile columns >= side_from, the main stream may only write columns left of that.
@@ -495,7 +474,7 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipEventRecord((*c.ev_sc)[g], c.stream));
       }
       if (c.timer) c.timer->end(c.stream);
-   } else if (SC && p.schur.cnt > 0 && c.balanced && c.d_ctr_pool && !c.d_sctab && *c.ctr_cursor < GEMM_CTR_SLOTS) {
+   } else if (SC && p.schur.cnt > 0 && c.d_ctr_pool && !c.d_sctab && *c.ctr_cursor < GEMM_CTR_SLOTS) {
       if (c.timer) c.timer->begin(c.stream, 5);
       const int wgs = ((p.schur.cnt + 7) / 8 * 8) / 8 * 9;
       hipLaunchKernelGGL(k_tile_gemm_bal<2>, dim3((wgs + 7) / 8 * 8), dim3(512), 0, c.stream, p.d_tasks + p.schur.off, p.schur.cnt, c.d_blks,
@@ -556,20 +535,17 @@ struct BlockInput {
    std::vector<double> btval;
 };
 
-// Waves per launch up to which the head solve sweeps use the register-lean "chain" kernels (k_head_fwd_chain / k_head_bwd_chain: all
-// loads up front, partial sums in registers, one LDS transpose) instead of k_head_fwd / k_head_bwd (a wave reduction per column).
-// Round 2 drew the line at 1024 waves; with supernodes capped at 16 columns the chain kernels win at every size (configs[3] share,
-// 256 x 50 000: leaf solve 13.5 -> 11.6 ms), so the line is gone; PIPS_HIP_CHAIN_MAX brings it back for tuning runs.  Deterministic
-// mode takes one kernel whatever the batch size: k_head_fwd (it writes slots) forward, the chain kernel backward.
-static const long long CHAIN_LAUNCH_MAX = getenv("PIPS_HIP_CHAIN_MAX") ? atoll(getenv("PIPS_HIP_CHAIN_MAX")) : (1LL << 40);
-
+// The head solve sweeps use the register-lean "chain" kernels (k_head_fwd_chain / k_head_bwd_chain: all loads up front, partial sums in
+// registers, one LDS transpose) at every launch size (round 2 drew a line at 1024 waves; with supernodes capped at 16 columns they win
+// everywhere: configs[3] share, leaf solve 13.5 -> 11.6 ms).  Deterministic mode takes k_head_fwd (it writes slots) forward, the chain
+// kernel backward.
 struct LevelRange {
    int simple_begin, simple_cnt, small_begin, small_cnt, large_begin, large_cnt;
    int small_lds = 0, large_lds = 0;   // doubles of LDS the widest L21 panel of the class needs (r * (w | 1)), capped at the kernel's capacity
 };
 
 // Multifrontal head: one launch per (level, front class); class = (workgroup size, width bound) of k_front.
-struct MfLaunch { int level, cls, begin, cnt, lds_doubles, lds_fwd = 0, lds_bwd = 0; };
+struct MfLaunch { int level, cls, begin, cnt, lds_doubles; };
 // doubles of the update matrix a front keeps: all r columns, or (border split) those of its rb rows of K
 static inline long long mf_unp(const BlockSym& bs, const HeadSupernode& s) {
    const long long uc = bs.mf_split ? s.rb : s.r;
@@ -578,10 +554,9 @@ static inline long long mf_unp(const BlockSym& bs, const HeadSupernode& s) {
 static inline int mf_class(int w, long long nf, long long unp, long long lds_budget) {
    const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
    if (pw + unp + 8 > lds_budget) return 6 + (nf <= 256 ? 0 : 1);   // update matrix stays in device memory
-   // more than one wave: 256 threads - the phases around the pivots are spread over them; PIPS_HIP_MF_128=1: 128 threads up to 128 rows
-   // (twice the fronts per compute unit where the registers, not the LDS, set the limit)
-   static const bool mid = getenv("PIPS_HIP_MF_128") && atoi(getenv("PIPS_HIP_MF_128")) != 0;
-   return (nf <= 64 ? 0 : (mid && nf <= 128) ? 1 : 2) + 3 * (w <= 16 ? 0 : 1);
+   // more than one wave: 256 threads - the phases around the pivots are spread over them (128 threads up to 128 rows - twice the fronts
+   // per compute unit where the registers set the limit - measured 15.3 against 15.0 ms on the 256-block chain: docs/HISTORY_r4.md)
+   return (nf <= 64 ? 0 : 2) + 3 * (w <= 16 ? 0 : 1);
 }
 
 // Tile geometry + the cost-model / amalgamation knobs (environment overrides are for tuning runs only).
@@ -596,8 +571,6 @@ static void apply_tuning(AnalyzeOptions& opt) {
    if (const char* rz = getenv("PIPS_HIP_RELAX_ZEROS")) opt.relax_zeros = atof(rz);   // share of explicit zeros per panel
    if (const char* ndd = getenv("PIPS_HIP_ND_DEPTH")) opt.nd_depth = atoi(ndd);        // dissection levels (0 = off)
    if (const char* ndm = getenv("PIPS_HIP_ND_MIN")) opt.nd_min_size = atoi(ndm);      // smallest segment that is still dissected
-   if (const char* hc = getenv("PIPS_HIP_HEAD_COST")) opt.head_cost = atof(hc);       // seconds per scattered update
-   if (const char* mr = getenv("PIPS_HIP_MFMA_RATE")) opt.mfma_rate = atof(mr);
    if (const char* ml = getenv("PIPS_HIP_MF_LDS")) opt.mf_lds_doubles = atoll(ml);   // LDS budget of a front in doubles (tests: small values force the device-memory variant)
    if (const char* sp = getenv("PIPS_HIP_MF_SPLIT")) opt.mf_split_nb_max = atoi(sp) == 0 ? 0 : std::min(176, std::max(atoi(sp), 2));   // border split: 0 = off, else the largest nb
 }
@@ -632,20 +605,11 @@ struct Engine {
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
    int *d_schur_cols = nullptr, *d_schur_slot = nullptr;
-   // ... and front-wise solves (k_front_fwd / k_front_bwd, one wave per front, update vectors child -> parent, leaves through the item
-   // lists: no atomics outside the tail rows).  OFF by default - measured on the configs[3] share (256 x 50 000): a pass takes 3.1 ms
-   // forward + 5.4 ms backward against 2.4 + 2.7 ms of the level kernels it replaces (k_head_fwd / k_head_bwd / k_head_solve_simple):
-   // a front's share of a sweep is a few hundred multiply-adds behind four or five dependent memory round trips (descriptor ->
-   // record -> lists / values -> gathered solution entries), and the thread-per-leaf kernels hide that latency behind 12.6 M
-   // threads where a wave per front cannot.  PIPS_HIP_MF_SOLVES=1 selects them (tests do).
-   bool mf_solves = false;
-   bool mf_bucket_by_class = true;   // launches of a level cut at occupancy classes (PIPS_HIP_MF_BUCKETS=spread: at 25 % LDS spread)
    int sn_width = 0;           // > 0: supernode width cap of this engine instead of the tuned default (the sparse root: a single block, every level is latency)
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
    double* d_mfU = nullptr;    // update matrices of the fronts
    double* d_mfLV = nullptr;   // d and l of the simple leaves below fronts, front by front
-   double* d_mfV = nullptr;    // update vectors of the fronts (multifrontal solves)
    int *d_roots = nullptr, *d_root_off = nullptr;   // fronts without a head parent, per block (k_root_assemble)
    BbBatch* d_bb_batches = nullptr;                 // border split (k_border_schur): batches of supernodes with border rows, block after block
    BbMeta* d_bb_meta = nullptr;
@@ -719,8 +683,6 @@ struct Engine {
       lf_rows = 0; lf_entries = 0;
       if (d_mfU) (void)hipFree(d_mfU);
       if (d_mfLV) (void)hipFree(d_mfLV);
-      if (d_mfV) (void)hipFree(d_mfV);
-      d_mfV = nullptr;
       for (void* q : {(void*)d_bb_batches, (void*)d_bb_meta, (void*)d_bb_off, (void*)d_bb_pos, (void*)d_bb_round_blk, (void*)d_bb_out})
          if (q) (void)hipFree(q);
       d_bb_out = nullptr;
@@ -830,7 +792,7 @@ struct Engine {
       if (!analyzed || !deterministic) return PIPS_OK;
       const int slots = (n_ranks >= 1 && n_ranks <= 8 && 8 % n_ranks == 0) ? 8 / n_ranks : 8;
       det_first_slot = slots == 8 ? 0 : rank * slots;
-      det_global = n_ranks > 1 && slots < 8 && !getenv("PIPS_HIP_DET_LOCAL_TREE");
+      det_global = n_ranks > 1 && slots < 8;
       const int gs = std::max(1, (nblk + slots - 1) / slots);     // blocks per group
       det_n_groups = (nblk + gs - 1) / gs;
       std::vector<int> grp(std::max(nblk, 1), 0);
@@ -907,8 +869,6 @@ struct Engine {
    double* d_bt_tmp = nullptr;
    int* d_gemm_ctr = nullptr;     // counter slots of the persistent update kernel
    int gemm_ctr_cursor = 0;
-   bool balanced_gemm = true;      // k_tile_gemm_bal for launches of >= 1024 tiles (PIPS_HIP_BALANCED_GEMM=0: static shares)
-   bool persistent_gemm = false;   // measured: no gain, and it starves the side stream (see k_tile_gemm_persist); PIPS_HIP_PERSISTENT_GEMM=1
    // ---- Schur SYRK in row-panel groups, so that a multi-rank root can reduce panel p while the leaves still compute p + 1 ..
    std::vector<TaskList> sc_groups;
    std::vector<int> sc_row_begin;          // panel p = Schur rows [sc_row_begin[p], sc_row_begin[p + 1])
@@ -952,7 +912,7 @@ struct Engine {
       TailCtx c{d_blks, &plan, d_arena, d_dtail, d_winv, d_psign, d_psign_off, d_bmap, d_inertia, stream,
                 timer.on ? &timer : nullptr, d_pref, side, ev_diag_in, ev_diag_out, false, d_sctab, d_uarena};
       if (!sc_groups.empty()) { c.sc_groups = &sc_groups; c.d_sc_tasks = d_sc_tasks; c.ev_sc = &ev_sc; }
-      if (persistent_gemm || balanced_gemm) { c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor; c.balanced = balanced_gemm; }
+      c.d_ctr_pool = d_gemm_ctr; c.ctr_cursor = &gemm_ctr_cursor;
       if (deterministic && d_gbuf) {
          c.det_rounds = &det_rounds; c.d_det_tasks = d_det_tasks; c.d_gbuf = d_gbuf; c.gstride = det_gstride(); c.sc_len = sc_len; c.d_blk_group = d_blk_group;
          c.n_groups = det_n_groups; c.first_slot = det_first_slot;
@@ -1012,7 +972,6 @@ struct Engine {
       const double launches = 2.0 * (max_levels + 2 * max_ntc) + 8;
       // multi-RHS sweeps over a sparse factor run at ~0.8 TB/s effective (measured, tools/banded_schur_probe.py)
       const double t_sol = ncols * 2.0 * l_bytes / 0.8e12 + std::ceil(ncols / 32.0) * launches * 12e-6;
-      if (getenv("PIPS_HIP_DEBUG_SCHUR")) fprintf(stderr, "[pips_hip] schur cost model: augmented %.1f ms, blocked solves %.1f ms\n", t_aug * 1e3, t_sol * 1e3);
       return t_sol < t_aug;
    }
 
@@ -1022,8 +981,6 @@ struct Engine {
       apply_tuning(opt);
       if (sn_width > 0 && !getenv("PIPS_HIP_SN_WIDTH")) opt.max_sn_width = std::min(HEAD_WMAX, sn_width);
       if (const char* sm = getenv("PIPS_HIP_SCHUR_MODE")) schur_mode = atoi(sm);
-      if (const char* pg = getenv("PIPS_HIP_PERSISTENT_GEMM")) persistent_gemm = atoi(pg) != 0;
-      if (const char* bg = getenv("PIPS_HIP_BALANCED_GEMM")) balanced_gemm = atoi(bg) != 0;
       bool any_border = false;
       for (int b = 0; b < nblk; ++b) any_border = any_border || !in[b].btrow.empty();
       {  // the border split (compact front panels) only exists with the multifrontal head
@@ -1044,8 +1001,6 @@ struct Engine {
          const char* env = getenv("PIPS_HIP_MF");
          const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
          mf = !(env && atoi(env) == 0) && !(hs && atoi(hs) != 0 && !deterministic);
-         mf_solves = getenv("PIPS_HIP_MF_SOLVES") && atoi(getenv("PIPS_HIP_MF_SOLVES")) != 0;
-         if (const char* bk = getenv("PIPS_HIP_MF_BUCKETS")) mf_bucket_by_class = std::string(bk) != "spread";
          const bool mf_wanted = mf;
          auto fronts_fit = [&]() {
             bool ok = mf_wanted;
@@ -1065,7 +1020,6 @@ struct Engine {
             return ok;
          };
          mf = fronts_fit();
-         mf_solves = mf_solves && mf && !deterministic;   // (deterministic mode keeps its slot-based forward substitution)
          bool any_split = false;
          for (int b = 0; b < nblk; ++b) any_split = any_split || sym[b].mf_split;
          // ... or k_border_schur's triangle + staged batch + row positions exceed the LDS (nb close to the cap under wide fronts whose
@@ -1076,7 +1030,6 @@ struct Engine {
             opt.mf_split_nb_max = 0;
             if ((rc = analyze_host(n_threads, schur_mode_eff != 2))) return rc;
             if (bb_too_big) mf = fronts_fit();   // (the fronts grew by their border columns: they must still fit)
-            mf_solves = mf_solves && mf;
          }
       }
 
@@ -1085,7 +1038,7 @@ struct Engine {
       kptr.assign(nblk + 1, 0);
       x_off.assign(nblk + 1, 0);
       std::vector<long long> bptr(nblk + 1, 0), rows_base(nblk + 1, 0), sn_base(nblk + 1, 0), bmap_off(nblk + 1, 0),
-         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0), mfLV_base(nblk + 1, 0), mfV_base(nblk + 1, 0);
+         upd_base(nblk + 1, 0), mfU_base(nblk + 1, 0), mfint_base(nblk + 1, 0), mfLV_base(nblk + 1, 0);
       long long arena = 0, xw = 0, winv = 0, dt = 0, sncol = 0, uar = 0;
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& s = sym[b];
@@ -1118,7 +1071,6 @@ struct Engine {
          mfU_base[b + 1] = mfU_base[b] + (mf ? s.mf_U_total : 0);
          mfint_base[b + 1] = mfint_base[b] + (mf ? (long long)s.mf_int.size() : 0);
          mfLV_base[b + 1] = mfLV_base[b] + (mf ? s.mf_LV_total : 0);
-         mfV_base[b + 1] = mfV_base[b] + (mf ? s.mf_V_total : 0);
          d.lv_off = mfLV_base[b];
          d.k_off = kptr[b]; d.b_off = bptr[b];
          sn_base[b + 1] = sn_base[b] + (long long)s.sn.size();
@@ -1222,7 +1174,6 @@ struct Engine {
             const BlockSym& bs = sym[k.blk];
             if (bs.mf_U[k.loc] >= 0) h_sns[i].U = (k.cls == 0 ? mfLV_base[k.blk] : mfU_base[k.blk]) + bs.mf_U[k.loc];
             if (bs.mf_meta[k.loc] >= 0) h_sns[i].mf = mfint_base[k.blk] + bs.mf_meta[k.loc];
-            if (mf_solves && bs.mf_V[k.loc] >= 0) h_sns[i].vslot = mfV_base[k.blk] + bs.mf_V[k.loc];   // (never together with the slot-based sweeps)
          }
          // factorisation slots: every scattering supernode; multifrontal head: only the simple leaves without a front above them scatter
          // (the fronts hand their update matrices on, k_root_assemble adds the last ones in a fixed order)
@@ -1235,12 +1186,12 @@ struct Engine {
          else { if (L.large_cnt++ == 0) L.large_begin = i; }
          if (mf && k.cls > 0) {
             // one launch per (level, variant, LDS bucket): the dynamic LDS of a launch is that of its largest front, and it decides how
-            // many fronts share a compute unit - a bucket spans at most a quarter more than its smallest member (small runs stay whole)
+            // many fronts share a compute unit
             bool open = mf_launches.empty() || mf_launches.back().level != k.level || mf_launches.back().cls != k.cls - 1;
             if (!open) {
                const MfLaunch& m = mf_launches.back();
                const int first_lds = keys[m.begin].lds;
-               if (mf_bucket_by_class) {
+               {
                   // how many fronts of the variant share a compute unit: the LDS decides up to the limit the registers set (123 VGPRs: four
                   // waves per SIMD - four workgroups of 256 threads, sixteen of 64); a bucket = one such class, since inside a class a
                   // smaller front gains nothing from a launch of its own and across a boundary every front of the launch loses a slot
@@ -1249,17 +1200,11 @@ struct Engine {
                      return std::min(kmax, (int)(163840 / ((long long)lds_doubles * 8 + 1024)));
                   };
                   if (m.cnt >= 256 && cls_of(k.lds) < cls_of(first_lds)) open = true;
-               } else if (m.cnt >= 2048 && k.lds > std::max(first_lds + first_lds / 4, first_lds + 256)) open = true;
+               }
             }
             if (open) mf_launches.push_back({k.level, k.cls - 1, i, 0, 0});
             ++mf_launches.back().cnt;
             mf_launches.back().lds_doubles = std::max(mf_launches.back().lds_doubles, k.lds);
-            {  // LDS of the solve kernels (k_front_fwd / k_front_bwd)
-               const int* H = sym[k.blk].mf_int.data() + sym[k.blk].mf_meta[k.loc];
-               const int wmax = (k.cls - 1) % 6 < 3 && k.cls - 1 < 6 ? 16 : 32, nf = s.w + s.r;
-               mf_launches.back().lds_fwd = std::max(mf_launches.back().lds_fwd, nf + H[5] + (H[6] + H[3] + 1) / 2 + 2);
-               mf_launches.back().lds_bwd = std::max(mf_launches.back().lds_bwd, nf + H[5] + 64 * wmax + wmax * wmax + (H[3] + 1) / 2 + 2);
-            }
          }
          const long long need = (long long)s.r * (s.w | 1);
          if (k.cls == 1) L.small_lds = (int)std::max<long long>(L.small_lds, std::min<long long>(need, 640));
@@ -1370,7 +1315,6 @@ struct Engine {
          if ((rc = dev_upload(&d_mfint, h_mfint, stream))) return rc;
          HIP_TRY(hipMalloc((void**)&d_mfU, (size_t)std::max<long long>(mfU_total, 1) * sizeof(double)));
          HIP_TRY(hipMalloc((void**)&d_mfLV, (size_t)std::max<long long>(mfLV_base[nblk], 1) * sizeof(double)));
-         HIP_TRY(hipMalloc((void**)&d_mfV, (size_t)std::max<long long>(mfV_base[nblk], 1) * sizeof(double)));
       }
       {  // both triangles, row by row: entry (i, j) of the lower CSR also appears in row j as (j, i)
          std::vector<int> frp(n_total + 1, 0);
@@ -1488,10 +1432,8 @@ struct Engine {
       }
       // ---- the simple leaves' L entries by target row (forward substitution as a gather, see d_lf_rows)
       {
-         const char* env = getenv("PIPS_HIP_LEAF_GATHER");
-         const bool want = env ? atoi(env) != 0 : true;
          const LevelRange* L0 = levels.empty() ? nullptr : &levels[0];
-         if (want && L0 && L0->simple_cnt > 0 && xw_total < (1LL << 31) && h_rowidx.size() < (1ull << 31)) {
+         if (L0 && L0->simple_cnt > 0 && xw_total < (1LL << 31) && h_rowidx.size() < (1ull << 31)) {
             std::vector<LeafDesc> h_leaf((size_t)L0->simple_cnt);
             for (int i = 0; i < L0->simple_cnt; ++i) {
                const SnDesc& sn = h_sns[L0->simple_begin + i];
@@ -1553,7 +1495,7 @@ struct Engine {
       if ((rc = dev_upload(&d_bt_rowsc, h_bt_rowsc, stream))) return rc;
       // ---- the border by LEAF row (t += alpha Br x0 as a gather, k_border_mult_rows): row pointers over the flat leaf space, Schur
       //      column and position in d_bval of every entry
-      if (bt_rows_total > 0 && nnzB_total > 0 && nnzB_total < (1LL << 31) && !getenv("PIPS_HIP_NO_BORDER_ROWS")) {
+      if (bt_rows_total > 0 && nnzB_total > 0 && nnzB_total < (1LL << 31)) {
          std::vector<int> rp((size_t)n_total + 1, 0);
          for (long long r = 0; r < bt_rows_total; ++r)
             for (int p = h_bt_rowptr[r]; p < h_bt_rowptr[r + 1]; ++p) ++rp[h_bt_xoff[r] + h_bt_colidx[p] + 1];
@@ -1572,13 +1514,12 @@ struct Engine {
          for (int b = 0; b < nblk; ++b) np[b] = in[b].n_primal;
          if ((rc = dev_upload(&d_nprimal, np, stream))) return rc;
       }
-      const bool diag_ahead = !getenv("PIPS_HIP_NO_DIAG_AHEAD");
+      // the diagonal tile of a column runs ahead on the side stream, its update first; tile rows start at their envelope (variants of the
+      // tail factorisation without either: docs/HISTORY_r1_r2.md)
       std::vector<const std::vector<int>*> firsts(nblk);
       for (int b = 0; b < nblk; ++b) firsts[b] = &sym[b].tile_first;
-      if ((rc = plan.build(h_blks, 0, false, diag_ahead, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts,
-                           diag_ahead && !getenv("PIPS_HIP_DIAG_UPDATE_LATE"))))
-         return rc;
-      if ((rc = sweep.build(h_blks, getenv("PIPS_HIP_NO_ENVELOPE") ? nullptr : &firsts))) return rc;
+      if ((rc = plan.build(h_blks, 0, false, true, &firsts, true))) return rc;
+      if ((rc = sweep.build(h_blks, &firsts))) return rc;
       {
          // border-backward sweep: worth it where the border rows of the factor (what it reads on top of a backward sweep) are no
          // more than what the forward sweep it saves would read, with a margin for the chain and the launches it also saves
@@ -1601,12 +1542,12 @@ struct Engine {
          // Both halves of solveCompressed from the augmented factor (forward_augmented / backward_augmented): one forward and one backward
          // sweep that also read the border rows, instead of two full solves (two sweeps each, a residual check each, two border
          // products) - pays as long as the border rows are not several times what a sweep reads anyway
-         const bool aug_paths = schur_mode_eff == 1 && nnzB_total > 0 && (sweep.enabled || plan.ntc_max == 0) && !deterministic && !mf_solves && spine_total == 0 &&
-                                !head_slots && CHAIN_LAUNCH_MAX >= (1LL << 40);
+         const bool aug_paths = schur_mode_eff == 1 && nnzB_total > 0 && (sweep.enabled || plan.ntc_max == 0) && !deterministic && spine_total == 0 &&
+                                !head_slots;
          aug_sweeps_ok = aug_paths && border_entries <= 3.0 * fwd_entries;
          if (const char* as = getenv("PIPS_HIP_AUG_SWEEPS")) aug_sweeps_ok = atoi(as) != 0 && aug_paths;
       }
-      if (diag_ahead && !side) {
+      if (!side) {
          // highest priority: the few workgroups of the diagonal chain must not queue behind the thousands of the column update
          int prio_lo = 0, prio_hi = 0;
          HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -1707,7 +1648,7 @@ struct Engine {
       if (!bb_fits(z))   // (analyze() has checked the same formula and taken the split off where it does not hold: an assertion)
          PIPS_FAIL(PIPS_ERR_STATE, "k_border_schur: %zu bytes of LDS for nb = %d (batch of %d doubles, %d rows)", lds, bb_nbmax, bb_stage, bb_poscap);
       // a block's batches are walked by `split` workgroups (each with its own accumulator): enough of them to fill the chip
-      const int split = getenv("PIPS_HIP_BB_SPLIT") ? std::max(1, atoi(getenv("PIPS_HIP_BB_SPLIT"))) : std::max(1, std::min(16, 256 / std::max(nblk, 1)));
+      const int split = std::max(1, std::min(16, 256 / std::max(nblk, 1)));
       auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered, double* out = nullptr,
                     long long out_stride = 0) -> int {
          if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1767,32 +1708,6 @@ struct Engine {
             default: rc = launch_front<512, 32, true>(m, SC, ldSC); break;
          }
          if (rc) return rc;
-      }
-      return PIPS_OK;
-   }
-   // multifrontal solves: the fronts of one level, forward (ascending levels) or backward
-   int launch_front_solves(int level, bool backward, double* xw, int border) {
-      for (const MfLaunch& m : mf_launches) {
-         if (m.level != level) continue;
-         const bool wide = !(m.cls < 3);   // classes 0-2: w <= 16
-         const size_t lds = (size_t)(backward ? m.lds_bwd : m.lds_fwd) * sizeof(double);
-         if (!backward) {
-            if (wide) {
-               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_fwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-               hipLaunchKernelGGL(k_front_fwd<32>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, d_mfV, xw);
-            } else {
-               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-               hipLaunchKernelGGL(k_front_fwd<16>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, d_mfV, xw);
-            }
-         } else {
-            if (wide) {
-               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-               hipLaunchKernelGGL(k_front_bwd<32>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, xw, border);
-            } else {
-               if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_front_bwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-               hipLaunchKernelGGL(k_front_bwd<16>, dim3(m.cnt), dim3(64), lds, stream, d_sns, m.begin, d_blks, d_rowidx, d_mfint, d_arena, d_mfLV, xw, border);
-            }
-         }
       }
       return PIPS_OK;
    }
@@ -1952,7 +1867,7 @@ struct Engine {
       // of the border and comes with k_scatter; fronts: assembled in LDS, written out whole) - only the tails are cleared
       hipLaunchKernelGGL(k_arena_clear, dim3(256, nblk), dim3(256), 0, stream, d_blks, d_arena, mf ? 1 : 0);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, (size_t)3 * nblk * sizeof(int), stream));
-      if (persistent_gemm || balanced_gemm) {
+      {
          if (!d_gemm_ctr) HIP_TRY(hipMalloc((void**)&d_gemm_ctr, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int)));
          HIP_TRY(hipMemsetAsync(d_gemm_ctr, 0, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int), stream));
          gemm_ctr_cursor = 0;
@@ -1987,8 +1902,7 @@ struct Engine {
       if (mf && n_roots > 0) {   // the last update matrices: into the tail and the Schur complement, front by front
          if (timer.on) timer.begin(stream, 1);
          // about 2048 workgroups in the launch (what is resident at once): half of a block's chunks on the tail's columns, half on the border's
-         const int asm_env = getenv("PIPS_HIP_ROOT_ASM_CHUNKS") ? atoi(getenv("PIPS_HIP_ROOT_ASM_CHUNKS")) : 0;
-         const int asm_half = asm_env > 0 ? asm_env : std::max(1, std::min(32, 1024 / std::max(nblk, 1)));
+         const int asm_half = std::max(1, std::min(32, 1024 / std::max(nblk, 1)));
          if (deterministic && d_gbuf && SC && d_round_blk) {
             for (size_t k = 0; k + 1 < round_off.size(); ++k) {
                const int cnt = round_off[k + 1] - round_off[k];
@@ -2091,15 +2005,6 @@ struct Engine {
             if (cnt > 0) hipLaunchKernelGGL(k_head_fwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, 0LL, sxv);
          }
          gather(gv_tail, d_vslot_val, xw);
-      } else if (mf_solves && nrhs == 1) {
-         for (size_t li = 0; li < levels.size(); ++li) {
-            const LevelRange& L = levels[li];
-            if (L.simple_cnt > 0)   // only the leaves without a front above them
-               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
-                                  L.simple_cnt, d_blks, d_rowidx, d_arena, xw, 0LL, 0, sx_atomic(), 0, 1);
-            int frc = launch_front_solves((int)li, false, xw, 0);
-            if (frc) return frc;
-         }
       } else
       for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0 && lf_rows > 0)   // the leaves' columns are final as they stand: every target row collects its sum
@@ -2111,12 +2016,9 @@ struct Engine {
          // small and large supernodes of one level are contiguous in d_sns
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         // few supernodes in the launch: a chain-like tree, take the latency-lean kernel; many: the high-occupancy one
-         if (cnt > 0 && (long long)cnt * nrhs < CHAIN_LAUNCH_MAX)
+         if (cnt > 0)
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_fwd_chain<16> : k_head_fwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
                                d_blks, d_rowidx, d_arena, xw, xws, 0);
-         else if (cnt > 0)
-            hipLaunchKernelGGL(k_head_fwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
       }
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
@@ -2127,14 +2029,13 @@ struct Engine {
       c.timer = nullptr;   // (the tail's own phase records belong to the factorisation)
       int rc = tail_fwd(c, xw, nrhs, xws);
       if (rc) return rc;
-      const bool mfs = mf_solves && nrhs == 1;
       // D^-1 of the head columns: fused into the backward kernels of the common path (chain kernels + thread-per-leaf kernel: they
       // read the diagonal's cache line anyway; the separate pass reads 88 bytes of descriptor per supernode - 12.9 M of them on the
       // configs[3] share); the other paths (spine kernels, deterministic mode, k_head_bwd) keep the pass
-      const bool fused_d = !mfs && spine_total == 0 && CHAIN_LAUNCH_MAX >= (1LL << 40);
+      const bool fused_d = spine_total == 0;
       if (nsn_total > 0 && !fused_d)
          hipLaunchKernelGGL(k_head_dscale, dim3(grid_for(nsn_total, 256), nrhs), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
-                            d_arena, xw, xws, mfs ? 1 : 0);
+                            d_arena, xw, xws, 0);
       rc = tail_bwd(c, xw, nrhs, xws);
       if (rc) return rc;
       timer.end(stream);
@@ -2142,27 +2043,13 @@ struct Engine {
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
                             d_arena, xw, xws, 1);
-      if (mfs) {
-         for (int l = (int)levels.size() - 1; l >= 0; --l) {
-            const LevelRange& L = levels[l];
-            int frc = launch_front_solves(l, true, xw, 0);
-            if (frc) return frc;
-            if (L.simple_cnt > 0)
-               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
-                                  L.simple_cnt, d_blks, d_rowidx, d_arena, xw, 0LL, 1, sx_atomic(), 0, 1);
-         }
-      } else
       for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         // (deterministic mode: always the same kernel, whatever the batch size - the two variants add in different orders; the
-         // chain kernel it is, unless the tuning switch brings the size-dependent choice back)
-         if (cnt > 0 && ((long long)cnt * nrhs < CHAIN_LAUNCH_MAX || (deterministic && CHAIN_LAUNCH_MAX >= (1LL << 40))))
+         if (cnt > 0)
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_bwd_chain<16> : k_head_bwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
                                d_blks, d_rowidx, d_arena, xw, xws, 0, fused_d ? 1 : 0);
-         else if (cnt > 0)
-            hipLaunchKernelGGL(k_head_bwd, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, xws);
          if (L.simple_cnt > 0 && d_leafdesc)
             hipLaunchKernelGGL(k_leaf_bwd, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_leafdesc, L.simple_cnt, d_rowidx, d_arena,
                                xw, xws, fused_d ? 1 : 0);
@@ -2493,24 +2380,13 @@ struct Engine {
       const ScatterCtx none{0, nullptr, nullptr, nullptr, nullptr};
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, 1), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, 1);
-      if (mf_solves) {   // (zero right-hand side: the diagonal scaling fused into k_front_bwd divides zeros)
-         for (int l = (int)levels.size() - 1; l >= 0; --l) {
-            const LevelRange& L = levels[l];
-            if ((rc = launch_front_solves(l, true, d_xw, 1))) return rc;
-            if (L.simple_cnt > 0)
-               hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt,
-                                  d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, none, 1, 1);
-         }
-      } else
       for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
-         if (cnt > 0 && (long long)cnt < CHAIN_LAUNCH_MAX)
+         if (cnt > 0)
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_bwd_chain<16> : k_head_bwd_chain<HEAD_WMAX>, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin,
                                d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, 0);
-         else if (cnt > 0)
-            hipLaunchKernelGGL(k_head_bwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1);
          if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt,
                                d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, none, 1);
@@ -2563,7 +2439,7 @@ struct DenseLdl {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list, d_ctr_pool};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -2582,10 +2458,9 @@ struct DenseLdl {
       if ((rc = dev_upload(&d_blks, h_blks, stream))) return rc;
       // one block only: right-looking (measured on MI355X, tools/root_probe.py: S=2000 4.3 -> 2.3 ms, S=16000 183 -> 45 ms;
       // panels of 1 tile column are best up to S = 8000, 2-3 beyond)
-      int panel = d.ntc <= 64 ? 1 : 2;
-      if (const char* pw = getenv("PIPS_HIP_ROOT_PANEL")) panel = atoi(pw);
+      const int panel = d.ntc <= 64 ? 1 : 2;
       // lookahead (second stream) pays once the trailing update of a panel outlasts a diagonal tile: S >= 6000 measured
-      const bool lookahead = panel > 0 && d.ntc >= 48 && !getenv("PIPS_HIP_ROOT_NO_LOOKAHEAD");
+      const bool lookahead = d.ntc >= 48;
       if ((rc = plan.build(h_blks, panel, lookahead))) return rc;
       if ((rc = sweep.build(h_blks, nullptr))) return rc;
       if (lookahead) {
@@ -2614,7 +2489,6 @@ struct DenseLdl {
       TailCtx c{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
       c.sweep = &sweep;
       c.bunch_kaufman = pivoting == 1;
-      if (root_persist_wgs > 0 && d_ctr_pool) { c.d_ctr_pool = d_ctr_pool; c.ctr_cursor = &ctr_cursor; c.root_persist_wgs = root_persist_wgs; }
       if (pivoting == 1 && dist_P <= 1) {
          c.d_pert_cnt = d_pert_cnt; c.d_pert_list = d_pert_list;
          c.bk_orig = last_A; c.bk_orig_ld = last_lda; c.bk_orig_rowmajor = last_rowmajor; c.d_bk_perm = perm.empty() ? nullptr : d_perm;
@@ -2629,10 +2503,6 @@ struct DenseLdl {
    // row next to its column (a symmetric permutation P kept for the following factorisations: the structure that needed it comes back
    // every iteration), factorises P A P^T again and goes on until no index is left without a pivot (at most BK_RETRIES times).  The
    // pair then sits inside one tile, where the 2 x 2 pivot is found.  Solves permute their right-hand side in and out.
-   // persistent trailing update (PIPS_HIP_ROOT_PERSIST=<workgroups>): see tail_factor / k_tile_gemm_persist
-   int root_persist_wgs = getenv("PIPS_HIP_ROOT_PERSIST") ? atoi(getenv("PIPS_HIP_ROOT_PERSIST")) : 0;
-   int* d_ctr_pool = nullptr;
-   int ctr_cursor = 0;
    static constexpr int BK_RETRIES = 8;
    static constexpr int BK_MAX_COLUMNS = 2048;   // columns per round whose original entries travel to the host for the partner choice
    std::vector<int> perm;              // perm[i] = original index at position i (empty: identity)
@@ -2682,20 +2552,6 @@ struct DenseLdl {
                if (!flagged[i] && !taken[i] && col[i] > 0.0 && (best < 0 || col[i] > col[best])) best = i;
             if (best < 0) continue;
             partner[c] = best; taken[best] = 1; any = true;
-         }
-         if (getenv("PIPS_HIP_BK_DEBUG")) {
-            int np_ = 0; for (int i = 0; i < n; ++i) np_ += partner[i] >= 0;
-            fprintf(stderr, "[pips_hip] dense root, attempt %d: %d indices without a pivot in their tile, %d paired with a row below; first: %d -> %d\n", attempt, cnt, np_, rec[0], rec[1]);
-            {
-               std::vector<double> dt(npad);
-               (void)hipMemcpy(dt.data(), d_dtail, (size_t)npad * sizeof(double), hipMemcpyDeviceToHost);
-               int bad = -1; double amin = 1e300, amax = 0;
-               for (int i = 0; i < n; ++i) { if (!(std::fabs(dt[i]) < 1e299) && bad < 0 && std::fabs(dt[i]) != 1e300) bad = i; if (std::fabs(dt[i]) < 1e299) { amin = std::min(amin, std::fabs(dt[i])); amax = std::max(amax, std::fabs(dt[i])); } }
-               fprintf(stderr, "   pivots: first non-finite at %d, |d| in [%.3e, %.3e]; d[380..388] = %.3e %.3e %.3e %.3e %.3e %.3e %.3e %.3e\n", bad, amin, amax, dt[380], dt[381], dt[382], dt[383], dt[384], dt[385], dt[386], dt[387]);
-            }
-            for (int q = 0; q < std::min(cnt, 4); ++q)
-               fprintf(stderr, "   pos %d (orig %d) -> pos %d (orig %d)\n", rec[2 * q], perm.empty() ? rec[2 * q] : perm[rec[2 * q]], rec[2 * q + 1],
-                       rec[2 * q + 1] < 0 ? -1 : (perm.empty() ? rec[2 * q + 1] : perm[rec[2 * q + 1]]));
          }
          if (!any) break;               // nothing below to pair with
          std::vector<int> cur(n);
@@ -2851,11 +2707,6 @@ struct DenseLdl {
             HIP_TRY(hipMalloc((void**)&d_pert_list, (size_t)2 * std::max(npad, 1) * sizeof(int)));
          }
          HIP_TRY(hipMemsetAsync(d_pert_cnt, 0, sizeof(int), stream));
-      }
-      if (root_persist_wgs > 0) {
-         if (!d_ctr_pool) HIP_TRY(hipMalloc((void**)&d_ctr_pool, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int)));
-         HIP_TRY(hipMemsetAsync(d_ctr_pool, 0, (size_t)GEMM_CTR_SLOTS * 8 * sizeof(int), stream));
-         ctr_cursor = 0;
       }
       hipLaunchKernelGGL(k_copy_lower_to_padded, dim3(grid_for((long long)npad * npad, 256)), dim3(256), 0, stream, A_dev,
                          lda, n, d_R, npad, npad, rowmajor, perm.empty() ? (const int*)nullptr : (const int*)d_perm);
@@ -4048,7 +3899,6 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    k->root->thr_rel = e->thr_rel;
    k->root->repl_rel = e->repl_rel;
    if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) { k->root->pivoting = atoi(pv) != 0; k->root_pivoting_set = true; }
-   if (const char* sg = getenv("PIPS_HIP_SOLVE_GRAPH")) k->solve_graph = atoi(sg) != 0;
    int rc = k->root->init();
    if (rc) return rc;
    // several ranks: the dense root factorised column-cyclically over the ranks instead of redundantly on every one of them
@@ -4321,9 +4171,11 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    static const bool root_async_env = getenv("PIPS_HIP_SPARSE_ROOT_ASYNC") && atoi(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC")) != 0 && !getenv("PIPS_HIP_ROOT_SYNC");
    const bool root_async = root_async_env && k->root_own_stream;
    if (!root_async) {
+      const int rec_main = tm.begin_i(e->stream, 13);     // (phase 13 = the root factorisation where it sits on the main stream: critical path)
       tm.begin(e->stream, 4);
       rc = r->factor(nullptr, 0);
       tm.end(e->stream);
+      tm.end_i(rec_main, e->stream);
       return rc;
    }
    if (!k->root_stream) {
@@ -4459,9 +4311,11 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    static const bool root_async_env = !getenv("PIPS_HIP_ROOT_SYNC");
    const bool root_async = root_async_env && k->root_own_stream && k->root->dist_P <= 1;   // the distributed root issues collectives: main stream
    if (!root_async) {
+      const int rec_main = tm.begin_i(e->stream, 13);
       tm.begin(e->stream, 4);
       rc = k->root->factor_dev(k->d_SC, k->S, 0);                                  // factorizeKKT (:1436-1464)
       tm.end(e->stream);
+      tm.end_i(rec_main, e->stream);
       return rc;
    }
    if (!k->root_stream) {
@@ -4605,15 +4459,21 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    k->timer.end(e->stream);
    }
    // Dsolve: eliminate z0 through C0, solve with the Schur complement, recover z0 (solveReducedLinkCons :384-466)
+   // the join with the root's stream is a phase of its own (11): what the main stream waits there is the part of the root factorisation
+   // that the first Lsolve did not hide - the exposed root time, measured instead of estimated
+   if (!capturing) {   // (a captured sequence: joined before the capture began)
+      const bool pending = k->root_pending;
+      if (pending) k->timer.begin(e->stream, 11);
+      if ((rc = k->root_wait())) return rc;
+      if (pending) k->timer.end(e->stream);
+   }
    k->timer.begin(e->stream, 7);
    if (k->mz0 > 0)
       hipLaunchKernelGGL(k_z0_elim, e->deterministic ? dim3(1) : dim3(grid_for(k->mz0, 128)), e->deterministic ? dim3(1) : dim3(128), 0, e->stream, 0, k->mz0, k->d_c0_rp, k->d_c0_ci, k->d_c0_val,
                          k->d_zdiag0, b0_dev + head, red);
    if (k->sparse) {
-      if (!capturing && (rc = k->root_wait())) return rc;
       if ((rc = k->root_sp->solve(red))) return rc;
    } else {
-      if (!capturing && (rc = k->root_wait())) return rc;   // (a captured sequence: joined before the capture began)
       if ((rc = k->root->solve_dev(red))) return rc;
    }
    if (k->mz0 > 0) {
@@ -4637,6 +4497,8 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       k->last_solve_path = 2;
       bool failed = false;
       if (verify) {
+         k->timer.end(e->stream);
+         k->timer.begin(e->stream, 12);   // (phase 12: the measure of the sweeps' result)
          // r_i = (b_i - Br_i x0) - K_i x_i over the blocks, measured like a refinement step would measure it
          HIP_TRY(hipMemcpyAsync(k->d_t, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
          if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, -1.0))) return rc;
@@ -4684,7 +4546,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    return PIPS_OK;
 }
 
-// solveCompressed as a replayed HIP graph (pips_hip_kkt_set_solve_graph / PIPS_HIP_SOLVE_GRAPH=1): the launch sequence of one call is
+// solveCompressed as a replayed HIP graph (pips_hip_kkt_set_solve_graph): the launch sequence of one call is
 // fixed between factorisations - dozens of launches on a launch-bound problem (configs[0]: ~50 kernels of a few microseconds each) -
 // so it is captured once per (right-hand-side pointers, Ltsolve path) and replayed.  What a capture cannot contain keeps the
 // direct path: adaptive refinement (it reads norms on the host between steps), reductions over several ranks, the sparse root,
@@ -4692,7 +4554,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
 static bool kkt_graph_eligible(const KktSystem* k) {
    const Engine* e = k->leaves;
    return k->solve_graph && !k->sparse && k->n_ranks <= 1 && !k->force_reduce && e->refine_tol == 0.0 && !e->deterministic && !e->timer.on &&
-          !k->timer.on && !(e->mf_solves);
+          !k->timer.on;
 }
 
 int pips_hip_kkt_solve_compressed(void* handle, double* b0_dev, double* b_leaf_dev) {

@@ -15,13 +15,7 @@
 namespace pips {
 
 constexpr int TILE = 128;
-#ifndef PIPS_KB
-#define PIPS_KB 16
-#endif
-#ifndef PIPS_DMA_QUARTER
-#define PIPS_DMA_QUARTER (PIPS_KB / 16)
-#endif
-constexpr int KB = PIPS_KB;     // k-depth of one LDS stage of the tile GEMM (16; 32 needs 132 KB of LDS: one workgroup per CU)
+constexpr int KB = 16;          // k-depth of one LDS stage of the tile GEMM (16; 32 needs 132 KB of LDS: one workgroup per CU)
 constexpr int LDS_PAD = 16;     // LDS row padding (doubles): 144*8 B = 1152 B -> half-wave k-groups hit disjoint banks
 constexpr int LDSW = TILE + LDS_PAD;
 
@@ -1020,10 +1014,7 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
 constexpr int BB_GMAX = 8;
 // register tile of k_border_schur: BB_TR rows x 4 columns of L_b D L_b^T per thread and step (BB_TR = 4: square tiles over the lower triangle;
 // 8: two row groups per tile - six LDS reads per 32 multiply-adds instead of four per 16)
-#ifndef PIPS_BB_TR
-#define PIPS_BB_TR 4
-#endif
-constexpr int BB_TR = PIPS_BB_TR;
+constexpr int BB_TR = 4;
 // tiles of a supernode with rp (a multiple of 4) padded border rows; tile t -> (column group tb of 4, row group ta of BB_TR)
 __host__ __device__ inline int bb_tile_count(int rp) {
    const int nt4 = rp >> 2;
@@ -1228,186 +1219,6 @@ __global__ __launch_bounds__(256) void k_border_schur_add(const int* __restrict_
 // touched by the border-backward sweep, Engine::solve_border_backward) behind the padded tail.
 __device__ __forceinline__ int xw_row(const BlkDesc& bd, int ra) { return ra < bd.n ? ra : bd.n_head + bd.m_pad + (ra - bd.n); }
 
-// ------------------------------------------------------------------------------------------------
-// multifrontal head, the solves: ONE WAVE per front (a front's share of a sweep is w (w + r) multiply-adds: what counts is how
-// many fronts are in flight), no FP64 atomics between fronts, the panel is read once per sweep with coalesced loads.
-//   forward  (levels ascending):  t = [b_J ; 0] + the children's update vectors at the recorded positions - the simple leaves'
-//            l_c y_c (their items, a lane per front row);  y_J = L11^-1 t_J;  u_J = t_rows - L21 y_J goes to the parent through
-//            the update-vector arena (a front without a head parent adds it to the tail rows of the work vector).
-//   backward (levels descending):  x_rows gathered from the work vector,  x_J = L11^-T (D^-1 y_J - L21^T x_rows);  then the
-//            leaves below the front:  x_c = y_c / d_c - l_c^T x_front.  The diagonal scaling is fused (k_head_dscale only sees the
-//            leaves without a front above them).
-// LDS: [ t / x of the front (nf) | leaf values (n_vals) | partial sums 64 x WMAX, Ld WMAX x WMAX (backward) | ints ].
-// ------------------------------------------------------------------------------------------------
-template <int WMAX>
-__global__ __launch_bounds__(64) void k_front_fwd(const SnDesc* __restrict__ sns, int sn_begin, const BlkDesc* __restrict__ blks,
-                                                 const int* __restrict__ rowidx, const int* __restrict__ mfint,
-                                                 const double* __restrict__ arena, const double* __restrict__ lvals,
-                                                 double* __restrict__ varena, double* __restrict__ xw) {
-   extern __shared__ __attribute__((aligned(16))) double mf_S[];
-   const SnDesc sn = sns[sn_begin + blockIdx.x];
-   const BlkDesc bd = blks[sn.blk];
-   const int w = sn.w, r = sn.r, nf = w + r, lane = threadIdx.x;
-   const int* H = mfint + sn.mf;
-   const int n_child = H[0], n_leaf = H[1], has_parent = H[2] & 1, n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
-   double* t = mf_S;
-   double* vals = t + nf;
-   int* relbuf = (int*)(vals + n_vals);
-   int* leafpart = relbuf + sum_rc;
-   double* xb = xw + bd.xw_off;
-   const double* P = arena + sn.panel;
-   {
-      const int* src = H + MF_HDR + 3 * n_child;
-      for (int idx = lane; idx < sum_rc + n_leafpart; idx += 64) relbuf[idx] = src[idx];
-      const double* lv = lvals + bd.lv_off + H[7];
-      for (int idx = lane; idx < n_vals; idx += 64) vals[idx] = lv[idx];
-      for (int i = lane; i < nf; i += 64) t[i] = i < w ? xb[sn.c0 + i] : 0.0;
-   }
-   // row `lane` of the pivot block, on its way while the front is assembled
-   double row[WMAX];
-#pragma unroll
-   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k < lane) ? P[lane + (long long)k * sn.ld] : 0.0;
-   __syncthreads();
-   if (n_leaf) {   // y_c of the leaves goes where their d sits (the forward sweep has no use for d)
-      const int* tab = leafpart + (nf + 1) + 2 * n_items;
-      for (int c = lane; c < n_leaf; c += 64) vals[tab[4 * c + 1]] = xb[tab[4 * c]];
-   }
-   {
-      int off = 0;
-      for (int c = 0; c < n_child; ++c) {
-         const int rc = H[MF_HDR + 3 * c + 1] & 0xffff;
-         const double* Vc = varena + sn.vslot + H[MF_HDR + 3 * c + 2];
-         for (int a = lane; a < rc; a += 64) t[relbuf[off + a]] += Vc[a];   // distinct positions inside a child
-         off += rc;
-         __syncthreads();
-      }
-   }
-   if (n_leaf) {
-      if (n_child == 0) __syncthreads();
-      const int* colptr = leafpart;
-      const int* it2 = leafpart + (nf + 1);
-      for (int q = lane; q < nf; q += 64) {
-         double acc = 0.0;
-         for (int it = colptr[q]; it < colptr[q + 1]; ++it) {
-            const int i0 = it2[2 * it];
-            const double* lv = vals + (i0 >> 9);
-            acc += lv[1 + (i0 & 15)] * lv[0];
-         }
-         t[q] -= acc;
-      }
-      __syncthreads();
-   }
-   // y_J = L11^-1 t_J: lane i < w owns t_i; column k travels by shuffle
-   double tv = lane < w ? t[lane] : 0.0;
-#pragma unroll
-   for (int k = 0; k < WMAX; ++k) {
-      if (k < w) {
-         const double yk = __shfl(tv, k);
-         tv -= row[k] * yk;                      // row[k] is 0 for k >= lane
-      }
-   }
-   if (lane < w) { t[lane] = tv; xb[sn.c0 + lane] = tv; }
-   __syncthreads();
-   // u_J = t_rows - L21 y_J
-   const int* rows = rowidx + sn.rows;
-   for (int i = w + lane; i < nf; i += 64) {
-      double acc = t[i];
-      if (i < sn.ld) {   // (the border entries of an update vector are never used)
-#pragma unroll
-         for (int k = 0; k < WMAX; ++k) if (k < w) acc -= P[i + (long long)k * sn.ld] * t[k];
-      }
-      if (has_parent) varena[sn.vslot + (i - w)] = acc;
-      else {
-         const int ra = rows[i - w];
-         if (ra < bd.n) atomic_add_f64(xb + ra, acc);   // tail rows: shared between the fronts that end there
-      }
-   }
-}
-
-template <int WMAX>
-__global__ __launch_bounds__(64) void k_front_bwd(const SnDesc* __restrict__ sns, int sn_begin, const BlkDesc* __restrict__ blks,
-                                                 const int* __restrict__ rowidx, const int* __restrict__ mfint,
-                                                 const double* __restrict__ arena, const double* __restrict__ lvals,
-                                                 double* __restrict__ xw, int border) {
-   extern __shared__ __attribute__((aligned(16))) double mf_S[];
-   const SnDesc sn = sns[sn_begin + blockIdx.x];
-   const BlkDesc bd = blks[sn.blk];
-   const int w = sn.w, r = sn.r, nf = w + r, lane = threadIdx.x;
-   const int* H = mfint + sn.mf;
-   const int n_child = H[0], n_leaf = H[1], n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
-   double* xf = mf_S;
-   double* vals = xf + nf;
-   double* part = vals + n_vals;               // [k][lane]
-   double* Ld = part + 64 * WMAX;              // [i][k]
-   int* leafpart = (int*)(Ld + WMAX * WMAX);
-   double* xb = xw + bd.xw_off;
-   const double* P = arena + sn.panel;
-   const int* rows = rowidx + sn.rows;
-   {
-      const int* src = H + MF_HDR + 3 * n_child + sum_rc;
-      for (int idx = lane; idx < n_leafpart; idx += 64) leafpart[idx] = src[idx];
-      const double* lv = lvals + bd.lv_off + H[7];
-      for (int idx = lane; idx < n_vals; idx += 64) vals[idx] = lv[idx];
-      for (int i = w + lane; i < nf; i += 64) {
-         const int ra = rows[i - w];
-         xf[i] = (ra < bd.n || border) ? xb[xw_row(bd, ra)] : 0.0;
-      }
-   }
-   double row[WMAX];
-#pragma unroll
-   for (int k = 0; k < WMAX; ++k) row[k] = (lane < w && k <= lane) ? P[lane + (long long)k * sn.ld] : 0.0;
-   double v;
-   {
-      // d_i sits at row[i]: pick it without a dynamic register index
-      double di = 1.0;
-#pragma unroll
-      for (int k = 0; k < WMAX; ++k) if (k == lane) di = row[k];
-      v = lane < w ? xb[sn.c0 + lane] / di : 0.0;
-   }
-   __syncthreads();
-   // s_k = sum over the rows of L21(a, k) x_a: every lane sums its rows, the 64 partial sums of a column are added by lane k
-   {
-      double p[WMAX];
-#pragma unroll
-      for (int k = 0; k < WMAX; ++k) p[k] = 0.0;
-      for (int i = w + lane; i < (border ? nf : sn.ld); i += 64) {
-         const double xi = xf[i];
-         const BelowRow br = below_row(arena, sn, i - w);
-#pragma unroll
-         for (int k = 0; k < WMAX; ++k) if (k < w) p[k] += br.p[k * br.stride] * xi;
-      }
-#pragma unroll
-      for (int k = 0; k < WMAX; ++k) if (k < w) part[k * 64 + lane] = p[k];
-      if (lane < w) {
-#pragma unroll
-         for (int k = 0; k < WMAX; ++k) if (k < lane) Ld[lane * WMAX + k] = row[k];
-      }
-      __syncthreads();
-      if (lane < w) {
-         double sk = 0.0;
-         for (int j = 0; j < 64; ++j) sk += part[lane * 64 + j];
-         v -= sk;
-      }
-   }
-   // x_J = L11^-T v: column i of L11^T is row i of L11; once x_i is final it leaves every v_k, k < i
-   for (int i = w - 1; i >= 0; --i) {
-      const double xi = __shfl(v, i);
-      if (lane < i) v -= Ld[i * WMAX + lane] * xi;
-   }
-   if (lane < w) { xb[sn.c0 + lane] = v; xf[lane] = v; }
-   __syncthreads();
-   if (n_leaf) {
-      const int* tab = leafpart + (nf + 1) + 2 * n_items;
-      for (int c = lane; c < n_leaf; c += 64) {
-         const int c0 = tab[4 * c], rc = tab[4 * c + 2];
-         const double* lv = vals + tab[4 * c + 1];
-         const int* rel = leafpart + tab[4 * c + 3];
-         double x = xb[c0] / lv[0];
-         for (int a = 0; a < rc; ++a) x -= lv[1 + a] * xf[rel[a]];
-         xb[c0] = x;
-      }
-   }
-}
 
 
 // forward / backward substitution for the simple leaves: y = b_c (unit pivot block); b[rows] -= l y   /   x_c = z_c - l^T x[rows]
@@ -1511,19 +1322,11 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
 // DMA fills is disjoint from the one the MFMA fragments are read from and puts an s_waitcnt vmcnt(0) in front of the next
 // ds_read, i.e. every wave sat out the full global-memory latency in the middle of every stage.  The asm form is invisible
 // to that bookkeeping; the wait is placed by hand (dma_wait) right before the barrier that hands the buffer over.
-#if defined(PIPS_DMA_BUILTIN)
-__device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base) {
-   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr_lane,
-                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
-__device__ __forceinline__ void dma_wait() {}
-#else
 __device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base) {
    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base;
    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
 
 // Staging: both panels are column-major with the tile's 128 rows contiguous, so one LDS-DMA wave-instruction moves one
 // k-column (1 KiB) straight into the [k][row] LDS image (no VGPR round trip, no ds_write).  Two LDS buffers: the DMA of
@@ -1549,9 +1352,6 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
    auto& Bs = sh.Bs;
    auto& Ds = sh.Ds;
    if (tix >= n_tasks) return;
-#if defined(PIPS_EXPERIMENT_CLOCK)
-   const unsigned long long re_ = __builtin_amdgcn_s_memrealtime();   // workgroup entry
-#endif
    const TileTask task = tasks[tix];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
@@ -1591,9 +1391,6 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[i][c] = 0.0;
 
-#if defined(PIPS_EXPERIMENT_CLOCK)
-   const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
-#endif
    const int nst = K / KB;
    const double* Al = Ap + 2 * lane;
    const double* Bl = Bp + 2 * lane;
@@ -1617,20 +1414,16 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
    const int clane = wc * 32 + (lane & 3);    // column-panel fragment offset (broadcast over the 4 blocks)
    for (int st = 0; st < nst; ++st) {
       const int buf = st & 1;
-#if !defined(PIPS_EXPERIMENT_NO_BARRIER)
       dma_wait();        // own DMA of this stage retired
       __syncthreads();   // everybody's DMA of this stage visible + buffer buf^1 free again
-#endif
       const double* Ab = As[buf] + (lane >> 4) * LDSW + rlane;
       const double* Bb = Bs[buf] + (lane >> 4) * LDSW + clane;
 #pragma unroll
       for (int q = 0; q < KB / 4; ++q) {
-#if !defined(PIPS_EXPERIMENT_NO_DMA)
          // the DMA of the next stage is issued after the first quarter of this stage's MFMAs, not right behind the barrier: the
          // matrix pipe is already busy when the address arithmetic and the four LDS-DMA instructions go out (+1.5 %; issuing
          // later still, or one instruction per quarter, loses 6-8 %: profiles/r1_fp64_issue_rates.txt)
-         if (q == PIPS_DMA_QUARTER && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1, buf ^ 1); }
-#endif
+         if (q == KB / 16 && st + 1 < nst) { issue(st + 1, buf ^ 1); load_d(st + 1, buf ^ 1); }
          double fr[4], fc[8];
 #pragma unroll
          for (int i = 0; i < 4; ++i) fr[i] = Ab[(4 * q) * LDSW + i * 16];
@@ -1649,11 +1442,6 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
       }
    }
 
-#if defined(PIPS_EXPERIMENT_CLOCK)
-   // diagnostic build only, 8 doubles per workgroup: shader cycles and 100 MHz ticks of the main loop, absolute ticks of
-   // entry / loop begin / loop end / exit, hardware id (XCC, SE, CU)
-   const unsigned long long t1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();
-#endif
    // epilogue: lane holds C(row = wr*64 + 16 i + (lane&15), col = wc*32 + 4 c + (lane>>4))
    if (MODE == 0 || MODE >= 3) {
       // read-modify-write of the C tile: all 32 loads go out before the first store (written as `*cp -= v` per element the
@@ -1673,18 +1461,6 @@ __device__ __forceinline__ void tile_gemm_body(int tix, GemmShared& sh, const Ti
             for (int c = 0; c < 2; ++c) c0[i * 16 + (long long)((2 * h + c) * 4) * ld] = cv[i][c] - acc[i][2 * h + c];
          __builtin_amdgcn_sched_barrier(0);
       }
-#if defined(PIPS_EXPERIMENT_CLOCK)
-      if (SC) {
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-         if (tid == 0) {
-            double* o = SC + 8 * (long long)tix;
-            o[0] = (double)(t1_ - t0_); o[1] = (double)(r1_ - r0_);
-            o[2] = (double)re_; o[3] = (double)r0_; o[4] = (double)r1_; o[5] = (double)__builtin_amdgcn_s_memrealtime();
-            o[6] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4 /*HW_ID*/);
-            o[7] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20 /*XCC_ID*/);
-         }
-      }
-#endif
       return;
    }
    if (MODE == 1) {
@@ -1743,12 +1519,8 @@ __global__ __launch_bounds__(512, 4) void k_tile_gemm(const TileTask* __restrict
                                                      double* __restrict__ gbuf = nullptr, long long gstride = 0,
                                                      const int* __restrict__ blk_group = nullptr) {
    __shared__ GemmShared sh;
-#if defined(PIPS_EXPERIMENT_NO_XCD)
-   const int tix = (int)blockIdx.x;
-#else
    const int per = (n_tasks + 7) >> 3;
    const int tix = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-#endif
    tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena, gbuf, gstride, blk_group);
 }
 
@@ -1805,49 +1577,6 @@ __global__ void k_reduce_groups(double* __restrict__ SC, int ld, int S, const do
    }
 }
 
-// Persistent variant for the deep-K updates: as many workgroups as the chip holds (two per CU), each pulls tiles from the slice
-// of its own XCD (read from the hardware register, not assumed from blockIdx) through a counter and, when that is empty,
-// steals from the other XCDs' slices.  Measured reasons (profiles/r2_gemm_experiments.txt): under FP64 matrix load the XCDs run
-// at different clocks (1.83 .. 1.92 GHz on one box), so a static 1/8 share finishes 5 % apart, and identical tiles take
-// 500 .. 790 us depending on how a CU's two workgroups share its matrix pipes.  The next tile's index is fetched while the
-// current one is being multiplied.  ctr: 8 counters of this launch, zero on entry.
-// OFF by default (PIPS_HIP_PERSISTENT_GEMM=1): on config 2 the 34 update launches take 74.9-76.2 ms against 74.0-74.2 ms with one
-// workgroup per tile (the drain it removes is already cheap - a CU left with one workgroup runs that one faster), and because
-// its workgroups hold every slot until the launch ends, the diagonal-tile chain on the side stream is no longer hidden behind the
-// column update: the factorisation went from 110 to 118 ms.
-template <int MODE>
-__global__ __launch_bounds__(512, 4) void k_tile_gemm_persist(const TileTask* __restrict__ tasks, int n_tasks,
-                                                             const BlkDesc* __restrict__ blks, double* __restrict__ arena,
-                                                             const double* __restrict__ dtail, const double* __restrict__ winv,
-                                                             const int* __restrict__ bmap, double* __restrict__ SC, int ldSC,
-                                                             const int* __restrict__ sctab, double* __restrict__ uarena,
-                                                             int* __restrict__ ctr) {
-   __shared__ GemmShared sh;
-   __shared__ int s_tix[2];
-   const int per = (n_tasks + 7) >> 3;
-   auto grab = [&]() -> int {   // thread 0 only
-      const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID[3:0] */) & 7);
-      for (int d = 0; d < 8; ++d) {
-         const int x = (xcc + d) & 7;
-         if (__hip_atomic_load(ctr + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per) continue;   // slice known to be empty
-         const int t = __hip_atomic_fetch_add(ctr + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         const int tix = x * per + t;
-         if (t < per && tix < n_tasks) return tix;
-      }
-      return -1;
-   };
-   if (threadIdx.x == 0) s_tix[0] = grab();
-   __syncthreads();
-   int cur = 0;
-   while (true) {
-      const int tix = s_tix[cur];
-      if (tix < 0) break;
-      if (threadIdx.x == 0) s_tix[cur ^ 1] = grab();   // latency hidden behind this tile
-      tile_gemm_body<MODE>(tix, sh, tasks, n_tasks, blks, arena, dtail, winv, bmap, SC, ldSC, sctab, uarena);
-      __syncthreads();   // all waves are out of the LDS buffers, s_tix[cur ^ 1] is visible
-      cur ^= 1;
-   }
-}
 
 // ------------------------------------------------------------------------------------------------
 // diagonal tile: LDL^T of the 128 x 128 tile held in registers, together with Winv = D^-1 L^-1
@@ -1949,11 +1678,9 @@ __global__ __launch_bounds__(256, 2) void k_tile_diag(const TileTask* __restrict
                                                   const long long* __restrict__ psign_off, int* __restrict__ inertia,
                                                   const double* __restrict__ pref) {
    __shared__ DiagShared sh;
-#if !defined(PIPS_DIAG_NO_SETPRIO)
    // The 128 pivots are one dependent chain, and this workgroup shares its SIMDs with waves of the update kernel that always have
    // an MFMA ready: highest issue priority for the chain (the update loses nothing measurable, the chain no longer queues).
    __builtin_amdgcn_s_setprio(3);
-#endif
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
@@ -2339,35 +2066,6 @@ __global__ __launch_bounds__(64) void k_head_fwd(const SnDesc* __restrict__ sns,
    }
 }
 
-// head backward: x_J = L11^-T (z_J - L21^T x_below); throughput variant
-__global__ __launch_bounds__(64) void k_head_bwd(const SnDesc* __restrict__ sns, int sn_begin,
-                                                const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                                const double* __restrict__ arena, double* __restrict__ xw, long long xw_stride,
-                                                int border = 0) {
-   __shared__ double y[HEAD_WMAX];
-   const SnDesc sn = sns[sn_begin + blockIdx.x];
-   const BlkDesc bd = blks[sn.blk];
-   const int w = sn.w, r = sn.r, ld = sn.ld, tid = threadIdx.x;
-   const double* P = arena + sn.panel;
-   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
-   const int* rows = rowidx + sn.rows;
-   for (int k = 0; k < w; ++k) {
-      double s = 0.0;
-      for (int a = tid; a < r; a += 64) {
-         const int ra = rows[a];
-         if (ra < bd.n || border) { const BelowRow br = below_row(arena, sn, a); s += br.p[k * br.stride] * xb[xw_row(bd, ra)]; }
-      }
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-      if (tid == 0) y[k] = xb[sn.c0 + k] - s;
-   }
-   __syncthreads();
-   for (int k = w - 1; k >= 0; --k) {
-      const double yk = y[k];
-      if (tid < k) y[tid] -= P[k + (long long)tid * ld] * yk;
-      __syncthreads();
-   }
-   if (tid < w) xb[sn.c0 + tid] = y[tid];
-}
 
 // head forward, latency-lean variant for launches with few supernodes (engine picks it per level).
 // On chain-like elimination trees a launch holds one supernode per block, so the kernel is a latency chain: all loads
@@ -2584,16 +2282,11 @@ __global__ __launch_bounds__(256) void k_tail_fwd(const TileTask* __restrict__ t
    if (j >= 1 && tid < TILE) vprev = xt[(j - 1) * TILE + tid] * dtail[bd.dt_off + (j - 1) * TILE + tid];
    double acc = xt[ti * TILE + row];
    double m[64];
-#if !defined(PIPS_SWEEP_LATE_LOADS)
    if (j >= 1) tile_load_half(m, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, row, half);
-#endif
    const double* Wj = winv + bd.winv_off + (long long)j * TILE * TILE;
    if (j >= 1) {
       if (tid < TILE) v[tid] = vprev;
       __syncthreads();
-#if defined(PIPS_SWEEP_LATE_LOADS)
-      tile_load_half(m, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, row, half);
-#endif
       const double s = tile_dot_half(m, v, half);
       if (half == 1) part[row] = s;
       __syncthreads();
@@ -2672,16 +2365,11 @@ __global__ __launch_bounds__(256) void k_tail_bwd(const TileTask* __restrict__ t
    double acc = tid < TILE ? xt[tj * TILE + tid] : 0.0;
    if (tj == i && tid < TILE) dsc = dtail[bd.dt_off + i * TILE + tid];
    tg_d2 m[32];
-#if !defined(PIPS_SWEEP_LATE_LOADS)
    if (upd) tile_tload(m, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, tid);
-#endif
    const double* Wi = winv + bd.winv_off + (long long)i * TILE * TILE;
    if (upd) {
       if (tid < TILE) v[tid] = vnext;
       __syncthreads();
-#if defined(PIPS_SWEEP_LATE_LOADS)
-      tile_tload(m, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, tid);
-#endif
       tile_tdot(m, v, outp, tid);
       __syncthreads();
       if (tid < TILE) acc -= outp[tid];

@@ -367,16 +367,12 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          return true;
       };
       // update-matrix offsets first (a parent's record refers to its children's and to its own)
-      out.mf_V.assign(nsn, -1);
-      out.mf_V_total = 0;
       for (int s = 0; s < nsn; ++s) {
          const HeadSupernode& sn = out.sn[s];
          if (is_simple(sn)) continue;
          out.mf_U[s] = out.mf_U_total;
          const int64_t uc = ucols(sn);
          out.mf_U_total += uc * sn.r - uc * (uc - 1) / 2;   // update columns 0 .. uc - 1, packed: column b holds rows b .. r - 1
-         out.mf_V[s] = out.mf_V_total;
-         out.mf_V_total += sn.r;
       }
       if (out.mf_U_total >= (int64_t)INT32_MAX || 18 * (int64_t)nsn >= (int64_t)INT32_MAX) out.mf_ok = false;
       // entries of K and of the border that fall into the panel of a front: (position in the packed panel, index into the block's
@@ -424,7 +420,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          for (int c : kids[s]) {
             out.mf_int.push_back((int)(out.mf_U[c] - out.mf_U[s]));
             out.mf_int.push_back(out.sn[c].r | (ucols(out.sn[c]) << 16));   // r_c, and the number of update columns the child hands over
-            out.mf_int.push_back((int)(out.mf_V[c] - out.mf_V[s]));
+            out.mf_int.push_back(0);   // (reserved: the record keeps three integers per child)
          }
          for (int c : kids[s]) {
             pos.clear();
@@ -494,7 +490,6 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_meta.assign(nsn, -1);
          out.mf_U_total = 0;
          out.mf_LV_total = 0;
-         out.mf_V_total = 0;
       }
    }
 

@@ -732,7 +732,7 @@ class KktSystem:
         cnt = np.zeros(16, np.int64)
         _check(lib.pips_hip_kkt_get_timing(self._h, _ptr(ms), _ptr(cnt), C.c_int(16)), "kkt get_timing")
         names = ["diag_zero", "leaf_factor", "reduce", "finalize", "root_factor", "lsolve_leaf", "lsolve_border_reduce", "dsolve", "ltsolve", "combine",
-                 "reduce_panels"]
+                 "reduce_panels", "root_wait", "solve_check", "root_factor_main_stream"]
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(names)}
 
     def last_ltsolve_from_factor(self):

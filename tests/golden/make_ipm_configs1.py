@@ -1,13 +1,14 @@
 """Generates tests/golden/ipm_configs1.json: final objective, primal / dual residual, complementarity and iteration count of the interior-
 point solve of the BASELINE.json configs[1] LP (64 blocks x 10 000 variables, 5000 equality rows per block, Schur dimension 2000: 641 000
 variables, 321 000 constraints - the LP bench.py's `ipm_end_to_end` solves: same generator, same seed, same tolerances) computed on the
-CPU: oracle/ipm_oracle.py (the restatement of the reference's Mehrotra + Gondzio loop) with every KKT system solved by MKL PARDISO with
-the reference's iparm (oracle/pardiso_mkl.py: METIS, matching + scaling, Bunch-Kaufman, two refinement steps; PardisoProjectSolver.C:68-77)
-on the assembled global matrix [D A^T; A -reg I] - the "CPU PARDISO path" of BASELINE.json's north_star without any of the product's
-Schur-complement code.  north_star: "final objective + primal/dual residuals matching the CPU PARDISO path to 1e-8 relative";
+CPU: oracle/ipm_oracle.py (the restatement of the reference's Mehrotra + Gondzio loop) with every KKT system solved by MKL PARDISO
+(oracle/pardiso_mkl.py: mtype -2, METIS, scaling, Bunch-Kaufman, two refinement steps; the reference's iparm of PardisoProjectSolver.C:68-77
+except the matching, which triples the fill of the whole arrowhead matrix and is switched off here - 20 M instead of 45 M factor entries per
+block, one analysis for all iterates) on the assembled global matrix [D A^T; A 0] - the "CPU PARDISO path" of BASELINE.json's north_star
+without any of the product's Schur-complement code.  north_star: "final objective + primal/dual residuals matching the CPU PARDISO path to 1e-8 relative";
 tests/test_ipm_gpu.py::test_configs1_matches_the_cpu_pardiso_path holds the device harness to that.
 
-    python tests/golden/make_ipm_configs1.py [--threads 6] [--small]      (full size: about an hour on 6-8 cores, ~12 GB)
+    python tests/golden/make_ipm_configs1.py [--threads 6] [--small]      (full size: about 2.5 hours on 6 cores, ~15 GB)
 """
 import argparse
 import json
@@ -45,7 +46,7 @@ def main():
         low = sp.tril(sp.csr_matrix(K), format="csr")
         low.sort_indices()
         if state["solver"] is None:
-            state["solver"] = pm.MklPardisoSolver(low, num_threads=a.threads)
+            state["solver"] = pm.MklPardisoSolver(low, num_threads=a.threads, matching=False, reuse_analysis=True)
         else:
             state["solver"].K = low          # same pattern every iterate
         state["solver"].matrixChanged()
@@ -58,7 +59,7 @@ def main():
     trace = []
     o = io.solve_lp(A, b, c, 150, MUTOL, ARTOL, trace, kkt_solver=kkt_solver)
     x, y = o["x"], o["y"]
-    res = {"what": "oracle/ipm_oracle.py over MKL PARDISO (reference iparm) on the global KKT matrix; see tests/golden/make_ipm_configs1.py",
+    res = {"what": "oracle/ipm_oracle.py over MKL PARDISO (reference iparm without the matching) on the global KKT matrix; see tests/golden/make_ipm_configs1.py",
            "seed": SEED, "shape": list(shape), "mutol": MUTOL, "artol": ARTOL, "status": int(o["status"]), "iterations": int(o["iterations"]),
            "objective": float(o["objective"]), "dual_objective": float(o["dual_objective"]), "mu": float(o["mu"]), "rnorm": float(o["rnorm"]),
            "dnorm": float(o["dnorm"]), "primal_residual_inf": float(np.abs(A @ x - b).max()),

@@ -39,6 +39,13 @@ def _check_line(d, n_gpus):
     assert step["leaf_factor"] > 0 and step["lsolve_leaf"] > 0 and 4 <= passes <= 8 and aug <= 4
     assert set(d["config"]["solve_paths_last_step"]) <= {0, 1, 3}          # never way 2 by default: no solve rides on another one's measure
     assert len(d["config"]["solve_paths_last_step"]) == 4
+    # the phases of the instrumented step are disjoint pieces of the main stream's time: their sum cannot exceed the host clock around that
+    # step, and what they leave out is launch gaps and the host's own work (large on these small workloads; within 2 % on the BASELINE
+    # shapes: profiles/r5_bench_other_configs.jsonl)
+    ph = d["phase_ms"]
+    assert 0.0 < ph["accounted"] <= 1.02 * ph["instrumented_step_wall"], ph
+    assert abs(ph["root_factor_exposed"] - (ph["step"]["root_wait"] + ph["step"]["root_factor_main_stream"])) < 2e-3
+    assert ph["step"]["root_wait"] <= ph["step"]["root_factor"] + 0.05      # the join waits for (part of) the root factorisation, nothing else
 
 
 def test_default_family_small():

@@ -345,7 +345,7 @@ class _TimeCoupledProblem(Problem):
             blk.update(W=Wp, K=K, dpos=dpos)
 
 
-@pytest.mark.parametrize("head", ["multifrontal", "multifrontal_devmem", "multifrontal_solves", "scatter"])
+@pytest.mark.parametrize("head", ["multifrontal", "multifrontal_devmem", "scatter"])
 @pytest.mark.parametrize("cut", ["model", "all_head"])
 @pytest.mark.parametrize("n_i", [600, 3000], ids=["chain_and_spine", "dissected"])
 def test_time_coupled_blocks_match_oracle(cut, n_i, head, monkeypatch):
@@ -357,8 +357,6 @@ def test_time_coupled_blocks_match_oracle(cut, n_i, head, monkeypatch):
         monkeypatch.setenv("PIPS_HIP_ND_DEPTH", "0")     # keeps the chain / spine kernels under test
     if head == "scatter":
         monkeypatch.setenv("PIPS_HIP_MF", "0")
-    if head == "multifrontal_solves":
-        monkeypatch.setenv("PIPS_HIP_MF_SOLVES", "1")    # front-wise sweeps (update vectors child -> parent) instead of the level kernels
 
     prob = _TimeCoupledProblem(5, 3, n_i, n_i // 2, 10, 8, 6)
     S, N = prob.S, prob.N

@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include "../include/pips_hip.h"
+#include "../pips-ipmpp_amd/csrc/common.h"
 #include "../pips-ipmpp_amd/csrc/kernels.hip.h"
 using namespace pips;
 
@@ -58,9 +60,6 @@ int main(int argc, char** argv) {
    double* U;   // scaled copy of the tail rows (B operand)
    CK(hipMalloc(&U, (size_t)bd.m_pad * bd.m_pad * sizeof(double)));
    CK(hipMemcpy(U, T, (size_t)bd.m_pad * bd.m_pad * sizeof(double), hipMemcpyDeviceToDevice));
-#if defined(PIPS_EXPERIMENT_CLOCK)
-   CK(hipMalloc(&dbg, tk.size() * 8 * sizeof(double)));
-#endif
    for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(e0));
       hipLaunchKernelGGL(k_tile_gemm<0>, dim3((unsigned)tk.size()), dim3(512), 0, 0, dtk, (int)tk.size(), dbd, T, dt, (const double*)nullptr, (const int*)nullptr, dbg, 0, (const int*)nullptr, U);
@@ -69,43 +68,5 @@ int main(int argc, char** argv) {
       const double fl = (double)tk.size() * 2.0 * TILE * TILE * (nt - 1) * TILE;
       printf("k_tile_gemm<0>: %zu tiles K=%d: %.3f ms  %.2f TFLOP/s\n", tk.size(), (nt - 1) * TILE, ms, fl / ms / 1e9);
    }
-#if defined(PIPS_EXPERIMENT_CLOCK)
-   {
-      std::vector<double> hd(tk.size() * 8);
-      CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
-      double cyc = 0, tick = 0, pro = 0, epi = 0, tmin = 1e300, tmax = 0;
-      for (size_t i = 0; i < tk.size(); ++i) {
-         const double* o = &hd[8 * i];
-         cyc += o[0]; tick += o[1]; pro += o[3] - o[2]; epi += o[5] - o[4];
-         tmin = std::min(tmin, o[2]); tmax = std::max(tmax, o[5]);
-      }
-      const double n = (double)tk.size();
-      printf("in-kernel clock: %.0f MHz; mean main-loop cycles per workgroup %.0f; main loop %.1f us, prologue %.2f us, epilogue %.2f us; first entry to last exit %.1f us\n",
-             cyc / tick * 100.0, cyc / n, tick / n * 0.01, pro / n * 0.01, epi / n * 0.01, (tmax - tmin) * 0.01);
-      // occupancy timeline: how many workgroups are inside their main loop, in 64 slices of the kernel's duration
-      const int NS = 64;
-      std::vector<double> inloop(NS, 0.0), resident(NS, 0.0);
-      const double span = tmax - tmin;
-      for (size_t i = 0; i < tk.size(); ++i) {
-         const double* o = &hd[8 * i];
-         for (int sl = 0; sl < NS; ++sl) {
-            const double a = tmin + span * sl / NS, b = tmin + span * (sl + 1) / NS;
-            inloop[sl] += std::max(0.0, std::min(b, o[4]) - std::max(a, o[3])) / (b - a);
-            resident[sl] += std::max(0.0, std::min(b, o[5]) - std::max(a, o[2])) / (b - a);
-         }
-      }
-      printf("workgroups in main loop / resident per time slice:\n");
-      for (int sl = 0; sl < NS; ++sl) printf("%s%.0f/%.0f", sl % 16 ? " " : "\n  ", inloop[sl], resident[sl]);
-      printf("\n");
-      if (FILE* f = fopen("../gpurun_out/mb_clock_stamps.csv", "w")) {
-         fprintf(f, "cycles,ticks,entry,loop_begin,loop_end,exit,hw_id,xcc_id\n");
-         for (size_t i = 0; i < tk.size(); ++i) {
-            const double* o = &hd[8 * i];
-            fprintf(f, "%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f\n", o[0], o[1], o[2] - tmin, o[3] - tmin, o[4] - tmin, o[5] - tmin, o[6], o[7]);
-         }
-         fclose(f);
-      }
-   }
-#endif
    return 0;
 }

@@ -1,7 +1,5 @@
 #!/bin/bash
-# GPU box: GEMM micro-benchmark variants (tools/Makefile)
+# GPU box: the update kernel alone (tools/microbench.hip: k_tile_gemm<0> on one block's deep-K column update).  usage: run_mb.sh [tile columns] [rows]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R/tools
-for v in microbench microbench_BUILTIN microbench_Q0 microbench_NO_DMA microbench_NO_BARRIER microbench_CLOCK; do
-  echo "== $v"; timeout 120 ./$v 32 2048 | grep -v "mfma_f64 peak"
-done
+timeout 120 ./microbench ${1:-32} ${2:-2048} | grep -v "mfma_f64 peak"
