@@ -696,5 +696,9 @@ def _leave():
 
 
 if __name__ == "__main__":
+    # a run that stops making progress says where: every thread's Python stack on stderr, then exit code 3 (the driver's bench finishes
+    # within minutes; PIPS_BENCH_WATCHDOG=<seconds> for the stress runs of tools/stress_exit.sh)
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("PIPS_BENCH_WATCHDOG", "3000")), exit=True)
     main()
     _leave()

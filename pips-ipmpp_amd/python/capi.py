@@ -63,7 +63,7 @@ SYMBOLS = [
     "pips_hip_kkt_set_root_inequalities", "pips_hip_kkt_set_zdiag0_dev",
     "pips_hip_kkt_root_inertia", "pips_hip_kkt_get_timing", "pips_hip_kkt_last_ltsolve_from_factor", "pips_hip_kkt_last_solve_path", "pips_hip_kkt_set_solve_check", "pips_hip_kkt_solve_check_counts", "pips_hip_kkt_set_solve_graph", "pips_hip_kkt_set_root_stream", "pips_hip_kkt_solve_graph_stats", "pips_hip_kkt_set_root_pivoting", "pips_hip_kkt_destroy",
     "pips_hip_malloc", "pips_hip_free", "pips_hip_memcpy_h2d", "pips_hip_memcpy_d2h", "pips_hip_memset",
-    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_comm_set_external_broadcast", "pips_hip_broadcast", "pips_hip_comm_has_broadcast", "pips_hip_allreduce_sum_rsag", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
+    "pips_hip_comm_unique_id", "pips_hip_comm_create", "pips_hip_comm_create_external", "pips_hip_comm_set_external_rsag", "pips_hip_comm_set_external_broadcast", "pips_hip_broadcast", "pips_hip_comm_has_broadcast", "pips_hip_allreduce_sum_rsag", "pips_hip_all_gather", "pips_hip_comm_size", "pips_hip_allreduce_sum", "pips_hip_comm_destroy",
     "pips_hip_vec_axpy", "pips_hip_vec_axpby", "pips_hip_vec_scale", "pips_hip_vec_copy", "pips_hip_vec_set",
     "pips_hip_vec_add_const", "pips_hip_vec_mul", "pips_hip_vec_div", "pips_hip_vec_add_product", "pips_hip_vec_add_quotient",
     "pips_hip_vec_divide_some", "pips_hip_vec_select_nonzeros", "pips_hip_vec_safe_invert", "pips_hip_vec_gondzio_projection", "pips_hip_vec_dot",
@@ -507,11 +507,11 @@ class LeafBatch:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(25, np.int64)
-        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(25)), "pips_hip_batch_info")
+        what = np.zeros(26, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(26)), "pips_hip_batch_info")
         keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK",
                 "ltsolve_from_augmented_factor", "multifrontal_head", "max_front", "update_matrix_bytes", "fronts_in_device_memory", "nnzL_head", "head_row_indices",
-                "nnzL_border", "augmented_sweeps", "augmented_passes", "tail_border_entries", "blocks_with_border_split"]
+                "nnzL_border", "augmented_sweeps", "augmented_passes", "tail_border_entries", "blocks_with_border_split", "walked_levels"]
         return {k: int(v) for k, v in zip(keys, what)}
 
     def sync(self):

@@ -103,7 +103,25 @@ def _worker(rank, world, port, out, kind):
         t.copy_(h)
         torch.cuda.synchronize()
 
-    r = _run(prob, mine, True, comm=pa.ExternalComm(allreduce), rank=rank, world=world, reps=2, sparse=kind.startswith("sparse"))
+    calls = []
+
+    def all_gather(ptr, chunk):     # in place: rank r's part at r * chunk
+        t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, chunk * world), device="cuda")
+        h = t.cpu()
+        parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, h[rank * chunk:(rank + 1) * chunk].clone())
+        t.copy_(torch.cat(parts))
+        torch.cuda.synchronize()
+        calls.append(chunk)
+
+    def reduce_scatter(ptr, chunk):
+        allreduce(ptr, chunk * world)
+
+    # a communicator WITH an all-gather (4 ranks): every rank's group slots travel once (pips_hip_all_gather) instead of an all-reduce in
+    # which the other ranks hold zeros - the same bits at an eighth ... a quarter of the bytes; the others keep the all-reduce fallback
+    comm = pa.ExternalComm(allreduce, reduce_scatter, all_gather, n_ranks=world, rank=rank) if world == 4 else pa.ExternalComm(allreduce)
+    r = _run(prob, mine, True, comm=comm, rank=rank, world=world, reps=2, sparse=kind.startswith("sparse"))
+    assert world != 4 or len(calls) >= 4        # two factorisations + two solveCompressed went through the all-gather
     assert np.array_equal(r[0]["SC"], r[1]["SC"]) and np.array_equal(r[0]["xl"], r[1]["xl"])
     np.savez(os.path.join(out, f"det{rank}.npz"), SC=r[0]["SC"], x0=r[0]["x0"], xl=r[0]["xl"], mine=np.array(mine), inertia=np.array(r[0]["inertia"]))
     dist.barrier()

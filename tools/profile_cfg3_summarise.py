@@ -3,10 +3,14 @@ with the kernel statistics; writes <tag>_cfg3_hbm_by_kernel.json and the head-tr
 Counter units and gfx950 corrections as in tools/profile_summarise.py (MI355X_MICROARCH.md: counters in KiB; streaming reads of
 8 / 16 bytes per lane report half their bytes: x 2048 per counter KiB; scattered sector reads, writes and atomics exactly: x 1024)
 - the calibration kernels of tools/pmc_calib measured those factors on this pool in round 2 (profiles/r2_bench_hbm_by_kernel.json).
-usage: profile_cfg3_summarise.py <gpurun_out/cfg3_<tag> dir> <tag>"""
+The chunked 8-byte reads of the solve sweeps (a panel of a few kilobytes per wave) take the x 2048 too: tools/pmc_calib, calib_chunk8,
+round 5 (2035 / 1981 bytes per counter KiB for 128-byte / 16-byte aligned pieces).
+usage: profile_cfg3_summarise.py <gpurun_out/cfg3_<tag> dir> <tag> [blocks per GPU] [n_i] [chain blocks]"""
 import csv, glob, json, os, re, sys
 
 out, tag = sys.argv[1], sys.argv[2]
+nb, ni, chain = (int(sys.argv[3]) if len(sys.argv) > 3 else 256), (int(sys.argv[4]) if len(sys.argv) > 4 else 50000), (int(sys.argv[5]) if len(sys.argv) > 5 else 2048)
+shape = {"family": "time-coupled", "blocks_per_gpu": nb, "n": ni, "schur_dim": 8000, "chain_blocks": chain}     # bench.py shape_key
 
 
 def short(name):
@@ -60,7 +64,7 @@ for k in sorted(set(fetch) | set(write)):
 rows.sort(key=lambda r: -(r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]) * r["dispatches_in_pmc_pass"])
 json.dump({"note": "FETCH_SIZE x 2048, WRITE_SIZE x 1024 bytes per counter KiB (see docstring); separate --pmc passes", "kernels": rows},
           open(os.path.join(out, f"{tag}_cfg3_hbm_by_kernel.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_factorize": head_bytes / N_FACT, "kernels": "k_front<*> + k_head_factor_simple + k_border_schur + k_root_assemble",
+json.dump({"shape": shape, "hbm_bytes_per_factorize": head_bytes / N_FACT, "kernels": "k_front<*> + k_head_factor_simple + k_border_schur + k_root_assemble",
            "solve_hbm_bytes_per_step": solve_bytes / N_FACT, "solve_kernels": sorted(SOLVE_KERNELS),
            "source": f"{tag}_cfg3_hbm_by_kernel.json", "factorizations_in_pass": N_FACT},
           open(os.path.join(out, f"{tag}_cfg3_head_traffic.json"), "w"), indent=1)
