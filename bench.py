@@ -186,9 +186,20 @@ def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho, family_blocks=None, fam
     dt = time.perf_counter() - t0
     st = ipm.stats()
     ipm.close()
-    return {"status": res["status"], "iterations": res["iterations"], "seconds": round(dt, 3), "iterations_per_s": round(res["iterations"] / dt, 3),
-            "objective": res["objective"], "mu": res["mu"], "rel_residual": res["rnorm"] / res["dnorm"], "factorizations": st["factorizations"],
-            "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i)}
+    out = {"status": res["status"], "iterations": res["iterations"], "seconds": round(dt, 3), "iterations_per_s": round(res["iterations"] / dt, 3),
+           "objective": res["objective"], "mu": res["mu"], "rel_residual": res["rnorm"] / res["dnorm"], "factorizations": st["factorizations"],
+           "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i)}
+    # the same LP through the CPU PARDISO path (tests/golden/ipm_configs1.json, made by tests/golden/make_ipm_configs1.py in the build
+    # container): north_star asks for agreement to 1e-8 relative; tests/test_ipm_gpu.py::test_configs1_matches_the_cpu_pardiso_path asserts it
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "ipm_configs1.json")))
+        if family_blocks is None and int(g["seed"]) == seed and [int(v) for v in g["shape"][:5]] == [N, n_i, my_i, n0, myl] and float(g["shape"][5]) == rho:
+            out["cpu_pardiso_path"] = {"objective": g["objective"], "iterations": g["iterations"], "rel_residual": g["rnorm"] / g["dnorm"],
+                                       "objective_rel_diff": abs(res["objective"] - g["objective"]) / abs(g["objective"]),
+                                       "source": "tests/golden/ipm_configs1.json"}
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(pa, seed, n_i, my_i, n0, myl, rho, n_blocks_total, bpg=64, block0=None, whole_block=False):
@@ -685,14 +696,19 @@ def main():
 
 
 def _leave():
-    """The line is out and the handles are closed: leave without the interpreter's and the runtimes' exit handlers (where the one run that
-    never returned most likely sat).  Under a profiler its exit handler writes the results: normal exit there, and with PIPS_BENCH_NORMAL_EXIT=1."""
+    """The line is out and the handles are closed: the process leaves through the interpreter's and the runtimes' normal exit handlers
+    (round 4 skipped them with os._exit after ONE run of this script had never returned past its JSON line; 164 runs through the normal exit in
+    round 5 - tools/stress_exit.sh, default and asynchronous root, small and full size - all ended).  Kept as a net: an
+    alarm with the default disposition - the kernel ends the process if the teardown stalls for a minute (nothing of the interpreter is needed
+    for that, unlike a watchdog thread, which finalisation freezes)."""
+    import signal
     sys.stdout.flush()
     sys.stderr.flush()
     tools = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
-    if "rocprof" in tools or os.environ.get("PIPS_BENCH_NORMAL_EXIT"):
+    if "rocprof" in tools:       # (a profiler writes its results in its own exit handler, which may take long)
         return
-    os._exit(0)
+    signal.signal(signal.SIGALRM, signal.SIG_DFL)
+    signal.alarm(60)
 
 
 if __name__ == "__main__":
@@ -701,4 +717,5 @@ if __name__ == "__main__":
     import faulthandler
     faulthandler.dump_traceback_later(float(os.environ.get("PIPS_BENCH_WATCHDOG", "3000")), exit=True)
     main()
+    faulthandler.cancel_dump_traceback_later()
     _leave()

@@ -174,8 +174,7 @@ int pips_hip_batch_inertia(void* handle, int b, int* pos, int* neg, int* zero);
  * what[6]=factor flops what[7]=border (TRSM+SYRK) flops what[8]=arena bytes what[9]=max tail tile columns
  * what[10]=bytes of the head-to-head update position tables what[11]=sum of non-empty border columns what[12]=sum nnz(K lower)
  * what[13]=1 if solveCompressed takes its Ltsolve from the augmented factor (one backward sweep) while no pivot is perturbed
- * what[14]=1 multifrontal head ... what[24]=blocks analysed with the border split of the fronts, what[25]=top levels of the head sweeps that one launch per
- * direction walks (python/capi.py LeafBatch.info names all) */
+ * what[14]=1 multifrontal head ... what[24]=blocks analysed with the border split of the fronts (python/capi.py LeafBatch.info names all) */
 int pips_hip_batch_info(void* handle, int64_t* what, int n_what);
 int pips_hip_batch_sync(void* handle);
 /* per-phase device time in ms (HIP events on the handle's stream) of the last pips_hip_batch_factor
@@ -309,9 +308,9 @@ int pips_hip_comm_create_external(void** comm, pips_hip_allreduce_cb allreduce, 
 typedef int (*pips_hip_reduce_scatter_cb)(void* user, double* buf_dev, size_t chunk);
 typedef int (*pips_hip_all_gather_cb)(void* user, double* buf_dev, size_t chunk);
 int pips_hip_comm_set_external_rsag(void* comm, int n_ranks, int rank, pips_hip_reduce_scatter_cb reduce_scatter, pips_hip_all_gather_cb all_gather);
-/* in-place all-gather of equal parts (rank r's part at buf_dev + r * chunk on entry); without an all-gather in the communicator: the
- * all-reduce, for which the other ranks' parts must be zero on entry */
-int pips_hip_all_gather(void* comm, double* buf_dev, size_t chunk, void* stream);
+/* in-place all-gather of n_parts (= number of ranks) equal parts (rank r's part at buf_dev + r * chunk on entry); without an all-gather in
+ * the communicator: the all-reduce, for which the other ranks' parts must be zero on entry */
+int pips_hip_all_gather(void* comm, double* buf_dev, size_t chunk, int n_parts, void* stream);
 /* Broadcast of n device doubles from rank `root` (the panel of the distributed root factorisation, pips_hip_dense_ldl_set_distributed;
  * the reference has every rank factorise the same matrix instead, DistributedRootLinearSystem.C:1436-1464).  The library's RCCL
  * communicator uses ncclBroadcast; a host-supplied communicator its broadcast callback (MPI_Bcast on device pointers) when one was

@@ -156,22 +156,22 @@ int pips_hip_allreduce_sum_rsag(void* comm, double* buf_dev, size_t n, void* str
    return 0;
 }
 
-/* In-place all-gather of equal parts: rank r's part lies at buf_dev + r * chunk on entry, all n_ranks * chunk doubles are every rank's on
- * return.  RCCL: ncclAllGather; a host-supplied communicator: its all-gather callback (pips_hip_comm_set_external_rsag), or - it has none -
+/* In-place all-gather of n_parts (= number of ranks) equal parts: rank r's part lies at buf_dev + r * chunk on entry, all n_parts * chunk
+ * doubles are every rank's on return.  RCCL: ncclAllGather; a host-supplied communicator: its all-gather callback (pips_hip_comm_set_external_rsag), or - it has none -
  * the all-reduce, for which the OTHER ranks' parts must be zero on entry (exact either way; the all-reduce moves n_ranks times the bytes).
  * Used by deterministic mode over several ranks: every rank's group buffers to every rank (Engine::det_global). */
-int pips_hip_all_gather(void* comm, double* buf_dev, size_t chunk, void* stream) {
+int pips_hip_all_gather(void* comm, double* buf_dev, size_t chunk, int n_parts, void* stream) {
    Comm* c = (Comm*)comm;
-   if (!c || !buf_dev) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_all_gather: bad arguments");
-   const size_t P = (size_t)c->n_ranks;
+   if (!c || !buf_dev || n_parts < 1) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_hip_all_gather: bad arguments");
+   const size_t P = (size_t)n_parts;   // (= the number of ranks; a host-supplied communicator that was given no rank count still knows how to all-reduce)
    if (c->external) {
-      if (!c->ext_all_gather) return pips_hip_allreduce_sum(comm, buf_dev, P * chunk, stream);
+      if (!c->ext_all_gather || c->n_ranks != n_parts) return pips_hip_allreduce_sum(comm, buf_dev, P * chunk, stream);
       if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) PIPS_FAIL(pips::PIPS_ERR_HIP, "stream sync before the external all-gather failed");
       const int rc = c->ext_all_gather(c->user, buf_dev, chunk);
       if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "external all-gather callback returned %d", rc);
       return 0;
    }
-   if (!g_rccl.all_gather) return pips_hip_allreduce_sum(comm, buf_dev, P * chunk, stream);
+   if (!g_rccl.all_gather || c->n_ranks != n_parts) return pips_hip_allreduce_sum(comm, buf_dev, P * chunk, stream);
    const int rc = g_rccl.all_gather(buf_dev + (size_t)c->rank * chunk, buf_dev, chunk, kNcclDouble, c->comm, (hipStream_t)stream);
    if (rc) PIPS_FAIL(pips::PIPS_ERR_RCCL, "ncclAllGather failed: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "?");
    return 0;

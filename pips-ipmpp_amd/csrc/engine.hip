@@ -605,13 +605,6 @@ struct Engine {
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
    int *d_schur_cols = nullptr, *d_schur_slot = nullptr;
-   // The top levels of the head's elimination forest hold a handful of supernodes per block: as launches they cost their fixed ~12 us
-   // each whatever they hold (20 level launches per direction on the time-coupled blocks, 26 on the dissected sparse root).  From level
-   // lwalk on - every level above holds at most WALK_MAX supernodes of any block - ONE launch per direction walks them: a workgroup per
-   // (block, right-hand side), a wave per supernode, a barrier between levels (the block's trees are independent of the other blocks': no
-   // hand-over between workgroups - the ticket scheme round 4 measured at launch cost needed one).  k_head_walk.
-   int lwalk = 0, n_walk = 0;               // first walked level, number of walked levels (0: none)
-   int *d_walk_ptr = nullptr, *d_walk_list = nullptr;
    int sn_width = 0;           // > 0: supernode width cap of this engine instead of the tuned default (the sparse root: a single block, every level is latency)
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
@@ -735,10 +728,6 @@ struct Engine {
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
       d_spine = d_spine_off = d_schur_cols = d_schur_slot = d_sctab = nullptr;
-      if (d_walk_ptr) (void)hipFree(d_walk_ptr);
-      if (d_walk_list) (void)hipFree(d_walk_list);
-      d_walk_ptr = d_walk_list = nullptr;
-      n_walk = 0;
       d_frowptr = d_fcol = d_fsrc = nullptr; d_flong = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
@@ -1283,40 +1272,6 @@ struct Engine {
          h_spine_off[b + 1] = (int)h_spine.size();
       }
       spine_total = (int)h_spine.size();
-      {  // walked levels (see lwalk): not with the spine kernels, nor where the forward sweep writes slots (deterministic mode)
-         n_walk = 0;
-         lwalk = (int)levels.size();
-         const int nl = (int)levels.size();
-         if (lstar == nlev && !deterministic && !head_slots && nl >= 4) {
-            std::vector<int> width(nl, 0), cnt(nl);
-            for (int b = 0; b < nblk; ++b) {
-               std::fill(cnt.begin(), cnt.end(), 0);
-               for (const HeadSupernode& hs : sym[b].sn) if (hs.level < nl) ++cnt[hs.level];
-               for (int l = 0; l < nl; ++l) width[l] = std::max(width[l], cnt[l]);
-            }
-            int lw = nl;
-            while (lw > 1 && width[lw - 1] <= WALK_MAX) --lw;     // (level 0 holds the simple leaves: never walked)
-            if (nl - lw >= 3) {
-               lwalk = lw;
-               n_walk = nl - lw;
-               std::vector<int> h_ptr((size_t)nblk * (n_walk + 1), 0), h_list;
-               for (int b = 0; b < nblk; ++b) {
-                  std::vector<std::vector<int>> per(n_walk);
-                  for (int l = 0; l < (int)sym[b].sn.size(); ++l) {
-                     const int lev = sym[b].sn[l].level;
-                     if (lev >= lwalk) per[lev - lwalk].push_back(sorted_id[b][l]);
-                  }
-                  for (int t = 0; t < n_walk; ++t) {
-                     h_ptr[(size_t)b * (n_walk + 1) + t] = (int)h_list.size();
-                     h_list.insert(h_list.end(), per[t].begin(), per[t].end());
-                  }
-                  h_ptr[(size_t)b * (n_walk + 1) + n_walk] = (int)h_list.size();
-               }
-               if (h_list.empty()) h_list.push_back(0);
-               if ((rc = dev_upload(&d_walk_ptr, h_ptr, stream)) || (rc = dev_upload(&d_walk_list, h_list, stream))) return rc;
-            }
-         }
-      }
       // ---- concatenated index arrays
       std::vector<int> h_rowidx, h_sncol, h_bmap, h_perm, h_upd;
       h_upd.reserve(upd_base[nblk]);
@@ -1758,17 +1713,6 @@ struct Engine {
       }
       return PIPS_OK;
    }
-   // the walked top levels of a sweep (see lwalk): forward after the launches of the levels below, backward before them
-   int walk_from() const { return n_walk > 0 ? lwalk : (int)levels.size(); }
-   void launch_walk(double* xw, long long xws, int nrhs, int backward, int border, int dscale) {
-      if (n_walk <= 0) return;
-      if (head_wcap <= 16)
-         hipLaunchKernelGGL(k_head_walk<16>, dim3(nblk, nrhs), dim3(64 * WALK_WAVES), 0, stream, d_walk_ptr, d_walk_list, n_walk, d_sns, d_blks, d_rowidx, d_arena,
-                            xw, xws, backward, border, dscale);
-      else
-         hipLaunchKernelGGL(k_head_walk<HEAD_WMAX>, dim3(nblk, nrhs), dim3(64 * WALK_WAVES), 0, stream, d_walk_ptr, d_walk_list, n_walk, d_sns, d_blks, d_rowidx,
-                            d_arena, xw, xws, backward, border, dscale);
-   }
    void gather(const GatherList& g, const double* vals, double* target) {
       if (g.n_targets > 0)
          hipLaunchKernelGGL(k_gather_slots, dim3(grid_for(g.n_targets, 256)), dim3(256), 0, stream, g.n_targets, g.d_tgt, g.d_off, g.d_slots, vals, target);
@@ -2063,9 +2007,8 @@ struct Engine {
             if (cnt > 0) hipLaunchKernelGGL(k_head_fwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, xw, 0LL, sxv);
          }
          gather(gv_tail, d_vslot_val, xw);
-      } else {
-      for (int li = 0; li < walk_from(); ++li) {
-         const LevelRange& L = levels[li];
+      } else
+      for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0 && lf_rows > 0)   // the leaves' columns are final as they stand: every target row collects its sum
             hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), nrhs), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
                                d_lf_val, xw, xws, (int)lf_rows);
@@ -2078,8 +2021,6 @@ struct Engine {
          if (cnt > 0)
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_fwd_chain<16> : k_head_fwd_chain<HEAD_WMAX>, dim3(cnt, nrhs), dim3(64), 0, stream, d_sns, begin,
                                d_blks, d_rowidx, d_arena, xw, xws, 0);
-      }
-      launch_walk(xw, xws, nrhs, 0, 0, 0);
       }
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
@@ -2104,9 +2045,7 @@ struct Engine {
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, nrhs), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx,
                             d_arena, xw, xws, 1);
-      // (deterministic mode: n_walk == 0 - its forward sweep writes slots level by level, and the two directions keep one structure)
-      launch_walk(xw, xws, nrhs, 1, 0, fused_d ? 1 : 0);
-      for (int l = walk_from() - 1; l >= 0; --l) {
+      for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
@@ -2371,8 +2310,7 @@ struct Engine {
       hipLaunchKernelGGL(k_permute_in, dim3(64, nblk, 1), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, b_dev, 0LL, d_xw, 0LL);
       timer.end(stream);
       timer.begin(stream, 8);
-      for (int li = 0; li < walk_from(); ++li) {
-         const LevelRange& L = levels[li];
+      for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0 && lf_rows > 0)
             hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
                                0LL, (int)lf_rows);
@@ -2387,7 +2325,6 @@ struct Engine {
             hipLaunchKernelGGL(head_wcap <= 16 ? k_head_fwd_chain<16> : k_head_fwd_chain<HEAD_WMAX>, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks,
                                d_rowidx, d_arena, d_xw, 0LL, 1);
       }
-      launch_walk(d_xw, 0LL, 1, 0, 1, 0);
       timer.end(stream);
       timer.begin(stream, 9);   // (one record of this phase per pass: the backward half books its tail sweep with the head's)
       TailCtx c = ctx();
@@ -2412,8 +2349,7 @@ struct Engine {
       c.timer = nullptr;
       int rc = tail_bwd(c, d_xw, 1, 0, 1);
       if (rc) return rc;
-      launch_walk(d_xw, 0LL, 1, 1, 1, 1);
-      for (int l = walk_from() - 1; l >= 0; --l) {
+      for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
@@ -2446,8 +2382,7 @@ struct Engine {
       const ScatterCtx none{0, nullptr, nullptr, nullptr, nullptr};
       if (spine_total > 0)
          hipLaunchKernelGGL(k_head_solve_spine, dim3(nblk, 1), dim3(64), 0, stream, d_spine, d_spine_off, d_sns, d_blks, d_rowidx, d_arena, d_xw, 0LL, 1, 1);
-      launch_walk(d_xw, 0LL, 1, 1, 1, 0);
-      for (int l = walk_from() - 1; l >= 0; --l) {
+      for (int l = (int)levels.size() - 1; l >= 0; --l) {
          const LevelRange& L = levels[l];
          const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
          const int cnt = L.small_cnt + L.large_cnt;
@@ -2468,7 +2403,7 @@ struct Engine {
 // dense root solver (DeSymIndefSolver replacement) on the same tile kernels
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int pips_hip_allreduce_sum(void* comm, double* buf_dev, size_t n, void* stream);
-extern "C" int pips_hip_all_gather(void* comm, double* buf_dev, size_t chunk, void* stream);
+extern "C" int pips_hip_all_gather(void* comm, double* buf_dev, size_t chunk, int n_parts, void* stream);
 extern "C" int pips_hip_broadcast(void* comm, double* buf_dev, size_t n, int root, void* stream);
 extern "C" int pips_hip_comm_has_broadcast(void* comm);
 
@@ -3304,7 +3239,6 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
       if (n_what > 23) what[23] = tail_border;
    }
    if (n_what > 24) { what[24] = 0; for (const BlockSym& s : e->sym) what[24] += s.mf_split ? 1 : 0; }   // blocks with the border split
-   if (n_what > 25) what[25] = e->n_walk;   // top levels of the head sweeps walked by one launch per direction (k_head_walk)
    return PIPS_OK;
 }
 
@@ -4207,7 +4141,7 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
       if (!k->d_gall) HIP_TRY(hipMalloc((void**)&k->d_gall, 8 * nnz * sizeof(double)));
       HIP_TRY(hipMemsetAsync(k->d_gall, 0, 8 * nnz * sizeof(double), e->stream));
       HIP_TRY(hipMemcpyAsync(k->d_gall + (size_t)e->det_first_slot * nnz, e->d_gbuf, (size_t)e->det_n_groups * nnz * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-      if ((rc = pips_hip_all_gather(k->comm, k->d_gall, (size_t)e->det_slots * nnz, e->stream))) return rc;   // every rank's slots to every rank: 1 x the bytes
+      if ((rc = pips_hip_all_gather(k->comm, k->d_gall, (size_t)e->det_slots * nnz, 8 / e->det_slots, e->stream))) return rc;   // every rank's slots to every rank: 1 x the bytes
       hipLaunchKernelGGL(k_reduce_groups, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(1024, (nnz + 255) / 256)), 1), dim3(256), 0, e->stream, r->d_kval, 0, (int)nnz,
                          k->d_gall, (long long)nnz, 8, 0);
    } else if (reduce) {
@@ -4301,7 +4235,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
       if (!k->d_gall) HIP_TRY(hipMalloc((void**)&k->d_gall, 8 * gs * sizeof(double)));
       HIP_TRY(hipMemsetAsync(k->d_gall, 0, 8 * gs * sizeof(double), e->stream));
       HIP_TRY(hipMemcpyAsync(k->d_gall + (size_t)e->det_first_slot * gs, e->d_gbuf, (size_t)e->det_n_groups * gs * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-      if ((rc = pips_hip_all_gather(k->comm, k->d_gall, (size_t)e->det_slots * gs, e->stream))) return rc;   // (the all-reduce of zeros it replaces moved 8 x the bytes)
+      if ((rc = pips_hip_all_gather(k->comm, k->d_gall, (size_t)e->det_slots * gs, 8 / e->det_slots, e->stream))) return rc;   // (the all-reduce of zeros it replaces moved 8 x the bytes)
       hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (k->S + 255) / 256)), k->S), dim3(256), 0, e->stream, k->d_SC, k->S, k->S, k->d_gall,
                          (long long)gs, 8, 0);
    } else if (reduce) {
@@ -4502,7 +4436,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
          if (!k->d_gvec_all) HIP_TRY(hipMalloc((void**)&k->d_gvec_all, (size_t)8 * k->S * sizeof(double)));
          HIP_TRY(hipMemsetAsync(k->d_gvec_all, 0, (size_t)8 * k->S * sizeof(double), e->stream));
          HIP_TRY(hipMemcpyAsync(k->d_gvec_all + (size_t)e->det_first_slot * k->S, e->d_gvec, (size_t)e->det_n_groups * k->S * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-         if ((rc = pips_hip_all_gather(k->comm, k->d_gvec_all, (size_t)e->det_slots * k->S, e->stream))) return rc;
+         if ((rc = pips_hip_all_gather(k->comm, k->d_gvec_all, (size_t)e->det_slots * k->S, 8 / e->det_slots, e->stream))) return rc;
          hipLaunchKernelGGL(k_reduce_groups, dim3(std::max(1, std::min(64, (k->S + 255) / 256)), 1), dim3(256), 0, e->stream, e->d_tvec, k->S, k->S, k->d_gvec_all,
                             (long long)k->S, 8, 0);
       } else {

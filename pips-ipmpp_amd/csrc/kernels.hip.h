@@ -2222,42 +2222,6 @@ __global__ __launch_bounds__(64) void k_head_bwd_chain(const SnDesc* __restrict_
    head_bwd_any<WCAP>(sn, bd, rowidx, arena, xw + xw_stride * blockIdx.y + bd.xw_off, red, border, dscale);
 }
 
-// The top levels of the head as ONE launch per direction: a workgroup per (block, right-hand side) walks the block's supernodes of the
-// levels from Engine::lwalk on, level by level - wave q takes the q-th, (q + WALK_WAVES)-th ... supernode of the level (the bodies of the
-// chain kernels), a barrier between levels.  The trees of a block are independent of the other blocks', so nothing is handed over between
-// workgroups; inside the workgroup the work vector goes through device memory: what a wave wrote (plain stores, and FP64 atomics that
-// execute in the L2) must be seen by the other waves of the compute unit through its vector L1 - writes complete before the barrier
-// (release fence), and the L1 is invalidated after it (acquire fence; before the barrier alone a slower wave's line could be fetched again
-// by a third wave in between).  lvl_ptr: per block n_lvl + 1 offsets into list (indices into sns).
-constexpr int WALK_WAVES = 8;    // (8 x (ys + red) = 35 KB of LDS; 16 waves would need dynamic LDS beyond 64 KB)
-constexpr int WALK_MAX = 16;     // a level is walked if no block holds more than this many of its supernodes (two rounds of the waves)
-template <int WCAP>
-__global__ __launch_bounds__(64 * WALK_WAVES) void k_head_walk(const int* __restrict__ lvl_ptr, const int* __restrict__ list, int n_lvl,
-                                                               const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
-                                                               const int* __restrict__ rowidx, const double* __restrict__ arena,
-                                                               double* __restrict__ xw, long long xw_stride, int backward, int border, int dscale) {
-   __shared__ double ys[WALK_WAVES][HEAD_WMAX];
-   __shared__ double red[WALK_WAVES][RED_ROWS][65];
-   const int wave = threadIdx.x >> 6;
-   const int* lp = lvl_ptr + (long long)blockIdx.x * (n_lvl + 1);
-   const BlkDesc bd = blks[blockIdx.x];
-   double* xb = xw + xw_stride * blockIdx.y + bd.xw_off;
-   for (int t = 0; t < n_lvl; ++t) {
-      const int L = backward ? n_lvl - 1 - t : t;
-      const int q1 = lp[L + 1];
-      for (int q = lp[L] + wave; q < q1; q += WALK_WAVES) {
-         const SnDesc sn = sns[list[q]];
-         if (!backward) head_fwd_any<WCAP>(sn, bd, rowidx, arena, xb, ys[wave], border);
-         else head_bwd_any<WCAP>(sn, bd, rowidx, arena, xb, red[wave], border, dscale);
-      }
-      if (t + 1 < n_lvl) {
-         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-         __syncthreads();
-         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-   }
-}
-
 // spine sweeps of the solve: one wave per (block, right-hand side) walks the block's spine supernodes inside one launch
 // (ascending for the forward sweep, descending for the backward one); see k_head_factor_spine for the fence
 __global__ __launch_bounds__(64) void k_head_solve_spine(const int* __restrict__ spine, const int* __restrict__ spine_off,

@@ -130,6 +130,46 @@ def test_config1_trace_follows_the_oracle_capture():
     assert np.abs(x[:n0] - g["x0"]).max() <= 1e-6 * max(1.0, np.abs(g["x0"]).max())
 
 
+GOLDEN_CONFIGS1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ipm_configs1.json")
+
+
+@pytest.mark.gpu
+def test_configs1_matches_the_cpu_pardiso_path():
+    """BASELINE.json north_star on the headline configuration: "final objective + primal/dual residuals matching the CPU PARDISO path to
+    1e-8 relative".  configs[1] (64 blocks x 10 000 variables, Schur dimension 2000: 641 000 variables, 321 000 constraints - the LP
+    bench.py's ipm_end_to_end solves) against tests/golden/ipm_configs1.json: the CPU restatement of the interior-point loop with every KKT
+    system solved by MKL PARDISO on the assembled global matrix (tests/golden/make_ipm_configs1.py; none of the product's Schur-complement
+    code is involved).  Iteration count within the reference's own allowance (t_pips.cpp:115-119: + 10 %)."""
+    import json
+    g = json.load(open(GOLDEN_CONFIGS1))
+    N, n_i, my_i, n0, myl = (int(v) for v in g["shape"][:5])
+    assert g["status"] == 0 and g["variables"] == n0 + N * n_i == 641000 and g["constraints"] == myl + N * my_i
+    blocks, F0, c, b, A = build_lp(int(g["seed"]), N, n_i, my_i, n0, myl, float(g["shape"][5]))
+    ipm = pa.IpmSolver(n0, myl, blocks, F0, c, b)
+    res = ipm.solve(max_iter=150, mutol=float(g["mutol"]), artol=float(g["artol"]))
+    assert res["status"] == 0, res
+    # final objective: 1e-8 relative
+    assert abs(res["objective"] - g["objective"]) <= 1e-8 * abs(g["objective"]), (res["objective"], g["objective"])
+    assert abs(res["dual_objective"] - g["dual_objective"]) <= 1e-7 * abs(g["dual_objective"])
+    assert g["iterations"] - 3 <= res["iterations"] <= int(np.ceil(1.1 * g["iterations"])), (res["iterations"], g["iterations"])
+    # primal / dual residuals: recomputed on the host from the device's solution (not the harness' own norms), relative to the data norm
+    # both codes terminate against (artol * dnorm), and at the level the CPU path reached
+    x, y = ipm.solution()
+    dnorm = float(g["dnorm"])
+    assert abs(res["dnorm"] - dnorm) <= 1e-12 * dnorm
+    rp = np.abs(A @ x - b).max()
+    slack = c - A.T @ y                       # = gamma at a dual-feasible point: must be non-negative up to the dual residual
+    rd = max(0.0, -slack.min())
+    tol = float(g["artol"]) * dnorm
+    assert rp <= max(tol, 10 * g["primal_residual_inf"]) and rd <= max(tol, 10 * g["dual_residual_inf"]), (rp, rd, tol)
+    assert res["rnorm"] <= tol and g["rnorm"] <= tol
+    assert x.min() >= -1e-9
+    # complementarity at the level of the termination rule (mu <= mutol on both sides)
+    assert res["mu"] <= float(g["mutol"]) and g["mu"] <= float(g["mutol"])
+    assert abs(x @ slack) / x.size <= 10 * float(g["mutol"])
+    ipm.close()
+
+
 def _infeasible_lp():
     """Two blocks whose linking row cannot hold: x >= 0, every block row forces sum(x_i) = 1, the linking row asks for
     sum over all x = -3."""

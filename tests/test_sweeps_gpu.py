@@ -181,76 +181,3 @@ def test_sweep_that_gives_up_is_reported(monkeypatch):
     s2.solve(y)
     assert np.linalg.norm(M @ y - x) / np.linalg.norm(x) < 1e-12
 
-
-@pytest.mark.parametrize("nrhs", [1, 3])
-def test_walked_top_levels_match_the_level_launches(nrhs, monkeypatch):
-    """The top levels of the head's elimination forest - a handful of supernodes per block each - are walked by ONE launch per direction
-    (k_head_walk: a workgroup per block, a wave per supernode, a barrier between levels) instead of a launch per level.  Time-coupled
-    blocks with all columns in the head (twenty-odd levels): the leaf solve and solveCompressed by sweeps of the augmented factor, against the
-    oracle, and against the same engine in deterministic mode (which keeps the level launches: its forward sweep writes slots)."""
-    import torch
-    from oracle import oracle as orc
-    from tests.test_leaf_gpu import _TimeCoupledProblem
-    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")
-    prob = _TimeCoupledProblem(5, 3, 3000, 1500, 10, 8, 6)
-    N, S = prob.N, prob.S
-
-    def system():
-        bt = pa.LeafBatch(N, S)
-        for b in range(N):
-            bt.set_block(b, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
-        bt.set_options(force_n_head=prob.n_leaf)
-        bt.analyze(2)
-        bt.set_refinement_backward_error(2, 1e-15)
-        for b in range(N):
-            bt.set_values(b, prob.blocks[b]["K"].val)
-        return bt
-    bt = system()
-    info = bt.info()
-    assert info["walked_levels"] >= 3 and info["n_levels"] > info["walked_levels"], info
-    SC = torch.zeros(S * S, dtype=torch.float64, device="cuda")
-    bt.factor(SC, S)
-    rng = np.random.default_rng(8)
-    # leaf solves: one and several right-hand sides
-    rhs = rng.standard_normal((nrhs, N * prob.n_leaf))
-    for q in range(nrhs):
-        x = torch.tensor(rhs[q], device="cuda")
-        bt.solve(x)
-        bt.sync()
-        xs = x.cpu().numpy().reshape(N, -1)
-        for b in range(N):
-            xo = rhs[q].reshape(N, -1)[b].copy()
-            prob.oracle_leaf(b).solve(xo)
-            assert np.linalg.norm(xs[b] - xo) <= 1e-9 * np.linalg.norm(xo)
-    if nrhs > 1:
-        s1 = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
-        s1.matrixChanged()
-        X = np.ascontiguousarray(rhs[:, :prob.n_leaf])
-        want = X.copy()
-        for q in range(nrhs):
-            prob.oracle_leaf(0).solve(want[q])
-        monkeypatch.setenv("PIPS_HIP_MULTI", "0")          # the per-right-hand-side scheme: grid.y = right-hand side, in the walk too
-        s1.solve(X)
-        assert np.abs(X - want).max() <= 1e-9 * np.abs(want).max()
-        s1.close()
-    # solveCompressed by sweeps of the augmented factor (border rows as targets / sources in the walked levels too)
-    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0)
-    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(N)]), device="cuda")
-    kkt.factorize(diag, torch.tensor(prob.x_diag0, device="cuda"))
-    b0h, blh = rng.standard_normal(S), rng.standard_normal(N * prob.n_leaf)
-    b0, bl = torch.tensor(b0h, device="cuda"), torch.tensor(blh, device="cuda")
-    kkt.solve_compressed(b0, bl)
-    bt.sync()
-    assert kkt.last_solve_path() == 3
-    SCo = np.tril(prob.oracle_finalize(prob.oracle_schur()))
-    root = orc.DenseRootSolver(S)
-    root.matrixChanged(SCo)
-    b0_o, bs_o = b0h.copy(), [blh.reshape(N, -1)[b].copy() for b in range(N)]
-    orc.solve_compressed(b0_o, bs_o, [prob.oracle_leaf(b) for b in range(N)], [prob.Bt_scipy(b) for b in range(N)], root, prob.n0, 0, 0, prob.myl, 0)
-    assert np.linalg.norm(b0.cpu().numpy() - b0_o) <= 1e-8 * np.linalg.norm(b0_o)
-    assert np.linalg.norm(bl.cpu().numpy() - np.concatenate(bs_o)) <= 1e-8 * np.linalg.norm(np.concatenate(bs_o))
-    kkt.close(); bt.close()
-    monkeypatch.setenv("PIPS_HIP_DETERMINISTIC", "1")
-    btd = system()
-    assert btd.info()["walked_levels"] == 0
-    btd.close()
