@@ -2442,7 +2442,7 @@ struct DenseLdl {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list, d_flagvec};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
@@ -2492,7 +2492,7 @@ struct DenseLdl {
       TailCtx c{d_blks, &plan, d_R, d_dtail, d_winv, d_psign, d_psign_off, nullptr, d_inertia, stream, nullptr, d_pref, side, ev_panel, ev_rest, true, nullptr, d_U};
       c.sweep = &sweep;
       c.bunch_kaufman = pivoting == 1;
-      if (pivoting == 1 && dist_P <= 1) {
+      if (pivoting == 1) {
          c.d_pert_cnt = d_pert_cnt; c.d_pert_list = d_pert_list;
          c.bk_orig = last_A; c.bk_orig_ld = last_lda; c.bk_orig_rowmajor = last_rowmajor; c.d_bk_perm = perm.empty() ? nullptr : d_perm;
          c.bk_isolate = bk_isolate;
@@ -2516,18 +2516,46 @@ struct DenseLdl {
    bool check_pending = false;
    int bk_isolate = 1;                 // factorisations check_pivots will look at take an index without a pivot OUT of the matrix (k_tile_diag_bk)
    int bk_refactorizations = 0;        // how often check_pivots had to factorise again (diagnostics / tests)
+   // indices (positions in the current order) the last factorisation found no pivot for: one rank - what its tile kernels recorded, in
+   // their order; a root distributed over several ranks - every rank recorded those of its own tile columns, the union (ascending) reaches
+   // every rank through an all-reduce of a 0 / 1 vector, so that all ranks go on to build the SAME pivot order
+   double* d_flagvec = nullptr;
+   int flagged_positions(std::vector<int>& pos) {
+      pos.clear();
+      int cnt = 0;
+      HIP_TRY(hipMemcpyAsync(&cnt, d_pert_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      std::vector<int> rec((size_t)2 * std::max(cnt, 0));
+      if (cnt > 0) HIP_TRY(hipMemcpy(rec.data(), d_pert_list, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
+      if (dist_P <= 1) {
+         for (int q = 0; q < cnt; ++q) pos.push_back(rec[2 * q]);
+         return PIPS_OK;
+      }
+      std::vector<double> flag((size_t)npad, 0.0);
+      for (int q = 0; q < cnt; ++q) if (rec[2 * q] >= 0 && rec[2 * q] < npad) flag[rec[2 * q]] = 1.0;
+      if (!d_flagvec) HIP_TRY(hipMalloc((void**)&d_flagvec, (size_t)npad * sizeof(double)));
+      HIP_TRY(hipMemcpy(d_flagvec, flag.data(), flag.size() * sizeof(double), hipMemcpyHostToDevice));
+      int rc = pips_hip_allreduce_sum(dist_comm, d_flagvec, (size_t)npad, stream);
+      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpy(flag.data(), d_flagvec, flag.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; ++i) if (flag[i] > 0.0) pos.push_back(i);
+      return PIPS_OK;
+   }
    int check_pivots() {
       if (!check_pending) return PIPS_OK;
       check_pending = false;
-      if (pivoting != 1 || dist_P > 1 || !d_pert_cnt) return PIPS_OK;
+      if (pivoting != 1 || !d_pert_cnt) return PIPS_OK;
       HIP_TRY(hipSetDevice(device));
+      std::vector<int> fpos;
       for (int attempt = 0; attempt < BK_RETRIES; ++attempt) {
-         int cnt = 0;
-         HIP_TRY(hipMemcpyAsync(&cnt, d_pert_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
-         HIP_TRY(hipStreamSynchronize(stream));
+         int rcf = flagged_positions(fpos);
+         if (rcf) return rcf;
+         const int cnt = (int)fpos.size();
          if (cnt <= 0) return PIPS_OK;
-         std::vector<int> rec((size_t)2 * cnt);
-         HIP_TRY(hipMemcpy(rec.data(), d_pert_list, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
+         std::vector<int> rec((size_t)2 * cnt, -1);
+         for (int q = 0; q < cnt; ++q) rec[2 * q] = fpos[q];
+         if (dist_P > 1) HIP_TRY(hipMemcpy(d_pert_list, rec.data(), std::min(rec.size(), (size_t)2 * npad) * sizeof(int), hipMemcpyHostToDevice));   // (k_bk_gather_columns reads the positions there)
          // positions (in the current order) -> partner positions.  For every index without a pivot the column of the ORIGINAL matrix comes
          // to the host; in the order the tiles reported them each takes the row with its largest entry that is still free (not itself
          // without a pivot, not taken by an earlier column): the row a 2 x 2 pivot with this column needs ([[0 A^T]; [A 0]]: a row of A).
@@ -2586,10 +2614,9 @@ struct DenseLdl {
       // indices without a pivot are left: they get the usual small replacement (and are reported as perturbed pivots - what the
       // regularisation loop of the caller reacts to) instead of being taken out of the matrix
       {
-         int cnt = 0;
-         HIP_TRY(hipMemcpyAsync(&cnt, d_pert_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
-         HIP_TRY(hipStreamSynchronize(stream));
-         if (cnt > 0) {
+         int rcf = flagged_positions(fpos);
+         if (rcf) return rcf;
+         if (!fpos.empty()) {
             bk_isolate = 0;
             const int rc = factor_enqueue();
             bk_isolate = 1;
@@ -2652,13 +2679,17 @@ struct DenseLdl {
          const size_t col0 = (size_t)(j + 1) * TILE + (size_t)j * TILE * npad;   // first entry below the diagonal tile of column j
          if (owner == dist_rank) {
             if (c.bunch_kaufman)
-               hipLaunchKernelGGL(k_tile_diag_bk, dim3(1), dim3(256), 0, stream, d_dist_tasks + dist_diag[j].off, c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_inertia);
+               hipLaunchKernelGGL(k_tile_diag_bk, dim3(1), dim3(256), 0, stream, d_dist_tasks + dist_diag[j].off, c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_inertia,
+                                  c.d_pert_cnt, c.d_pert_list, c.bk_orig, c.bk_orig_ld, c.bk_orig_rowmajor, c.d_bk_perm, c.bk_isolate);
             else
                hipLaunchKernelGGL(k_tile_diag, dim3(1), dim3(256), 0, stream, d_dist_tasks + dist_diag[j].off, c.d_blks, c.d_arena, c.d_dtail, c.d_winv,
                                   c.d_psign, c.d_psign_off, c.d_inertia, c.d_pref);
             if (dist_trsm[j].cnt > 0)
                hipLaunchKernelGGL(k_tile_gemm<1>, dim3((dist_trsm[j].cnt + 7) / 8 * 8), dim3(512), 0, stream, d_dist_tasks + dist_trsm[j].off, dist_trsm[j].cnt,
                                   c.d_blks, c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+            // (the owner looks for multipliers a whole-column search would not allow, as on one rank: DenseLdl::check_pivots)
+            if (c.bunch_kaufman && c.d_pert_cnt && dist_trsm[j].cnt > 0)
+               hipLaunchKernelGGL(k_bk_growth, dim3(TILE), dim3(256), 0, stream, c.d_blks, c.d_arena, j, 1e8, c.d_pert_cnt, c.d_pert_list);
             HIP_TRY(hipMemcpyAsync(d_panel, d_winv + (size_t)j * TILE * TILE, (size_t)TILE * TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipMemcpyAsync(d_panel + (size_t)TILE * TILE, d_dtail + (size_t)j * TILE, TILE * sizeof(double), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipMemsetAsync(d_panel + (size_t)TILE * TILE + TILE, 0, 8 * sizeof(double), stream));
@@ -2697,14 +2728,14 @@ struct DenseLdl {
    int factor_dev(const double* A_dev, int lda, int rowmajor) {
       last_A = A_dev; last_lda = lda; last_rowmajor = rowmajor;
       int rc = factor_enqueue();
-      check_pending = pivoting == 1 && dist_P <= 1;
+      check_pending = pivoting == 1;
       return rc;
    }
    int factor_enqueue() {
       const double* A_dev = last_A;
       const int lda = last_lda, rowmajor = last_rowmajor;
       HIP_TRY(hipSetDevice(device));
-      if (pivoting == 1 && dist_P <= 1) {
+      if (pivoting == 1) {
          if (!d_pert_cnt) {
             HIP_TRY(hipMalloc((void**)&d_pert_cnt, sizeof(int)));
             HIP_TRY(hipMalloc((void**)&d_pert_list, (size_t)2 * std::max(npad, 1) * sizeof(int)));
