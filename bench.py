@@ -55,15 +55,21 @@ def update_kernel_algorithmic_flops(m, nb):
 
 
 def update_kernel_traffic(n_blocks, n_i, S, world):
-    """HBM bytes of the update kernel per factorize from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes over this very command, FETCH_SIZE doubled per MI355X_MICROARCH.md); only valid for the profiled workload."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_bench_update_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), "")
-    if world != 1 or n_blocks != 64 or n_i != 10000 or S != 2000 or not os.path.exists(path):
+    """HBM bytes of the update kernel per factorize from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes over this very command, FETCH_SIZE doubled per MI355X_MICROARCH.md and tools/pmc_calib); only valid for the profiled
+    workload (configs[1])."""
+    import glob
+    import re
+    if world != 1 or n_blocks != 64 or n_i != 10000 or S != 2000:
         return None
-    try:
-        return json.load(open(path))["hbm_bytes_per_factorize"]
-    except Exception:
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_update_traffic.json")),
+                   key=lambda q: -int(re.match(r"r(\d+)_", os.path.basename(q)).group(1)))
+    for path in files:
+        try:
+            return json.load(open(path))["hbm_bytes_per_factorize"]
+        except Exception:
+            continue
+    return None
 
 
 def head_traffic(shape, key="hbm_bytes_per_factorize"):
@@ -634,7 +640,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_label(a.family, world, bpg, n_i, my_i, a.rho, S, whole, myl),
-                       "shape": shape,
+                       "shape": shape, "deterministic": bool(os.environ.get("PIPS_HIP_DETERMINISTIC") not in (None, "", "0")),
                        "family": (a.family if a.family == "random" else "time-coupled (surrogate for SURVEY 8d config 4 = BASELINE configs[3]: "
                                   "the random generator's fill at n_i = 50 000 gives dense factors, BASELINE.md)"), "root": ("sparse (CSR Schur complement, linking rows dissected around x0, one-block multifrontal engine)"
                                                     if sparse_root else "dense LDL^T"), "sparse_head": "multifrontal (k_front)" if info.get("multifrontal_head") else "scatter (FP64 atomics)",

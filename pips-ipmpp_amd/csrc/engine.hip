@@ -4455,7 +4455,10 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       // groups in the fixed tree of k_reduce_groups, the ranks' parts by the all-reduce - and added to b0 on every rank.  Guarantee:
       // run-to-run reproducibility for any rank count, and equal bits for 1 and 2 ranks (a two-operand all-reduce has one order);
       // with 4 or 8 ranks the association of the per-rank partial sums is the all-reduce's (ring / tree, per chunk), not this tree
+      k->timer.begin(e->stream, 5);
       if ((rc = e->solve(b_leaf_dev))) return rc;
+      k->timer.end(e->stream);
+      k->timer.begin(e->stream, 6);
       HIP_TRY(hipMemsetAsync(e->d_gvec, 0, (size_t)8 * k->S * sizeof(double), e->stream));
       HIP_TRY(hipMemsetAsync(e->d_tvec, 0, (size_t)k->S * sizeof(double), e->stream));
       if (e->bt_rows_total > 0) {
@@ -4476,6 +4479,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       if ((k->n_ranks > 1 || k->force_reduce) && (rc = pips_hip_allreduce_sum(k->comm, e->d_tvec, (size_t)k->S, e->stream))) return rc;
       }
       hipLaunchKernelGGL(k_axpy, dim3(grid_for(k->S, 256)), dim3(256), 0, e->stream, red, e->d_tvec, 1.0, (long long)k->S);
+      k->timer.end(e->stream);
    } else {
    // Lsolve: ranks > 0 zero b0, every child adds -Br^T K^-1 b_i, all-reduce (sLinsysRootAug.C:323-344)
    if (k->n_ranks > 1 && k->rank > 0) HIP_TRY(hipMemsetAsync(red, 0, (size_t)k->S * sizeof(double), e->stream));

@@ -8,7 +8,7 @@ run --blocks-per-gpu 4 --n 1000 --schur-dim 200 --rho 0.01 --steps 20 --warmup 3
 run --blocks-per-gpu 64 --n 10000 --schur-dim 4000 --rho 0.001 --steps 3 --warmup 1
 run --blocks-per-gpu 32 --n 2000 --schur-dim 16000 --rho 0.005 --steps 3 --warmup 1
 run --blocks-per-gpu 256 --n 2000 --schur-dim 4000 --rho 0.005 --steps 3 --warmup 1
-PIPS_HIP_DETERMINISTIC=1 python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | grep '^{' >> $O
+PIPS_HIP_DETERMINISTIC=1 python3 $R/bench.py --no-cpu-baseline --no-ipm --steps 3 --warmup 1 2>/dev/null | grep '^{' >> $O
 PIPS_HIP_DETERMINISTIC=1 python3 $R/bench.py --family time-coupled --blocks-per-gpu 256 --n 50000 --no-cpu-baseline --no-ipm --steps 3 --warmup 1 2>/dev/null | grep '^{' >> $O
 # round 5: the 256-block chain rounds 3-4 measured (31 linking rows per pair), for continuity with their numbers; and without the per-solve measure
 run --family time-coupled --blocks-per-gpu 256 --n 50000 --chain-blocks 256 --no-ipm --steps 6 --warmup 2
