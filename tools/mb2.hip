@@ -74,49 +74,6 @@ __global__ __launch_bounds__(512) void k_mixed(double* out, int iters, int fma_p
    }
 }
 
-// the FP64 matrix pipe beside memory traffic: waves 0-3 of a workgroup issue v_mfma_f64_4x4x4 from registers, waves 4-7 stream a large buffer
-// (16 bytes per lane and load, `stride_ws` workgroups apart) - does the MFMA rate fall with the bytes per second the memory system moves, as
-// the update kernel's does (57.9 TFLOP/s beside 2.3 TB/s of HBM traffic against 72.4 from registers alone)?  loads_per_it: 16-byte loads of a
-// streaming wave per 8 MFMAs of an MFMA wave.
-typedef double double2_t __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(512) void k_mfma4_stream(double* out, int iters, const double2_t* __restrict__ buf, long long n2, int loads_per_it, int sleep,
-                                                      unsigned long long* bytes) {
-   __shared__ volatile int done;
-   const int wave = threadIdx.x >> 6;
-   if (threadIdx.x == 0) done = 0;
-   __syncthreads();
-   if (wave < 4) {
-      double acc[8];
-      for (int i = 0; i < 8; ++i) acc[i] = 0;
-      double a = threadIdx.x * 1e-3, b = threadIdx.x * 2e-3;
-      for (int it = 0; it < iters; ++it) {
-#pragma unroll
-         for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
-      }
-      double s = 0;
-      for (int i = 0; i < 8; ++i) s += acc[i];
-      out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-      if (threadIdx.x == 0) done = 1;     // the streaming waves of this workgroup stop when its first MFMA wave is through
-   } else if (loads_per_it > 0) {
-      double s = 0;
-      long long idx = ((long long)blockIdx.x * 256 + (threadIdx.x - 256)) % n2;
-      const long long step = (long long)gridDim.x * 256;
-      unsigned long long cnt = 0;
-      while (!done) {
-         for (int q = 0; q < loads_per_it; ++q) {
-            const double2_t v = buf[idx];
-            s += v.x + v.y;
-            idx += step;
-            if (idx >= n2) idx -= n2;
-         }
-         cnt += loads_per_it;
-         for (int z = 0; z < sleep; ++z) __builtin_amdgcn_s_sleep(8);
-      }
-      if (s == 1.2345e300) out[0] = s;
-      if ((threadIdx.x & 63) == 0) atomicAdd(bytes, cnt * 64ULL * 16ULL);
-   }
-}
-
 int main() {
    hipEvent_t e0, e1;
    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -166,29 +123,6 @@ int main() {
       CK(hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost));
       printf("sustained mfma4x4x4 from registers: first launch %.2f, last %.2f, lowest %.2f TFLOP/s; shader clock right after: %.0f MHz\n", first, last, lo,
              (double)hclk[0] / hclk[1] * 100.0);
-   }
-   {
-      double2_t* big;
-      const long long n2 = (1LL << 28);      // 4 GiB: well beyond the Infinity Cache
-      CK(hipMalloc(&big, n2 * 16));
-      CK(hipMemset(big, 0, n2 * 16));
-      const int wg = 512, it3 = 400000;      // ~ 55 ms of MFMA per launch
-      unsigned long long* dbytes; unsigned long long hb = 0;
-      CK(hipMalloc(&dbytes, 8));
-      const int cfgs[7][2] = {{0, 0}, {1, 64}, {1, 16}, {1, 4}, {2, 2}, {4, 1}, {8, 0}};   // (loads per trip, sleeps between trips): rising bandwidth
-      for (auto& c : cfgs) {
-         double tf = 0, tb = 0;
-         for (int rep = 0; rep < 4; ++rep) {
-            CK(hipMemset(dbytes, 0, 8));
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_mfma4_stream, dim3(wg), dim3(512), 0, 0, out, it3, big, n2, c[0], c[1], dbytes);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            CK(hipEventElapsedTime(&ms, e0, e1));
-            CK(hipMemcpy(&hb, dbytes, 8, hipMemcpyDeviceToHost));
-            tf = (double)wg * 4 * it3 * 8 * 512.0 / ms / 1e9; tb = (double)hb / ms / 1e9;
-         }
-         printf("mfma4x4x4 (2 waves per SIMD) beside streaming reads (%d loads per trip, %d sleeps): %7.2f ms  %6.2f TFLOP/s  %5.2f TB/s read\n", c[0], c[1], ms, tf, tb);
-      }
    }
    return 0;
 }
