@@ -573,8 +573,7 @@ def main():
 
     upd_flops = nb_blocks * update_kernel_algorithmic_flops(int(round(m_avg)), int(round(nb_avg)))
     groups = [
-        group("tail update", ("k_tile_gemm<0>" if os.environ.get("PIPS_HIP_BALANCED_GEMM") == "0" else "k_tile_gemm_bal<0>")
-              + " (v_mfma_f64_4x4x4_4b_f64)", "mfma", upd_ms, upd_launches, upd_flops,
+        group("tail update", "k_tile_gemm_bal<0> (v_mfma_f64_4x4x4_4b_f64)", "mfma", upd_ms, upd_launches, upd_flops,
               "sum_j 2 (128 j) [tc below + tc (tc + 1) / 2 + nb tc] per block (DESIGN.md 4)"),
         group("Schur SYRK", "k_tile_gemm_bal<2>", "mfma", tm["schur"][0], tm["schur"][1], nb_blocks * nb_avg * (nb_avg + 1) * m_avg,
               "nb (nb + 1) m per block"),

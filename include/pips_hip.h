@@ -243,7 +243,7 @@ int pips_hip_kkt_set_root_pivoting(void* handle, int mode);
  * ms[8]=Ltsolve  ms[9]=x_i = z_i - u_i  ms[10]=panel-wise Schur reduction on its own stream, summed over the panels (ms[2] is
  * then what the main stream waited for it: the exposed part).  What bench.py's phase table is made of. */
 int pips_hip_kkt_get_timing(void* handle, double* ms, int64_t* cnt, int n);
-/* solveCompressed as a captured and replayed HIP graph (also PIPS_HIP_SOLVE_GRAPH=1): the launch sequence of a call is fixed between
+/* solveCompressed as a captured and replayed HIP graph : the launch sequence of a call is fixed between
  * factorisations, so it is captured once per (b0, b_leaf pointers, Ltsolve path) and replayed - what pays on launch-bound problems and
  * inside the outer BiCGStab, whose preconditioner this call is (LinearSystem.C:550-798).  Only with a fixed number of refinement steps
  * (pips_hip_batch_set_refinement with tol = 0: the adaptive variant reads norms on the host between steps), one rank, the dense root;
