@@ -2259,6 +2259,37 @@ struct Engine {
          if (den > 0.0) { const double q = h_norms[b] / den; if (!(q <= worst)) worst = q; }
       }
       *worst_out = worst;
+      last_refine_measure = worst;
+      return PIPS_OK;
+   }
+
+   // the measure of a solveCompressed by sweeps in one launch (k_measure_leaf_rows): x = the result, b = the leaf right-hand side as the
+   // caller gave it, x0 = the root solution.  Same quantity and same host formula as residual_measure on (b - Br x0, x); available where
+   // every row of K is short and the border is held by leaf row
+   bool can_measure_fused() const { return refine_steps > 0 && d_norms && n_flong == 0 && !deterministic && (bt_rows_total == 0 || d_br_rowptr); }
+   int residual_measure_fused(const double* b_dev, const double* x0_dev, const double* x_dev, double* worst_out) {
+      timer.begin(stream, 11);
+      HIP_TRY(hipMemsetAsync(d_norms, 0, (size_t)3 * nblk * sizeof(double), stream));
+      hipLaunchKernelGGL(k_measure_leaf_rows, dim3(std::max(absmax_chunks(), (int)std::min<long long>(256, n_total / std::max(nblk, 1) / 2048 + 1)), nblk), dim3(256), 0, stream,
+                         d_blks, d_frowptr, d_fcol, d_fsrc, d_kval, x_dev, b_dev, bt_rows_total > 0 ? d_br_rowptr : (const int*)nullptr, d_br_sc, d_br_src, d_bval, x0_dev,
+                         d_norms, nblk);
+      HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)3 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
+      timer.end(stream);
+      if (refine_mode == 1 && h_amax.empty()) {
+         h_amax.resize(nblk);
+         std::vector<BlkDesc> tmp(nblk);
+         HIP_TRY(hipMemcpyAsync(tmp.data(), d_blks, (size_t)nblk * sizeof(BlkDesc), hipMemcpyDeviceToHost, stream));
+         HIP_TRY(hipStreamSynchronize(stream));
+         for (int b = 0; b < nblk; ++b) h_amax[b] = tmp[b].repl_abs / (repl_rel > 0 ? repl_rel : 1.0);
+      }
+      HIP_TRY(hipStreamSynchronize(stream));
+      double worst = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+         const double den = refine_mode == 1 ? h_amax[b] * h_norms[2 * nblk + b] + h_norms[nblk + b] : h_norms[nblk + b];
+         if (den > 0.0) { const double q = h_norms[b] / den; if (!(q <= worst)) worst = q; }
+      }
+      *worst_out = worst;
+      last_refine_measure = worst;
       return PIPS_OK;
    }
 
@@ -4538,10 +4569,14 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
          k->timer.end(e->stream);
          k->timer.begin(e->stream, 12);   // (phase 12: the measure of the sweeps' result)
          // r_i = (b_i - Br_i x0) - K_i x_i over the blocks, measured like a refinement step would measure it
-         HIP_TRY(hipMemcpyAsync(k->d_t, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-         if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, -1.0))) return rc;
          double worst = 0.0;
-         if ((rc = e->residual_measure(k->d_t, b_leaf_dev, &worst))) return rc;
+         if (e->can_measure_fused()) {
+            if ((rc = e->residual_measure_fused(k->d_bsave, red, b_leaf_dev, &worst))) return rc;
+         } else {
+            HIP_TRY(hipMemcpyAsync(k->d_t, k->d_bsave, (size_t)e->n_total * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            if ((rc = pips_hip_batch_border_mult_dev(e, red, k->d_t, -1.0))) return rc;
+            if ((rc = e->residual_measure(k->d_t, b_leaf_dev, &worst))) return rc;
+         }
          ++k->checked_solves;
          k->sweeps_since_check = 0;
          if (worst <= e->refine_tol) {

@@ -2923,6 +2923,56 @@ __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __re
    }
 }
 
+// The measure of a solveCompressed by sweeps in ONE pass (KktSystem: every such solve is measured): for the rows i of block b
+//    rhs_i = b_i - (Br x0)_i,   r_i = rhs_i - (K x)_i,   out[b] = max |r_i|,  out[nblk + b] = max |rhs_i|,  out[2 nblk + b] = max |x_i|
+// - what a copy of the right-hand side, the border product (k_border_mult_rows), k_full_spmv_sub and three k_vec_block_absmax passes
+// computed in six launches over the same vectors (1.2 ms per solve on the 256 x 50 000 time-coupled blocks, 0.3 of them those passes).
+// grid (chunks, block), eight lanes per row as in k_full_spmv_sub; every row must be short (the caller checks n_flong == 0); a NaN
+// counts as +Inf.  out[] zeroed by the caller.
+__global__ __launch_bounds__(256) void k_measure_leaf_rows(const BlkDesc* __restrict__ blks, const int* __restrict__ frowptr, const int* __restrict__ fcol,
+                                                           const int* __restrict__ fsrc, const double* __restrict__ val, const double* __restrict__ x,
+                                                           const double* __restrict__ b, const int* __restrict__ br_rowptr, const int* __restrict__ br_sc,
+                                                           const int* __restrict__ br_src, const double* __restrict__ bval, const double* __restrict__ x0,
+                                                           double* __restrict__ out, int nblk) {
+   const BlkDesc bd = blks[blockIdx.y];
+   const int l = threadIdx.x & 7;
+   const double inf = __longlong_as_double(0x7ff0000000000000LL);
+   double mr = 0.0, mb = 0.0, mx = 0.0;
+   const int n8 = (bd.n + 31) & ~31;   // (whole waves take part in the shuffles)
+   for (int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; k < n8; k += (gridDim.x * blockDim.x) >> 3) {
+      const bool row = k < bd.n;
+      const long long i = bd.x_off + (row ? k : 0);
+      double s = 0.0, t = 0.0;   // (K x)_i and (Br x0)_i, a share per lane
+      if (row) {
+         const int p1 = frowptr[i + 1];
+         for (int p = frowptr[i] + l; p < p1; p += 8) s += val[fsrc[p]] * x[bd.x_off + fcol[p]];
+         if (br_rowptr) {
+            const int q1 = br_rowptr[i + 1];
+            for (int q = br_rowptr[i] + l; q < q1; q += 8) t += bval[br_src[q]] * x0[br_sc[q]];
+         }
+      }
+      s += __shfl_xor(s, 1); t += __shfl_xor(t, 1);
+      s += __shfl_xor(s, 2); t += __shfl_xor(t, 2);
+      s += __shfl_xor(s, 4); t += __shfl_xor(t, 4);
+      if (row && l == 0) {
+         const double rhs = b[i] - t, r = fabs(rhs - s), ar = fabs(rhs), xi = fabs(x[i]);
+         mr = fmax(mr, r <= 1.7976931348623157e308 ? r : inf);
+         mb = fmax(mb, ar <= 1.7976931348623157e308 ? ar : inf);
+         mx = fmax(mx, xi <= 1.7976931348623157e308 ? xi : inf);
+      }
+   }
+   __shared__ double red[3][256];
+   red[0][threadIdx.x] = mr; red[1][threadIdx.x] = mb; red[2][threadIdx.x] = mx;
+   __syncthreads();
+   for (int h = 128; h > 0; h >>= 1) {
+      if ((int)threadIdx.x < h)
+         for (int q = 0; q < 3; ++q) red[q][threadIdx.x] = fmax(red[q][threadIdx.x], red[q][threadIdx.x + h]);
+      __syncthreads();
+   }
+   if (threadIdx.x < 3 && red[threadIdx.x][0] > 0.0)
+      atomicMax((unsigned long long*)(out + threadIdx.x * nblk + blockIdx.y), (unsigned long long)__double_as_longlong(red[threadIdx.x][0]));
+}
+
 // the long rows (the dense x0 rows of a sparse Schur complement factorised as a one-block system): one workgroup per row
 __global__ __launch_bounds__(256) void k_full_spmv_sub_long(const long long* __restrict__ long_rows, const int* __restrict__ frowptr,
                                                            const int* __restrict__ fcol, const int* __restrict__ fsrc,
