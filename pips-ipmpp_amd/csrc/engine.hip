@@ -4231,9 +4231,12 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    HIP_TRY(hipGetLastError());
    // The root engine's factorisation is a chain of small launches (the dissected root: 26 levels of fronts + the hubs' tile): on a stream
    // of its own it runs beside the leaf sweeps of the next solveCompressed's Lsolve, as the dense root does (root_wait() joins before
-   // Dsolve, the next factorisation, queries): 40.6 -> 39.9 ms per unit on the configs[3] share.  OPT-IN (PIPS_HIP_SPARSE_ROOT_ASYNC=1):
-   // one bench run of about fifteen with it did not finish within its time limit on the GPU box and the cause has not been found.
-   static const bool root_async_env = getenv("PIPS_HIP_SPARSE_ROOT_ASYNC") && atoi(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC")) != 0 && !getenv("PIPS_HIP_ROOT_SYNC");
+   // Dsolve, the next factorisation, queries): 39.9 -> 38.9 ms per unit on the configs[3] shape, 43.5 -> 42.7 on the 256-block chain
+   // (tools/ab_async_root.sh, alternating on one box).  Default since round 5 (PIPS_HIP_SPARSE_ROOT_ASYNC=0 / PIPS_HIP_ROOT_SYNC keep the
+   // main stream): round 4 had one bench run of about two dozen with it not finish inside its time limit and made it opt-in; 148 full-size
+   // runs and 60 small ones in round 5 (tools/stress_exit.sh, tools/stress_async.sh, every run under a watchdog) all ended, and the
+   // mechanism is the dense root's, which has been the default since round 2.
+   static const bool root_async_env = !(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC") && atoi(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC")) == 0) && !getenv("PIPS_HIP_ROOT_SYNC");
    const bool root_async = root_async_env && k->root_own_stream;
    if (!root_async) {
       const int rec_main = tm.begin_i(e->stream, 13);     // (phase 13 = the root factorisation where it sits on the main stream: critical path)
