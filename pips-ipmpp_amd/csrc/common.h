@@ -103,6 +103,11 @@ struct BlockSym {
    // ---- multifrontal head (symbolic.cpp "multifrontal metadata"): every head supernode that is not a simple leaf is a front
    //      (w + r) x (w + r) whose update matrix (r x r, packed lower) goes to its parent front instead of being scattered
    bool mf_ok = false;                  // every front fits the LDS budget (AnalyzeOptions::mf_lds_doubles)
+   // mf_konly: per front with border rows the record k_border_rows reads { n_pairs, n_ent, (local id of C, b0 | b1 << 16) ..., (a | k << 16, index of the border value) ... },
+   // kb_off[s] its offset (-1: none); kb_tail: (local id of C, q0 | q1 << 16) runs of at most 16 tail rows of supernodes with border rows (k_border_tail)
+   std::vector<int> kb_rec, kb_tail;
+   std::vector<int64_t> kb_off;
+   bool mf_konly = false;               // (with mf_split) the fronts hold the rows of K only: their border rows are formed afterwards in gather form (k_border_rows)
    bool mf_split = false;               // border split (symbolic.cpp): update matrices keep only the columns of K rows, the border x border
                                         // part of the Schur contribution comes from the finished panels (k_border_schur)
    int mf_max_front = 0;                // largest w + r among the fronts
@@ -165,6 +170,7 @@ struct AnalyzeOptions {
    int64_t mf_lds_doubles = 19200;   // LDS budget of one front (150 KB of the 160 KB): the packed front if it fits, else its w panel
                                      // columns (the update matrix then stays in device memory); neither, or more than
                                      // MF_MAX_FRONT rows: the block is not multifrontal
+   bool mf_konly = false;       // fronts on the rows of K only where the border split applies (BlockSym::mf_konly)
    int mf_split_nb_max = 176;   // border split of the update matrices where the block has at most this many non-empty border columns
                                 // (k_border_schur keeps the packed nb x nb triangle in LDS: 176 -> 122 KB); 0 = never
    double relax_zeros = 0.4;  // supernode amalgamation: admissible share of explicit zeros in a panel (0 = fundamental)

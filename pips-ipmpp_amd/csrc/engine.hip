@@ -547,9 +547,11 @@ struct LevelRange {
 // Multifrontal head: one launch per (level, front class); class = (workgroup size, width bound) of k_front.
 struct MfLaunch { int level, cls, begin, cnt, lds_doubles; };
 // doubles of the update matrix a front keeps: all r columns, or (border split) those of its rb rows of K
+// rows a front holds below its pivot block: all, or (fronts on the rows of K only, BlockSym::mf_konly) its rows of K
+static inline int mf_rows(const BlockSym& bs, const HeadSupernode& s) { return bs.mf_konly ? s.rb : s.r; }
 static inline long long mf_unp(const BlockSym& bs, const HeadSupernode& s) {
-   const long long uc = bs.mf_split ? s.rb : s.r;
-   return uc * s.r - uc * (uc - 1) / 2;
+   const long long uc = bs.mf_split ? s.rb : s.r, r = mf_rows(bs, s);
+   return uc * r - uc * (uc - 1) / 2;
 }
 static inline int mf_class(int w, long long nf, long long unp, long long lds_budget) {
    const long long r = nf - w, pw = std::max<long long>(w * nf - (long long)w * (w - 1) / 2, (long long)w * ((r + 3) / 4 * 4));
@@ -605,6 +607,14 @@ struct Engine {
    int schur_mode_eff = 1;    // what analyze() settled on
    std::vector<int> schur_cols;   // non-empty Schur columns (any block), ascending
    int *d_schur_cols = nullptr, *d_schur_slot = nullptr;
+   // fronts on the rows of K only (BlockSym::mf_konly): records and lists of k_border_rows / k_border_tail
+   int* d_kb_rec = nullptr;
+   long long* d_kb_off = nullptr;       // per supernode (sorted id): offset of its record, -1 none
+   int* d_kb_list = nullptr;            // fronts with border rows, level after level
+   std::vector<int> kb_level_off;       // offsets into d_kb_list per level (size levels + 1)
+   std::vector<int> kb_level_pairs, kb_level_lds;   // per level: most pairs of one front, bytes of the largest border-row block (LDS of k_border_rows)
+   int* d_kb_tail = nullptr;
+   int n_kb_tail = 0;
    int sn_width = 0;           // > 0: supernode width cap of this engine instead of the tuned default (the sparse root: a single block, every level is latency)
    bool mf = false;            // multifrontal head (k_front): update matrices go from child to parent front, no FP64 atomics in the head
    std::vector<MfLaunch> mf_launches;
@@ -728,6 +738,8 @@ struct Engine {
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
       d_spine = d_spine_off = d_schur_cols = d_schur_slot = d_sctab = nullptr;
+      for (void* q : {(void*)d_kb_rec, (void*)d_kb_off, (void*)d_kb_list, (void*)d_kb_tail}) if (q) (void)hipFree(q);
+      d_kb_rec = nullptr; d_kb_off = nullptr; d_kb_list = nullptr; d_kb_tail = nullptr; n_kb_tail = 0; kb_level_off.clear(); kb_level_pairs.clear(); kb_level_lds.clear();
       d_frowptr = d_fcol = d_fsrc = nullptr; d_flong = nullptr;
       d_rowidx = d_upd = d_sncol = d_bmap = d_perm = d_inertia = d_krowptr = d_kcolidx = d_bt_rowptr = d_bt_colidx = d_bt_rowsc = nullptr;
       d_psign = nullptr;
@@ -990,6 +1002,10 @@ struct Engine {
          const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
          if ((env && atoi(env) == 0) || (hs && atoi(hs) != 0 && !deterministic)) opt.mf_split_nb_max = 0;
       }
+      // fronts on the rows of K only where the border split applies (PIPS_HIP_MF_KONLY=1; off by default: on the configs[3] share the fronts fall
+      // from 9.7 to 4.0 ms, forming the border rows afterwards costs 8.0 - DESIGN.md 4.1c): not in deterministic mode (the border rows of the dense
+      // tail take their head contributions with atomics, k_border_tail) and with supernodes of at most 16 columns (k_border_rows<., 16>)
+      opt.mf_konly = opt.mf_split_nb_max > 0 && !deterministic && opt.max_sn_width <= 16 && getenv("PIPS_HIP_MF_KONLY") && atoi(getenv("PIPS_HIP_MF_KONLY")) != 0;
       int rc = analyze_host(n_threads, schur_mode != 2);
       if (rc) return rc;
       schur_mode_eff = (schur_mode == 2 && any_border) ? 2 : 1;
@@ -1013,7 +1029,7 @@ struct Engine {
                   if (sym[b].mf_meta[l] < 0) continue;
                   const HeadSupernode& s = sym[b].sn[l];
                   const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
-                  const long long nf = s.w + s.r, pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));
+                  const long long fr = mf_rows(sym[b], s), nf = s.w + fr, pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((fr + 3) / 4 * 4));
                   const long long packed = pw + mf_unp(sym[b], s) + 8, panel = pw + 8;
                   const long long extra = H[5] + (H[6] + H[3] + 1) / 2 + 2;
                   if ((packed > opt.mf_lds_doubles ? panel : packed) + extra > 20352) ok = false;   // 159 KB of the 160
@@ -1056,7 +1072,7 @@ struct Engine {
          d.n = s.n; d.n_head = s.n_head; d.m = s.m; d.m_pad = s.m_pad; d.nb = s.nb; d.nb_pad = s.nb_pad; d.ldT = s.ldT;
          d.ntc = s.m_pad / TILE;
          d.ntr = s.m > 0 ? s.ldT / TILE : 0;
-         d.mf_split = (mf && s.mf_split) ? 1 : 0;
+         d.mf_split = (mf && s.mf_split) ? (s.mf_konly ? 2 : 1) : 0;   // 2: fronts on the rows of K only (k_border_rows forms their border rows)
          d.U = uar;
          uar += (long long)s.m_pad * s.m_pad;
          d.thr_rel = 0; d.repl_rel = 1e-8; d.repl_abs = 1;
@@ -1100,7 +1116,7 @@ struct Engine {
             for (const HeadSupernode& s : sym[b].sn) {
                if (is_simple(s)) continue;
                if ((int)lev_cnt.size() <= s.level) { lev_cnt.resize(s.level + 1, 0); lev_b.resize(s.level + 1, 0); lev_w.resize(s.level + 1, 0); }
-               const int c = mf_class(s.w, s.w + s.r, mf_unp(sym[b], s), opt.mf_lds_doubles);
+               const int c = mf_class(s.w, s.w + mf_rows(sym[b], s), mf_unp(sym[b], s), opt.mf_lds_doubles);
                ++lev_cnt[s.level];
                if (c < 6) { lev_b[s.level] = std::max(lev_b[s.level], c % 3); lev_w[s.level] = std::max(lev_w[s.level], c / 3); }
             }
@@ -1111,14 +1127,15 @@ struct Engine {
             // class 1: small (one wave); class 2: large (256 threads)
             int cls = (s.w <= 8 && s.r <= 64) ? 1 : 2, lds = 0;
             if (mf && !is_simple(s)) {
-               int c = mf_class(s.w, s.w + s.r, mf_unp(sym[b], s), opt.mf_lds_doubles);
+               const long long fr = mf_rows(sym[b], s);
+               int c = mf_class(s.w, s.w + fr, mf_unp(sym[b], s), opt.mf_lds_doubles);
                if (c < 6 && lev_cnt[s.level] <= MF_MERGE_MAX) c = lev_b[s.level] + 3 * lev_w[s.level];
                cls = 1 + c;
                // LDS of a front: the packed front (or its panel columns) + 8 doubles of slack, the leaves' values, and as ints the
                // children's position lists and the leaf part of the record (common.h "Front record")
-               const long long nf = s.w + s.r;
+               const long long nf = s.w + fr;
                const int* H = sym[b].mf_int.data() + sym[b].mf_meta[l];
-               const long long pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((s.r + 3) / 4 * 4));   // packed panel / aligned L21 copy
+               const long long pw = std::max<long long>(s.w * nf - (long long)s.w * (s.w - 1) / 2, (long long)s.w * ((fr + 3) / 4 * 4));   // packed panel / aligned L21 copy
                lds = (int)(pw + (c >= 6 ? 0 : mf_unp(sym[b], s)) + 8 + H[5] + (H[6] + H[3] + 1) / 2 + 2);
             }
             if (is_simple(s)) cls = 0;
@@ -1263,6 +1280,43 @@ struct Engine {
                 (rc = dev_upload(&d_bb_pos, h_bbpos, stream)) || (rc = dev_upload(&d_bb_off, h_bb_off_keep, stream))) return rc;
          }
          bb_doubles = bb_total - arena_total;
+      }
+      {  // gather-form metadata of the blocks whose fronts hold the rows of K only
+         std::vector<int> h_rec, h_list, h_tail;
+         std::vector<long long> h_off((size_t)std::max(nsn_total, 1), -1);
+         std::vector<std::vector<int>> by_level(levels.size());
+         kb_level_pairs.assign(levels.size(), 0); kb_level_lds.assign(levels.size(), 0);
+         bool any = false;
+         for (int b = 0; b < nblk && mf; ++b) {
+            const BlockSym& bs = sym[b];
+            if (!bs.mf_konly) continue;
+            any = true;
+            for (int l = 0; l < (int)bs.sn.size(); ++l) {
+               if (bs.kb_off[l] < 0) continue;
+               const int* R = bs.kb_rec.data() + bs.kb_off[l];
+               const int np = R[0], ne = R[1];
+               h_off[sorted_id[b][l]] = (long long)h_rec.size();
+               h_rec.push_back(np); h_rec.push_back(ne);
+               for (int q = 0; q < np; ++q) { h_rec.push_back(sorted_id[b][R[2 + 2 * q]]); h_rec.push_back(R[3 + 2 * q]); }
+               h_rec.insert(h_rec.end(), R + 2 + 2 * np, R + 2 + 2 * np + 2 * ne);
+               const HeadSupernode& sj = bs.sn[l];
+               if (sj.level >= (int)by_level.size()) PIPS_FAIL(PIPS_ERR_STATE, "analyze: internal error, level of a front with border rows");
+               by_level[sj.level].push_back(sorted_id[b][l]);
+               kb_level_pairs[sj.level] = std::max(kb_level_pairs[sj.level], np);
+               kb_level_lds[sj.level] = std::max(kb_level_lds[sj.level], (int)(sj.w * ((sj.r - sj.rb + 3) / 4 * 4) * sizeof(double)));
+            }
+            for (size_t q = 0; q + 1 < bs.kb_tail.size(); q += 2) { h_tail.push_back(sorted_id[b][bs.kb_tail[q]]); h_tail.push_back(bs.kb_tail[q + 1]); }
+         }
+         kb_level_off.assign(levels.size() + 1, 0);
+         for (size_t l = 0; l < by_level.size(); ++l) { h_list.insert(h_list.end(), by_level[l].begin(), by_level[l].end()); kb_level_off[l + 1] = (int)h_list.size(); }
+         n_kb_tail = (int)(h_tail.size() / 2);
+         if (any) {
+            if (h_rec.empty()) h_rec.push_back(0);
+            if (h_list.empty()) h_list.push_back(0);
+            if (h_tail.empty()) h_tail.push_back(0);
+            if ((rc = dev_upload(&d_kb_rec, h_rec, stream)) || (rc = dev_upload(&d_kb_off, h_off, stream)) || (rc = dev_upload(&d_kb_list, h_list, stream)) ||
+                (rc = dev_upload(&d_kb_tail, h_tail, stream))) return rc;
+         }
       }
       // spine lists: per block, ascending local index = postorder (children before parents)
       std::vector<int> h_spine, h_spine_off(nblk + 1, 0);
@@ -1695,6 +1749,19 @@ struct Engine {
       }
       return PIPS_OK;
    }
+   // the border rows of the fronts of one level that hold the rows of K only (k_border_rows): a wave per pair - one wave per front where the
+   // fronts of the level have a few pairs, four or eight where some have many
+   void launch_border_rows(size_t l, hipStream_t st) {
+      const int cnt = kb_level_off[l + 1] - kb_level_off[l];
+      if (cnt == 0) return;
+      const int* lst = d_kb_list + kb_level_off[l];
+      if (kb_level_pairs[l] <= 3 || (cnt >= 16384 && kb_level_pairs[l] <= 8))
+         hipLaunchKernelGGL((k_border_rows<64, 16>), dim3(cnt), dim3(64), kb_level_lds[l], st, lst, d_sns, d_blks, d_rowidx, d_kb_rec, d_kb_off, d_arena, d_arena, d_bval);
+      else if (cnt <= 4096 && kb_level_pairs[l] > 8)
+         hipLaunchKernelGGL((k_border_rows<512, 16>), dim3(cnt), dim3(512), kb_level_lds[l], st, lst, d_sns, d_blks, d_rowidx, d_kb_rec, d_kb_off, d_arena, d_arena, d_bval);
+      else
+         hipLaunchKernelGGL((k_border_rows<256, 16>), dim3(cnt), dim3(256), kb_level_lds[l], st, lst, d_sns, d_blks, d_rowidx, d_kb_rec, d_kb_off, d_arena, d_arena, d_bval);
+   }
    int launch_fronts(int level, double* SC, int ldSC) {
       int rc = PIPS_OK;
       for (const MfLaunch& m : mf_launches) {
@@ -1915,6 +1982,14 @@ struct Engine {
          } else
             hipLaunchKernelGGL(k_root_assemble, dim3(nblk, 2 * asm_half), dim3(256), 0, stream, (const int*)nullptr, d_root_off, d_roots, d_sns, d_blks, d_rowidx, d_bmap,
                                d_arena, d_mfU, SC, ldSC, d_sctab, (double*)nullptr, 0LL, (const int*)nullptr, asm_half, asm_half);
+         if (timer.on) timer.end(stream);
+      }
+      if (mf && d_kb_list) {   // fronts on the rows of K only: their border rows now, level by level, from the finished panels; then the head's part
+                               // of the dense tail's border rows.  (Forming level l on a second stream beside the fronts above it, which need
+                               // nothing of it, was measured: no gain, 17.4 against 16.7 ms of head on the configs[3] share.)
+         if (timer.on) timer.begin(stream, 1);
+         for (size_t l = 0; l + 1 < kb_level_off.size(); ++l) launch_border_rows(l, stream);
+         if (n_kb_tail > 0) hipLaunchKernelGGL(k_border_tail<16>, dim3(n_kb_tail), dim3(64), 0, stream, d_kb_tail, d_sns, d_blks, d_rowidx, d_arena);
          if (timer.on) timer.end(stream);
       }
       if (mf && n_bb > 0 && SC) {   // border split: the border x border part of every block's Schur contribution, from the finished panels
@@ -3301,6 +3376,7 @@ int pips_hip_batch_info(void* handle, int64_t* what, int n_what) {
       if (n_what > 23) what[23] = tail_border;
    }
    if (n_what > 24) { what[24] = 0; for (const BlockSym& s : e->sym) what[24] += s.mf_split ? 1 : 0; }   // blocks with the border split
+   if (n_what > 25) { what[25] = 0; for (const BlockSym& s : e->sym) what[25] += (e->mf && s.mf_konly) ? 1 : 0; }   // ... whose fronts hold the rows of K only
    return PIPS_OK;
 }
 
@@ -4833,6 +4909,7 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
    AnalyzeOptions opt;
    apply_tuning(opt);
    opt.force_n_head = force_n_head;
+   opt.mf_konly = opt.mf_split_nb_max > 0 && opt.max_sn_width <= 16 && getenv("PIPS_HIP_MF_KONLY") && atoi(getenv("PIPS_HIP_MF_KONLY")) != 0;   // (as Engine::analyze outside deterministic mode)
    CsrPattern K{n, n, krow, jcol};
    CsrPattern B{0, n, nullptr, nullptr};
    if (Bt_rowptr && S > 0) B = CsrPattern{S, n, Bt_rowptr, Bt_colidx};
@@ -4843,7 +4920,7 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
    if (what && n_what > 16) {   // multifrontal head: usable, border split taken, doubles of update matrices, doubles of border rows kept beside the panels
       const BlockSym& bs = sym[0];
       what[13] = bs.mf_ok ? 1 : 0;
-      what[14] = bs.mf_split ? 1 : 0;
+      what[14] = bs.mf_split ? (bs.mf_konly ? 2 : 1) : 0;
       what[15] = bs.mf_U_total;
       what[16] = 0;
       for (const HeadSupernode& hs : bs.sn) if (hs.ld < hs.w + hs.r) what[16] += (int64_t)hs.w * (hs.r - hs.rb);
@@ -4863,6 +4940,29 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
          fclose(f);
          fprintf(stderr, "[pips_hip] multifrontal: ok %d, largest front %d, update matrices %lld doubles, records %zu ints\n", (int)bs.mf_ok, bs.mf_max_front,
                  (long long)bs.mf_U_total, bs.mf_int.size());
+         if (bs.mf_konly) {   // gather-form records: pairs per front and their sizes, level by level
+            std::vector<long long> lp, lf, lmax, lwork;
+            long long pairs = 0, fronts = 0, work = 0, rowsum = 0;
+            for (size_t si = 0; si < bs.sn.size(); ++si) {
+               if (bs.kb_off[si] < 0) continue;
+               const HeadSupernode& s = bs.sn[si];
+               const int* R = bs.kb_rec.data() + bs.kb_off[si];
+               if ((int)lp.size() <= s.level) { lp.resize(s.level + 1, 0); lf.resize(s.level + 1, 0); lmax.resize(s.level + 1, 0); lwork.resize(s.level + 1, 0); }
+               long long wk = 0;
+               for (int q = 0; q < R[0]; ++q) {
+                  const HeadSupernode& c = bs.sn[R[2 + 2 * q]];
+                  const int ns = (R[3 + 2 * q] >> 16) - (R[3 + 2 * q] & 0xffff);
+                  wk += (long long)(c.r - c.rb) * ns * c.w;
+                  rowsum += c.r - c.rb;
+               }
+               lp[s.level] += R[0]; ++lf[s.level]; lmax[s.level] = std::max<long long>(lmax[s.level], R[0]); lwork[s.level] += wk;
+               pairs += R[0]; ++fronts; work += wk;
+            }
+            fprintf(stderr, "[pips_hip] gather-form border rows: %lld fronts, %lld pairs (%.1f border rows each), %lld multiply-adds, %zu tail runs\n", fronts, pairs,
+                    pairs ? (double)rowsum / pairs : 0.0, work, bs.kb_tail.size() / 2);
+            for (size_t l = 0; l < lp.size(); ++l)
+               fprintf(stderr, "   level %2zu: %6lld fronts %7lld pairs, most %4lld, %9lld multiply-adds\n", l, lf[l], lp[l], lmax[l], lwork[l]);
+         }
       }
    }
    if (perm) std::copy(sym[0].perm.begin(), sym[0].perm.end(), perm);

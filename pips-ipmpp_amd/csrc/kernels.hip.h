@@ -654,7 +654,9 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    double* F = mf_F;
    const SnDesc sn = sns[sn_begin + blockIdx.x];
    const BlkDesc bd = blks[sn.blk];
-   const int w = sn.w, r = sn.r, nf = w + r, tid = threadIdx.x, lane = tid & 63, i = tid;
+   // fronts on the rows of K only (BlkDesc::mf_split == 2): the front ends with its rb rows of K - its border rows are formed afterwards from
+   // the finished panels (k_border_rows), nothing of the border travels from front to front
+   const int w = sn.w, r = bd.mf_split == 2 ? sn.rb : sn.r, nf = w + r, tid = threadIdx.x, lane = tid & 63, i = tid;
    const int* H = mfint + sn.mf;
    const int n_child = H[0], n_leaf = H[1], n_ent = H[2] >> 1, n_leafpart = H[3], n_items = H[4], n_vals = H[5], sum_rc = H[6];
    // update columns the front keeps and hands on: all r, or (border split, BlkDesc::mf_split) only those of its rb rows of K - the
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(BLOCK) void k_front(const SnDesc* __restrict__ sns,
    }
    }
    __syncthreads();   // every wave has taken its rows out of the packed panel: the region becomes the L21 copy Lt[k * rp + a]
-   if (sn.bb >= 0 && tid < w) { const int rpb = (r - sn.rb + 3) & ~3; bbarena[sn.bb + w * rpb + tid] = dk[tid]; }
+   if (sn.bb >= 0 && tid < w) { const int rpb = (sn.r - sn.rb + 3) & ~3; bbarena[sn.bb + w * rpb + tid] = dk[tid]; }
    if (i >= w && i < nf) {
 #pragma unroll
       for (int k = 0; k < WMAX; ++k)
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
       for (int k = 0; k < nq; ++k) {
          const int b0 = s_b0[k], b1 = s_b1[k];
          if (b0 >= b1) continue;   // (uniform: every thread reads the same LDS words)
-         const int r = s_r[k], rb = s_rb[k];
+         const int rb = s_rb[k], r = bd.mf_split == 2 ? rb : s_r[k];   // (fronts on the rows of K only hand over a K x K update matrix)
          const int* rows = rowidx + s_rows[k];
          const double* U = uarena + s_U[k];
          // entries (a, b), b in [b0, b1), a in [b, r): column b holds r - b of them
@@ -993,6 +995,183 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
             }
          }
          __syncthreads();   // the next front may reach the same entries from other threads
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fronts on the rows of K only (BlockSym::mf_konly): the border rows of a supernode in GATHER form.
+//    L_b(J) = ( B_J - sum_C L_b(C) D_C L_{J,C}^T ) L_JJ^-T D_J^-1
+// over the supernodes C below J that hold border rows and have below-rows q in [b0, b1) inside J's columns (L_{J,C}: those rows of C's
+// panel; the update segments of the symbolic phase list exactly these pairs).  A border row never influences a pivot, so none of this
+// needs to ride through the fronts: k_front factorises the rows of K (fronts of ~33 rows instead of ~130 on the time-coupled blocks),
+// and this kernel forms the border rows afterwards, level by level, from finished panels.
+// One workgroup per supernode J, its border rows X (nbj x w) in LDS; the waves take J's pairs round-robin, the lanes along the border rows of C
+// (L_b(C) from the border-row arena, coalesced; matched to J's rows through an LDS map border id -> row of J), d_C(c) L_C(q, c) wave-uniform,
+// the products are added to X with LDS atomics (no return value).  A first version held X in registers (one wave per J, the pairs one after the
+// other behind three barriers each, the border's entries in a serial loop): 19.6 ms per factorisation of the configs[3] share, latency from end to end.
+// rec: per J  { n_pairs, n_ent, (C, b0 | b1 << 16) x n_pairs, (a | k << 16, src) x n_ent } with the entries of the border that fall into J's
+// columns (src: index into the block's border values).  fin: the arena again, read-only (finished panels and border rows of lower levels).
+// ------------------------------------------------------------------------------------------------
+constexpr int BR_IDMAX = 192;      // border ids of a block under the border split: < 176
+constexpr int BR_PCHUNK = 64;      // pairs whose descriptors are staged at once
+struct BrPair { long long panel, bb, rows; int wC, nbc, ldC, ns, b0, pad; };   // what a pair needs of its supernode C (panel: at row w_C + b0)
+template <int BLOCK, int WMAX>
+__global__ __launch_bounds__(BLOCK) void k_border_rows(const int* __restrict__ list, const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
+                                                       const int* __restrict__ rowidx, const int* __restrict__ rec, const long long* __restrict__ rec_off,
+                                                       double* __restrict__ arena, const double* __restrict__ fin, const double* __restrict__ bval) {
+   extern __shared__ __attribute__((aligned(16))) double br_X[];       // X[k * rp + a]: border row a of J, column k
+   constexpr int NW = BLOCK / 64;
+   __shared__ short map[BR_IDMAX], kq[NW * WMAX];
+   __shared__ double ljj[WMAX * WMAX], dj[WMAX], dl[NW * WMAX * WMAX];
+   __shared__ BrPair pd[BR_PCHUNK];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int jid = list[blockIdx.x];
+   const SnDesc J = sns[jid];
+   const int* H = rec + rec_off[jid];
+   const int bn = blks[J.blk].n;
+   const long long b_off = blks[J.blk].b_off;
+   const int w = J.w, nbj = J.r - J.rb, rp = (nbj + 3) & ~3;
+   const int n_pairs = H[0], n_ent = H[1];
+   double* X = br_X;
+   // ---- everything the front needs that does not depend on another load of this kernel is requested here, in one go
+   for (int p = tid; p < n_pairs && p < BR_PCHUNK; p += BLOCK) {
+      const int seg = H[3 + 2 * p], b0 = seg & 0xffff;
+      const SnDesc C = sns[H[2 + 2 * p]];
+      pd[p] = BrPair{C.panel + C.w + b0, C.bb, C.rows, C.w, C.r - C.rb, C.ld, (seg >> 16) - b0, b0, C.rb};
+   }
+   for (int idx = tid; idx < w * rp; idx += BLOCK) X[idx] = 0.0;
+   for (int g = tid; g < BR_IDMAX; g += BLOCK) map[g] = -1;
+   {  // the pivot block of J, for the last step
+      const double* PJ = fin + J.panel;
+      for (int idx = tid; idx < w * w; idx += BLOCK) {
+         const int k = idx / w, j = idx - k * w;
+         ljj[k * WMAX + j] = k > j ? PJ[k + (long long)j * J.ld] : 0.0;
+      }
+      if (tid < w) dj[tid] = PJ[tid + (long long)tid * J.ld];
+   }
+   __syncthreads();
+   for (int a = tid; a < nbj; a += BLOCK) map[rowidx[J.rows + J.rb + a] - bn] = (short)a;
+   {  // the border's own entries in J's columns: distinct (row, column) positions
+      const int* E = H + 2 + 2 * n_pairs;
+      const double* bv = bval + b_off;
+      for (int e = tid; e < n_ent; e += BLOCK) {
+         const int ak = E[2 * e];
+         X[(ak >> 16) * rp + (ak & 0xffff)] = bv[E[2 * e + 1]];
+      }
+   }
+   __syncthreads();
+   // a wave per pair, round-robin; the lanes along the border rows of C.  The segment's rows of C's panel are staged in the wave's own piece of
+   // LDS (coalesced reads, then wave-uniform LDS reads: straight-line code, every load of a pair in flight at once - a first version read them
+   // with uniform global loads behind a branch per column and waited for each)
+   double* dlw = dl + wave * (WMAX * WMAX);
+   short* kqw = kq + wave * WMAX;
+   for (int p0 = 0; p0 < n_pairs; p0 += BR_PCHUNK) {
+      if (p0 > 0) {   // (fronts with more pairs than one chunk of descriptors: the next chunk)
+         __syncthreads();
+         for (int p = p0 + tid; p < n_pairs && p < p0 + BR_PCHUNK; p += BLOCK) {
+            const int seg = H[3 + 2 * p], b0 = seg & 0xffff;
+            const SnDesc C = sns[H[2 + 2 * p]];
+            pd[p - p0] = BrPair{C.panel + C.w + b0, C.bb, C.rows, C.w, C.r - C.rb, C.ld, (seg >> 16) - b0, b0, C.rb};
+         }
+         __syncthreads();
+      }
+      const int pn = n_pairs - p0 < BR_PCHUNK ? n_pairs - p0 : BR_PCHUNK;
+      for (int p = wave; p < pn; p += NW) {
+         const BrPair P = pd[p];
+         const int wC = P.wC, nbc = P.nbc, rpC = (nbc + 3) & ~3, ns = P.ns, w4 = (wC + 3) & ~3;
+         const double* PC = fin + P.panel;
+         const double* LbC = fin + P.bb;
+         for (int idx = lane; idx < ns * w4; idx += 64) {
+            const int c = idx / ns, qi = idx - c * ns;
+            dlw[qi * WMAX + c] = c < wC ? PC[qi + (long long)c * P.ldC] : 0.0;
+         }
+         if (lane < ns) kqw[lane] = (short)(rowidx[P.rows + P.b0 + lane] - J.c0);
+         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+         for (int t = lane; t < nbc; t += 64) {
+            const int aj = map[rowidx[P.rows + P.pad + t] - bn];      // (P.pad: rb of C.  Every border row of C is one of J's: C has a row in J's columns)
+            double lbd[WMAX];
+#pragma unroll
+            for (int c = 0; c < WMAX; ++c) {                          // (clamped index: unconditional loads, all in flight; the pivots follow the rows in the border-row arena)
+               const int cc = c < wC ? c : wC - 1;
+               const double v = LbC[cc * rpC + t] * LbC[wC * rpC + cc];
+               lbd[c] = c < wC ? v : 0.0;
+            }
+            if (aj < 0) continue;
+            for (int qi = 0; qi < ns; ++qi) {
+               const double* dq = dlw + qi * WMAX;
+               double sum = 0.0;
+#pragma unroll
+               for (int c = 0; c < 4; ++c) sum += lbd[c] * dq[c];
+               if (wC > 4) {
+#pragma unroll
+                  for (int c = 4; c < 8; ++c) sum += lbd[c] * dq[c];
+               }
+               if (wC > 8) {
+#pragma unroll
+                  for (int c = 8; c < 12; ++c) sum += lbd[c] * dq[c];
+               }
+               if (wC > 12) {
+#pragma unroll
+                  for (int c = 12; c < 16; ++c) sum += lbd[c] * dq[c];
+               }
+               lds_add(X + kqw[qi] * rp + aj, -sum);
+            }
+         }
+         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+      }
+   }
+   __syncthreads();
+   // Y = X L_JJ^-T (unit lower L_JJ): Y(:, k) = X(:, k) - sum_{j < k} Y(:, j) L_JJ(k, j);  L_b(:, k) = Y(:, k) / d_k
+   // (in place in LDS, every thread on its own rows: no array of w values in registers, the compiler would hoist all of L_JJ beside it)
+   double* Q = arena + J.bb;
+   for (int a = tid; a < nbj; a += BLOCK) {
+      Q[a] = X[a] / dj[0];
+      for (int k = 1; k < w; ++k) {
+         double v = X[k * rp + a];
+         for (int j = 0; j < k; ++j) v -= X[j * rp + a] * ljj[k * WMAX + j];
+         X[k * rp + a] = v;
+         Q[k * rp + a] = v / dj[k];
+      }
+   }
+}
+
+// ... and the same contribution for the border rows of the DENSE TAIL (the tail panel's rows m_pad .. of the columns the supernode C reaches):
+//    T(border row a, tail column of row q) -= sum_c L_b(C)(a, c) d_C(c) L_C(q, c)       q in [q0, q1): the tail rows of C
+// for every supernode C with border rows and tail rows - with whole fronts this part of the update matrices reached the tail through
+// k_root_assemble.  One wave per (C, chunk of its tail rows); targets are shared between supernodes: FP64 atomics (the mode is not taken in
+// deterministic mode).  list: (C, q0 | q1 << 16) pairs.
+template <int WMAX>
+__global__ __launch_bounds__(64) void k_border_tail(const int* __restrict__ list, const SnDesc* __restrict__ sns, const BlkDesc* __restrict__ blks,
+                                                    const int* __restrict__ rowidx, double* __restrict__ arena) {
+   __shared__ double dl[WMAX * WMAX];
+   __shared__ int tcol[WMAX];
+   const int lane = threadIdx.x;
+   const SnDesc C = sns[list[2 * blockIdx.x]];
+   const BlkDesc bd = blks[C.blk];
+   const int seg = list[2 * blockIdx.x + 1], q0 = seg & 0xffff, q1 = seg >> 16, ns = q1 - q0;   // ns <= WMAX (the host cuts longer runs)
+   const int wC = C.w, nbc = C.r - C.rb, rpC = (nbc + 3) & ~3, ldC = C.ld;
+   const double* PC = arena + C.panel;
+   for (int idx = lane; idx < ns * wC; idx += 64) {
+      const int qi = idx / wC, c = idx - qi * wC;
+      dl[qi * WMAX + c] = PC[c + (long long)c * ldC] * PC[(wC + q0 + qi) + (long long)c * ldC];
+   }
+   if (lane < ns) tcol[lane] = rowidx[C.rows + q0 + lane] - bd.n_head;
+   __syncthreads();
+   const double* LbC = arena + C.bb;
+   double* T = arena + bd.T;
+   for (int a = lane; a < nbc; a += 64) {
+      double lb[WMAX];
+#pragma unroll
+      for (int c = 0; c < WMAX; ++c) lb[c] = c < wC ? LbC[c * rpC + a] : 0.0;
+      const int tr = bd.m_pad + (rowidx[C.rows + C.rb + a] - bd.n);
+      for (int qi = 0; qi < ns; ++qi) {
+         double sum = 0.0;
+#pragma unroll
+         for (int c = 0; c < WMAX; ++c) sum += c < wC ? lb[c] * dl[qi * WMAX + c] : 0.0;
+         atomic_add_f64(T + tr + (long long)tcol[qi] * bd.ldT, -sum);
       }
    }
 }

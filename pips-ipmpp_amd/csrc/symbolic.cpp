@@ -256,6 +256,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
    // border split (see "multifrontal metadata" below): a front keeps its border rows only in the border-row arena, its panel holds
    // the w + rb rows of K - compact, so that the solve sweeps do not drag the border rows' cache lines along
    out.mf_split = nb > 0 && nb <= opt.mf_split_nb_max;
+   out.mf_konly = out.mf_split && opt.mf_konly;
    for (auto& sn : out.sn) {
       const int* rows = out.rowidx.data() + sn.rows;
       sn.rb = (int)(std::lower_bound(rows, rows + sn.r, n) - rows);
@@ -336,6 +337,10 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
       // (uc = rb of them, each with all r rows below: K x K and border x K); the border x border part is formed once per block from the
       // finished panels, -sum_J L_b(J) D_J L_b(J)^T (k_border_schur).  Taken where that kernel's accumulator fits the LDS.
       auto ucols = [&](const HeadSupernode& sn) { return out.mf_split ? sn.rb : sn.r; };
+      // rows a front holds below its pivot block: all of them, or (mf_konly) the rows of K only - the border rows of such a front are formed
+      // afterwards, row-parallel, from the finished panels of its descendants (k_border_rows); what is handed from front to front is then
+      // the K x K part alone, and a front is the size its rows of K give it (time-coupled blocks: ~33 rows instead of ~130)
+      auto frows = [&](const HeadSupernode& sn) { return out.mf_konly ? sn.rb : sn.r; };
       std::vector<std::vector<int>> kids(nsn), leaves(nsn);
       for (int s = 0; s < nsn; ++s) {
          const HeadSupernode& sn = out.sn[s];
@@ -345,9 +350,9 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             (is_simple(sn) ? leaves[p] : kids[p]).push_back(s);
          }
          if (!is_simple(sn)) {
-            const int64_t nf = sn.w + sn.r;
+            const int64_t nf = sn.w + frows(sn);
             out.mf_max_front = std::max(out.mf_max_front, (int)nf);
-            const int64_t cw = (int64_t)sn.w * nf - (int64_t)sn.w * (sn.w - 1) / 2, lt = (int64_t)sn.w * ((sn.r + 3) / 4 * 4);
+            const int64_t cw = (int64_t)sn.w * nf - (int64_t)sn.w * (sn.w - 1) / 2, lt = (int64_t)sn.w * ((frows(sn) + 3) / 4 * 4);
             if (nf > MF_MAX_FRONT || std::max(cw, lt) + 8 > opt.mf_lds_doubles) out.mf_ok = false;
          }
       }
@@ -357,7 +362,7 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          const int* rows = out.rowidx.data() + c.rows;
          const int* prow = out.rowidx.data() + p.rows;
          int q = 0;
-         for (int a = 0; a < c.r; ++a) {
+         for (int a = 0; a < frows(c); ++a) {
             const int ra = rows[a];
             if (ra < p.c0 + p.w) { pos.push_back(ra - p.c0); continue; }
             while (q < p.r && prow[q] < ra) ++q;
@@ -372,19 +377,26 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          if (is_simple(sn)) continue;
          out.mf_U[s] = out.mf_U_total;
          const int64_t uc = ucols(sn);
-         out.mf_U_total += uc * sn.r - uc * (uc - 1) / 2;   // update columns 0 .. uc - 1, packed: column b holds rows b .. r - 1
+         out.mf_U_total += uc * frows(sn) - uc * (uc - 1) / 2;   // update columns 0 .. uc - 1, packed: column b holds rows b .. r - 1
       }
       if (out.mf_U_total >= (int64_t)INT32_MAX || 18 * (int64_t)nsn >= (int64_t)INT32_MAX) out.mf_ok = false;
       // entries of K and of the border that fall into the panel of a front: (position in the packed panel, index into the block's
       // value array; border entries as -1 - index) - k_front adds them to its zeroed LDS panel instead of reading the panel from the
       // arena, which holds these few entries among zeros (an LP's dual columns: the diagonal and two border entries in ~100 rows)
-      std::vector<std::vector<int>> kent(nsn);
+      std::vector<std::vector<int>> kent(nsn), kb_ent(nsn);
       if (out.mf_ok) {
          auto add_entry = [&](int c, int r, int src) {
             const int si = out.sn_of_col[c];
             const HeadSupernode& sn = out.sn[si];
             if (is_simple(sn)) return;
-            const int k = c - sn.c0, nf = sn.w + sn.r;
+            if (out.mf_konly && r >= n) {                // a border entry: k_border_rows starts the border rows of the front from it
+               const int* bq = out.rowidx.data() + sn.rows;
+               const int a = (int)(std::lower_bound(bq + sn.rb, bq + sn.r, r) - (bq + sn.rb));
+               kb_ent[si].push_back(a | ((c - sn.c0) << 16));
+               kb_ent[si].push_back(-1 - src);            // (the caller passes -1 - p for border entries)
+               return;
+            }
+            const int k = c - sn.c0, nf = sn.w + frows(sn);
             int fi;
             if (r < sn.c0 + sn.w) fi = r - sn.c0;
             else {
@@ -411,15 +423,15 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          if (is_simple(sn)) continue;
          const int64_t base = (int64_t)out.mf_int.size();
          out.mf_meta[s] = base;
-         const int nf = sn.w + sn.r, n_leaf = (int)leaves[s].size();
+         const int nf = sn.w + frows(sn), n_leaf = (int)leaves[s].size();
          int sum_rc = 0;
-         for (int c : kids[s]) sum_rc += out.sn[c].r;
+         for (int c : kids[s]) sum_rc += frows(out.sn[c]);
          int hdr[MF_HDR] = {(int)kids[s].size(), n_leaf, out.sn_parent[s] >= 0 ? 1 : 0, 0, 0, 0, sum_rc, 0};
          const size_t hpos = out.mf_int.size();
          out.mf_int.insert(out.mf_int.end(), hdr, hdr + MF_HDR);
          for (int c : kids[s]) {
             out.mf_int.push_back((int)(out.mf_U[c] - out.mf_U[s]));
-            out.mf_int.push_back(out.sn[c].r | (ucols(out.sn[c]) << 16));   // r_c, and the number of update columns the child hands over
+            out.mf_int.push_back(frows(out.sn[c]) | (ucols(out.sn[c]) << 16));   // r_c, and the number of update columns the child hands over
             out.mf_int.push_back(0);   // (reserved: the record keeps three integers per child)
          }
          for (int c : kids[s]) {
@@ -451,10 +463,10 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
             out.mf_U[c] = out.mf_LV_total + n_vals;
             tab.push_back(lf.c0);
             tab.push_back(n_vals);
-            tab.push_back(lf.r);
+            tab.push_back(frows(lf));
             tab.push_back(loff);
             lists.insert(lists.end(), pos.begin(), pos.end());
-            for (int b = 0; b < ucols(lf); ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (lf.r << 4) | b); item_b.push_back(loff); }
+            for (int b = 0; b < ucols(lf); ++b) { item_col.push_back(pos[b]); item_a.push_back((n_vals << 9) | (frows(lf) << 4) | b); item_b.push_back(loff); }
             n_vals += 1 + lf.r;
          }
          out.mf_LV_total += n_vals;
@@ -476,6 +488,46 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
          out.mf_int[hpos + 4] = n_items;
          out.mf_int[hpos + 5] = n_vals;
          append_entries();
+      }
+      if (out.mf_ok && out.mf_konly) {
+         // gather-form metadata (k_border_rows / k_border_tail): for every supernode C with border rows that takes part in the multifrontal
+         // scheme, the runs of its below-rows inside one target supernode's columns -> a pair of that target; its tail rows -> k_border_tail
+         std::vector<std::vector<int>> pairs(nsn);
+         for (int c = 0; c < nsn; ++c) {
+            const HeadSupernode& sn = out.sn[c];
+            if (sn.rb >= sn.r || (is_simple(sn) && out.sn_parent[c] < 0)) continue;
+            const int* rows = out.rowidx.data() + sn.rows;
+            int b0 = 0;
+            while (b0 < sn.rb && rows[b0] < n_head) {
+               const int tgi = out.sn_of_col[rows[b0]];
+               const HeadSupernode& tg = out.sn[tgi];
+               int b1 = b0 + 1;
+               while (b1 < sn.rb && rows[b1] < tg.c0 + tg.w) ++b1;
+               pairs[tgi].push_back(c);
+               pairs[tgi].push_back(b0 | (b1 << 16));
+               b0 = b1;
+            }
+            for (int q0 = b0; q0 < sn.rb; q0 += 16) {        // (rows b0 .. rb - 1: the tail rows)
+               out.kb_tail.push_back(c);
+               out.kb_tail.push_back(q0 | (std::min(q0 + 16, sn.rb) << 16));
+            }
+         }
+         out.kb_off.assign(nsn, -1);
+         for (int s2 = 0; s2 < nsn; ++s2) {
+            const HeadSupernode& sn = out.sn[s2];
+            if (is_simple(sn) || sn.rb >= sn.r) {
+               if (!pairs[s2].empty()) PIPS_FAIL(PIPS_ERR_STATE, "analyze_block: internal error, supernode %d without border rows below one with", sn.c0);
+               continue;
+            }
+            out.kb_off[s2] = (int64_t)out.kb_rec.size();
+            out.kb_rec.push_back((int)(pairs[s2].size() / 2));
+            out.kb_rec.push_back((int)(kb_ent[s2].size() / 2));
+            out.kb_rec.insert(out.kb_rec.end(), pairs[s2].begin(), pairs[s2].end());
+            for (size_t e = 0; e < kb_ent[s2].size(); e += 2) {
+               out.kb_rec.push_back(kb_ent[s2][e]);
+               out.kb_rec.push_back(kb_ent[s2][e + 1]);        // index of the border value inside the block's border values
+            }
+         }
       }
       if (!out.mf_ok && out.mf_split) {   // compact panels need the multifrontal head: analyse again with full panels
          AnalyzeOptions full = opt;

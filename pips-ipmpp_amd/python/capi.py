@@ -507,11 +507,11 @@ class LeafBatch:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(25, np.int64)
-        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(25)), "pips_hip_batch_info")
+        what = np.zeros(26, np.int64)
+        _check(lib.pips_hip_batch_info(self._h, _ptr(what), C.c_int(26)), "pips_hip_batch_info")
         keys = ["nnzL", "n", "n_head", "m", "n_sn", "n_levels", "flops_factor", "flops_border", "arena_bytes", "ntc", "upd_table_bytes", "nb", "nnzK",
                 "ltsolve_from_augmented_factor", "multifrontal_head", "max_front", "update_matrix_bytes", "fronts_in_device_memory", "nnzL_head", "head_row_indices",
-                "nnzL_border", "augmented_sweeps", "augmented_passes", "tail_border_entries", "blocks_with_border_split"]
+                "nnzL_border", "augmented_sweeps", "augmented_passes", "tail_border_entries", "blocks_with_border_split", "blocks_with_k_only_fronts"]
         return {k: int(v) for k, v in zip(keys, what)}
 
     def sync(self):

@@ -41,9 +41,11 @@ def _oracle(prob, b0, bl):
     return b0_o, np.concatenate(bs_o)
 
 
-@pytest.mark.parametrize("shape", ["dense_tail", "small", "time_coupled", "time_coupled_all_head"])
+@pytest.mark.parametrize("shape", ["dense_tail", "small", "time_coupled", "time_coupled_all_head", "time_coupled_k_only_fronts"])
 def test_augmented_sweeps_match_oracle_and_refined_path(shape, monkeypatch):
     monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")     # (the cost model would pick it or not by the shape; here it is under test)
+    if shape == "time_coupled_k_only_fronts":
+        monkeypatch.setenv("PIPS_HIP_MF_KONLY", "1")   # the border rows the sweeps read come from k_border_rows / k_border_tail
     if shape == "dense_tail":
         prob = Problem(3, 4, 1000, 500, 100, 100, 0.01)
     elif shape == "small":
@@ -51,6 +53,7 @@ def test_augmented_sweeps_match_oracle_and_refined_path(shape, monkeypatch):
     else:
         prob = _TimeCoupledProblem(5, 3, 3000, 1500, 10, 8, 6)
     bt, kkt = _system(prob, force_head=shape == "time_coupled_all_head")
+    assert bt.info()["blocks_with_k_only_fronts"] == (prob.N if shape == "time_coupled_k_only_fronts" else 0)
     diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in range(prob.N)]), device="cuda")
     xd0 = torch.tensor(prob.x_diag0, device="cuda")
     kkt.factorize(diag, xd0)

@@ -345,18 +345,21 @@ class _TimeCoupledProblem(Problem):
             blk.update(W=Wp, K=K, dpos=dpos)
 
 
-@pytest.mark.parametrize("head", ["multifrontal", "multifrontal_devmem", "scatter"])
+@pytest.mark.parametrize("head", ["multifrontal", "multifrontal_devmem", "multifrontal_k_only", "scatter"])
 @pytest.mark.parametrize("cut", ["model", "all_head"])
 @pytest.mark.parametrize("n_i", [600, 3000], ids=["chain_and_spine", "dissected"])
 def test_time_coupled_blocks_match_oracle(cut, n_i, head, monkeypatch):
     """n_i = 600, dissection switched off: the head is one chain per block (level-scheduled bottom, spine kernels on top);
     n_i = 3000: the dual-row separators of the nested dissection cut each block into independent segments.
-    head: the multifrontal head kernels (fronts in LDS / update matrices in device memory) or the scattering ones."""
+    head: the multifrontal head kernels (fronts in LDS / update matrices in device memory / fronts on the rows of K only) or the scattering ones."""
     import torch
     if n_i == 600:
         monkeypatch.setenv("PIPS_HIP_ND_DEPTH", "0")     # keeps the chain / spine kernels under test
     if head == "scatter":
         monkeypatch.setenv("PIPS_HIP_MF", "0")
+    if head == "multifrontal_k_only":
+        # fronts on the rows of K only, their border rows formed afterwards in gather form (DESIGN.md 4.1c; opt-in)
+        monkeypatch.setenv("PIPS_HIP_MF_KONLY", "1")
 
     prob = _TimeCoupledProblem(5, 3, n_i, n_i // 2, 10, 8, 6)
     S, N = prob.S, prob.N
@@ -388,6 +391,7 @@ def test_time_coupled_blocks_match_oracle(cut, n_i, head, monkeypatch):
         assert info["fronts_in_device_memory"] > 0, info
     assert bt.schur_mode() in (1, 2)
     assert info["multifrontal_head"] == (0 if head == "scatter" else 1), info
+    assert info["blocks_with_k_only_fronts"] == (N if head == "multifrontal_k_only" else 0), info
     if cut == "all_head" and n_i == 600:
         assert info["n_levels"] >= 10, info          # really chain-like
         assert info["n_sn"] < 0.9 * info["n_head"]    # amalgamation merged columns

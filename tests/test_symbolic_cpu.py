@@ -213,9 +213,16 @@ def test_border_split_of_the_multifrontal_head(monkeypatch):
     K, dpos = pa.kkt_leaf_assemble(6000, W)
     Bt = pa.border_assemble(6000, my_i, 0, c3["n0"], 0, A=T, F=F)
     on = pa.symbolic_probe(K, 6000, Bt=Bt)
+    monkeypatch.setenv("PIPS_HIP_MF_KONLY", "1")
+    konly = pa.symbolic_probe(K, 6000, Bt=Bt)
+    monkeypatch.delenv("PIPS_HIP_MF_KONLY")
     monkeypatch.setenv("PIPS_HIP_MF_SPLIT", "0")
     off = pa.symbolic_probe(K, 6000, Bt=Bt)
     assert on["multifrontal"] == 1 and on["border_split"] == 1 and off["border_split"] == 0
+    # round 5 (opt-in): fronts over the rows of K only - the update matrices lose their border rows as well, everything stored is the same
+    assert konly["border_split"] == 2 and konly["update_matrix_doubles"] < 0.25 * on["update_matrix_doubles"]
+    for k in ("nnzL", "n_sn", "n_levels", "arena_bytes", "border_row_arena_doubles"):
+        assert konly[k] == on[k], k
     assert on["nnzL"] == off["nnzL"] and on["n_sn"] == off["n_sn"] and on["n_levels"] == off["n_levels"]
     assert on["update_matrix_doubles"] < 0.5 * off["update_matrix_doubles"]
     assert on["border_row_arena_doubles"] > 0 and off["border_row_arena_doubles"] == 0
