@@ -715,7 +715,9 @@ struct Engine {
       for (void* p : {(void*)d_det_tasks, (void*)d_gbuf, (void*)d_blk_group, (void*)d_gvec, (void*)d_tvec})
          if (p) (void)hipFree(p);
       d_det_tasks = nullptr; d_gbuf = nullptr; d_blk_group = nullptr; d_gvec = d_tvec = nullptr;
-      g_btm_grp.release(); g_sc_grp.release();
+      g_btm_grp.release(); g_sc_grp.release(); g_bslot_grp.release();
+      for (void* q : {(void*)d_bg_ent, (void*)d_bg_ptr, (void*)d_bg_idx, (void*)d_bg_val, (void*)d_bg_slot}) if (q) (void)hipFree(q);
+      d_bg_ent = nullptr; d_bg_ptr = d_bg_slot = nullptr; d_bg_idx = nullptr; d_bg_val = nullptr; n_bg_targets = n_bg_ent = 0; det_aug_ready = false;
       if (d_slot_val) (void)hipFree(d_slot_val);
       if (d_vslot_val) (void)hipFree(d_vslot_val);
       d_slot_val = d_vslot_val = nullptr;
@@ -876,10 +878,86 @@ struct Engine {
          if ((rc = upload_gather(ent, g_btm_grp))) return rc;
          HIP_TRY(hipMalloc((void**)&d_gvec, (size_t)8 * S * sizeof(double)));
          HIP_TRY(hipMalloc((void**)&d_tvec, (size_t)S * sizeof(double)));
+         if ((rc = build_det_aug(grp))) return rc;
       }
+      if (!det_aug_ready) aug_sweeps_ok = false;   // (deterministic mode takes the sweeps of the augmented factor only through forward_augmented_det)
+      return PIPS_OK;
+   }
+   // Deterministic forward sweep of the augmented factor (forward_augmented_det).  Per (block, border id): the head supernodes that hold that
+   // border row, in the order of the supernode array - entry = where its w factors L_b(a, 0 .. w-1) lie (the border-row arena of a front
+   // under the border split, else the panel) and the first of its w columns in the work vector.  And the gather of the blocks' border slots
+   // into the group slots of d_gvec.
+   int build_det_aug(const std::vector<int>& grp) {
+      det_aug_ready = false;
+      for (void* q : {(void*)d_bg_ent, (void*)d_bg_ptr, (void*)d_bg_idx, (void*)d_bg_val, (void*)d_bg_slot}) if (q) (void)hipFree(q);
+      d_bg_ent = nullptr; d_bg_ptr = d_bg_slot = nullptr; d_bg_idx = nullptr; d_bg_val = nullptr; n_bg_targets = n_bg_ent = 0;
+      g_bslot_grp.release();
+      if (!aug_sweeps_ok || h_sns_keep.empty()) return PIPS_OK;
+      std::vector<long long> tbase(nblk + 1, 0);
+      for (int b = 0; b < nblk; ++b) tbase[b + 1] = tbase[b] + h_blks[b].nb;
+      const long long nt = tbase[nblk];
+      if (nt == 0) return PIPS_OK;
+      std::vector<long long> cnt((size_t)nt + 1, 0);
+      auto for_rows = [&](auto&& fn) {
+         for (size_t i = 0; i < h_sns_keep.size(); ++i) {
+            const SnDesc& sn = h_sns_keep[i];
+            if (sn.rb >= sn.r) continue;
+            const BlockSym& bs = sym[sn.blk];
+            const int loc = bs.sn_of_col[(size_t)sn.c0];
+            const int* rows = bs.rowidx.data() + bs.sn[loc].rows;
+            for (int a = sn.rb; a < sn.r; ++a) fn(sn, tbase[sn.blk] + (rows[a] - bs.n), a);
+         }
+      };
+      for_rows([&](const SnDesc&, long long t, int) { ++cnt[(size_t)t + 1]; });
+      for (long long t = 0; t < nt; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+      // entries in the order of the supernode array (a supernode's border rows side by side: the threads of k_border_rowdot_det read them
+      // coalesced); per target the indices of its entries, ascending
+      const long long n_ent = cnt[(size_t)nt];
+      if (n_ent >= (1LL << 31) || xw_total >= (1LL << 32)) return PIPS_OK;   // (index widths of the lists; the refined path stays)
+      std::vector<BgEntry> ent((size_t)n_ent);
+      std::vector<int> idx((size_t)n_ent);
+      std::vector<long long> fill(cnt.begin(), cnt.end() - 1);
+      bool ok = true;
+      long long e_next = 0;
+      for_rows([&](const SnDesc& sn, long long t, int a) {
+         BgEntry e;
+         const bool in_panel = sn.ld >= sn.w + sn.r;
+         const int stride = in_panel ? sn.ld : ((sn.r - sn.rb + 3) & ~3);
+         if (!in_panel && sn.bb < 0) ok = false;
+         if (stride > 65535 || sn.w > 65535) ok = false;
+         e.off = in_panel ? sn.panel + sn.w + a : sn.bb + (a - sn.rb);
+         e.y = (unsigned)(h_blks[sn.blk].xw_off + sn.c0); e.stride = (unsigned short)stride; e.w = (unsigned short)sn.w;
+         idx[(size_t)fill[(size_t)t]++] = (int)e_next;
+         ent[(size_t)e_next++] = e;
+      });
+      if (!ok) return PIPS_OK;   // (a layout this sweep does not read: the refined path stays)
+      std::vector<long long> slot((size_t)nt);
+      std::vector<SlotEntry> col;
+      for (int b = 0; b < nblk; ++b)
+         for (int g = 0; g < h_blks[b].nb; ++g) {
+            slot[(size_t)(tbase[b] + g)] = h_blks[b].xw_off + h_blks[b].n_head + h_blks[b].m_pad + g;
+            col.push_back({(long long)grp[b] * S + sym[b].bmap[(size_t)g], slot[(size_t)(tbase[b] + g)]});
+         }
+      int rc;
+      if ((rc = dev_upload(&d_bg_ent, ent, stream)) || (rc = dev_upload(&d_bg_ptr, cnt, stream)) || (rc = dev_upload(&d_bg_idx, idx, stream)) ||
+          (rc = dev_upload(&d_bg_slot, slot, stream)) || (rc = upload_gather(col, g_bslot_grp)))
+         return rc;
+      HIP_TRY(hipMalloc((void**)&d_bg_val, (size_t)std::max<long long>(n_ent, 1) * sizeof(double)));
+      n_bg_ent = n_ent;
+      n_bg_targets = nt;
+      det_aug_ready = true;
       return PIPS_OK;
    }
    GatherList g_btm, g_bm;        // border products: rows per Schur column, entries per leaf row
+   // deterministic mode, forward sweep of the augmented factor: the border slots of the work vector are gathered, target by target, from the
+   // border rows of the head supernodes (k_border_gather_det: no atomics, fixed order) and then group-wise into d_gvec like Br^T z
+   BgEntry* d_bg_ent = nullptr;
+   long long *d_bg_ptr = nullptr, *d_bg_slot = nullptr;
+   int* d_bg_idx = nullptr;
+   double* d_bg_val = nullptr;
+   long long n_bg_targets = 0, n_bg_ent = 0;
+   GatherList g_bslot_grp;
+   bool det_aug_ready = false;
    double* d_bt_tmp = nullptr;
    int* d_gemm_ctr = nullptr;     // counter slots of the persistent update kernel
    int gemm_ctr_cursor = 0;
@@ -1598,8 +1676,8 @@ struct Engine {
          // Both halves of solveCompressed from the augmented factor (forward_augmented / backward_augmented): one forward and one backward
          // sweep that also read the border rows, instead of two full solves (two sweeps each, a residual check each, two border
          // products) - pays as long as the border rows are not several times what a sweep reads anyway
-         const bool aug_paths = schur_mode_eff == 1 && nnzB_total > 0 && (sweep.enabled || plan.ntc_max == 0) && !deterministic && spine_total == 0 &&
-                                !head_slots;
+         const bool aug_paths = schur_mode_eff == 1 && nnzB_total > 0 && (sweep.enabled || plan.ntc_max == 0) && spine_total == 0 &&
+                                (deterministic || !head_slots);   // (deterministic mode: forward_augmented_det, if set_det_groups can build its lists)
          aug_sweeps_ok = aug_paths && border_entries <= 3.0 * fwd_entries;
          if (const char* as = getenv("PIPS_HIP_AUG_SWEEPS")) aug_sweeps_ok = atoi(as) != 0 && aug_paths;
       }
@@ -2341,7 +2419,7 @@ struct Engine {
    // the measure of a solveCompressed by sweeps in one launch (k_measure_leaf_rows): x = the result, b = the leaf right-hand side as the
    // caller gave it, x0 = the root solution.  Same quantity and same host formula as residual_measure on (b - Br x0, x); available where
    // every row of K is short and the border is held by leaf row
-   bool can_measure_fused() const { return refine_steps > 0 && d_norms && n_flong == 0 && !deterministic && (bt_rows_total == 0 || d_br_rowptr); }
+   bool can_measure_fused() const { return refine_steps > 0 && d_norms && n_flong == 0 && (bt_rows_total == 0 || d_br_rowptr); }   // (deterministic mode too: a row is summed by eight lanes in a fixed tree, the maxima do not depend on an order)
    int residual_measure_fused(const double* b_dev, const double* x0_dev, const double* x_dev, double* worst_out) {
       timer.begin(stream, 11);
       HIP_TRY(hipMemsetAsync(d_norms, 0, (size_t)3 * nblk * sizeof(double), stream));
@@ -2440,6 +2518,48 @@ struct Engine {
       if (nb_pad_max > 0)
          hipLaunchKernelGGL(k_tail_border_fwd, dim3(nb_pad_max / TILE, nblk), dim3(256), 0, stream, d_blks, d_arena, d_dtail, d_xw);
       hipLaunchKernelGGL(k_border_collect, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_bmap, d_xw, red);
+      timer.end(stream);
+      ++aug_passes;
+      HIP_TRY(hipGetLastError());
+      return PIPS_OK;
+   }
+   // The same sweep in deterministic mode: the head by the slot / gather scheme of solve_once (no atomics), the border slots of every block by
+   // k_border_gather_det from the finished head part (target by target, fixed order), the dense tail's border rows by k_tail_border_fwd (one
+   // writer per row).  The border slots stay in the work vector: the caller gathers them group-wise (g_bslot_grp) like Br^T z.
+   int forward_augmented_det(const double* b_dev) {
+      if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
+      if (!det_aug_ready || !head_slots) PIPS_FAIL(PIPS_ERR_STATE, "forward_augmented_det: not prepared");
+      HIP_TRY(hipSetDevice(device));
+      timer.begin(stream, 7);
+      hipLaunchKernelGGL(k_border_fill, dim3(8, nblk), dim3(256), 0, stream, d_blks, d_bmap, (const double*)nullptr, d_xw, 0.0);
+      hipLaunchKernelGGL(k_permute_in, dim3(64, nblk, 1), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, b_dev, 0LL, d_xw, 0LL);
+      timer.end(stream);
+      timer.begin(stream, 8);
+      const ScatterCtx sxv{2, nullptr, d_vslot_val, d_xw, nullptr};
+      for (size_t li = 0; li < levels.size(); ++li) {
+         const LevelRange& L = levels[li];
+         gather(gv_levels[li], d_vslot_val, d_xw);
+         if (L.simple_cnt > 0 && lf_rows > 0)
+            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
+                               0LL, (int)lf_rows);
+         else if (L.simple_cnt > 0)
+            hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt, d_blks,
+                               d_rowidx, d_arena, d_xw, 0LL, 0, sxv);
+         const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+         const int cnt = L.small_cnt + L.large_cnt;
+         if (cnt > 0) hipLaunchKernelGGL(k_head_fwd, dim3(cnt, 1), dim3(64), 0, stream, d_sns, begin, d_blks, d_rowidx, d_arena, d_xw, 0LL, sxv);
+      }
+      gather(gv_tail, d_vslot_val, d_xw);
+      hipLaunchKernelGGL(k_border_rowdot_det, dim3(grid_for(n_bg_ent, 256, 1 << 20)), dim3(256), 0, stream, n_bg_ent, d_bg_ent, d_arena, d_xw, d_bg_val);
+      hipLaunchKernelGGL(k_border_gather_det, dim3((unsigned)((n_bg_targets + 3) / 4)), dim3(256), 0, stream, n_bg_targets, d_bg_ptr, d_bg_idx, d_bg_slot, d_bg_val, d_xw);
+      timer.end(stream);
+      timer.begin(stream, 9);
+      TailCtx c = ctx();
+      c.timer = nullptr;
+      int rc = tail_fwd(c, d_xw);
+      if (rc) return rc;
+      if (nb_pad_max > 0)
+         hipLaunchKernelGGL(k_tail_border_fwd, dim3(nb_pad_max / TILE, nblk), dim3(256), 0, stream, d_blks, d_arena, d_dtail, d_xw);
       timer.end(stream);
       ++aug_passes;
       HIP_TRY(hipGetLastError());
@@ -4507,7 +4627,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    }
    // several ranks (or the forced reduction of the tests): the checks are decided together - see KktSystem::solve_check_every
    const bool joint = k->n_ranks > 1 || k->force_reduce;
-   const bool can_measure = !capturing && e->refine_tol > 0.0 && e->refine_steps > 0 && !(e->deterministic && e->d_gvec);
+   const bool can_measure = !capturing && e->refine_tol > 0.0 && e->refine_steps > 0;
    // (whether the ranks exchange the outcome may depend only on what is equal on every rank: the settings the host gives all ranks alike,
    // and "some rank's analysis chose the sweeps" - the cost model decides per rank - settled once per analysis by an all-reduce)
    if (joint && can_measure && k->solve_check_every > 0 && k->joint_aug_gen != e->analysis_gen) {
@@ -4566,12 +4686,17 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       // run-to-run reproducibility for any rank count, and equal bits for 1 and 2 ranks (a two-operand all-reduce has one order);
       // with 4 or 8 ranks the association of the per-rank partial sums is the all-reduce's (ring / tree, per chunk), not this tree
       k->timer.begin(e->stream, 5);
-      if ((rc = e->solve(b_leaf_dev))) return rc;
+      if (use_aug) { if ((rc = e->forward_augmented_det(b_leaf_dev))) return rc; }   // (the blocks' border slots hold -L_b y = -Br^T K^-1 b)
+      else {
+         if ((rc = e->solve(b_leaf_dev))) return rc;
+         lsolve_steps = e->last_refine_steps;
+      }
       k->timer.end(e->stream);
       k->timer.begin(e->stream, 6);
       HIP_TRY(hipMemsetAsync(e->d_gvec, 0, (size_t)8 * k->S * sizeof(double), e->stream));
       HIP_TRY(hipMemsetAsync(e->d_tvec, 0, (size_t)k->S * sizeof(double), e->stream));
-      if (e->bt_rows_total > 0) {
+      if (use_aug) e->gather(e->g_bslot_grp, e->d_xw, e->d_gvec);
+      else if (e->bt_rows_total > 0) {
          hipLaunchKernelGGL(k_border_rowdot, dim3(grid_for(e->bt_rows_total, 256)), dim3(256), 0, e->stream, e->d_bt_rowptr, e->d_bt_colidx, e->d_bval,
                             e->d_bt_xoff, b_leaf_dev, e->d_bt_tmp, e->bt_rows_total, -1.0);
          e->gather(e->g_btm_grp, e->d_bt_tmp, e->d_gvec);

@@ -2797,6 +2797,36 @@ __global__ __launch_bounds__(256) void k_leaf_border(const int* __restrict__ lis
    }
 }
 
+// ... deterministic mode, forward: the border slot of (block, border id) from the head supernodes that hold that border row,
+//    x_border = - sum_J sum_k L_b(J)(a, k) y_J(k),
+// in two steps without atomics: every (supernode, border row) product by a thread of its own - the entries are in the order of the supernode
+// array, a supernode's rows side by side, so the loads along k are coalesced - then one wave per target adds the products of its list
+// (entry p of the list on lane p % 64: a fixed assignment; the lanes' sums in the fixed tree of the shuffles): equal bits from run to run.
+// Entry: where the w factors of the row lie (stride between them) and the first of J's columns in the work vector.
+// (A first version gathered the factors per target: 1560 entries per wave, every factor a sector of its own - 10 ms per sweep on the configs[3] share.)
+struct BgEntry { long long off; unsigned y; unsigned short stride, w; };
+__global__ void k_border_rowdot_det(long long n_ent, const BgEntry* __restrict__ ent, const double* __restrict__ arena, const double* __restrict__ xw,
+                                    double* __restrict__ val) {
+   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n_ent; p += (long long)gridDim.x * blockDim.x) {
+      const BgEntry e = ent[p];
+      const double* L = arena + e.off;
+      const double* y = xw + e.y;
+      double s = 0.0;
+      for (int k = 0; k < (int)e.w; ++k) s += L[(long long)k * e.stride] * y[k];
+      val[p] = s;
+   }
+}
+__global__ __launch_bounds__(256) void k_border_gather_det(long long n_targets, const long long* __restrict__ ptr, const int* __restrict__ idx,
+                                                           const long long* __restrict__ slot, const double* __restrict__ val, double* __restrict__ xw) {
+   const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+   if (t >= n_targets) return;
+   const int lane = threadIdx.x & 63;
+   double acc = 0.0;
+   for (long long p = ptr[t] + lane; p < ptr[t + 1]; p += 64) acc += val[idx[p]];
+   for (int h = 32; h > 0; h >>= 1) acc += __shfl_xor(acc, h);
+   if (lane == 0) xw[slot[t]] = -acc;
+}
+
 // ... the border rows of the dense tail, forward: x_border(ib) -= sum_j T(border tile row ib, tile column j) (d_j z_j), z = what
 // k_tail_rows_fwd left (its rows are D^-1-scaled).  grid (border tile rows, blocks), 256 threads: thread = (row, half of the columns)
 __global__ __launch_bounds__(256) void k_tail_border_fwd(const BlkDesc* __restrict__ blks, const double* __restrict__ arena,

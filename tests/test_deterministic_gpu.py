@@ -149,6 +149,103 @@ def test_bit_identical_between_one_and_several_ranks(tmp_path, kind, world, monk
         assert tuple(g["inertia"][-1]) == one["inertia"][-1]
 
 
+def _run_aug(prob, mine, deterministic, comm=None, rank=0, world=1, reps=2):
+    """factorize + two solveCompressed with adaptive refinement on (the setting under which the sweeps of the augmented factor are taken and
+    measured): results and the path of every solve"""
+    S = prob.S
+    bt = pa.LeafBatch(len(mine), S)
+    bt.set_deterministic(deterministic)
+    for i, b in enumerate(mine):
+        bt.set_block(i, prob.blocks[b]["K"], prob.n_i, prob.blocks[b]["Bt"])
+    bt.analyze(4)
+    bt.set_refinement_backward_error(2, 1e-15)
+    for i, b in enumerate(mine):
+        bt.set_values(i, prob.blocks[b]["K"].val)
+    kkt = pa.KktSystem(bt, prob.n0, 0, prob.myl, 0, F0=prob.F0, comm=comm, rank=rank, n_ranks=world)
+    diag = torch.tensor(np.concatenate([prob.blocks[b]["diag"] for b in mine]), device="cuda")
+    xd0 = torch.tensor(prob.x_diag0, device="cuda")
+    rng = np.random.default_rng(5)
+    rhs = [(rng.standard_normal(S), [rng.standard_normal(prob.n_leaf) for _ in range(prob.N)]) for _ in range(2)]
+    out = []
+    for _ in range(reps):
+        kkt.factorize(diag, xd0)
+        res = dict(x0=[], xl=[], paths=[])
+        for b0_full, bs_full in rhs:
+            b0 = torch.tensor(b0_full, device="cuda")
+            bl = torch.tensor(np.concatenate([bs_full[b] for b in mine]), device="cuda")
+            kkt.solve_compressed(b0, bl)
+            bt.sync()
+            res["x0"].append(b0.cpu().numpy()); res["xl"].append(bl.cpu().numpy().reshape(len(mine), -1)); res["paths"].append(kkt.last_solve_path())
+        res["aug"] = bt.info()["augmented_sweeps"]
+        res["checks"] = kkt.solve_check_counts()
+        out.append(res)
+    kkt.close(); bt.close()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["random", "banded"])
+def test_augmented_sweeps_in_deterministic_mode(kind, monkeypatch):
+    """Round 5: deterministic mode takes both halves of solveCompressed from the augmented factor too (Engine::forward_augmented_det: the head
+    through the slot scheme, the blocks' border slots gathered target by target - k_border_gather_det - and group-wise into the root's
+    right-hand side; the backward sweep is a gather anyway).  Bit-identical over runs and handles, measured like the default mode's (path 3),
+    and the same solution as the default mode's sweeps and as deterministic mode's refined path."""
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")     # (the cost model decides by the shape; here the path is under test)
+    prob = _problem(kind)
+    mine = list(range(prob.N))
+    runs = _run_aug(prob, mine, True) + _run_aug(prob, mine, True)
+    assert runs[0]["aug"] == 1 and runs[0]["paths"] == [3, 3] and runs[0]["checks"][1] == 0, runs[0]
+    for r in runs[1:]:
+        assert r["paths"] == [3, 3]
+        for q in range(2):
+            assert np.array_equal(r["x0"][q], runs[0]["x0"][q]) and np.array_equal(r["xl"][q], runs[0]["xl"][q])
+    ref = _run_aug(prob, mine, False, reps=1)[0]
+    assert ref["paths"] == [3, 3]
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "0")
+    refined = _run_aug(prob, mine, True, reps=1)[0]
+    assert refined["aug"] == 0 and all(p in (0, 1) for p in refined["paths"])
+    for other in (ref, refined):
+        for q in range(2):
+            assert np.linalg.norm(other["x0"][q] - runs[0]["x0"][q]) <= 1e-9 * np.linalg.norm(other["x0"][q])
+            assert np.linalg.norm(other["xl"][q] - runs[0]["xl"][q]) <= 1e-9 * np.linalg.norm(other["xl"][q])
+
+
+def _worker_aug(rank, world, port, out, kind):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = _problem(kind)
+    mine = [int(b) for b in np.nonzero(pa.map_children_to_ranks(prob.N, world) == rank)[0]]
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(pa.capi._DeviceDoubles(ptr, n), device="cuda")
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+        torch.cuda.synchronize()
+
+    r = _run_aug(prob, mine, True, comm=pa.ExternalComm(allreduce), rank=rank, world=world, reps=1)[0]
+    np.savez(os.path.join(out, f"aug{rank}.npz"), x0=np.array(r["x0"]), xl=np.array(r["xl"]), mine=np.array(mine), paths=np.array(r["paths"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world", [("banded", 2), ("random", 4)])
+def test_augmented_sweeps_in_deterministic_mode_over_ranks(tmp_path, kind, world, monkeypatch):
+    """... and between one rank and 2 / 4 processes sharing the GPU: the border slots go through the same eight group slots as Br^T z."""
+    monkeypatch.setenv("PIPS_HIP_AUG_SWEEPS", "1")
+    port = 29500 + (os.getpid() % 2000) + 61 + 3 * world
+    mp.start_processes(_worker_aug, args=(world, port, str(tmp_path), kind), nprocs=world, join=True, start_method="spawn")
+    prob = _problem(kind)
+    one = _run_aug(prob, list(range(prob.N)), True, reps=1)[0]
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), f"aug{r}.npz"))
+        assert list(g["paths"]) == [3, 3] == one["paths"]
+        for q in range(2):
+            assert np.array_equal(g["x0"][q], one["x0"][q])
+            for i, b in enumerate(g["mine"]):
+                assert np.array_equal(g["xl"][q][i], one["xl"][q][b])
+
+
 def test_ipm_is_bit_reproducible(monkeypatch):
     """With PIPS_HIP_DETERMINISTIC=1 (the default of pips_hip_batch_set_deterministic for batches the harness creates) the whole
     interior-point run - every iterate's mu, residual, objectives, step lengths, and the final point - repeats to the bit; the
