@@ -15,7 +15,9 @@ ap.add_argument("--chunk", type=int, default=160, help="border columns per multi
 ap.add_argument("--level", choices=["1", "1.5", "1.5b"], default="1", help="1: adapters only, the host's K4-K6 loop ships dense border columns; "
                 "1.5: pips_hip_ldl_set_border + pips_hip_ldl_factor_schur - CSR border up, S x S term down; "
                 "1.5b: the same through the array-of-handles entries (pips_hip_ldl_factor_schur_batch / pips_hip_ldl_solve_batch): the leaves of the rank as one batch")
+ap.add_argument("--dense-rhs", action="store_true", help="level 1: ship the dense-ified border columns whole (pips_hip_ldl_solve) instead of the rows colSparsity marks (pips_hip_ldl_solve_sparse)")
 a = ap.parse_args()
+t_parts = [0.0, 0.0, 0.0]    # level 1: host dense-ify, solve call (PCIe + device), host sparse product
 seed, N_total, n_i, S, rho = 20261002, 64, 10000, 2000, 1e-3
 my_i, n0, myl = n_i // 2, S // 2, S // 2
 solvers, Bts = [], []
@@ -43,9 +45,18 @@ for b in range(a.blocks):
         cols = np.nonzero(np.diff(Bt.indptr) > 0)[0]
         for k in range(0, len(cols), a.chunk):               # K4: dense-ify, K5: multi-RHS solve, K6: sparse product
             ids = cols[k:k + a.chunk]
-            dense = np.ascontiguousarray(Bt[ids].toarray())
-            s.solve(dense)
+            t1 = time.perf_counter()
+            sub = Bt[ids]
+            dense = np.ascontiguousarray(sub.toarray())
+            t2 = time.perf_counter()
+            if a.dense_rhs:
+                s.solve(dense)
+            else:       # what the adapter's solve(nrhss, rhss, colSparsity) does with the pattern the reference builds (DistributedLinearSystem.C:903)
+                cs = np.zeros(sub.shape[1], np.int32); cs[np.unique(sub.indices)] = 1
+                s.solve_sparse(dense, cs)
+            t3 = time.perf_counter()
             SC[ids, :] -= (Bt @ dense.T).T
+            t_parts[0] += t2 - t1; t_parts[1] += t3 - t2; t_parts[2] += time.perf_counter() - t3
         t_schur += time.perf_counter() - t0
     solvers.append(s); Bts.append(Bt)
     print(f"block {b}: factor {t_fac / (b + 1) * 1e3:.1f} ms, Schur term {t_schur / (b + 1):.2f} s (running means)", file=sys.stderr, flush=True)
@@ -80,9 +91,10 @@ for r in range(4):
     t_sc.append(time.perf_counter() - t0)
 scale = N_total / a.blocks
 unit = (t_fac + t_schur) * scale + t_root + 4 * np.median(t_sc) * scale
-print(json.dumps({"path": "drop-in DoubleLinearSolver adapters only (host pointers, reference K4-K6 host loop)" if a.level == "1" else
+print(json.dumps({"path": ("drop-in DoubleLinearSolver adapters only (host pointers, reference K4-K6 host loop; " + ("dense right-hand sides up" if a.dense_rhs else "colSparsity honoured: only the marked rows go up") + ")") if a.level == "1" else
                           "level 1.5: adapters + pips_hip_ldl_factor_schur (CSR border up, S x S Schur term down; solves through host pointers)" if a.level == "1.5" else
                           "level 1.5b: array-of-handles entries - all leaves of the rank as one batch (pips_hip_ldl_factor_schur_batch, pips_hip_ldl_solve_batch; host pointers)", "blocks_run": a.blocks, "chunk_columns": a.chunk,
                   "seconds_per_block": {"analyze_once": t_an / a.blocks, "factor": t_fac / a.blocks, "schur_term": t_schur / a.blocks},
+                  "schur_term_parts_per_unit": {"host_densify": t_parts[0] * scale, "solve_calls": t_parts[1] * scale, "host_sparse_product": t_parts[2] * scale},
                   "seconds_per_unit": {"leaf_factor": t_fac * scale, "leaf_schur": t_schur * scale, "root_factor": t_root, "solve_compressed_x4": 4 * float(np.median(t_sc)) * scale,
                                        "total": unit}, "units_per_s": 1.0 / unit}))
