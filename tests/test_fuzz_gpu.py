@@ -1,6 +1,6 @@
 """Seeded sweep over shapes, sparsity patterns and analysis settings: Schur complement, solves and inertia of the batched
 leaf path against the oracle.  Every case is small enough for the CPU oracle; the settings cover the corners the fixed
-tests do not combine (forced cuts x Schur mode x amalgamation x dissection x spine x multi-RHS scheme)."""
+tests do not combine (forced cuts x Schur mode x amalgamation x dissection x spine x multi-RHS scheme x front rows)."""
 import os
 
 import numpy as np
@@ -41,6 +41,8 @@ def test_random_configuration(case, monkeypatch):
     monkeypatch.setenv("PIPS_HIP_RELAX_ZEROS", str(rng.choice([0.0, 0.4, 0.7])))
     monkeypatch.setenv("PIPS_HIP_SPINE", str(int(rng.integers(0, 2))))
     monkeypatch.setenv("PIPS_HIP_MULTI", str(int(rng.integers(0, 2))))
+    # (drawn from a generator of its own so that the cases above keep their shapes) fronts on the rows of K only where the border split applies
+    monkeypatch.setenv("PIPS_HIP_MF_KONLY", str(int(np.random.default_rng(7000 + case).integers(0, 2))))
     prob = Problem(500 + case, N, n_i, my_i, n0, myl, rho, diag_lo=float(rng.choice([-2, -4])), diag_hi=float(rng.choice([2, 4])))
     if structured:
         for blk in prob.blocks:
