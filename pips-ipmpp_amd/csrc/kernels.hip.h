@@ -3136,35 +3136,42 @@ __global__ void k_full_spmv_sub(const int* __restrict__ frowptr, const int* __re
 //    rhs_i = b_i - (Br x0)_i,   r_i = rhs_i - (K x)_i,   out[b] = max |r_i|,  out[nblk + b] = max |rhs_i|,  out[2 nblk + b] = max |x_i|
 // - what a copy of the right-hand side, the border product (k_border_mult_rows), k_full_spmv_sub and three k_vec_block_absmax passes
 // computed in six launches over the same vectors (1.2 ms per solve on the 256 x 50 000 time-coupled blocks, 0.3 of them those passes).
-// grid (chunks, block), eight lanes per row as in k_full_spmv_sub; every row must be short (the caller checks n_flong == 0); a NaN
-// counts as +Inf.  out[] zeroed by the caller.
+// grid (chunks, block), tiles of 256 rows; every row must be short (the caller checks n_flong == 0); a NaN counts as +Inf.  out[] zeroed
+// by the caller.
 __global__ __launch_bounds__(256) void k_measure_leaf_rows(const BlkDesc* __restrict__ blks, const int* __restrict__ frowptr, const int* __restrict__ fcol,
                                                            const int* __restrict__ fsrc, const double* __restrict__ val, const double* __restrict__ x,
                                                            const double* __restrict__ b, const int* __restrict__ br_rowptr, const int* __restrict__ br_sc,
                                                            const int* __restrict__ br_src, const double* __restrict__ bval, const double* __restrict__ x0,
                                                            double* __restrict__ out, int nblk) {
+   // Rows are short (6 entries on the time-coupled blocks): with a few lanes per row every round of 32 rows is a chain of four dependent loads
+   // (row pointers -> indices -> values and x -> the row's b and x) and the waves wait 91 % of their cycles (SQ_WAIT_ANY).  Here a tile of 256
+   // rows streams ALL its entries through LDS - the threads take the tile's entries side by side (coalesced index reads, one round of gathers
+   // for the whole tile) - and then every thread adds up the segment of its own row: one chain per 256 rows instead of one per 32.
+   constexpr int MCH = 2048;                       // entries of a tile handled at once
+   __shared__ double prod[MCH];
    const BlkDesc bd = blks[blockIdx.y];
-   const int l = threadIdx.x & 7;
+   const int tid = threadIdx.x;
    const double inf = __longlong_as_double(0x7ff0000000000000LL);
    double mr = 0.0, mb = 0.0, mx = 0.0;
-   const int n8 = (bd.n + 31) & ~31;   // (whole waves take part in the shuffles)
-   for (int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; k < n8; k += (gridDim.x * blockDim.x) >> 3) {
+   for (int k0 = blockIdx.x * 256; k0 < bd.n; k0 += gridDim.x * 256) {
+      const int k = k0 + tid;
       const bool row = k < bd.n;
-      const long long i = bd.x_off + (row ? k : 0);
-      double s = 0.0, t = 0.0;   // (K x)_i and (Br x0)_i, a share per lane
-      if (row) {
-         const int p1 = frowptr[i + 1];
-         for (int p = frowptr[i] + l; p < p1; p += 8) s += val[fsrc[p]] * x[bd.x_off + fcol[p]];
-         if (br_rowptr) {
-            const int q1 = br_rowptr[i + 1];
-            for (int q = br_rowptr[i] + l; q < q1; q += 8) t += bval[br_src[q]] * x0[br_sc[q]];
-         }
+      const long long i = bd.x_off + (row ? k : bd.n - 1);
+      const int p0 = frowptr[i], p1 = row ? frowptr[i + 1] : p0;
+      const int q0 = br_rowptr ? br_rowptr[i] : 0, q1 = (br_rowptr && row) ? br_rowptr[i + 1] : q0;
+      const double bi = b[i], xi0 = x[i];
+      const int p_lo = frowptr[bd.x_off + k0], p_hi = frowptr[bd.x_off + min(k0 + 256, bd.n)];
+      double s = 0.0, t = 0.0;   // (K x)_i and (Br x0)_i
+      for (int q = q0; q < q1; ++q) t += bval[br_src[q]] * x0[br_sc[q]];
+      for (int c0 = p_lo; c0 < p_hi; c0 += MCH) {
+         const int c1 = min(c0 + MCH, p_hi);
+         for (int q = c0 + tid; q < c1; q += 256) prod[q - c0] = val[fsrc[q]] * x[bd.x_off + fcol[q]];
+         __syncthreads();
+         for (int q = max(p0, c0); q < min(p1, c1); ++q) s += prod[q - c0];
+         __syncthreads();
       }
-      s += __shfl_xor(s, 1); t += __shfl_xor(t, 1);
-      s += __shfl_xor(s, 2); t += __shfl_xor(t, 2);
-      s += __shfl_xor(s, 4); t += __shfl_xor(t, 4);
-      if (row && l == 0) {
-         const double rhs = b[i] - t, r = fabs(rhs - s), ar = fabs(rhs), xi = fabs(x[i]);
+      if (row) {
+         const double rhs = bi - t, r = fabs(rhs - s), ar = fabs(rhs), xi = fabs(xi0);
          mr = fmax(mr, r <= 1.7976931348623157e308 ? r : inf);
          mb = fmax(mb, ar <= 1.7976931348623157e308 ? ar : inf);
          mx = fmax(mx, xi <= 1.7976931348623157e308 ? xi : inf);
