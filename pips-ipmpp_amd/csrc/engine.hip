@@ -2150,7 +2150,7 @@ struct Engine {
             const LevelRange& L = levels[li];
             gather(gv_levels[li], d_vslot_val, xw);
             if (L.simple_cnt > 0 && lf_rows > 0)
-               hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
+               hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 255) / 256), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
                                   d_lf_val, xw, 0LL, (int)lf_rows);
             else if (L.simple_cnt > 0)
                hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin,
@@ -2163,7 +2163,7 @@ struct Engine {
       } else
       for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0 && lf_rows > 0)   // the leaves' columns are final as they stand: every target row collects its sum
-            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), nrhs), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
+            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 255) / 256), nrhs), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src,
                                d_lf_val, xw, xws, (int)lf_rows);
          else if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, nrhs), dim3(256), 0, stream, d_sns, L.simple_begin,
@@ -2496,7 +2496,7 @@ struct Engine {
       timer.begin(stream, 8);
       for (const LevelRange& L : levels) {
          if (L.simple_cnt > 0 && lf_rows > 0)
-            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
+            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 255) / 256), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
                                0LL, (int)lf_rows);
          else if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt, d_blks,
@@ -2540,7 +2540,7 @@ struct Engine {
          const LevelRange& L = levels[li];
          gather(gv_levels[li], d_vslot_val, d_xw);
          if (L.simple_cnt > 0 && lf_rows > 0)
-            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 31) / 32), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
+            hipLaunchKernelGGL(k_leaf_fwd_gather, dim3((unsigned)((lf_rows + 255) / 256), 1), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, d_xw,
                                0LL, (int)lf_rows);
          else if (L.simple_cnt > 0)
             hipLaunchKernelGGL(k_head_solve_simple, dim3((L.simple_cnt + 255) / 256, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt, d_blks,
