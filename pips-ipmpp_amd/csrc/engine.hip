@@ -2024,8 +2024,8 @@ struct Engine {
       if (nnzB_total > 0 && schur_mode_eff == 1)
          hipLaunchKernelGGL(k_scatter, dim3(grid_for(nnzB_total, 256)), dim3(256), 0, stream, d_bdst, d_bval, d_arena, nnzB_total);
       hipLaunchKernelGGL(k_tail_pad_diag, dim3(nblk), dim3(128), 0, stream, d_blks, d_arena, nblk);
-      hipLaunchKernelGGL(k_pref_init, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, d_kval, d_kdiag, d_pref, d_nprimal,
-                         d_krowptr, d_kcolidx);
+      hipLaunchKernelGGL(k_pref_rows, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_kval, d_kdiag, d_res, d_nprimal, d_krowptr, d_kcolidx);   // (d_res: scratch of the solves)
+      hipLaunchKernelGGL(k_pref_init, dim3(32, nblk), dim3(256), 0, stream, d_blks, d_perm, d_perm_off, (const double*)d_res, d_pref);
       if (timer.on) timer.end(stream);
       // the whole-factor record (phase 6) was pushed first; close it at the end
       const size_t total_rec = 0;

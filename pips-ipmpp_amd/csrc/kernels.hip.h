@@ -173,35 +173,57 @@ __global__ void k_tail_pad_diag(const BlkDesc* __restrict__ blks, double* __rest
    for (int t = bd.m + threadIdx.x; t < bd.m_pad; t += blockDim.x) arena[bd.T + t + (long long)t * bd.ldT] = 1.0;
 }
 
-// pivot reference magnitudes, permuted order, same layout as the work vectors (xw_off, length n_head + m_pad)
-__global__ void k_pref_init(const BlkDesc* __restrict__ blks, const int* __restrict__ perm,
-                            const long long* __restrict__ perm_off, const double* __restrict__ kval,
-                            const long long* __restrict__ kdiag, double* __restrict__ pref, const int* __restrict__ n_primal,
-                            const int* __restrict__ krowptr, const int* __restrict__ kcolidx) {
-   // primal row: |a_kk|.  dual row: |a_kk| + sum_j K_kj^2 / |K_jj| over its primal neighbours j, i.e. the magnitude of the
-   // normal-equation diagonal (W D^-1 W^T)_kk the pivot is built from - so that a pivot which cancels to rounding noise
-   // (rank-deficient W) is recognised whatever sign the noise has, also when the dual diagonal itself is zero.
+// pivot reference magnitudes:
+//    primal row: |a_kk|.  dual row: |a_kk| + sum_j K_kj^2 / |K_jj| over its primal neighbours j, i.e. the magnitude of the
+//    normal-equation diagonal (W D^-1 W^T)_kk the pivot is built from - so that a pivot which cancels to rounding noise
+//    (rank-deficient W) is recognised whatever sign the noise has, also when the dual diagonal itself is zero.
+// k_pref_rows: per row in the caller's order, a tile of 256 rows per workgroup - the tile's entries of the lower CSR (consecutive) stream
+// through LDS, all threads side by side (K_kj^2 / |K_jj| does not depend on the row), then a thread per row adds its segment.  (A thread per
+// row of the permuted order walked its entries alone, two dependent gathers each: 1.07 ms per factorisation of the configs[3] share, the waves
+// waiting 95 % of their cycles; with the tiles 0.83 ms - a vector of |a_jj| beside it, one gather instead of two: no better.)  k_pref_init: into the permuted order, same layout as the work vectors (xw_off, length n_head + m_pad; the
+// tail's padding gets 1).
+__global__ __launch_bounds__(256) void k_pref_rows(const BlkDesc* __restrict__ blks, const double* __restrict__ kval, const long long* __restrict__ kdiag,
+                                                   double* __restrict__ rowref, const int* __restrict__ n_primal, const int* __restrict__ krowptr,
+                                                   const int* __restrict__ kcolidx) {
+   constexpr int PCH = 4096;
+   __shared__ double prod[PCH];
    const BlkDesc bd = blks[blockIdx.y];
-   const int* p = perm + perm_off[blockIdx.y];
-   const int np = n_primal[blockIdx.y];
-   const int len = bd.n_head + bd.m_pad;
-   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x) {
-      double v = 1.0;
-      if (k < bd.n) {
-         const int i = p[k];
-         v = fabs(kval[kdiag[bd.x_off + i]]);
-         if (np >= 0 && i >= np) {
-            for (int q = krowptr[bd.x_off + i]; q < krowptr[bd.x_off + i + 1]; ++q) {
+   const int np = n_primal[blockIdx.y], tid = threadIdx.x;
+   for (int k0 = blockIdx.x * 256; k0 < bd.n; k0 += gridDim.x * 256) {
+      const int i = k0 + tid;
+      const bool row = i < bd.n;
+      const long long gi = bd.x_off + (row ? i : bd.n - 1);
+      double v = fabs(kval[kdiag[gi]]);
+      if (np >= 0 && k0 + 256 > np) {    // (a tile of primal rows only: nothing to add)
+         const int p0 = krowptr[gi], p1 = row ? krowptr[gi + 1] : p0;
+         const int p_lo = krowptr[bd.x_off + k0], p_hi = krowptr[bd.x_off + min(k0 + 256, bd.n)];
+         for (int c0 = p_lo; c0 < p_hi; c0 += PCH) {
+            const int c1 = min(c0 + PCH, p_hi);
+            for (int q = c0 + tid; q < c1; q += 256) {
                const int j = kcolidx[q];
+               double pr = 0.0;
                if (j < np) {
-                  const double dj = fabs(kval[kdiag[bd.x_off + j]]);
-                  if (dj > 0.0) v += kval[q] * kval[q] / dj;
+                  const double dj = fabs(kval[kdiag[bd.x_off + j]]), a = kval[q];
+                  if (dj > 0.0) pr = a * a / dj;
                }
+               prod[q - c0] = pr;
             }
+            __syncthreads();
+            if (i >= np)
+               for (int q = max(p0, c0); q < min(p1, c1); ++q) v += prod[q - c0];
+            __syncthreads();
          }
       }
-      pref[bd.xw_off + k] = v;
+      if (row) rowref[gi] = v;
    }
+}
+__global__ void k_pref_init(const BlkDesc* __restrict__ blks, const int* __restrict__ perm, const long long* __restrict__ perm_off,
+                            const double* __restrict__ rowref, double* __restrict__ pref) {
+   const BlkDesc bd = blks[blockIdx.y];
+   const int* p = perm + perm_off[blockIdx.y];
+   const int len = bd.n_head + bd.m_pad;
+   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < len; k += gridDim.x * blockDim.x)
+      pref[bd.xw_off + k] = k < bd.n ? rowref[bd.x_off + p[k]] : 1.0;
 }
 
 // tail columns: reference := max(reference, |diagonal after the head has been eliminated|)
