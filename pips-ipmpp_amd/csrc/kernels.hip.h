@@ -2324,8 +2324,13 @@ __device__ __forceinline__ void head_fwd_body(const SnDesc& sn, const BlkDesc& b
       if (ra >= bd.n && !border) break;  // border rows do not take part in solves with K_i (border != 0: forward sweep of the augmented
                                          // factor - the border slots of the work vector collect -L_b y)
       const BelowRow br = below_row(arena, sn, a);
+      // the w factors of the row: unconditional loads (clamped index), all in flight at once - a loop of run-time length waits for every one
+      double pv[WB];
+#pragma unroll
+      for (int k = 0; k < WB; ++k) pv[k] = br.p[(k < w ? k : w - 1) * br.stride];
       double s = 0.0;
-      for (int k = 0; k < w; ++k) s += br.p[k * br.stride] * ys[k];
+#pragma unroll
+      for (int k = 0; k < WB; ++k) s += k < w ? pv[k] * ys[k] : 0.0;
       atomic_add_f64(xb + xw_row(bd, ra), -s);
    }
    wave_lds_sync();   // ys is reused by the caller's next supernode / right-hand side
@@ -2387,9 +2392,11 @@ __device__ __forceinline__ void head_bwd_body(const SnDesc& sn, const BlkDesc& b
       if (ra >= bd.n && !border) break;
       const double xa = xb[xw_row(bd, ra)];
       const BelowRow br = below_row(arena, sn, a);   // (border rows - border-backward sweep only - may live in the border-row arena)
+      double pv[WB];                                  // (clamped index: unconditional loads, all in flight at once)
 #pragma unroll
-      for (int k = 0; k < WB; ++k)
-         if (k < w) part[k] += br.p[k * br.stride] * xa;
+      for (int k = 0; k < WB; ++k) pv[k] = br.p[(k < w ? k : w - 1) * br.stride];
+#pragma unroll
+      for (int k = 0; k < WB; ++k) part[k] += k < w ? pv[k] * xa : 0.0;
    }
    if (WB == 1) {   // a single sum: plain wave reduction
       double s = part[0];
