@@ -2858,11 +2858,11 @@ struct DenseLdl {
    // of all of them on every rank (DistributedRootLinearSystem.C:1436-1464 has every rank call dsytrf on the same matrix).  At the
    // end every rank holds the complete factor, so the solves stay local and replicated.  The panel travels by pips_hip_broadcast
    // (ncclBroadcast / the host's broadcast callback; a host communicator without one: as an all-reduce in which the other ranks
-   // contribute zeros - exact, twice the bytes).  NOT TIMED: the GPU box has one device; correctness with 2 and 4 processes sharing it
-   // (tests/test_dist_root_gpu.py).
+   // contribute zeros - exact, twice the bytes).  One column of lookahead (round 5): see factor_distributed.  NOT TIMED: the GPU box has one
+   // device; correctness with 2 and 4 processes sharing it (tests/test_dist_root_gpu.py).
    void* dist_comm = nullptr;
    int dist_rank = 0, dist_P = 1;
-   std::vector<TaskList> dist_diag, dist_trsm, dist_upd;
+   std::vector<TaskList> dist_diag, dist_trsm, dist_next, dist_upd;   // dist_next[j]: this rank's tiles of column j + 1 under panel j; dist_upd[j]: of its columns >= j + 2
    TileTask* d_dist_tasks = nullptr;
    double* d_panel = nullptr;
    int set_distributed(void* comm, int rank, int P) {
@@ -2872,7 +2872,7 @@ struct DenseLdl {
       dist_comm = comm; dist_rank = rank; dist_P = P;
       const int ntc = npad / TILE;
       std::vector<TileTask> all;
-      dist_diag.assign(ntc, {}); dist_trsm.assign(ntc, {}); dist_upd.assign(ntc, {});
+      dist_diag.assign(ntc, {}); dist_trsm.assign(ntc, {}); dist_next.assign(ntc, {}); dist_upd.assign(ntc, {});
       for (int j = 0; j < ntc; ++j) {
          dist_diag[j].off = (long long)all.size();
          all.push_back({0, j, j, 0});
@@ -2880,22 +2880,32 @@ struct DenseLdl {
          dist_trsm[j].off = (long long)all.size();
          for (int ti = j + 1; ti < ntc; ++ti) all.push_back({0, ti, j, 0});
          dist_trsm[j].cnt = (int)((long long)all.size() - dist_trsm[j].off);
+         dist_next[j].off = (long long)all.size();
+         if (j + 1 < ntc && (j + 1) % P == rank)
+            for (int ti = j + 1; ti < ntc; ++ti) all.push_back({0, ti, j + 1, j | ((j + 1) << 16)});   // C(ti, tk) -= L(ti, j) U(tk, j)^T
+         dist_next[j].cnt = (int)((long long)all.size() - dist_next[j].off);
          dist_upd[j].off = (long long)all.size();
-         for (int tk = j + 1; tk < ntc; ++tk)
+         for (int tk = j + 2; tk < ntc; ++tk)
             if (tk % P == rank)
-               for (int ti = tk; ti < ntc; ++ti) all.push_back({0, ti, tk, j | ((j + 1) << 16)});   // C(ti, tk) -= L(ti, j) U(tk, j)^T
+               for (int ti = tk; ti < ntc; ++ti) all.push_back({0, ti, tk, j | ((j + 1) << 16)});
          dist_upd[j].cnt = (int)((long long)all.size() - dist_upd[j].off);
       }
       if (d_dist_tasks) { (void)hipFree(d_dist_tasks); d_dist_tasks = nullptr; }
       int rc = dev_upload(&d_dist_tasks, all, stream);
       if (rc) return rc;
       if (!d_panel) HIP_TRY(hipMalloc((void**)&d_panel, ((size_t)TILE * TILE + TILE + 8 + 2 * (size_t)npad * TILE) * sizeof(double)));
+      if (!side) {   // one column of lookahead: the bulk of a panel's update runs beside the factorisation and the broadcast of the next column
+         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+         HIP_TRY(hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&ev_rest, hipEventDisableTiming));
+      }
       return PIPS_OK;
    }
    int factor_distributed() {
       const TailCtx c = ctx();
       const int ntc = npad / TILE;
       const size_t ld_bytes = (size_t)npad * sizeof(double);
+      bool side_busy = false;
       for (int j = 0; j < ntc; ++j) {
          const int owner = j % dist_P;
          const size_t rows = (size_t)npad - (size_t)(j + 1) * TILE;
@@ -2935,10 +2945,25 @@ struct DenseLdl {
                HIP_TRY(hipMemcpy2DAsync(d_U + col0, ld_bytes, Up, rows * sizeof(double), rows * sizeof(double), TILE, hipMemcpyDeviceToDevice, stream));
             }
          }
+         // One column of lookahead.  Panel j is applied in two pieces: this rank's tiles of column j + 1 on the main stream - the owner of that
+         // column goes on to factorise and broadcast it - and its columns >= j + 2 (the bulk) on the side stream, beside that.  Column j + 1
+         // also takes the bulk of panel j - 1: the main stream joins it first (ev_rest as recorded before this iteration's bulk).
+         const bool ahead = side && !getenv("PIPS_HIP_DIST_NO_LOOKAHEAD");
+         hipStream_t bulk = ahead ? side : stream;
+         if (ahead) {
+            if (side_busy) HIP_TRY(hipStreamWaitEvent(stream, ev_rest, 0));
+            HIP_TRY(hipEventRecord(ev_panel, stream));          // panel j is in d_R / d_U on this rank
+            HIP_TRY(hipStreamWaitEvent(side, ev_panel, 0));
+         }
          if (dist_upd[j].cnt > 0)
-            hipLaunchKernelGGL(k_tile_gemm<3>, dim3((dist_upd[j].cnt + 7) / 8 * 8), dim3(512), 0, stream, d_dist_tasks + dist_upd[j].off, dist_upd[j].cnt, c.d_blks,
+            hipLaunchKernelGGL(k_tile_gemm<3>, dim3((dist_upd[j].cnt + 7) / 8 * 8), dim3(512), 0, bulk, d_dist_tasks + dist_upd[j].off, dist_upd[j].cnt, c.d_blks,
+                               c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
+         if (ahead) { HIP_TRY(hipEventRecord(ev_rest, side)); side_busy = true; }
+         if (dist_next[j].cnt > 0)
+            hipLaunchKernelGGL(k_tile_gemm<3>, dim3((dist_next[j].cnt + 7) / 8 * 8), dim3(512), 0, stream, d_dist_tasks + dist_next[j].off, dist_next[j].cnt, c.d_blks,
                                c.d_arena, c.d_dtail, c.d_winv, c.d_bmap, (double*)nullptr, 0, (const int*)nullptr, c.d_uarena);
       }
+      if (side_busy) HIP_TRY(hipStreamWaitEvent(stream, ev_rest, 0));
       // every rank counted the pivots of its own diagonal tiles: the sum is the inertia
       hipLaunchKernelGGL(k_inertia_to_double, dim3(1), dim3(64), 0, stream, d_inertia, d_panel, 0, d_inertia);
       HIP_TRY(hipMemsetAsync(d_panel + 3, 0, 5 * sizeof(double), stream));

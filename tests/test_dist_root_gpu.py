@@ -97,6 +97,23 @@ def test_column_cyclic_root_matches_lapack_on_every_rank(tmp_path, world, n0, m,
             assert np.array_equal(first, g["X"])           # the same factor on every rank
 
 
+def test_lookahead_of_the_distributed_root_changes_no_bit(tmp_path, monkeypatch):
+    """Round 5: panel j is applied in two pieces - this rank's tiles of column j + 1 on the main stream (its owner then factorises and
+    broadcasts that column), the bulk on a second stream beside it.  Every tile still takes the panels in ascending order: the solution has
+    the bits of the factorisation without the second stream (PIPS_HIP_DIST_NO_LOOKAHEAD=1), on 4 processes sharing the GPU."""
+    world, n0, m = 4, 700, 330
+    outs = []
+    for k, env in enumerate((None, "1")):
+        if env:
+            monkeypatch.setenv("PIPS_HIP_DIST_NO_LOOKAHEAD", env)      # (inherited by the spawned ranks)
+        d = tmp_path / f"run{k}"
+        d.mkdir()
+        mp.start_processes(_worker, args=(world, 29500 + (os.getpid() % 2000) + 91 + k, str(d), n0, m, 0, False), nprocs=world, join=True, start_method="spawn")
+        outs.append([np.load(os.path.join(str(d), f"rank{r}.npz"))["X"] for r in range(world)])
+    for r in range(world):
+        assert np.array_equal(outs[0][r], outs[1][r]) and np.array_equal(outs[0][r], outs[0][0])
+
+
 @pytest.mark.parametrize("world,n0,m", [(4, 128, 160), (2, 256, 300)])
 def test_distributed_root_pairs_pivots_beyond_the_tile_on_every_rank(tmp_path, world, n0, m):
     """A leading block that is singular inside its own tiles ([[0 A^T]; [A -C C^T]]) on a root distributed over 4 / 2 ranks: the owners of the
