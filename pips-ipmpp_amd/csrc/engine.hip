@@ -70,7 +70,7 @@ struct TailPlan {
    // first: per block the tile-row envelope of its tail (BlockSym::tile_first); tiles left of it hold structural zeros and
    // get no task, update depths start at the envelope (a banded tail costs band^2 per column instead of column^2)
    int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false, bool split_diag = false,
-             const std::vector<const std::vector<int>*>* first = nullptr, bool diag_ahead = false) {
+             const std::vector<const std::vector<int>*>* first = nullptr, bool diag_ahead = false, bool pair2 = false) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -101,19 +101,36 @@ struct TailPlan {
                }
          end(upd_diag[j]);
          begin(upd[j]);
+         // pair2 (left-looking batches with the diagonal tiles ahead): tile columns j (even) and j + 1 share a launch for everything left of
+         // column j - the two tiles of a tile row read the same rows of L, side by side in the task list (one XCD, one after the other) -
+         // and column j + 1 takes its last step, with column j, in the launch of its own (one tile deep).  The diagonal tile two columns
+         // ahead rides along the same way, so that the short launch holds no deep task.
+         const bool two = pair2 && panel == 0 && split_diag && diag_ahead;
+         const bool odd = two && (j & 1);
          if (j > p0 && split_diag && diag_ahead)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j + 1) {
-                  const int k0 = std::max(p0, fst(b, j + 1));
-                  if (k0 < j) all.push_back({b, j + 1, j + 1, k0 | (j << 16)});
+                  const int k0 = std::max(p0, fst(b, j + 1)), lo = odd ? std::max(k0, j - 1) : k0;
+                  if (lo < j) all.push_back({b, j + 1, j + 1, lo | (j << 16)});
+               }
+         if (two && !odd && j > p0)
+            for (int b = 0; b < nblk; ++b)
+               if (blks[b].ntc > j + 2) {
+                  const int k0 = std::max(p0, fst(b, j + 2));
+                  if (k0 < j) all.push_back({b, j + 2, j + 2, k0 | (j << 16)});
                }
          if (j > p0)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j)
                   for (int ti = split_diag ? j + 1 : j; ti < blks[b].ntr; ++ti) {
-                     if (j < fst(b, ti)) continue;                                  // outside the envelope: stays zero
-                     const int k0 = std::max({p0, fst(b, ti), fst(b, j)});
-                     if (k0 < j) all.push_back({b, ti, j, k0 | (j << 16)});
+                     if (j >= fst(b, ti)) {                                         // (else outside the envelope: stays zero)
+                        const int k0 = std::max({p0, fst(b, ti), fst(b, j)}), lo = odd ? std::max(k0, j - 1) : k0;
+                        if (lo < j) all.push_back({b, ti, j, lo | (j << 16)});
+                     }
+                     if (two && !odd && ti > j + 1 && blks[b].ntc > j + 1 && j + 1 >= fst(b, ti)) {
+                        const int k0 = std::max({p0, fst(b, ti), fst(b, j + 1)});
+                        if (k0 < j) all.push_back({b, ti, j + 1, k0 | (j << 16)});
+                     }
                   }
          end(upd[j]);
          begin(diag[j]);
@@ -1652,7 +1669,9 @@ struct Engine {
       // tail factorisation without either: docs/HISTORY_r1_r2.md)
       std::vector<const std::vector<int>*> firsts(nblk);
       for (int b = 0; b < nblk; ++b) firsts[b] = &sym[b].tile_first;
-      if ((rc = plan.build(h_blks, 0, false, true, &firsts, true))) return rc;
+      // two tile columns per launch of the left-looking tail update (TailPlan::build, pair2): 73.2 -> 71.8 ms of update per configs[1] unit
+      const bool pair2 = !(getenv("PIPS_HIP_TWO_COLUMNS") && atoi(getenv("PIPS_HIP_TWO_COLUMNS")) == 0);
+      if ((rc = plan.build(h_blks, 0, false, true, &firsts, true, pair2))) return rc;
       if ((rc = sweep.build(h_blks, &firsts))) return rc;
       {
          // border-backward sweep: worth it where the border rows of the factor (what it reads on top of a backward sweep) are no
