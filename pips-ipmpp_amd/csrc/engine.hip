@@ -70,7 +70,7 @@ struct TailPlan {
    // first: per block the tile-row envelope of its tail (BlockSym::tile_first); tiles left of it hold structural zeros and
    // get no task, update depths start at the envelope (a banded tail costs band^2 per column instead of column^2)
    int build(const std::vector<BlkDesc>& blks, int panel = 0, bool lookahead = false, bool split_diag = false,
-             const std::vector<const std::vector<int>*>* first = nullptr, bool diag_ahead = false, bool pair2 = false) {
+             const std::vector<const std::vector<int>*>* first = nullptr, bool diag_ahead = false, int pair2 = 1) {
       std::vector<TileTask> all;
       ntc_max = 0;
       for (auto& b : blks) ntc_max = std::max(ntc_max, b.ntc);
@@ -101,36 +101,38 @@ struct TailPlan {
                }
          end(upd_diag[j]);
          begin(upd[j]);
-         // pair2 (left-looking batches with the diagonal tiles ahead): tile columns j (even) and j + 1 share a launch for everything left of
-         // column j - the two tiles of a tile row read the same rows of L, side by side in the task list (one XCD, one after the other) -
-         // and column j + 1 takes its last step, with column j, in the launch of its own (one tile deep).  The diagonal tile two columns
-         // ahead rides along the same way, so that the short launch holds no deep task.
-         const bool two = pair2 && panel == 0 && split_diag && diag_ahead;
-         const bool odd = two && (j & 1);
+         // pair2 = P (left-looking batches with the diagonal tiles ahead): the tile columns of a group g .. g + P - 1 share the launch of column
+         // g for everything left of the group - the tiles of a tile row read the same rows of L, side by side in the task list (one XCD, one
+         // after the other) - and column g + q takes the rest, the q columns of its own group, in the launch of its own (q tiles deep).  The
+         // diagonal tiles up to the next group's first ride along the same way, so that the short launches hold no deep task.
+         const int P = (pair2 > 1 && panel == 0 && split_diag && diag_ahead) ? pair2 : 1;
+         const int g = j / P * P, q = j - g;
          if (j > p0 && split_diag && diag_ahead)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j + 1) {
-                  const int k0 = std::max(p0, fst(b, j + 1)), lo = odd ? std::max(k0, j - 1) : k0;
+                  const int k0 = std::max(p0, fst(b, j + 1)), lo = q > 0 ? std::max(k0, g) : k0;
                   if (lo < j) all.push_back({b, j + 1, j + 1, lo | (j << 16)});
                }
-         if (two && !odd && j > p0)
+         if (P > 1 && q == 0 && j > p0)
             for (int b = 0; b < nblk; ++b)
-               if (blks[b].ntc > j + 2) {
-                  const int k0 = std::max(p0, fst(b, j + 2));
-                  if (k0 < j) all.push_back({b, j + 2, j + 2, k0 | (j << 16)});
+               for (int d = j + 2; d <= j + P && d < blks[b].ntc; ++d) {
+                  const int k0 = std::max(p0, fst(b, d));
+                  if (k0 < j) all.push_back({b, d, d, k0 | (j << 16)});
                }
          if (j > p0)
             for (int b = 0; b < nblk; ++b)
                if (blks[b].ntc > j)
                   for (int ti = split_diag ? j + 1 : j; ti < blks[b].ntr; ++ti) {
                      if (j >= fst(b, ti)) {                                         // (else outside the envelope: stays zero)
-                        const int k0 = std::max({p0, fst(b, ti), fst(b, j)}), lo = odd ? std::max(k0, j - 1) : k0;
+                        const int k0 = std::max({p0, fst(b, ti), fst(b, j)}), lo = q > 0 ? std::max(k0, g) : k0;
                         if (lo < j) all.push_back({b, ti, j, lo | (j << 16)});
                      }
-                     if (two && !odd && ti > j + 1 && blks[b].ntc > j + 1 && j + 1 >= fst(b, ti)) {
-                        const int k0 = std::max({p0, fst(b, ti), fst(b, j + 1)});
-                        if (k0 < j) all.push_back({b, ti, j + 1, k0 | (j << 16)});
-                     }
+                     if (P > 1 && q == 0)
+                        for (int c = j + 1; c < j + P && c < blks[b].ntc && c < ti; ++c)
+                           if (c >= fst(b, ti)) {
+                              const int k0 = std::max({p0, fst(b, ti), fst(b, c)});
+                              if (k0 < j) all.push_back({b, ti, c, k0 | (j << 16)});
+                           }
                   }
          end(upd[j]);
          begin(diag[j]);
@@ -1669,8 +1671,9 @@ struct Engine {
       // tail factorisation without either: docs/HISTORY_r1_r2.md)
       std::vector<const std::vector<int>*> firsts(nblk);
       for (int b = 0; b < nblk; ++b) firsts[b] = &sym[b].tile_first;
-      // two tile columns per launch of the left-looking tail update (TailPlan::build, pair2): 73.2 -> 71.8 ms of update per configs[1] unit
-      const bool pair2 = !(getenv("PIPS_HIP_TWO_COLUMNS") && atoi(getenv("PIPS_HIP_TWO_COLUMNS")) == 0);
+      // tile columns per launch of the left-looking tail update (TailPlan::build, pair2).  configs[1], ms per unit / ms of update, two boxes:
+      // 1 column 125.0 - 126.8 / 73.8 - 74.7; 2: 123.6 - 124.0 / 72.4; 3: 122.0 / 70.8; 4: 120.0 - 121.7 / 70.3 - 71.0; 6: 120.5 / 70.3; 8: 120.8 / 70.9
+      const int pair2 = getenv("PIPS_HIP_TWO_COLUMNS") ? std::max(1, std::min(8, atoi(getenv("PIPS_HIP_TWO_COLUMNS")))) : 4;   // (1: a column per launch)
       if ((rc = plan.build(h_blks, 0, false, true, &firsts, true, pair2))) return rc;
       if ((rc = sweep.build(h_blks, &firsts))) return rc;
       {
