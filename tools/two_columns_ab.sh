@@ -1,4 +1,4 @@
-# GPU box: the left-looking tail update with P tile columns per launch (PIPS_HIP_TWO_COLUMNS=P; default 2, 1 = one column per launch) - tests at P, then configs[1] A/B
+# GPU box: the left-looking tail update with P tile columns per launch (PIPS_HIP_TWO_COLUMNS=P; default 4, 1 = one column per launch) - tests at P, then configs[1] A/B
 R=${GRAFT_REPO_ROOT:-/root/repo}
 P=${1:-4}
 cd $R; PIPS_HIP_TWO_COLUMNS=$P timeout 900 python3 -m pytest tests/test_leaf_gpu.py tests/test_golden.py tests/test_kkt_gpu.py tests/test_fuzz_gpu.py -q -m gpu -x 2>&1 | tail -3
