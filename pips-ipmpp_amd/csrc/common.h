@@ -185,4 +185,19 @@ struct AnalyzeOptions {
 int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, const AnalyzeOptions& opt,
                   BlockSym& out);
 
+// ---- task list of the single-launch dense root (rootplan.cpp; kernel: rootkernel.hip.h) -------------------------------
+// Cost model of the list schedule in microseconds (measured on MI355X): a K = 128 step of the update kernel with two
+// workgroups per compute unit / with the unit to itself, the fixed cost of an update task (operand latency + C tile round trip), trsm
+// and diagonal tile.
+struct RootPlanParams {
+   int workers = 510;       // workgroup slots for the bulk: 256 compute units x 2, less the chain's unit
+   int chain_slots = 2;     // > 0: the chain of the diagonal tiles has a compute unit of its own (a task list of its own); 0: one list
+   int chain_width = 2;     // tiles this close to the diagonal have their trsm and completing update on the chain's list
+   int qmin = 4;            // an update that does not finish its tile waits until it is this many tile columns deep
+   int urgent = 1;          // tiles within this distance of the chain's diagonal tile are updated whatever the depth
+   double t_step = 31.0, t_step_alone = 22.0, t0 = 8.0, t_trsm = 40.0, t_trsm_alone = 26.0, t_diag = 85.0;
+};
+// tasks / chain_tasks: (kind 0 UPD / 1 TRSM / 2 DIAG, i, j, k0 | k1 << 16) quadruples in ticket order
+int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& chain_tasks, double* makespan_us);
+
 }  // namespace pips

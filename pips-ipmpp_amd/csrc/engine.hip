@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "kernels.hip.h"
+#include "rootkernel.hip.h"
 #include "pips_hip.h"
 
 namespace pips {
@@ -2690,13 +2691,101 @@ struct DenseLdl {
       if (side) (void)hipStreamDestroy(side);
       if (ev_panel) (void)hipEventDestroy(ev_panel);
       if (ev_rest) (void)hipEventDestroy(ev_rest);
-      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list, d_flagvec};
+      void* ptrs[] = {d_blks, d_R, d_U, d_winv, d_dtail, d_xw, d_in, d_pref, d_psign, d_psign_off, d_kptr, d_inertia, d_dist_tasks, d_panel, d_perm, d_pert_cnt, d_pert_list, d_flagvec,
+                      d_C, d_rtasks, d_rflags};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
       plan.release();
       sweep.release();
    }
    SweepRt sweep;
+   // ---- the factorisation as ONE dependency-driven launch (rootkernel.hip.h, rootplan.cpp): static pivot order on one rank.  Bunch-Kaufman
+   // (a 454-register diagonal kernel) and the root distributed over ranks keep the launch-per-step driver (tail_factor / factor_distributed);
+   // PIPS_HIP_ROOT_LAUNCHES=1 keeps it everywhere (the tests run both).
+   bool single_launch = !getenv("PIPS_HIP_ROOT_LAUNCHES");
+   double* d_C = nullptr;          // the accumulating tiles (scratch): L goes to d_R, U to d_U, each written once per launch
+   TileTask* d_rtasks = nullptr;
+   int n_rtasks = 0, n_rbulk = 0;
+   int* d_rflags = nullptr;        // ctl[4] | prog[ntc * ntc] | rowdone[ntc] | dready[ntc]
+   double plan_makespan_us = 0.0;
+   long long root_poll_limit = 400000;   // polls before a wait inside the launch gives up (some 0.1 s: a factorisation takes 2 - 40 ms)
+   bool root_error_pending = false;
+   int ensure_single_launch() {
+      if (d_rtasks) return PIPS_OK;
+      const int ntc = npad / TILE;
+      RootPlanParams pp;
+      if (const char* q = getenv("PIPS_HIP_ROOT_QMIN")) pp.qmin = std::max(1, atoi(q));
+      if (const char* q = getenv("PIPS_HIP_ROOT_CHAIN_CU")) pp.chain_slots = atoi(q) != 0 ? 2 : 0;   // 0: one list, the chain wherever its workgroups land (A/B)
+      if (pp.chain_slots == 0) pp.workers = 512;
+      if (const char* q = getenv("PIPS_HIP_ROOT_CHAIN_WIDTH")) pp.chain_width = atoi(q);
+      if (const char* q = getenv("PIPS_HIP_ROOT_URGENT")) pp.urgent = atoi(q);
+      if (const char* q = getenv("PIPS_HIP_ROOT_TDIAG")) pp.t_diag = atof(q);
+      if (const char* q = getenv("PIPS_HIP_ROOT_TSTEP")) pp.t_step = atof(q);
+      std::vector<int> t, tc;
+      int rc = build_root_plan(ntc, pp, t, tc, &plan_makespan_us);
+      if (rc) return rc;
+      n_rbulk = (int)(t.size() / 4);
+      t.insert(t.end(), tc.begin(), tc.end());
+      n_rtasks = (int)(t.size() / 4);
+      HIP_TRY(hipMalloc((void**)&d_rtasks, std::max<size_t>(t.size(), 4) * sizeof(int)));
+      HIP_TRY(hipMemcpy(d_rtasks, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc((void**)&d_rflags, ((size_t)4 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int)));
+      HIP_TRY(hipMalloc((void**)&d_C, (size_t)npad * npad * sizeof(double)));
+      if (const char* pl = getenv("PIPS_HIP_SWEEP_POLL_LIMIT")) root_poll_limit = atoll(pl);
+      return PIPS_OK;
+   }
+   int factor_single_launch() {
+      const int ntc = npad / TILE;
+      HIP_TRY(hipMemsetAsync(d_rflags, 0, ((size_t)4 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int), stream));
+      RootArgs a{};
+      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad;
+      a.C = d_C; a.R = d_R; a.U = d_U; a.winv = d_winv; a.dtail = d_dtail; a.pref = d_pref; a.psign = d_psign; a.inertia = d_inertia;
+      a.ctl = d_rflags; a.prog = d_rflags + 4; a.rowdone = a.prog + (size_t)ntc * ntc; a.dready = a.rowdone + ntc;
+      a.blk = d_blks; a.poll_limit = root_poll_limit;
+      a.diag_blocked = getenv("PIPS_HIP_ROOT_DIAG_BARRIERS") ? 0 : 1;
+      const char* trace_file = getenv("PIPS_HIP_ROOT_TRACE");   // diagnostics: per-task clocks of this launch into a file (tools/root_trace.py)
+      long long* d_trace = nullptr;
+      if (trace_file) {
+         HIP_TRY(hipMalloc((void**)&d_trace, ((size_t)3 * n_rtasks + 32 * (size_t)ntc) * sizeof(long long)));
+         HIP_TRY(hipMemsetAsync(d_trace, 0, ((size_t)3 * n_rtasks + 32 * (size_t)ntc) * sizeof(long long), stream));
+         a.trace = d_trace;
+      }
+      hipLaunchKernelGGL(k_root_ldl, dim3(n_rtasks), dim3(512), 0, stream, a);
+      HIP_TRY(hipGetLastError());
+      root_error_pending = true;
+      if (trace_file) {
+         std::vector<long long> h((size_t)3 * n_rtasks + 32 * (size_t)ntc);
+         std::vector<int> ht((size_t)4 * n_rtasks);
+         HIP_TRY(hipStreamSynchronize(stream));
+         HIP_TRY(hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+         HIP_TRY(hipMemcpy(ht.data(), d_rtasks, ht.size() * sizeof(int), hipMemcpyDeviceToHost));
+         (void)hipFree(d_trace);
+         if (FILE* f = fopen(trace_file, "w")) {
+            for (int t = 0; t < n_rtasks; ++t)
+               fprintf(f, "%d %d %d %d %d %lld %lld %lld\n", t, ht[4 * t], ht[4 * t + 1], ht[4 * t + 2], ht[4 * t + 3], h[3 * (size_t)t], h[3 * (size_t)t + 1], h[3 * (size_t)t + 2]);
+            fclose(f);
+         }
+         if (FILE* f = fopen((std::string(trace_file) + ".diag").c_str(), "w")) {   // phase clocks of the diagonal tiles (blocked variant)
+            for (int jj = 0; jj < ntc; ++jj) {
+               for (int q = 0; q < 26; ++q) fprintf(f, "%lld ", h[(size_t)3 * n_rtasks + 32 * (size_t)jj + q]);
+               fprintf(f, "\n");
+            }
+            fclose(f);
+         }
+      }
+      return PIPS_OK;
+   }
+   // a wait inside the launch that gave up raised the error word; read at the host's next synchronisation point with this handle
+   int take_root_error(const char* who) {
+      if (!root_error_pending || !d_rflags) return PIPS_OK;
+      root_error_pending = false;
+      int w = 0;
+      HIP_TRY(hipMemcpyAsync(&w, d_rflags + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (w) PIPS_FAIL(PIPS_ERR_HIP, "%s: the single-launch root factorisation gave up waiting for a tile after %lld polls (its factors are invalid); "
+                                     "PIPS_HIP_ROOT_LAUNCHES=1 selects the launch-per-step factorisation", who, root_poll_limit);
+      return PIPS_OK;
+   }
    int init() {
       HIP_TRY(hipSetDevice(device));
       int rc = PIPS_OK;
@@ -3015,14 +3104,17 @@ struct DenseLdl {
          }
          HIP_TRY(hipMemsetAsync(d_pert_cnt, 0, sizeof(int), stream));
       }
+      const bool single = single_launch && pivoting == 0 && dist_P <= 1;
+      if (single) { const int rcs = ensure_single_launch(); if (rcs) return rcs; }
+      double* d_work = single ? d_C : d_R;   // where the matrix is accumulated: a scratch copy (single launch) or in place
       hipLaunchKernelGGL(k_copy_lower_to_padded, dim3(grid_for((long long)npad * npad, 256)), dim3(256), 0, stream, A_dev,
-                         lda, n, d_R, npad, npad, rowmajor, perm.empty() ? (const int*)nullptr : (const int*)d_perm);
-      hipLaunchKernelGGL(k_pref_tail, dim3(8, 1), dim3(256), 0, stream, d_blks, d_R, d_pref, 1);
+                         lda, n, d_work, npad, npad, rowmajor, perm.empty() ? (const int*)nullptr : (const int*)d_perm);
+      hipLaunchKernelGGL(k_pref_tail, dim3(8, 1), dim3(256), 0, stream, d_blks, d_work, d_pref, 1);
       hipLaunchKernelGGL(k_block_absmax_init, dim3(1), dim3(256), 0, stream, d_blks, 1);
       hipLaunchKernelGGL(k_block_absmax, dim3(8, 1), dim3(256), 0, stream, d_pref, d_kptr, d_blks);
       hipLaunchKernelGGL(k_block_absmax_finish, dim3(1), dim3(256), 0, stream, d_blks, 1, thr_rel, repl_rel);
       HIP_TRY(hipMemsetAsync(d_inertia, 0, 3 * sizeof(int), stream));
-      int rc = dist_P > 1 ? factor_distributed() : tail_factor(ctx(), nullptr, 0);
+      int rc = single ? factor_single_launch() : (dist_P > 1 ? factor_distributed() : tail_factor(ctx(), nullptr, 0));
       if (rc) return rc;
       factored = true;
       return PIPS_OK;
@@ -4112,7 +4204,7 @@ int pips_hip_dense_ldl_factor(void* handle, const double* A_host, int lda) {
    if (rc) return rc;
    if ((rc = d->check_pivots())) return rc;     // (the staged copy d_in stays valid: a new pivot order factorises from it again)
    HIP_TRY(hipStreamSynchronize(d->stream));
-   return PIPS_OK;
+   return d->take_root_error("pips_hip_dense_ldl_factor");
 }
 
 int pips_hip_dense_ldl_factor_dev(void* handle, const double* A_dev, int lda) {
@@ -4151,6 +4243,7 @@ int pips_hip_dense_ldl_inertia(void* handle, int* pos, int* neg, int* zero) {
    HIP_TRY(hipMemcpyAsync(d->h_inertia, d->d_inertia, 3 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
    HIP_TRY(hipStreamSynchronize(d->stream));
    { const int rce = d->sweep.take_error("pips_hip_dense_ldl_inertia"); if (rce) return rce; }
+   { const int rce = d->take_root_error("pips_hip_dense_ldl_inertia"); if (rce) return rce; }
    if (pos) *pos = d->h_inertia[0];
    if (neg) *neg = d->h_inertia[1];
    if (zero) *zero = d->h_inertia[2];

@@ -1,0 +1,157 @@
+// Task list of the single-launch dense root (rootkernel.hip.h: k_root_ldl): a list schedule of the tile DAG of a left-looking tiled
+// LDL^T, built once per Schur dimension on the host.  The reference hands the whole matrix to dsytrf (DeSymIndefSolver.C:56-118);
+// here the factorisation is ntc (ntc + 1) / 2 tiles whose updates are cut into K ranges by THIS schedule: a discrete-event simulation
+// of `workers` workgroup slots with a cost model picks, whenever a slot is free, the most urgent task that is ready
+//   1. the diagonal tile of the chain column           (DIAG j: everything waits for it)
+//   2. the triangular solves of finished columns       (TRSM (i, j), columns left to right, rows top down)
+//   3. updates, nearest column first                   (UPD (i, j, k0, k1): with every column that is final by now - as deep as it gets -
+//                                                       provided that finishes the tile, is at least qmin tile columns deep, or the tile
+//                                                       is one the chain needs next)
+// and the order in which tasks START is the ticket order of the launch.  Tiles far right of the chain are therefore touched rarely and
+// deeply (K of a thousand and more: the update kernel's efficient regime), tiles next to it promptly; the chain of diagonal tiles gets
+// a slot the moment it is ready because every task of the launch has the same footprint.  A task's dependencies have all FINISHED in
+// the simulation before it starts, so they precede it in the list: the launch cannot deadlock, and where the model is off a workgroup
+// polls a little.  tools/root_schedule_sim.py is the prototype this restates.
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "common.h"
+
+namespace pips {
+
+int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& chain_tasks, double* makespan_us) {
+   tasks.clear();
+   chain_tasks.clear();
+   if (ntc <= 0) return PIPS_OK;
+   const int W = std::max(p.workers, 1);
+   auto at = [ntc](int i, int j) { return (size_t)i * ntc + j; };
+   std::vector<int> prog((size_t)ntc * ntc, 0), rowdone(ntc, 0);
+   std::vector<char> busy((size_t)ntc * ntc, 0), queued((size_t)ntc * ntc, 0), trsm_done((size_t)ntc * ntc, 0), dready(ntc, 0);
+   int chain = 0;
+   struct Cand { int prio, j, i; };
+   auto worse = [](const Cand& a, const Cand& b) { return a.prio != b.prio ? a.prio > b.prio : (a.j != b.j ? a.j > b.j : a.i > b.i); };
+   std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> ready(worse), ready_chain(worse);
+   struct Event { double t; long long seq; int kind, i, j, k1, on_chain; };
+   auto later = [](const Event& a, const Event& b) { return a.t != b.t ? a.t > b.t : a.seq > b.seq; };
+   std::priority_queue<Event, std::vector<Event>, decltype(later)> events(later);
+
+   // what tile (i, j) could start now: -1 nothing, else the kind; k1 of an update
+   auto startable = [&](int i, int j, int& k1) -> int {
+      if (busy[at(i, j)]) return -1;
+      if (prog[at(i, j)] == j) {
+         if (i == j) return dready[j] ? -1 : (j == chain ? 2 : -1);
+         return (dready[j] && !trsm_done[at(i, j)]) ? 1 : -1;
+      }
+      const int a = std::min({rowdone[i], rowdone[j], j}), q = a - prog[at(i, j)];
+      if (q <= 0) return -1;
+      const bool urgent = j <= chain + p.urgent && i <= j + p.urgent;
+      if (a == j || q >= p.qmin || urgent) { k1 = a; return 0; }
+      return -1;
+   };
+   // The chain's own list: DIAG (j), and for the tiles within chain_width of the diagonal the triangular solves and the updates that
+   // COMPLETE a tile.  The critical path DIAG j -> TRSM (j + 1, j) -> last update of C(j + 1, j + 1) -> DIAG j + 1 needs tile (j + 1, j)
+   // complete when DIAG j ends, which needs TRSM (j + 1, j - 1) one step earlier, and so on: a tile d below the diagonal has d - 1 chain
+   // steps of slack.  On the bulk list such a task waits for its turn behind a few hundred deep updates (traced: the completing update
+   // of (60, 59) was drawn 270 us after it could have run); the chain's two workgroups are idle most of a step and take them at once.
+   auto on_chain = [&](int kind, int i, int j, int k1) {
+      return p.chain_slots > 0 && (kind == 2 || (kind == 1 && i - j <= p.chain_width) || (kind == 0 && k1 == j && i - j < p.chain_width));
+   };
+   auto consider = [&](int i, int j) {
+      if (queued[at(i, j)]) return;
+      int k1 = 0;
+      const int kind = startable(i, j, k1);
+      if (kind < 0) return;
+      queued[at(i, j)] = 1;
+      const Cand c{kind == 2 ? 0 : (kind == 1 ? 1 : 2), j, i};
+      if (on_chain(kind, i, j, k1)) ready_chain.push(c); else ready.push(c);
+   };
+
+   double t = 0.0;
+   long long seq = 0;
+   int free_slots = W, free_chain = std::max(p.chain_slots, 0), diag_done = 0;
+   consider(0, 0);
+   while (diag_done < ntc) {
+      for (int pass = 0; pass < 2; ++pass) {
+         auto& heap = pass == 0 ? ready_chain : ready;
+         while (!heap.empty() && (pass == 0 ? free_chain > 0 : free_slots > 0)) {
+            const Cand c = heap.top();
+            heap.pop();
+            queued[at(c.i, c.j)] = 0;
+            int k1 = 0;
+            const int kind = startable(c.i, c.j, k1);
+            if (kind < 0) continue;
+            if (kind != 0) k1 = c.j;
+            const int k0 = prog[at(c.i, c.j)];
+            const bool ch = on_chain(kind, c.i, c.j, k1);
+            if (ch != (pass == 0)) {   // an update that has become a completing one (or the other way round) since it was queued: the other heap's
+               queued[at(c.i, c.j)] = 1;
+               (ch ? ready_chain : ready).push(c);
+               if (pass == 1) continue;
+               break;   // (pass 0 found a bulk task: the bulk pass takes it)
+            }
+            const bool alone = ch || W - free_slots < W / 2;   // fewer workgroups than compute units: a tile has its matrix pipe to itself
+            const double dur = kind == 2 ? p.t_diag : (kind == 1 ? (alone ? p.t_trsm_alone : p.t_trsm) : p.t0 + (k1 - k0) * (alone ? p.t_step_alone : p.t_step));
+            busy[at(c.i, c.j)] = 1;
+            std::vector<int>& out = ch ? chain_tasks : tasks;
+            out.push_back(kind);
+            out.push_back(c.i);
+            out.push_back(c.j);
+            out.push_back(k0 | (k1 << 16));
+            events.push(Event{t + dur, seq++, kind, c.i, c.j, k1, ch ? 1 : 0});
+            if (ch) --free_chain; else --free_slots;
+         }
+      }
+      if (events.empty()) PIPS_FAIL(PIPS_ERR_STATE, "root plan: the schedule stalled at column %d of %d", chain, ntc);
+      const Event e = events.top();
+      events.pop();
+      t = e.t;
+      if (e.on_chain) ++free_chain; else ++free_slots;
+      busy[at(e.i, e.j)] = 0;
+      if (e.kind == 2) {
+         dready[e.j] = 1;
+         ++diag_done;
+         chain = e.j + 1;
+         for (int i = e.j + 1; i < ntc; ++i) consider(i, e.j);
+         for (int j = chain; j <= std::min(chain + p.urgent, ntc - 1); ++j)
+            for (int i = j; i <= std::min(j + p.urgent, ntc - 1); ++i) consider(i, j);
+      } else if (e.kind == 1) {
+         trsm_done[at(e.i, e.j)] = 1;
+         rowdone[e.i] = e.j + 1;
+         for (int j = e.j + 1; j <= e.i; ++j) consider(e.i, j);       // tiles of row i
+         for (int i = e.i; i < ntc; ++i) consider(i, e.i);            // tiles of column i (U(i, .) is their B operand)
+      } else {
+         prog[at(e.i, e.j)] = e.k1;
+         consider(e.i, e.j);
+      }
+   }
+   // (every trsm has been started: a diagonal tile needs its row complete; the last events only retire)
+   if (makespan_us) {
+      while (!events.empty()) { t = std::max(t, events.top().t); events.pop(); }
+      *makespan_us = t;
+   }
+   return PIPS_OK;
+}
+
+}  // namespace pips
+
+// C entry for the tests (no device involved): tasks as (kind, i, j, k0 | k1 << 16) quadruples
+extern "C" int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int* out, long long cap, long long* n_tasks,
+                                    long long* n_chain_tasks, double* makespan_us) {
+   pips::RootPlanParams p;
+   if (workers > 0) p.workers = workers;
+   if (qmin > 0) p.qmin = qmin;
+   if (urgent >= 0) p.urgent = urgent;
+   if (chain_slots >= 0) p.chain_slots = chain_slots;
+   std::vector<int> tasks, chain;
+   const int rc = pips::build_root_plan(ntc, p, tasks, chain, makespan_us);
+   if (rc) return rc;
+   if (n_tasks) *n_tasks = (long long)tasks.size() / 4;
+   if (n_chain_tasks) *n_chain_tasks = (long long)chain.size() / 4;
+   if (out) {   // the bulk list, then the chain list
+      if ((long long)(tasks.size() + chain.size()) > cap) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_root_plan_build: %zu ints needed, %lld given", tasks.size() + chain.size(), cap);
+      std::copy(tasks.begin(), tasks.end(), out);
+      std::copy(chain.begin(), chain.end(), out + tasks.size());
+   }
+   return pips::PIPS_OK;
+}
