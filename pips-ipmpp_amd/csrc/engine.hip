@@ -2705,8 +2705,8 @@ struct DenseLdl {
    bool single_launch = !getenv("PIPS_HIP_ROOT_LAUNCHES");
    double* d_C = nullptr;          // the accumulating tiles (scratch): L goes to d_R, U to d_U, each written once per launch
    TileTask* d_rtasks = nullptr;
-   int n_rtasks = 0, n_rbulk = 0;
-   int* d_rflags = nullptr;        // ctl[4] | prog[ntc * ntc] | rowdone[ntc] | dready[ntc]
+   int n_rtasks = 0, n_rdeep = 0, n_rurgent = 0;
+   int* d_rflags = nullptr;        // ctl[8] | prog[ntc * ntc] | rowdone[ntc] | dready[ntc]
    double plan_makespan_us = 0.0;
    long long root_poll_limit = 400000;   // polls before a wait inside the launch gives up (some 0.1 s: a factorisation takes 2 - 40 ms)
    bool root_error_pending = false;
@@ -2721,26 +2721,29 @@ struct DenseLdl {
       if (const char* q = getenv("PIPS_HIP_ROOT_URGENT")) pp.urgent = atoi(q);
       if (const char* q = getenv("PIPS_HIP_ROOT_TDIAG")) pp.t_diag = atof(q);
       if (const char* q = getenv("PIPS_HIP_ROOT_TSTEP")) pp.t_step = atof(q);
-      std::vector<int> t, tc;
-      int rc = build_root_plan(ntc, pp, t, tc, &plan_makespan_us);
+      if (const char* q = getenv("PIPS_HIP_ROOT_URGENT_WIDTH")) pp.urgent_width = atoi(q);
+      std::vector<int> t, tu, tc;
+      int rc = build_root_plan(ntc, pp, t, tu, tc, &plan_makespan_us);
       if (rc) return rc;
-      n_rbulk = (int)(t.size() / 4);
+      n_rdeep = (int)(t.size() / 4);
+      n_rurgent = (int)(tu.size() / 4);
+      t.insert(t.end(), tu.begin(), tu.end());
       t.insert(t.end(), tc.begin(), tc.end());
       n_rtasks = (int)(t.size() / 4);
       HIP_TRY(hipMalloc((void**)&d_rtasks, std::max<size_t>(t.size(), 4) * sizeof(int)));
       HIP_TRY(hipMemcpy(d_rtasks, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc((void**)&d_rflags, ((size_t)4 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int)));
+      HIP_TRY(hipMalloc((void**)&d_rflags, ((size_t)8 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int)));
       HIP_TRY(hipMalloc((void**)&d_C, (size_t)npad * npad * sizeof(double)));
-      if (const char* pl = getenv("PIPS_HIP_SWEEP_POLL_LIMIT")) root_poll_limit = atoll(pl);
+      if (const char* pl = getenv("PIPS_HIP_ROOT_POLL_LIMIT")) root_poll_limit = atoll(pl);
       return PIPS_OK;
    }
    int factor_single_launch() {
       const int ntc = npad / TILE;
-      HIP_TRY(hipMemsetAsync(d_rflags, 0, ((size_t)4 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int), stream));
+      HIP_TRY(hipMemsetAsync(d_rflags, 0, ((size_t)8 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int), stream));
       RootArgs a{};
-      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad;
+      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_deep = n_rdeep; a.n_urgent = n_rurgent; a.ntc = ntc; a.ld = npad;
       a.C = d_C; a.R = d_R; a.U = d_U; a.winv = d_winv; a.dtail = d_dtail; a.pref = d_pref; a.psign = d_psign; a.inertia = d_inertia;
-      a.ctl = d_rflags; a.prog = d_rflags + 4; a.rowdone = a.prog + (size_t)ntc * ntc; a.dready = a.rowdone + ntc;
+      a.ctl = d_rflags; a.prog = d_rflags + 8; a.rowdone = a.prog + (size_t)ntc * ntc; a.dready = a.rowdone + ntc;
       a.blk = d_blks; a.poll_limit = root_poll_limit;
       a.diag_blocked = getenv("PIPS_HIP_ROOT_DIAG_BARRIERS") ? 0 : 1;
       const char* trace_file = getenv("PIPS_HIP_ROOT_TRACE");   // diagnostics: per-task clocks of this launch into a file (tools/root_trace.py)

@@ -23,13 +23,14 @@
 namespace pips {
 
 struct RootArgs {
-   const TileTask* tasks;   // blk = kind (0 UPD, 1 TRSM, 2 DIAG), ti, tj, pad = k0 | k1 << 16: the bulk list, then the chain list
-   int n_tasks, n_bulk, ntc, ld;   // n_tasks = all of them; [0, n_bulk) the bulk list, [n_bulk, n_tasks) the chain list
+   const TileTask* tasks;   // blk = kind (0 UPD, 1 TRSM, 2 DIAG), ti, tj, pad = k0 | k1 << 16: the deep list, the urgent list, the chain's list
+   int n_tasks, n_deep, n_urgent, ntc, ld;   // n_tasks = all of them: [0, n_deep) deep, [n_deep, n_deep + n_urgent) urgent, the rest the chain's
    double *C, *R, *U, *winv, *dtail;
    const double* pref;
    const signed char* psign;
    int* inertia;
-   int* ctl;                // [0] ticket of the bulk list, [1] error word, [2] ticket of the chain list, [3] the chain's compute unit (key + 1)
+   int* ctl;                // [0] ticket of the deep list, [1] error word, [2] ticket of the chain's list, [3] the chain's compute unit (key + 1),
+                            // [4] ticket of the urgent list, [5] a diagonal tile is being factorised
    int *prog, *rowdone, *dready;
    const BlkDesc* blk;      // thr_rel / repl_rel / repl_abs / m of the one block
    long long poll_limit;
@@ -534,6 +535,7 @@ __device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s
       ok = root_wait_ge(a.prog + (long long)tj * ntc + tj, tj, a.poll_limit, &s_ok);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 1] = wall_clock64();
       if (ok) {
+         if (tid == 0) __hip_atomic_store(a.ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the unit's other workgroup starts no update beside the pivots)
          bool done = false;
          if (a.diag_blocked) done = root_diag_blocked(a, sh.d2, tj);
          if (!done) {
@@ -543,6 +545,7 @@ __device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s
       }
       else if (tid == 0) a.ctl[1] = 1;
       root_publish(a.dready + tj, 1);
+      if (tid == 0) __hip_atomic_store(a.ctl + 5, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
       return;
    }
@@ -610,20 +613,48 @@ __device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s
    if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
 }
 
+// are the tasks a task waits for finished?  (thread 0 only; the same conditions root_task waits for)
+__device__ __forceinline__ bool root_task_ready(const RootArgs& a, const TileTask& task) {
+   auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+   const int ti = task.ti, tj = task.tj, ntc = a.ntc;
+   if (task.blk == ROOT_DIAG) return ld(a.prog + (long long)tj * ntc + tj) >= tj;
+   if (task.blk == ROOT_TRSM) return ld(a.dready + tj) >= 1 && ld(a.prog + (long long)ti * ntc + tj) >= tj;
+   const int k0 = task.pad & 0xffff, k1 = task.pad >> 16;
+   return ld(a.rowdone + ti) >= k1 && ld(a.rowdone + tj) >= k1 && ld(a.prog + (long long)ti * ntc + tj) >= k0;
+}
+// the head of a list if it is ready (and still the head when claimed): its index in the joint list, else -1
+__device__ __forceinline__ int root_try_take(const RootArgs& a, int base, int n, int* ticket) {
+   const int h = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   if (h >= n) return -1;
+   if (!root_task_ready(a, a.tasks[base + h])) return -1;
+   int expected = h;
+   return __hip_atomic_compare_exchange_strong(ticket, &expected, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? base + h : -1;
+}
+// the next task of a list whatever its state (the workgroup will wait inside root_task), -1 when the list is empty
+__device__ __forceinline__ int root_draw(int base, int n, int* ticket) {
+   if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) return -1;
+   const int c = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   return c < n ? base + c : -1;
+}
+
 __global__ __launch_bounds__(512, 4) void k_root_ldl(RootArgs a) {
    __shared__ RootShared sh;
    __shared__ int s_t, s_ok, s_mine;
-   // Two lists, each in the order of the schedule.  The chain of the diagonal tiles (DIAG j -> TRSM (j + 1, j) -> last update of C(j + 1, j + 1)
-   // -> DIAG j + 1) is strictly sequential and every column waits for it; beside the matrix-pipe waves of an update tile its 128 dependent
-   // pivots take 2.4 x as long (traced).  So the compute unit the launch's first workgroup lands on belongs to the chain: a workgroup that
-   // starts there STAYS and draws from the chain list until it is empty (one of the two works, the other waits for its turn: nothing
-   // competes for the unit's issue slots); all others take one task of the bulk list and leave; whoever finds its own list empty helps
-   // with the other.  Both lists are subsequences of ONE topological order and each is drawn in order; the chain's workgroups are
-   // resident from the start (they do not depend on the dispatcher sending more), so the argument of the single list carries over:
-   // among the waiting workgroups the one earliest in that order waits for a task that has been drawn.
+   // Three lists, each in the order of the schedule (rootplan.cpp).
+   //  The chain's: DIAG j -> TRSM (j + 1, j) -> last update of C(j + 1, j + 1) -> DIAG j + 1 is strictly sequential and every column waits
+   //  for it; beside the matrix-pipe waves of an update tile its 128 dependent pivots take 2.4 x as long (traced).  So the compute unit the
+   //  launch's first workgroup lands on belongs to the chain: a workgroup that starts there STAYS, takes the head of the chain's list when
+   //  it is ready, else (no diagonal tile being factorised on the unit) the head of the urgent list when that is ready, else looks again.
+   //  Urgent: any other workgroup looks at the head of the urgent list first and takes it only if it can run at once; otherwise it draws
+   //  from the deep list, does that one task - waiting inside it if it must - and leaves.  A workgroup that finds the deep list empty
+   //  draws from the urgent list, then from the chain's.
+   // No cycle of waiting workgroups: all three lists are subsequences of ONE topological order and each is taken in order.  Let x be the
+   // first task of that order which is not finished; everything it waits for is.  On the deep list it is drawn already, or is the next
+   // ticket while every deep task in a slot is later than x - impossible, they were drawn before it - so a slot is free or frees up.  On
+   // the urgent or the chain's list it is the head, ready, and the chain's two workgroups never wait inside a task.
    if (threadIdx.x == 0) {
       int mine = 0;
-      if (a.n_tasks > a.n_bulk) {
+      if (a.n_tasks > a.n_deep + a.n_urgent) {
          const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID */), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID[3:0] */);
          const int key = 1 + (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));   // XCC, shader engine / array, compute unit
          int seen = __hip_atomic_load(a.ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -637,20 +668,27 @@ __global__ __launch_bounds__(512, 4) void k_root_ldl(RootArgs a) {
    }
    __syncthreads();
    const bool mine = s_mine != 0;
+   const int ub = a.n_deep, cb = a.n_deep + a.n_urgent, n_chain = a.n_tasks - cb;
    for (;;) {
       if (threadIdx.x == 0) {
-         const int n_chain = a.n_tasks - a.n_bulk;
          int t = -1;
-         for (int pass = 0; pass < 2 && t < 0; ++pass) {
-            if ((pass == 0) == mine) {
-               if (n_chain > 0 && __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_chain) {
-                  const int c = __hip_atomic_fetch_add(a.ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if (c < n_chain) t = a.n_bulk + c;
-               }
-            } else if (__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_bulk) {
-               const int c = __hip_atomic_fetch_add(a.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-               if (c < a.n_bulk) t = c;
+         if (mine) {
+            long long spins = 0;
+            for (;;) {
+               t = root_try_take(a, cb, n_chain, a.ctl + 2);
+               if (t < 0 && __hip_atomic_load(a.ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) t = root_try_take(a, ub, a.n_urgent, a.ctl + 4);
+               if (t >= 0) break;
+               const bool chain_empty = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_chain;
+               const bool urgent_empty = __hip_atomic_load(a.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_urgent;
+               if (chain_empty && urgent_empty) { t = root_draw(0, a.n_deep, a.ctl); break; }   // (-1: everything is taken)
+               __builtin_amdgcn_s_sleep(2);
+               if (++spins > a.poll_limit) { a.ctl[1] = 1; t = root_draw(cb, n_chain, a.ctl + 2); if (t < 0) t = root_draw(ub, a.n_urgent, a.ctl + 4); break; }
             }
+         } else {
+            t = root_try_take(a, ub, a.n_urgent, a.ctl + 4);
+            if (t < 0) t = root_draw(0, a.n_deep, a.ctl);
+            if (t < 0) t = root_draw(ub, a.n_urgent, a.ctl + 4);
+            if (t < 0) t = root_draw(cb, n_chain, a.ctl + 2);
          }
          s_t = t;
       }

@@ -20,8 +20,9 @@
 
 namespace pips {
 
-int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& chain_tasks, double* makespan_us) {
+int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& urgent_tasks, std::vector<int>& chain_tasks, double* makespan_us) {
    tasks.clear();
+   urgent_tasks.clear();
    chain_tasks.clear();
    if (ntc <= 0) return PIPS_OK;
    const int W = std::max(p.workers, 1);
@@ -31,8 +32,9 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
    int chain = 0;
    struct Cand { int prio, j, i; };
    auto worse = [](const Cand& a, const Cand& b) { return a.prio != b.prio ? a.prio > b.prio : (a.j != b.j ? a.j > b.j : a.i > b.i); };
-   std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> ready(worse), ready_chain(worse);
-   struct Event { double t; long long seq; int kind, i, j, k1, on_chain; };
+   typedef std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> Heap;
+   Heap heaps[3] = {Heap(worse), Heap(worse), Heap(worse)};   // 0 the chain's, 1 urgent, 2 deep
+   struct Event { double t; long long seq; int kind, i, j, k1, cls; };
    auto later = [](const Event& a, const Event& b) { return a.t != b.t ? a.t > b.t : a.seq > b.seq; };
    std::priority_queue<Event, std::vector<Event>, decltype(later)> events(later);
 
@@ -49,13 +51,22 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
       if (a == j || q >= p.qmin || urgent) { k1 = a; return 0; }
       return -1;
    };
-   // The chain's own list: DIAG (j), and for the tiles within chain_width of the diagonal the triangular solves and the updates that
-   // COMPLETE a tile.  The critical path DIAG j -> TRSM (j + 1, j) -> last update of C(j + 1, j + 1) -> DIAG j + 1 needs tile (j + 1, j)
-   // complete when DIAG j ends, which needs TRSM (j + 1, j - 1) one step earlier, and so on: a tile d below the diagonal has d - 1 chain
-   // steps of slack.  On the bulk list such a task waits for its turn behind a few hundred deep updates (traced: the completing update
-   // of (60, 59) was drawn 270 us after it could have run); the chain's two workgroups are idle most of a step and take them at once.
-   auto on_chain = [&](int kind, int i, int j, int k1) {
-      return p.chain_slots > 0 && (kind == 2 || (kind == 1 && i - j <= p.chain_width) || (kind == 0 && k1 == j && i - j < p.chain_width));
+   // Three classes, three lists (each in the order its tasks start here):
+   //  0 the chain's own: DIAG (j), TRSM (j + 1, j), the update that completes C(j + 1, j + 1) - strictly sequential, on the compute unit
+   //    the launch keeps for them;
+   //  1 urgent: what the chain needs next from the tiles within urgent_width of the diagonal - their trsm, the updates that complete them,
+   //    the shallow updates of the tiles right at the chain.  The critical path needs tile (j + 1, j) complete when DIAG j ends, which needs
+   //    TRSM (j + 1, j - 1) one step earlier, and so on: a tile d below the diagonal has d - 1 chain steps of slack.  In ONE list with the
+   //    deep updates such a task waits for its turn behind a few hundred of them (traced: the completing update of (60, 59) was drawn
+   //    270 us after it could have run); from its own list any arriving workgroup takes it the moment it is ready;
+   //  2 deep: everything else.
+   auto task_class = [&](int kind, int i, int j, int k1) {
+      if (p.chain_slots > 0 && (kind == 2 || (kind == 1 && i - j <= p.chain_width) || (kind == 0 && k1 == j && i - j < p.chain_width))) return 0;
+      if (p.urgent_width > 0) {
+         if (kind == 1 && i - j <= p.urgent_width) return 1;
+         if (kind == 0 && ((k1 == j && i - j < p.urgent_width) || (j <= chain + p.urgent && i <= j + p.urgent))) return 1;
+      }
+      return 2;
    };
    auto consider = [&](int i, int j) {
       if (queued[at(i, j)]) return;
@@ -63,8 +74,7 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
       const int kind = startable(i, j, k1);
       if (kind < 0) return;
       queued[at(i, j)] = 1;
-      const Cand c{kind == 2 ? 0 : (kind == 1 ? 1 : 2), j, i};
-      if (on_chain(kind, i, j, k1)) ready_chain.push(c); else ready.push(c);
+      heaps[task_class(kind, i, j, kind == 0 ? k1 : j)].push(Cand{kind == 2 ? 0 : (kind == 1 ? 1 : 2), j, i});
    };
 
    double t = 0.0;
@@ -72,8 +82,8 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
    int free_slots = W, free_chain = std::max(p.chain_slots, 0), diag_done = 0;
    consider(0, 0);
    while (diag_done < ntc) {
-      for (int pass = 0; pass < 2; ++pass) {
-         auto& heap = pass == 0 ? ready_chain : ready;
+      for (int pass = 0; pass < 3; ++pass) {
+         Heap& heap = heaps[pass];
          while (!heap.empty() && (pass == 0 ? free_chain > 0 : free_slots > 0)) {
             const Cand c = heap.top();
             heap.pop();
@@ -83,30 +93,30 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
             if (kind < 0) continue;
             if (kind != 0) k1 = c.j;
             const int k0 = prog[at(c.i, c.j)];
-            const bool ch = on_chain(kind, c.i, c.j, k1);
-            if (ch != (pass == 0)) {   // an update that has become a completing one (or the other way round) since it was queued: the other heap's
+            const int cls = task_class(kind, c.i, c.j, k1);
+            if (cls != pass) {   // an update that has changed its class since it was queued (it now completes its tile, the chain has moved): the other heap's
                queued[at(c.i, c.j)] = 1;
-               (ch ? ready_chain : ready).push(c);
-               if (pass == 1) continue;
-               break;   // (pass 0 found a bulk task: the bulk pass takes it)
+               heaps[cls].push(c);
+               if (cls < pass) { pass = cls - 1; break; }   // (an earlier pass has work again)
+               continue;
             }
-            const bool alone = ch || W - free_slots < W / 2;   // fewer workgroups than compute units: a tile has its matrix pipe to itself
+            const bool alone = cls == 0 || W - free_slots < W / 2;   // fewer workgroups than compute units: a tile has its matrix pipe to itself
             const double dur = kind == 2 ? p.t_diag : (kind == 1 ? (alone ? p.t_trsm_alone : p.t_trsm) : p.t0 + (k1 - k0) * (alone ? p.t_step_alone : p.t_step));
             busy[at(c.i, c.j)] = 1;
-            std::vector<int>& out = ch ? chain_tasks : tasks;
+            std::vector<int>& out = cls == 0 ? chain_tasks : (cls == 1 ? urgent_tasks : tasks);
             out.push_back(kind);
             out.push_back(c.i);
             out.push_back(c.j);
             out.push_back(k0 | (k1 << 16));
-            events.push(Event{t + dur, seq++, kind, c.i, c.j, k1, ch ? 1 : 0});
-            if (ch) --free_chain; else --free_slots;
+            events.push(Event{t + dur, seq++, kind, c.i, c.j, k1, cls});
+            if (cls == 0) --free_chain; else --free_slots;
          }
       }
       if (events.empty()) PIPS_FAIL(PIPS_ERR_STATE, "root plan: the schedule stalled at column %d of %d", chain, ntc);
       const Event e = events.top();
       events.pop();
       t = e.t;
-      if (e.on_chain) ++free_chain; else ++free_slots;
+      if (e.cls == 0) ++free_chain; else ++free_slots;
       busy[at(e.i, e.j)] = 0;
       if (e.kind == 2) {
          dready[e.j] = 1;
@@ -136,22 +146,26 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
 }  // namespace pips
 
 // C entry for the tests (no device involved): tasks as (kind, i, j, k0 | k1 << 16) quadruples
-extern "C" int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int* out, long long cap, long long* n_tasks,
-                                    long long* n_chain_tasks, double* makespan_us) {
+extern "C" int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int urgent_width, int* out, long long cap, long long* n_tasks,
+                                    long long* n_urgent_tasks, long long* n_chain_tasks, double* makespan_us) {
    pips::RootPlanParams p;
    if (workers > 0) p.workers = workers;
    if (qmin > 0) p.qmin = qmin;
    if (urgent >= 0) p.urgent = urgent;
    if (chain_slots >= 0) p.chain_slots = chain_slots;
-   std::vector<int> tasks, chain;
-   const int rc = pips::build_root_plan(ntc, p, tasks, chain, makespan_us);
+   if (urgent_width >= 0) p.urgent_width = urgent_width;
+   std::vector<int> tasks, urg, chain;
+   const int rc = pips::build_root_plan(ntc, p, tasks, urg, chain, makespan_us);
    if (rc) return rc;
    if (n_tasks) *n_tasks = (long long)tasks.size() / 4;
+   if (n_urgent_tasks) *n_urgent_tasks = (long long)urg.size() / 4;
    if (n_chain_tasks) *n_chain_tasks = (long long)chain.size() / 4;
-   if (out) {   // the bulk list, then the chain list
-      if ((long long)(tasks.size() + chain.size()) > cap) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_root_plan_build: %zu ints needed, %lld given", tasks.size() + chain.size(), cap);
+   if (out) {   // the deep list, the urgent list, the chain's list
+      if ((long long)(tasks.size() + urg.size() + chain.size()) > cap)
+         PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_root_plan_build: %zu ints needed, %lld given", tasks.size() + urg.size() + chain.size(), cap);
       std::copy(tasks.begin(), tasks.end(), out);
-      std::copy(chain.begin(), chain.end(), out + tasks.size());
+      std::copy(urg.begin(), urg.end(), out + tasks.size());
+      std::copy(chain.begin(), chain.end(), out + tasks.size() + urg.size());
    }
    return pips::PIPS_OK;
 }
