@@ -390,6 +390,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import pips_ipmpp_amd as pa
+    import families
 
     n_i, my_i = a.n, a.n // 2
     bpg = a.blocks_per_gpu
@@ -401,7 +402,7 @@ def main():
         # (Readers/Distributed/DistributedTree.C:62-89): a rank draws ONLY its own blocks (every block has its own generator), so host
         # memory and set-up time per rank do not depend on the number of ranks.  With fewer ranks than the chain needs the problem is
         # the chain's first world * bpg blocks and the linking rows they touch (TimeCoupledChain.prefix).
-        whole = pa.config3_chain(n_i, a.chain_blocks, a.schur_dim)
+        whole = families.config3_chain(n_i, a.chain_blocks, a.schur_dim)
         if n_blocks_total > whole.G:
             raise SystemExit(f"bench.py: {world} rank(s) x {bpg} blocks exceed the chain's {whole.G} blocks (--chain-blocks)")
         chain = whole.prefix(n_blocks_total)

@@ -12,11 +12,11 @@ host memory per rank does not grow with the number of ranks.  `CONFIG3` is BASEL
 linking rows: 3 or 4 per pair).  `prefix(k)` is the sub-problem of the first k blocks (their linking rows only: every one of
 them is touched by a block that is present), what `bench.py` runs on fewer than the 8 GPUs of configs[3].
 
-Used by bench.py --family time-coupled, the tools and the tests."""
+Used by bench.py --family time-coupled, the tools and the tests; lives beside them, not in the product package."""
 import numpy as np
 import scipy.sparse as sp
 
-from . import capi as pa
+import pips_ipmpp_amd as pa
 
 
 def _csr(M):

@@ -2865,6 +2865,7 @@ struct DenseLdl {
       int cnt = 0;
       HIP_TRY(hipMemcpyAsync(&cnt, d_pert_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
+      cnt = std::min(cnt, npad);   // (an index flagged by the tile kernel AND the growth check counts twice: the kernels stop writing at npad records)
       std::vector<int> rec((size_t)2 * std::max(cnt, 0));
       if (cnt > 0) HIP_TRY(hipMemcpy(rec.data(), d_pert_list, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
       if (dist_P <= 1) {
@@ -3231,6 +3232,8 @@ struct KktSystem {
    // together: each solveCompressed ends with a one-number all-reduce "did any rank's check fail"; if so every rank restores its
    // right-hand side and all go the refined way (a rank's inaccurate -Br^T K^-1 b taints x0 for everybody).
    int solve_check_every = 1, sweeps_since_check = 0;
+   long long solves_since_factor = 0;   // equal on every rank: which solveCompressed calls are scheduled for a measure (every solve_check_every-th)
+   double* h_flag = nullptr;            // pinned: the one-number exchange of settle() without a host wait before the collective
    long long checked_solves = 0, failed_checks = 0;
    double* d_flag = nullptr;
    bool joint_aug_any = false;        // several ranks: some rank's analysis chose the sweeps (all-reduced once per analysis)
@@ -3258,6 +3261,7 @@ struct KktSystem {
       if (ev_root_done) (void)hipEventDestroy(ev_root_done);
       if (comm_stream) (void)hipStreamDestroy(comm_stream);
       if (ev_reduced) (void)hipEventDestroy(ev_reduced);
+      if (h_flag) (void)hipHostFree(h_flag);
       void* ptrs[] = {d_SC, d_t, d_fin_val, d_fin_idx, d_c0_val, d_red, d_c0_rp, d_c0_ci, d_packed, d_xdiag_pos, d_zlink_pos, d_sc_rowptr, d_gall, d_gvec_all, d_bsave, d_b0save, d_flag};
       for (void* p : ptrs)
          if (p) (void)hipFree(p);
@@ -4611,6 +4615,7 @@ int pips_hip_kkt_factorize(void* handle, const double* leaf_diag_dev, const doub
    Engine* e = k->leaves;
    HIP_TRY(hipSetDevice(e->device));
    ++k->factor_gen;
+   k->solves_since_factor = 0;
    if (k->sparse) return kkt_factorize_sparse(k, leaf_diag_dev, xdiag0_dev, zdiag_link_dev);
    int rc;
    PhaseTimer& tm = k->timer;
@@ -4785,14 +4790,18 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       k->joint_aug_gen = e->analysis_gen;
    }
    const bool joint_check = joint && can_measure && k->solve_check_every > 0 && k->joint_aug_any;
+   // Which calls measure is decided by a counter that is equal on every rank (solveCompressed calls since the factorisation; the first one
+   // is always scheduled): several ranks then exchange the outcome only on scheduled calls - none could have measured on the others -
+   // instead of ending every call with a latency-bound collective and two host waits.
+   const bool scheduled = k->solve_check_every > 0 && (k->solves_since_factor++ % k->solve_check_every) == 0;
    if (can_measure && e->aug_sweeps_ok && k->aug_failed_gen != k->factor_gen) {
       const bool validated = k->aug_validated_gen == k->factor_gen;
       const bool may_check = !joint || joint_check;      // (a measure may fail: several ranks must be able to act on it together)
-      if (validated || (k->checked_witness && may_check)) {   // the first solve after a factorisation: a checked sweep pair, or the refined pass
+      if (validated || (k->checked_witness && may_check && (!joint || scheduled))) {   // the first solve after a factorisation: a checked sweep pair, or the refined pass
          int pert = 1;
          if ((rc = e->perturbed_leaf_pivots(&pert))) return rc;
          use_aug = pert == 0;
-         const bool due = use_aug && validated && may_check && k->solve_check_every > 0 && ++k->sweeps_since_check >= k->solve_check_every;
+         const bool due = use_aug && validated && may_check && scheduled;
          verify = use_aug && (!validated || due);
       }
    }
@@ -4807,14 +4816,14 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
       bool redo = my_check_failed;
       if (joint_check) {
          if (!k->d_flag) HIP_TRY(hipMalloc((void**)&k->d_flag, sizeof(double)));
-         double flag = my_check_failed ? 1.0 : 0.0;
-         HIP_TRY(hipMemcpyAsync(k->d_flag, &flag, sizeof(double), hipMemcpyHostToDevice, e->stream));
-         HIP_TRY(hipStreamSynchronize(e->stream));   // (the source is a stack variable)
+         if (!k->h_flag) HIP_TRY(hipHostMalloc((void**)&k->h_flag, 2 * sizeof(double), hipHostMallocDefault));
+         k->h_flag[0] = my_check_failed ? 1.0 : 0.0;   // (pinned: the copy is queued, nothing waits before the collective)
+         HIP_TRY(hipMemcpyAsync(k->d_flag, k->h_flag, sizeof(double), hipMemcpyHostToDevice, e->stream));
          int rcf = pips_hip_allreduce_sum(k->comm, k->d_flag, 1, e->stream);
          if (rcf) return rcf;
-         HIP_TRY(hipMemcpyAsync(&flag, k->d_flag, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+         HIP_TRY(hipMemcpyAsync(k->h_flag + 1, k->d_flag, sizeof(double), hipMemcpyDeviceToHost, e->stream));
          HIP_TRY(hipStreamSynchronize(e->stream));
-         redo = flag > 0.0;
+         redo = k->h_flag[1] > 0.0;
       }
       if (!redo) return PIPS_OK;
       ++k->failed_checks;
@@ -4933,7 +4942,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
             failed = true;   // not good enough without refinement: the refined path on the saved right-hand side, no sweeps on these factors
       }
       k->timer.end(e->stream);
-      if (failed || joint_check) return settle(failed);
+      if (failed || (joint_check && scheduled)) return settle(failed);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
    } else {
@@ -4960,7 +4969,7 @@ static int kkt_solve_compressed_enqueue(KktSystem* k, double* b0_dev, double* b_
    k->timer.begin(e->stream, 9);
    hipLaunchKernelGGL(k_axpy, dim3(grid_for(e->n_total, 256)), dim3(256), 0, e->stream, b_leaf_dev, k->d_t, -1.0, e->n_total);
    k->timer.end(e->stream);
-   if (joint_check) return settle(false);   // (another rank's check may have failed)
+   if (joint_check && scheduled) return settle(false);   // (another rank's check may have failed)
    }
    HIP_TRY(hipGetLastError());
    return PIPS_OK;

@@ -2140,7 +2140,7 @@ __global__ __launch_bounds__(256) void k_tile_diag_bk(const TileTask* __restrict
                }
                __syncthreads();
             }
-            if (tid == 0 && gk0 + p < bd.m) { const int slot = atomicAdd(pert_cnt, 1); pert_list[2 * slot] = gk0 + p; pert_list[2 * slot + 1] = s_best[0] > 0.0 ? s_idx[0] : -1; }
+            if (tid == 0 && gk0 + p < bd.m) { const int slot = atomicAdd(pert_cnt, 1); if (slot < bd.m_pad) { pert_list[2 * slot] = gk0 + p; pert_list[2 * slot + 1] = s_best[0] > 0.0 ? s_idx[0] : -1; } }   // (the list holds m_pad records)
             __syncthreads();
          }
          // isolate != 0 (a factorisation DenseLdl::check_pivots will look at): an index without a pivot is taken out of the matrix - a pivot
@@ -3422,7 +3422,7 @@ __global__ __launch_bounds__(256) void k_bk_growth(const BlkDesc* __restrict__ b
       if (tid < h && s_best[tid + h] > s_best[tid]) { s_best[tid] = s_best[tid + h]; s_idx[tid] = s_idx[tid + h]; }
       __syncthreads();
    }
-   if (tid == 0 && s_best[0] > limit) { const int slot = atomicAdd(pert_cnt, 1); pert_list[2 * slot] = p; pert_list[2 * slot + 1] = s_idx[0]; }
+   if (tid == 0 && s_best[0] > limit) { const int slot = atomicAdd(pert_cnt, 1); if (slot < bd.m_pad) { pert_list[2 * slot] = p; pert_list[2 * slot + 1] = s_idx[0]; } }
 }
 
 // |A(perm[i], perm[c_q])| for the columns c_q = list[2 q] DenseLdl::check_pivots looks for partners for (A: the caller's symmetric matrix,

@@ -51,7 +51,7 @@ SYMBOLS = [
     "pips_hip_ldl_solve_dev", "pips_hip_ldl_solve_sparse", "pips_hip_ldl_factor_schur_batch", "pips_hip_ldl_solve_batch", "pips_hip_ldl_solve_batch_dev",
     "pips_hip_ldl_inertia_batch",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
-    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_set_distributed", "pips_hip_dense_ldl_destroy",
+    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_set_distributed", "pips_hip_dense_ldl_destroy", "pips_root_plan_build",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
     "pips_hip_batch_last_refinement_steps", "pips_hip_batch_set_refinement_backward_error",
     "pips_hip_batch_last_refinement_measure", "pips_hip_batch_analyze",

@@ -11,4 +11,3 @@ __path__.append(_os.path.join(_root, "pips-ipmpp_amd", "python"))
 
 from .capi import *  # noqa: F401,F403,E402
 from . import capi  # noqa: E402,F401
-from .families import time_coupled_blocks, TimeCoupledChain, config3_chain, share_range, CONFIG3, CONFIG3_SHARE  # noqa: E402,F401

@@ -16,6 +16,7 @@ import pytest
 import scipy.sparse as sp
 
 import pips_ipmpp_amd as pa
+import families
 
 pytestmark = pytest.mark.gpu
 
@@ -130,7 +131,7 @@ def test_config5_share_dense_linking_root_16000():
 _CACHE = {}
 
 
-energy_like_blocks = pa.time_coupled_blocks
+energy_like_blocks = families.time_coupled_blocks
 
 
 @pytest.mark.parametrize("sparse_root", [False, True], ids=["dense_root", "sparse_root"])

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import pips_ipmpp_amd as pa
+import families
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -18,37 +19,37 @@ def _same(a, b):
 
 
 def test_configs3_chain_has_schur_dimension_8000_on_any_number_of_ranks():
-    ch = pa.config3_chain(n_i=50000)
+    ch = families.config3_chain(n_i=50000)
     assert ch.G == 2048 and ch.S == 8000 and ch.n0 == 95 and ch.myl == 7905
     per_pair = np.diff(ch.row0)
     assert per_pair.sum() == 7905 and per_pair.min() == 3 and per_pair.max() == 4
     for world in (1, 2, 4, 8):
-        ranges = [pa.share_range(ch.G, r, world) for r in range(world)]
+        ranges = [families.share_range(ch.G, r, world) for r in range(world)]
         assert ranges[0][0] == 0 and ranges[-1][1] == 2048 and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
         assert {hi - lo for lo, hi in ranges} == {2048 // world}
     # the same rule as the library's map (pips_map_children_to_ranks)
     owner = pa.map_children_to_ranks(2048, 8) if hasattr(pa, "map_children_to_ranks") else None
     if owner is not None:
         for r in range(8):
-            lo, hi = pa.share_range(2048, r, 8)
+            lo, hi = families.share_range(2048, r, 8)
             assert set(owner[lo:hi]) == {r}
     # rounds 3-4 measured the 256-block chain: 31 rows on every pair
-    old = pa.config3_chain(n_i=50000, G=256)
+    old = families.config3_chain(n_i=50000, G=256)
     assert old.S == 8000 and set(np.diff(old.row0)) == {31}
 
 
 def test_a_rank_generates_its_own_blocks_only_and_they_do_not_depend_on_the_partition(monkeypatch):
-    ch = pa.config3_chain(n_i=400, G=16, S=95 + 60)
+    ch = families.config3_chain(n_i=400, G=16, S=95 + 60)
     calls = []
-    orig = pa.TimeCoupledChain.block
+    orig = families.TimeCoupledChain.block
 
     def counted(self, i):
         calls.append(i)
         return orig(self, i)
-    monkeypatch.setattr(pa.TimeCoupledChain, "block", counted)
+    monkeypatch.setattr(families.TimeCoupledChain, "block", counted)
     whole = ch.blocks(0, 16)
     calls.clear()
-    lo, hi = pa.share_range(16, 5, 8)
+    lo, hi = families.share_range(16, 5, 8)
     mine = ch.blocks(lo, hi)
     assert calls == [10, 11]
     for (W, T, F), (W2, T2, F2) in zip(mine, whole[lo:hi]):
@@ -66,7 +67,7 @@ def test_a_rank_generates_its_own_blocks_only_and_they_do_not_depend_on_the_part
 
 
 def test_prefix_is_the_sub_problem_of_the_first_blocks():
-    ch = pa.config3_chain(n_i=400)
+    ch = families.config3_chain(n_i=400)
     sub = ch.prefix(256)
     assert sub.n_blocks == 256 and sub.myl == int(ch.row0[256]) == 988 and sub.S == 1083 and ch.S == 8000
     for b in (0, 100, 255):
@@ -90,7 +91,7 @@ def test_bench_labels_and_one_gpu_reference_come_from_the_problem_and_the_profil
         spec.loader.exec_module(b)
     finally:
         sys.argv = sys_argv
-    whole = pa.config3_chain(50000)
+    whole = families.config3_chain(50000)
     full = b.workload_label("time-coupled", 8, 256, 50000, 25000, 0, 8000, whole, 7905)
     assert "Schur dim 8000" in full and full.endswith("[BASELINE configs[3]]") and "all of it on 8 GPU(s)" in full
     part = whole.prefix(2 * 256)

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import pips_ipmpp_amd as pa
+import families
 from oracle import oracle as orc
 from tests.util import Problem
 
@@ -207,8 +208,8 @@ def test_border_split_of_the_multifrontal_head(monkeypatch):
     border-row arena), the stored factor is the same; a block with more border columns than the LDS triangle takes, or the switch off,
     keeps whole update matrices and full panels."""
     import pips_ipmpp_amd as pa
-    c3 = pa.CONFIG3_SHARE
-    blocks, F0, my_i, myl = pa.time_coupled_blocks(3, 6000, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], 5)
+    c3 = families.CONFIG3_SHARE
+    blocks, F0, my_i, myl = families.time_coupled_blocks(3, 6000, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], 5)
     W, T, F = blocks[1]
     K, dpos = pa.kkt_leaf_assemble(6000, W)
     Bt = pa.border_assemble(6000, my_i, 0, c3["n0"], 0, A=T, F=F)

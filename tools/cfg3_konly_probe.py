@@ -4,10 +4,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 import pips_ipmpp_amd as pa
+import families
 import bench
 nb, n_i = (int(a) for a in sys.argv[1:3]) if len(sys.argv) >= 3 else (256, 50000)
-c3 = pa.CONFIG3_SHARE
-blocks, F0, my_i, myl = pa.time_coupled_blocks(nb, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
+c3 = families.CONFIG3_SHARE
+blocks, F0, my_i, myl = families.time_coupled_blocks(nb, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
 for variant in ("with border", "K only"):
     def data(b):
         W, T, F = blocks[b]

@@ -4,11 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import pips_ipmpp_amd as pa
+import families
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n_i = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 sparse_root = len(sys.argv) > 3 and sys.argv[3] == "1"
 L, n0, bw, nnz_row, seed = 31, 95, 12, 10, 20261004
-blocks, F0, my_i, myl = pa.time_coupled_blocks(N, n_i, L, n0, bw, nnz_row, seed)
+blocks, F0, my_i, myl = families.time_coupled_blocks(N, n_i, L, n0, bw, nnz_row, seed)
 S, nleaf = n0 + myl, n_i + my_i
 bt = pa.LeafBatch(N, S)
 diags, vals = [], []

@@ -2,10 +2,11 @@ import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import pips_ipmpp_amd as pa
+import families
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n_i = 50000
-c3 = pa.CONFIG3_SHARE
-blocks, F0, my_i, myl = pa.time_coupled_blocks(N, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
+c3 = families.CONFIG3_SHARE
+blocks, F0, my_i, myl = families.time_coupled_blocks(N, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
 n0 = c3["n0"]; S = n0 + myl
 res = {}
 for det in (1, 0):

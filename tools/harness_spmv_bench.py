@@ -5,10 +5,11 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pips_ipmpp_amd as pa
+import families
 
-c3 = pa.CONFIG3_SHARE
+c3 = families.CONFIG3_SHARE
 N, n_i = int(os.environ.get("SPMV_BLOCKS", "256")), 50000
-blocks, F0, my_i, myl = pa.time_coupled_blocks(N, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
+blocks, F0, my_i, myl = families.time_coupled_blocks(N, n_i, c3["L"], c3["n0"], c3["bw"], c3["nnz_row"], c3["seed"])
 n0 = c3["n0"]
 rng = np.random.default_rng(0)
 c = rng.uniform(0.5, 1.5, n0 + N * n_i)
