@@ -95,10 +95,10 @@ int pips_hip_dense_ldl_set_pivoting(void* handle, int mode);
 /* With the static order on one rank the factorisation is ONE launch of tile tasks that wait for each other through flags
  * (csrc/rootkernel.hip.h), in the order of a list schedule the host builds once per dimension (csrc/rootplan.cpp).  This entry returns
  * that schedule for ntc tile columns of 128 (no device involved; tests): (kind 0 update / 1 trsm / 2 diagonal tile, tile row, tile column,
- * k0 | k1 << 16) quadruples - the deep list, then the urgent list, then the chain's list, each in ticket order.  workers, qmin, urgent,
- * chain_slots, urgent_width < 0 (workers, qmin <= 0): the defaults.  out may be NULL (counts only). */
-int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int urgent_width, int* out, long long cap,
-                         long long* n_tasks, long long* n_urgent_tasks, long long* n_chain_tasks, double* makespan_us);
+ * k0 | k1 << 16) quadruples - the bulk list, then the chain's list, each in ticket order.  workers, qmin <= 0, urgent, chain_slots < 0:
+ * the defaults.  out may be NULL (counts only). */
+int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int* out, long long cap, long long* n_tasks,
+                         long long* n_chain_tasks, double* makespan_us);
 /* Several ranks hold the same matrix (the reduced Schur complement): factorise it column-cyclically over the ranks instead of
  * redundantly on each (DistributedRootLinearSystem.C:1436-1464 does the latter).  Tile column j belongs to rank j mod n_ranks; the
  * owner's panel reaches every rank through the communicator (pips_hip_comm_create / _create_external), every rank ends with the

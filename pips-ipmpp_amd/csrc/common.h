@@ -193,13 +193,11 @@ struct RootPlanParams {
    int workers = 510;       // workgroup slots for the bulk: 256 compute units x 2, less the chain's unit
    int chain_slots = 2;     // > 0: the chain of the diagonal tiles has a compute unit of its own (a task list of its own); 0: one list
    int chain_width = 1;     // tiles this close to the diagonal have their trsm and completing update on the chain's list
-   int urgent_width = 0;    // > 0: trsm and completing updates this close to the diagonal on an urgent list any workgroup takes the moment its head is
-                            // ready (built and measured: S = 16 000 31.8 against 29.8 ms without - the list is in-order and its head blocks)
    int qmin = 4;            // an update that does not finish its tile waits until it is this many tile columns deep
    int urgent = 1;          // tiles within this distance of the chain's diagonal tile are updated whatever the depth
    double t_step = 31.0, t_step_alone = 22.0, t0 = 8.0, t_trsm = 40.0, t_trsm_alone = 26.0, t_diag = 85.0;
 };
-// tasks (deep) / urgent_tasks / chain_tasks: (kind 0 UPD / 1 TRSM / 2 DIAG, i, j, k0 | k1 << 16) quadruples in ticket order
-int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& urgent_tasks, std::vector<int>& chain_tasks, double* makespan_us);
+// tasks / chain_tasks: (kind 0 UPD / 1 TRSM / 2 DIAG, i, j, k0 | k1 << 16) quadruples in ticket order
+int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& chain_tasks, double* makespan_us);
 
 }  // namespace pips

@@ -2705,7 +2705,7 @@ struct DenseLdl {
    bool single_launch = !getenv("PIPS_HIP_ROOT_LAUNCHES");
    double* d_C = nullptr;          // the accumulating tiles (scratch): L goes to d_R, U to d_U, each written once per launch
    TileTask* d_rtasks = nullptr;
-   int n_rtasks = 0, n_rdeep = 0, n_rurgent = 0;
+   int n_rtasks = 0, n_rbulk = 0;
    int* d_rflags = nullptr;        // ctl[8] | prog[ntc * ntc] | rowdone[ntc] | dready[ntc]
    double plan_makespan_us = 0.0;
    long long root_poll_limit = 400000;   // polls before a wait inside the launch gives up (some 0.1 s: a factorisation takes 2 - 40 ms)
@@ -2717,17 +2717,10 @@ struct DenseLdl {
       if (const char* q = getenv("PIPS_HIP_ROOT_QMIN")) pp.qmin = std::max(1, atoi(q));
       if (const char* q = getenv("PIPS_HIP_ROOT_CHAIN_CU")) pp.chain_slots = atoi(q) != 0 ? 2 : 0;   // 0: one list, the chain wherever its workgroups land (A/B)
       if (pp.chain_slots == 0) pp.workers = 512;
-      if (const char* q = getenv("PIPS_HIP_ROOT_CHAIN_WIDTH")) pp.chain_width = atoi(q);
-      if (const char* q = getenv("PIPS_HIP_ROOT_URGENT")) pp.urgent = atoi(q);
-      if (const char* q = getenv("PIPS_HIP_ROOT_TDIAG")) pp.t_diag = atof(q);
-      if (const char* q = getenv("PIPS_HIP_ROOT_TSTEP")) pp.t_step = atof(q);
-      if (const char* q = getenv("PIPS_HIP_ROOT_URGENT_WIDTH")) pp.urgent_width = atoi(q);
-      std::vector<int> t, tu, tc;
-      int rc = build_root_plan(ntc, pp, t, tu, tc, &plan_makespan_us);
+      std::vector<int> t, tc;
+      int rc = build_root_plan(ntc, pp, t, tc, &plan_makespan_us);
       if (rc) return rc;
-      n_rdeep = (int)(t.size() / 4);
-      n_rurgent = (int)(tu.size() / 4);
-      t.insert(t.end(), tu.begin(), tu.end());
+      n_rbulk = (int)(t.size() / 4);
       t.insert(t.end(), tc.begin(), tc.end());
       n_rtasks = (int)(t.size() / 4);
       HIP_TRY(hipMalloc((void**)&d_rtasks, std::max<size_t>(t.size(), 4) * sizeof(int)));
@@ -2741,7 +2734,7 @@ struct DenseLdl {
       const int ntc = npad / TILE;
       HIP_TRY(hipMemsetAsync(d_rflags, 0, ((size_t)8 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int), stream));
       RootArgs a{};
-      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_deep = n_rdeep; a.n_urgent = n_rurgent; a.ntc = ntc; a.ld = npad;
+      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad;
       a.C = d_C; a.R = d_R; a.U = d_U; a.winv = d_winv; a.dtail = d_dtail; a.pref = d_pref; a.psign = d_psign; a.inertia = d_inertia;
       a.ctl = d_rflags; a.prog = d_rflags + 8; a.rowdone = a.prog + (size_t)ntc * ntc; a.dready = a.rowdone + ntc;
       a.blk = d_blks; a.poll_limit = root_poll_limit;

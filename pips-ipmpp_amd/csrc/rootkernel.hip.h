@@ -23,14 +23,13 @@
 namespace pips {
 
 struct RootArgs {
-   const TileTask* tasks;   // blk = kind (0 UPD, 1 TRSM, 2 DIAG), ti, tj, pad = k0 | k1 << 16: the deep list, the urgent list, the chain's list
-   int n_tasks, n_deep, n_urgent, ntc, ld;   // n_tasks = all of them: [0, n_deep) deep, [n_deep, n_deep + n_urgent) urgent, the rest the chain's
+   const TileTask* tasks;   // blk = kind (0 UPD, 1 TRSM, 2 DIAG), ti, tj, pad = k0 | k1 << 16: the bulk list, then the chain's list
+   int n_tasks, n_bulk, ntc, ld;   // n_tasks = all of them: [0, n_bulk) bulk, the rest the chain's
    double *C, *R, *U, *winv, *dtail;
    const double* pref;
    const signed char* psign;
    int* inertia;
-   int* ctl;                // [0] ticket of the deep list, [1] error word, [2] ticket of the chain's list, [3] the chain's compute unit (key + 1),
-                            // [4] ticket of the urgent list, [5] a diagonal tile is being factorised
+   int* ctl;                // [0] ticket of the bulk list, [1] error word, [2] ticket of the chain's list, [3] the chain's compute unit (key + 1)
    int *prog, *rowdone, *dready;
    const BlkDesc* blk;      // thr_rel / repl_rel / repl_abs / m of the one block
    long long poll_limit;
@@ -307,6 +306,49 @@ __device__ __forceinline__ double fma3(double nm, double sv, double in) {
    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(nm), "v"(sv), "v"(in));
    return out;
 }
+// pivots 8 P .. 8 P + 7 of root_diag_wave: 32 - 8 P places of v are alive
+template <int P>
+__device__ __forceinline__ void root_diag_wave_steps(double (&v)[DB], double* __restrict__ mine, const double* __restrict__ S1, bool lo, int r) {
+   constexpr int NC = DB - 8 * P;   // v[0 .. NC)
+#pragma unroll 1
+   for (int k = 8 * P; k < 8 * P + 8; ++k) {
+      mine[k * DLD] = v[0];
+      const double piv = root_readlane_f64(v[0], k);
+      const double dinv = pivot_rcp(piv);
+      const double nm = (lo && r <= k) ? 0.0 : -(v[0] * dinv);
+      // (the line beyond row 31 is whatever follows in LDS: it only reaches places of v that are spent)
+      const double* s = S1 + k * DLD + k;
+      double sa[8], sb[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sa[c] = s[c];
+      if (NC > 8) {
+#pragma unroll
+         for (int c = 0; c < 8; ++c) sb[c] = s[8 + c];
+      }
+#pragma unroll
+      for (int c = 1; c < 8; ++c) v[c - 1] = fma3(nm, sa[c], v[c]);
+      if (NC > 16) {
+#pragma unroll
+         for (int c = 0; c < 8; ++c) sa[c] = s[16 + c];
+      }
+      if (NC > 8) {
+#pragma unroll
+         for (int c = 8; c < 16; ++c) v[c - 1] = fma3(nm, sb[c - 8], v[c]);
+      }
+      if (NC > 24) {
+#pragma unroll
+         for (int c = 0; c < 8; ++c) sb[c] = s[24 + c];
+      }
+      if (NC > 16) {
+#pragma unroll
+         for (int c = 16; c < 24; ++c) v[c - 1] = fma3(nm, sa[c - 16], v[c]);
+      }
+      if (NC > 24) {
+#pragma unroll
+         for (int c = 24; c < 32; ++c) v[c - 1] = fma3(nm, sb[c - 24], v[c]);
+      }
+   }
+}
 __device__ __noinline__ void root_diag_wave(RootDiagShared2* shp, int b, int rows_left, double thr_rel, double repl_rel, double repl_abs,
                                             double* __restrict__ Lout, int ld) {
    RootDiagShared2& sh = *shp;
@@ -325,30 +367,11 @@ __device__ __noinline__ void root_diag_wave(RootDiagShared2* shp, int b, int row
    // The pivots are taken as they come: the rule of fix_pivot is applied to all 32 of them at once after the loop (lane r looks at
    // pivot r), and a sub-block with a pivot the rule rejects makes the whole tile start over in the careful kernel (root_diag_role).
    // On the dependent path of a step: two v_readlane, the reciprocal, one multiply.
-#pragma unroll 1
-   for (int k = 0; k < DB; ++k) {
-      mine[k * DLD] = v[0];
-      const double piv = root_readlane_f64(v[0], k);
-      const double dinv = pivot_rcp(piv);
-      const double nm = (lo && r <= k) ? 0.0 : -(v[0] * dinv);
-      // (the line beyond row 31 is whatever follows in LDS: it only reaches places of v that are spent)
-      const double* s = S1 + k * DLD + k;
-      double sa[8], sb[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { sa[c] = s[c]; sb[c] = s[8 + c]; }
-#pragma unroll
-      for (int c = 1; c < 8; ++c) v[c - 1] = fma3(nm, sa[c], v[c]);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) sa[c] = s[16 + c];
-#pragma unroll
-      for (int c = 8; c < 16; ++c) v[c - 1] = fma3(nm, sb[c - 8], v[c]);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) sb[c] = s[24 + c];
-#pragma unroll
-      for (int c = 16; c < 24; ++c) v[c - 1] = fma3(nm, sa[c - 16], v[c]);
-#pragma unroll
-      for (int c = 24; c < 32; ++c) v[c - 1] = fma3(nm, sb[c - 24], v[c]);
-   }
+   // (four loops of eight pivots: after 8 p pivots only 32 - 8 p places of v are alive - 31, 23, 15, 7 multiply-adds per pivot instead of 31)
+   root_diag_wave_steps<0>(v, mine, S1, lo, r);
+   root_diag_wave_steps<1>(v, mine, S1, lo, r);
+   root_diag_wave_steps<2>(v, mine, S1, lo, r);
+   root_diag_wave_steps<3>(v, mine, S1, lo, r);
    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
    // pivot r as it was taken (the diagonal of L D), the rule, the counts
    {
@@ -535,7 +558,6 @@ __device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s
       ok = root_wait_ge(a.prog + (long long)tj * ntc + tj, tj, a.poll_limit, &s_ok);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 1] = wall_clock64();
       if (ok) {
-         if (tid == 0) __hip_atomic_store(a.ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the unit's other workgroup starts no update beside the pivots)
          bool done = false;
          if (a.diag_blocked) done = root_diag_blocked(a, sh.d2, tj);
          if (!done) {
@@ -545,7 +567,6 @@ __device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s
       }
       else if (tid == 0) a.ctl[1] = 1;
       root_publish(a.dready + tj, 1);
-      if (tid == 0) __hip_atomic_store(a.ctl + 5, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
       return;
    }
@@ -613,24 +634,7 @@ __device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s
    if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
 }
 
-// are the tasks a task waits for finished?  (thread 0 only; the same conditions root_task waits for)
-__device__ __forceinline__ bool root_task_ready(const RootArgs& a, const TileTask& task) {
-   auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-   const int ti = task.ti, tj = task.tj, ntc = a.ntc;
-   if (task.blk == ROOT_DIAG) return ld(a.prog + (long long)tj * ntc + tj) >= tj;
-   if (task.blk == ROOT_TRSM) return ld(a.dready + tj) >= 1 && ld(a.prog + (long long)ti * ntc + tj) >= tj;
-   const int k0 = task.pad & 0xffff, k1 = task.pad >> 16;
-   return ld(a.rowdone + ti) >= k1 && ld(a.rowdone + tj) >= k1 && ld(a.prog + (long long)ti * ntc + tj) >= k0;
-}
-// the head of a list if it is ready (and still the head when claimed): its index in the joint list, else -1
-__device__ __forceinline__ int root_try_take(const RootArgs& a, int base, int n, int* ticket) {
-   const int h = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-   if (h >= n) return -1;
-   if (!root_task_ready(a, a.tasks[base + h])) return -1;
-   int expected = h;
-   return __hip_atomic_compare_exchange_strong(ticket, &expected, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? base + h : -1;
-}
-// the next task of a list whatever its state (the workgroup will wait inside root_task), -1 when the list is empty
+// the next task of a list (the workgroup waits inside root_task for what the task needs), -1 when the list is empty
 __device__ __forceinline__ int root_draw(int base, int n, int* ticket) {
    if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) return -1;
    const int c = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -640,21 +644,20 @@ __device__ __forceinline__ int root_draw(int base, int n, int* ticket) {
 __global__ __launch_bounds__(512, 4) void k_root_ldl(RootArgs a) {
    __shared__ RootShared sh;
    __shared__ int s_t, s_ok, s_mine;
-   // Three lists, each in the order of the schedule (rootplan.cpp).
-   //  The chain's: DIAG j -> TRSM (j + 1, j) -> last update of C(j + 1, j + 1) -> DIAG j + 1 is strictly sequential and every column waits
-   //  for it; beside the matrix-pipe waves of an update tile its 128 dependent pivots take 2.4 x as long (traced).  So the compute unit the
-   //  launch's first workgroup lands on belongs to the chain: a workgroup that starts there STAYS, takes the head of the chain's list when
-   //  it is ready, else (no diagonal tile being factorised on the unit) the head of the urgent list when that is ready, else looks again.
-   //  Urgent: any other workgroup looks at the head of the urgent list first and takes it only if it can run at once; otherwise it draws
-   //  from the deep list, does that one task - waiting inside it if it must - and leaves.  A workgroup that finds the deep list empty
-   //  draws from the urgent list, then from the chain's.
-   // No cycle of waiting workgroups: all three lists are subsequences of ONE topological order and each is taken in order.  Let x be the
-   // first task of that order which is not finished; everything it waits for is.  On the deep list it is drawn already, or is the next
-   // ticket while every deep task in a slot is later than x - impossible, they were drawn before it - so a slot is free or frees up.  On
-   // the urgent or the chain's list it is the head, ready, and the chain's two workgroups never wait inside a task.
+   // Two lists, each in the order of the schedule (rootplan.cpp).  The chain of the diagonal tiles - DIAG j -> TRSM (j + 1, j) -> last
+   // update of C(j + 1, j + 1) -> DIAG j + 1 - is strictly sequential and every column waits for it; beside the matrix-pipe waves of an
+   // update tile its 128 dependent pivots take 2.4 x as long (traced).  So the compute unit the launch's first workgroup lands on belongs
+   // to the chain: a workgroup that starts there STAYS and draws from the chain's list until it is empty (one of the two works, the other
+   // waits for its turn: nothing competes for the unit's issue slots); every other workgroup takes one task of the bulk list and leaves;
+   // whoever finds its own list empty helps with the other.
+   // No cycle of waiting workgroups: both lists are subsequences of ONE topological order and each is drawn in order.  Let x be the first
+   // task of that order which is not finished; everything it waits for is.  If x is drawn it runs.  If not, it is the next ticket of its
+   // list and every drawn task of that list is earlier, hence finished: on the chain's list its two resident workgroups are free to draw
+   // it (they do not depend on the dispatcher sending more workgroups - the first version did, and hung once the chain unit's XCD had
+   // used up its share of the grid); on the bulk list the slots those tasks held are free.
    if (threadIdx.x == 0) {
       int mine = 0;
-      if (a.n_tasks > a.n_deep + a.n_urgent) {
+      if (a.n_tasks > a.n_bulk) {
          const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID */), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID[3:0] */);
          const int key = 1 + (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));   // XCC, shader engine / array, compute unit
          int seen = __hip_atomic_load(a.ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -668,28 +671,11 @@ __global__ __launch_bounds__(512, 4) void k_root_ldl(RootArgs a) {
    }
    __syncthreads();
    const bool mine = s_mine != 0;
-   const int ub = a.n_deep, cb = a.n_deep + a.n_urgent, n_chain = a.n_tasks - cb;
+   const int n_chain = a.n_tasks - a.n_bulk;
    for (;;) {
       if (threadIdx.x == 0) {
-         int t = -1;
-         if (mine) {
-            long long spins = 0;
-            for (;;) {
-               t = root_try_take(a, cb, n_chain, a.ctl + 2);
-               if (t < 0 && __hip_atomic_load(a.ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) t = root_try_take(a, ub, a.n_urgent, a.ctl + 4);
-               if (t >= 0) break;
-               const bool chain_empty = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_chain;
-               const bool urgent_empty = __hip_atomic_load(a.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_urgent;
-               if (chain_empty && urgent_empty) { t = root_draw(0, a.n_deep, a.ctl); break; }   // (-1: everything is taken)
-               __builtin_amdgcn_s_sleep(2);
-               if (++spins > a.poll_limit) { a.ctl[1] = 1; t = root_draw(cb, n_chain, a.ctl + 2); if (t < 0) t = root_draw(ub, a.n_urgent, a.ctl + 4); break; }
-            }
-         } else {
-            t = root_try_take(a, ub, a.n_urgent, a.ctl + 4);
-            if (t < 0) t = root_draw(0, a.n_deep, a.ctl);
-            if (t < 0) t = root_draw(ub, a.n_urgent, a.ctl + 4);
-            if (t < 0) t = root_draw(cb, n_chain, a.ctl + 2);
-         }
+         int t = mine ? root_draw(a.n_bulk, n_chain, a.ctl + 2) : root_draw(0, a.n_bulk, a.ctl);
+         if (t < 0) t = mine ? root_draw(0, a.n_bulk, a.ctl) : root_draw(a.n_bulk, n_chain, a.ctl + 2);
          s_t = t;
       }
       __syncthreads();

@@ -20,9 +20,8 @@
 
 namespace pips {
 
-int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& urgent_tasks, std::vector<int>& chain_tasks, double* makespan_us) {
+int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& chain_tasks, double* makespan_us) {
    tasks.clear();
-   urgent_tasks.clear();
    chain_tasks.clear();
    if (ntc <= 0) return PIPS_OK;
    const int W = std::max(p.workers, 1);
@@ -33,7 +32,7 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
    struct Cand { int prio, j, i; };
    auto worse = [](const Cand& a, const Cand& b) { return a.prio != b.prio ? a.prio > b.prio : (a.j != b.j ? a.j > b.j : a.i > b.i); };
    typedef std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> Heap;
-   Heap heaps[3] = {Heap(worse), Heap(worse), Heap(worse)};   // 0 the chain's, 1 urgent, 2 deep
+   Heap heaps[3] = {Heap(worse), Heap(worse), Heap(worse)};   // 0 the chain's, 2 everything else (1 unused)
    struct Event { double t; long long seq; int kind, i, j, k1, cls; };
    auto later = [](const Event& a, const Event& b) { return a.t != b.t ? a.t > b.t : a.seq > b.seq; };
    std::priority_queue<Event, std::vector<Event>, decltype(later)> events(later);
@@ -51,21 +50,16 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
       if (a == j || q >= p.qmin || urgent) { k1 = a; return 0; }
       return -1;
    };
-   // Three classes, three lists (each in the order its tasks start here):
+   // Two classes, two lists (each in the order its tasks start here):
    //  0 the chain's own: DIAG (j), TRSM (j + 1, j), the update that completes C(j + 1, j + 1) - strictly sequential, on the compute unit
-   //    the launch keeps for them;
-   //  1 urgent: what the chain needs next from the tiles within urgent_width of the diagonal - their trsm, the updates that complete them,
-   //    the shallow updates of the tiles right at the chain.  The critical path needs tile (j + 1, j) complete when DIAG j ends, which needs
-   //    TRSM (j + 1, j - 1) one step earlier, and so on: a tile d below the diagonal has d - 1 chain steps of slack.  In ONE list with the
-   //    deep updates such a task waits for its turn behind a few hundred of them (traced: the completing update of (60, 59) was drawn
-   //    270 us after it could have run); from its own list any arriving workgroup takes it the moment it is ready;
-   //  2 deep: everything else.
+   //    the launch keeps for them (chain_width > 1 adds the trsm / completing updates of the next diagonals: measured slower, the unit's
+   //    second workgroup then multiplies beside the pivots);
+   //  2 everything else.
+   // (Also built and measured, S = 16 000, against 29.6 ms with these two: an "urgent" list for the tiles next to the chain that any
+   //  arriving workgroup takes the moment its head is ready, 31.8 ms - in order, so a head that is not ready blocks the ones behind it; and
+   //  a second unit of its own for the next diagonals, 29.5 - 30.1 ms - the waiting only moves one diagonal further out.  Removed.)
    auto task_class = [&](int kind, int i, int j, int k1) {
       if (p.chain_slots > 0 && (kind == 2 || (kind == 1 && i - j <= p.chain_width) || (kind == 0 && k1 == j && i - j < p.chain_width))) return 0;
-      if (p.urgent_width > 0) {
-         if (kind == 1 && i - j <= p.urgent_width) return 1;
-         if (kind == 0 && ((k1 == j && i - j < p.urgent_width) || (j <= chain + p.urgent && i <= j + p.urgent))) return 1;
-      }
       return 2;
    };
    auto consider = [&](int i, int j) {
@@ -103,7 +97,7 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
             const bool alone = cls == 0 || W - free_slots < W / 2;   // fewer workgroups than compute units: a tile has its matrix pipe to itself
             const double dur = kind == 2 ? p.t_diag : (kind == 1 ? (alone ? p.t_trsm_alone : p.t_trsm) : p.t0 + (k1 - k0) * (alone ? p.t_step_alone : p.t_step));
             busy[at(c.i, c.j)] = 1;
-            std::vector<int>& out = cls == 0 ? chain_tasks : (cls == 1 ? urgent_tasks : tasks);
+            std::vector<int>& out = cls == 0 ? chain_tasks : tasks;
             out.push_back(kind);
             out.push_back(c.i);
             out.push_back(c.j);
@@ -146,26 +140,22 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
 }  // namespace pips
 
 // C entry for the tests (no device involved): tasks as (kind, i, j, k0 | k1 << 16) quadruples
-extern "C" int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int urgent_width, int* out, long long cap, long long* n_tasks,
-                                    long long* n_urgent_tasks, long long* n_chain_tasks, double* makespan_us) {
+extern "C" int pips_root_plan_build(int ntc, int workers, int qmin, int urgent, int chain_slots, int* out, long long cap, long long* n_tasks,
+                                    long long* n_chain_tasks, double* makespan_us) {
    pips::RootPlanParams p;
    if (workers > 0) p.workers = workers;
    if (qmin > 0) p.qmin = qmin;
    if (urgent >= 0) p.urgent = urgent;
    if (chain_slots >= 0) p.chain_slots = chain_slots;
-   if (urgent_width >= 0) p.urgent_width = urgent_width;
-   std::vector<int> tasks, urg, chain;
-   const int rc = pips::build_root_plan(ntc, p, tasks, urg, chain, makespan_us);
+   std::vector<int> tasks, chain;
+   const int rc = pips::build_root_plan(ntc, p, tasks, chain, makespan_us);
    if (rc) return rc;
    if (n_tasks) *n_tasks = (long long)tasks.size() / 4;
-   if (n_urgent_tasks) *n_urgent_tasks = (long long)urg.size() / 4;
    if (n_chain_tasks) *n_chain_tasks = (long long)chain.size() / 4;
-   if (out) {   // the deep list, the urgent list, the chain's list
-      if ((long long)(tasks.size() + urg.size() + chain.size()) > cap)
-         PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_root_plan_build: %zu ints needed, %lld given", tasks.size() + urg.size() + chain.size(), cap);
+   if (out) {   // the bulk list, then the chain's list
+      if ((long long)(tasks.size() + chain.size()) > cap) PIPS_FAIL(pips::PIPS_ERR_ARG, "pips_root_plan_build: %zu ints needed, %lld given", tasks.size() + chain.size(), cap);
       std::copy(tasks.begin(), tasks.end(), out);
-      std::copy(urg.begin(), urg.end(), out + tasks.size());
-      std::copy(chain.begin(), chain.end(), out + tasks.size() + urg.size());
+      std::copy(chain.begin(), chain.end(), out + tasks.size());
    }
    return pips::PIPS_OK;
 }

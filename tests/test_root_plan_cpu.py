@@ -12,17 +12,16 @@ lib = pa.capi.lib
 lib.pips_root_plan_build.restype = C.c_int
 
 
-def build(ntc, workers=-1, qmin=-1, urgent=-1, chain_slots=-1, urgent_width=-1):
-    n, nu, nc, ms = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_double()
-    rc = lib.pips_root_plan_build(ntc, workers, qmin, urgent, chain_slots, urgent_width, None, C.c_longlong(0), C.byref(n), C.byref(nu), C.byref(nc), C.byref(ms))
+def build(ntc, workers=-1, qmin=-1, urgent=-1, chain_slots=-1):
+    n, nc, ms = C.c_longlong(), C.c_longlong(), C.c_double()
+    rc = lib.pips_root_plan_build(ntc, workers, qmin, urgent, chain_slots, None, C.c_longlong(0), C.byref(n), C.byref(nc), C.byref(ms))
     assert rc == 0
-    tot = n.value + nu.value + nc.value
-    out = np.zeros(4 * tot, dtype=np.int32)
-    rc = lib.pips_root_plan_build(ntc, workers, qmin, urgent, chain_slots, urgent_width, out.ctypes.data_as(C.POINTER(C.c_int)), C.c_longlong(out.size),
-                                  C.byref(n), C.byref(nu), C.byref(nc), C.byref(ms))
+    out = np.zeros(4 * (n.value + nc.value), dtype=np.int32)
+    rc = lib.pips_root_plan_build(ntc, workers, qmin, urgent, chain_slots, out.ctypes.data_as(C.POINTER(C.c_int)), C.c_longlong(out.size),
+                                  C.byref(n), C.byref(nc), C.byref(ms))
     assert rc == 0
     t = out.reshape(-1, 4)
-    return t[:n.value], t[n.value:n.value + nu.value], t[n.value + nu.value:], ms.value
+    return t[:n.value], t[n.value:], ms.value
 
 
 def replay(ntc, lists):
@@ -70,23 +69,24 @@ def replay(ntc, lists):
 
 
 @pytest.mark.parametrize("ntc", [1, 2, 3, 5, 16, 40])
-@pytest.mark.parametrize("variant", ["default", "one_list", "urgent_list", "few_workers"])
+@pytest.mark.parametrize("variant", ["default", "one_list", "few_workers"])
 def test_lists_are_consistent_with_the_tile_dag(ntc, variant):
-    kw = {"default": {}, "one_list": dict(chain_slots=0), "urgent_list": dict(urgent_width=4), "few_workers": dict(workers=3, qmin=2)}[variant]
-    deep, urg, chain, makespan = build(ntc, **kw)
-    assert len(deep) + len(urg) + len(chain) >= ntc * (ntc + 1) // 2
+    kw = {"default": {}, "one_list": dict(chain_slots=0), "few_workers": dict(workers=3, qmin=2)}[variant]
+    bulk, chain, makespan = build(ntc, **kw)
+    assert len(bulk) + len(chain) >= ntc * (ntc + 1) // 2
     if variant == "one_list":
-        assert len(chain) == 0 and len(urg) == 0
+        assert len(chain) == 0
     if variant == "default" and ntc >= 2:
-        assert len(chain) >= 2 * ntc - 1 and len(urg) == 0     # DIAG (j), TRSM (j + 1, j), the completing update of the next diagonal tile
-    replay(ntc, [deep, urg, chain])
+        assert len(chain) >= 2 * ntc - 1     # DIAG (j), TRSM (j + 1, j), the completing update of the next diagonal tile
+    replay(ntc, [bulk, chain])
     assert makespan > 0
 
 
 def test_far_tiles_are_updated_deeply():
     """What the schedule is for: tiles far right of the chain take their columns in few, deep pieces (the update kernel's efficient regime)."""
-    deep, urg, chain, _ = build(125)
-    upd = deep[deep[:, 0] == 0]
+    bulk, chain, _ = build(125)
+    upd = bulk[bulk[:, 0] == 0]
     depth = (upd[:, 3] >> 16) - (upd[:, 3] & 0xffff)
     assert depth.mean() > 10
-    assert (depth * 1.0).sum() + sum(((l[l[:, 0] == 0][:, 3] >> 16) - (l[l[:, 0] == 0][:, 3] & 0xffff)).sum() for l in (urg, chain)) == sum(j * (125 - j) for j in range(125))
+    cu = chain[chain[:, 0] == 0]
+    assert depth.sum() + ((cu[:, 3] >> 16) - (cu[:, 3] & 0xffff)).sum() == sum(j * (125 - j) for j in range(125))
