@@ -57,7 +57,10 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
    //  2 everything else.
    // (Also built and measured, S = 16 000, against 29.6 ms with these two: an "urgent" list for the tiles next to the chain that any
    //  arriving workgroup takes the moment its head is ready, 31.8 ms - in order, so a head that is not ready blocks the ones behind it; and
-   //  a second unit of its own for the next diagonals, 29.5 - 30.1 ms - the waiting only moves one diagonal further out.  Removed.)
+   //  a second unit of its own for the next diagonals, 29.5 - 30.1 ms - the waiting only moves one diagonal further out; and a head start
+   //  of 128 - 400 places in the bulk list for the trsm / completing updates next to the chain: no change, the chain then waits for the
+   //  tile's update before that one.  What the chain waits for where the chip is saturated is bulk work next to it that is in line
+   //  behind a few hundred deep updates; only a scheduler with priorities, not a list, takes that away.  Removed.)
    auto task_class = [&](int kind, int i, int j, int k1) {
       if (p.chain_slots > 0 && (kind == 2 || (kind == 1 && i - j <= p.chain_width) || (kind == 0 && k1 == j && i - j < p.chain_width))) return 0;
       return 2;
@@ -129,7 +132,6 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
          consider(e.i, e.j);
       }
    }
-   // (every trsm has been started: a diagonal tile needs its row complete; the last events only retire)
    if (makespan_us) {
       while (!events.empty()) { t = std::max(t, events.top().t); events.pop(); }
       *makespan_us = t;
