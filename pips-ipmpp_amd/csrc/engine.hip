@@ -2243,45 +2243,45 @@ struct Engine {
       return PIPS_OK;
    }
 
-   // The interleaved multi-vector sweep reads every entry of L once per chunk instead of once per right-hand side, but runs
-   // one workgroup per tile / supernode instead of one per (tile, right-hand side): it pays when the per-right-hand-side
-   // sweeps would be bandwidth-bound (many blocks with dense tails), not when a chunk is a latency chain anyway (a single
-   // block, sparse structured factors).  Measured: one config-2 block, 256 rhs: 11 ms separate / 43 ms interleaved.
+   // The interleaved multi-vector sweep reads every entry of L once per panel of 32 right-hand sides instead of once per right-hand side
+   // and multiplies on the matrix pipe; the per-right-hand-side sweeps (grid.y = right-hand side) re-read L each time.  Round 2 measured
+   // one config-2 block, 256 rhs: 11 ms separate / 43 ms interleaved - with a scalar multiply-add loop in the tile kernels; with the
+   // matrix-pipe tiles and all panels in every launch the interleaved sweep wins from a few right-hand sides on.
    bool use_multi(int nr) const {
       if (const char* f = getenv("PIPS_HIP_MULTI")) return atoi(f) != 0 && nr >= 2;
-      double tail_bytes = 0.0;
-      for (const BlockSym& s : sym) tail_bytes += 4.0 * (double)s.m_pad * s.m_pad;
-      return nr >= 8 && tail_bytes * nr > 6.0e9;
+      return nr >= 8;
    }
 
-   // up to MQ right-hand sides at X + q * x_stride in one interleaved sweep (kernels.hip.h "multi-vector solves"); xm holds
-   // MQ * xw_total doubles
+   // nr right-hand sides at X + q * x_stride in one interleaved sweep (kernels.hip.h "multi-vector solves"): panels of MQ, every launch
+   // takes all of them (grid.y / grid.z); xm holds ceil(nr / MQ) * MQ * xw_total doubles
    int solve_once_multi(double* X, int nr, long long x_stride, double* xm) {
-      const dim3 pg(64, nblk);
-      hipLaunchKernelGGL(k_mpermute, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, X, x_stride, nr, xm, 0);
+      const int np = (nr + MQ - 1) / MQ;
+      const long long ps = (long long)MQ * xw_total;
+      const dim3 pg(64, nblk, np);
+      hipLaunchKernelGGL(k_mpermute, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, X, x_stride, nr, xm, 0, ps);
       auto head = [&](const LevelRange& L, int backward) {
          const int cnt = L.simple_cnt + L.small_cnt + L.large_cnt;   // contiguous: sorted by (level, class)
          if (cnt == 0) return;
          const int begin = L.simple_cnt > 0 ? L.simple_begin : (L.small_cnt > 0 ? L.small_begin : L.large_begin);
-         hipLaunchKernelGGL(k_mhead, dim3((cnt + 3) / 4), dim3(256), 0, stream, d_sns, begin, cnt, d_blks, d_rowidx, d_arena, xm, backward);
+         hipLaunchKernelGGL(k_mhead, dim3((cnt + 3) / 4, np), dim3(256), 0, stream, d_sns, begin, cnt, d_blks, d_rowidx, d_arena, xm, backward, ps);
       };
       for (const LevelRange& L : levels) head(L, 0);
       for (const LevelRange& L : levels_top) head(L, 0);
       const TailPlan& p = plan;
       for (int j = 0; j < p.ntc_max; ++j)
          if (p.fwd[j].cnt > 0)
-            hipLaunchKernelGGL(k_mtail_fwd, dim3(p.fwd[j].cnt), dim3(256), 0, stream, p.d_tasks + p.fwd[j].off, d_blks, d_arena, d_dtail,
-                               d_winv, xm, j);
+            hipLaunchKernelGGL(k_mtail_fwd, dim3(p.fwd[j].cnt, np), dim3(256), 0, stream, p.d_tasks + p.fwd[j].off, d_blks, d_arena, d_dtail,
+                               d_winv, xm, j, ps);
       if (nsn_total > 0)
-         hipLaunchKernelGGL(k_mhead_dscale, dim3(grid_for((long long)nsn_total * MQ, 256)), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
-                            d_arena, xm);
+         hipLaunchKernelGGL(k_mhead_dscale, dim3(grid_for((long long)nsn_total * MQ, 256), np), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
+                            d_arena, xm, ps);
       for (int i = p.ntc_max - 1; i >= 0; --i)
          if (p.bwd[i].cnt > 0)
-            hipLaunchKernelGGL(k_mtail_bwd, dim3(p.bwd[i].cnt), dim3(256), 0, stream, p.d_tasks + p.bwd[i].off, d_blks, d_arena, d_dtail,
-                               d_winv, xm, i);
+            hipLaunchKernelGGL(k_mtail_bwd, dim3(p.bwd[i].cnt, np), dim3(256), 0, stream, p.d_tasks + p.bwd[i].off, d_blks, d_arena, d_dtail,
+                               d_winv, xm, i, ps);
       for (int l = (int)levels_top.size() - 1; l >= 0; --l) head(levels_top[l], 1);
       for (int l = (int)levels.size() - 1; l >= 0; --l) head(levels[l], 1);
-      hipLaunchKernelGGL(k_mpermute, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, X, x_stride, nr, xm, 1);
+      hipLaunchKernelGGL(k_mpermute, pg, dim3(256), 0, stream, d_blks, d_perm, d_perm_off, X, x_stride, nr, xm, 1, ps);
       HIP_TRY(hipGetLastError());
       return PIPS_OK;
    }
@@ -2291,14 +2291,17 @@ struct Engine {
    // length n_total at distance x_stride.
    double *d_mx_xw = nullptr, *d_mx_rhs = nullptr, *d_mx_res = nullptr;
    int mx_cap = 0;
-   int ensure_multi_buffers() {
-      const int chunk_max = 32;
-      if (mx_cap == 0) {
+   static constexpr int MULTI_CHUNK_MAX = 256;   // right-hand sides per pass (eight panels)
+   int ensure_multi_buffers(int want = 32) {
+      want = std::min(MULTI_CHUNK_MAX, (std::max(want, 32) + MQ - 1) / MQ * MQ);
+      if (mx_cap < want) {
          HIP_TRY(hipSetDevice(device));
-         HIP_TRY(hipMalloc((void**)&d_mx_xw, (size_t)chunk_max * std::max<long long>(xw_total, 1) * sizeof(double)));
-         HIP_TRY(hipMalloc((void**)&d_mx_rhs, (size_t)chunk_max * std::max<long long>(n_total, 1) * sizeof(double)));
-         HIP_TRY(hipMalloc((void**)&d_mx_res, (size_t)chunk_max * std::max<long long>(n_total, 1) * sizeof(double)));
-         mx_cap = chunk_max;
+         HIP_TRY(hipStreamSynchronize(stream));
+         for (double** p : {&d_mx_xw, &d_mx_rhs, &d_mx_res}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+         HIP_TRY(hipMalloc((void**)&d_mx_xw, (size_t)want * std::max<long long>(xw_total, 1) * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_mx_rhs, (size_t)want * std::max<long long>(n_total, 1) * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_mx_res, (size_t)want * std::max<long long>(n_total, 1) * sizeof(double)));
+         mx_cap = want;
       }
       return PIPS_OK;
    }
@@ -2310,8 +2313,9 @@ struct Engine {
             if (int rc = solve(X_dev + (long long)r * x_stride)) return rc;
          return PIPS_OK;
       }
-      const int chunk_max = 32;
-      int rc0 = ensure_multi_buffers();
+      const bool multi = use_multi(nrhs);
+      const int chunk_max = multi ? MULTI_CHUNK_MAX : 32;   // (the per-right-hand-side sweeps keep their 32 work vectors)
+      int rc0 = ensure_multi_buffers(std::min(nrhs, chunk_max));
       if (rc0) return rc0;
       for (int r0 = 0; r0 < nrhs; r0 += chunk_max) {
          const int nr = std::min(chunk_max, nrhs - r0);
@@ -2319,7 +2323,7 @@ struct Engine {
          if (refine_steps > 0)
             HIP_TRY(hipMemcpy2DAsync(d_mx_rhs, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
                                      (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
-         int rc = use_multi(nr) ? solve_once_multi(X, nr, x_stride, d_mx_xw) : solve_once(X, nr, x_stride, d_mx_xw);
+         int rc = multi ? solve_once_multi(X, nr, x_stride, d_mx_xw) : solve_once(X, nr, x_stride, d_mx_xw);
          if (rc) return rc;
          for (int it = 0; it < refine_steps; ++it) {
             HIP_TRY(hipMemcpyAsync(d_mx_res, d_mx_rhs, (size_t)nr * n_total * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -2332,11 +2336,9 @@ struct Engine {
             if (n_flong > 0)
                hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong, nr), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval,
                                   d_mx_xw, d_mx_res, d_rowbase, n_total);
-            rc = use_multi(nr) ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
+            rc = multi ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
             if (rc) return rc;
-            for (int r = 0; r < nr; ++r)
-               hipLaunchKernelGGL(k_axpy, dim3(grid_for(n_total, 256)), dim3(256), 0, stream, X + (long long)r * x_stride,
-                                  d_mx_res + (long long)r * n_total, 1.0, n_total);
+            hipLaunchKernelGGL(k_maxpy, dim3(grid_for(n_total, 256, 1024), nr), dim3(256), 0, stream, X, x_stride, d_mx_res, n_total, 1.0, n_total);
          }
       }
       HIP_TRY(hipGetLastError());

@@ -2924,11 +2924,16 @@ __global__ void k_border_collect(const BlkDesc* __restrict__ blks, const int* __
 // ------------------------------------------------------------------------------------------------
 constexpr int MQ = 32;
 
-// grid (x, block); transposing gather / scatter between nr vectors at distance x_stride and the interleaved work array
+// grid (x, block, panel); transposing gather / scatter between nr vectors at distance x_stride and the interleaved work array.  More than
+// MQ right-hand sides go in PANELS of MQ: panel p is an interleaved work array of its own at xm + p * panel_stride (right-hand sides
+// 32 p .. 32 p + 31), and every multi-vector kernel takes its panel from the grid
 __global__ void k_mpermute(const BlkDesc* __restrict__ blks, const int* __restrict__ perm, const long long* __restrict__ perm_off,
-                           double* __restrict__ x, long long x_stride, int nr, double* __restrict__ xm, int out) {
+                           double* __restrict__ x, long long x_stride, int nr, double* __restrict__ xm, int out, long long panel_stride = 0) {
    const BlkDesc bd = blks[blockIdx.y];
    const int* p = perm + perm_off[blockIdx.y];
+   xm += panel_stride * blockIdx.z;
+   x += (long long)MQ * blockIdx.z * x_stride;
+   nr = min(MQ, nr - MQ * (int)blockIdx.z);
    const long long len = (long long)(out ? bd.n : bd.n_head + bd.m_pad) * MQ;
    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < len; idx += (long long)gridDim.x * blockDim.x) {
       const int k = (int)(idx / MQ), q = (int)(idx % MQ);
@@ -3007,9 +3012,10 @@ __device__ __forceinline__ void mhead_body(const SnDesc& sn, const BlkDesc& bd, 
 
 __global__ __launch_bounds__(256) void k_mhead(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                               const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xm, int backward) {
+                                              const double* __restrict__ arena, double* __restrict__ xm, int backward, long long panel_stride = 0) {
    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
    if (i >= cnt) return;
+   xm += panel_stride * blockIdx.y;
    const SnDesc sn = sns[sn_begin + i];
    const BlkDesc bd = blks[sn.blk];
    if (sn.w == 1) mhead_body<1>(sn, bd, rowidx, arena, xm, backward);
@@ -3018,7 +3024,8 @@ __global__ __launch_bounds__(256) void k_mhead(const SnDesc* __restrict__ sns, i
 }
 
 __global__ void k_mhead_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,
-                               const double* __restrict__ arena, double* __restrict__ xm) {
+                               const double* __restrict__ arena, double* __restrict__ xm, long long panel_stride = 0) {
+   xm += panel_stride * blockIdx.y;
    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (long long)nsn * MQ; idx += (long long)gridDim.x * blockDim.x) {
       const SnDesc sn = sns[idx / MQ];
       const BlkDesc bd = blks[sn.blk];
@@ -3027,13 +3034,17 @@ __global__ void k_mhead_dscale(const SnDesc* __restrict__ sns, int nsn, const Bl
    }
 }
 
-// acc[i] -= sum_c M(g*16 + i, c) V[c][q]   (TRANSPOSED = 0)   or   acc[i] -= sum_r M(r, g*16 + i) V[r][q]   (TRANSPOSED = 1)
-// for a 128 x 128 column-major tile M.  256 threads: q = tid & 31, g = tid >> 5.  The tile is staged through LDS sixteen
-// columns (rows) at a time with coalesced loads; inside a 32-lane group the staged entry is a broadcast read.
+// acc += sign * M V (TRANSPOSED = 0) or sign * M^T V (TRANSPOSED = 1) for a 128 x 128 column-major tile M and 32 right-hand sides V[k][q]
+// (the interleaved layout IS the [k][column] image the matrix-pipe fragments are read from), on the FP64 matrix cores: 256 threads = 4
+// waves, wave w owns rows 32 w .. 32 w + 31 of the result, a lane the elements (row 32 w + 16 h + (lane & 15), right-hand side 4 c +
+// (lane >> 4)), h < 2, c < 8.  The tile is staged through LDS sixteen k at a time, as the [k][row] image in both cases (the transposed
+// case transposes while staging).  (The round-2 version was a scalar multiply-add loop over the LDS tile: DoubleLinearSolver::solve(nrhs)
+// behind the adapters spent 11 of its 13 ms per 160 right-hand sides there and in re-reading L per right-hand side.)
+constexpr int MVQ = MQ + 8;   // LDS row length of V: the four k of a fragment read land in different banks
 template <int TRANSPOSED>
-__device__ __forceinline__ void mtile_apply(double (&acc)[16], const double* __restrict__ M, long long ldm,
-                                            const double (*V)[MQ], double (*Lt)[TILE + 1], int tid, double sign) {
-   const int q = tid & 31, g = tid >> 5;
+__device__ __forceinline__ void mtile_apply(double (&acc)[2][8], const double* __restrict__ M, long long ldm,
+                                            const double (*V)[MVQ], double (*Lt)[TILE + 1], int tid, double sign) {
+   const int lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, ej = lane & 3;
    for (int c0 = 0; c0 < TILE; c0 += 16) {
       __syncthreads();
       if (!TRANSPOSED) {
@@ -3051,28 +3062,36 @@ __device__ __forceinline__ void mtile_apply(double (&acc)[16], const double* __r
       }
       __syncthreads();
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) {
-         const double v = sign * V[c0 + cc][q];
+      for (int st = 0; st < 4; ++st) {
+         const double f0 = Lt[4 * st + ek][32 * w + er], f1 = Lt[4 * st + ek][32 * w + 16 + er];
+         double fc[8];
 #pragma unroll
-         for (int i = 0; i < 16; ++i) acc[i] += Lt[cc][g * 16 + i] * v;
+         for (int c = 0; c < 8; ++c) fc[c] = sign * V[c0 + 4 * st + ek][4 * c + ej];
+#pragma unroll
+         for (int c = 0; c < 8; ++c) {
+            acc[0][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], f0, acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], f1, acc[1][c], 0, 0, 0);
+         }
       }
    }
 }
 
-// tail forward step j for 32 right-hand sides: tiles i >= j:  b_i -= L(i,j-1) (d z)_{j-1} ; tile i == j: z_j = Winv_j b_j
+// tail forward step j for 32 right-hand sides: tiles i >= j:  b_i -= L(i,j-1) (d z)_{j-1} ; tile i == j: z_j = Winv_j b_j.  grid (tasks, panels)
 __global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                   const double* __restrict__ arena, const double* __restrict__ dtail,
-                                                  const double* __restrict__ winv, double* __restrict__ xm, int j) {
-   __shared__ double V[TILE][MQ];
+                                                  const double* __restrict__ winv, double* __restrict__ xm, int j, long long panel_stride = 0) {
+   __shared__ double V[TILE][MVQ];
    __shared__ double Lt[16][TILE + 1];
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
-   const int tid = threadIdx.x, q = tid & 31, g = tid >> 5, ti = task.ti, ld = bd.ldT;
-   double* xt = xm + (bd.xw_off + bd.n_head) * MQ;
-   double acc[16];
+   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, ti = task.ti, ld = bd.ldT;
+   double* xt = xm + panel_stride * blockIdx.y + (bd.xw_off + bd.n_head) * MQ;
+   double acc[2][8];
 #pragma unroll
-   for (int i = 0; i < 16; ++i) acc[i] = xt[(long long)(ti * TILE + g * 16 + i) * MQ + q];
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[h][c] = xt[(long long)(ti * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
    if (j >= 1) {
       for (int idx = tid; idx < TILE * MQ; idx += 256) {
          const int c = idx >> 5, qq = idx & 31;
@@ -3083,27 +3102,33 @@ __global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ 
    if (ti == j) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { V[g * 16 + i][q] = acc[i]; acc[i] = 0.0; }
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+         for (int c = 0; c < 8; ++c) { V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c]; acc[h][c] = 0.0; }
       mtile_apply<0>(acc, winv + bd.winv_off + (long long)j * TILE * TILE, TILE, V, Lt, tid, 1.0);
    }
 #pragma unroll
-   for (int i = 0; i < 16; ++i) xt[(long long)(ti * TILE + g * 16 + i) * MQ + q] = acc[i];
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xt[(long long)(ti * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek] = acc[h][c];
 }
 
-// tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} ; tile j == i: x_i = Winv_i^T (d_i z_i)
+// tail backward step i (descending): tiles j <= i:  z_j -= L(i+1,j)^T x_{i+1} ; tile j == i: x_i = Winv_i^T (d_i z_i).  grid (tasks, panels)
 __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                   const double* __restrict__ arena, const double* __restrict__ dtail,
-                                                  const double* __restrict__ winv, double* __restrict__ xm, int i) {
-   __shared__ double V[TILE][MQ];
+                                                  const double* __restrict__ winv, double* __restrict__ xm, int i, long long panel_stride = 0) {
+   __shared__ double V[TILE][MVQ];
    __shared__ double Lt[16][TILE + 1];
    const TileTask task = tasks[blockIdx.x];
    if (task.blk < 0) return;
    const BlkDesc bd = blks[task.blk];
-   const int tid = threadIdx.x, q = tid & 31, g = tid >> 5, tj = task.ti, ld = bd.ldT;
-   double* xt = xm + (bd.xw_off + bd.n_head) * MQ;
-   double acc[16];
+   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, tj = task.ti, ld = bd.ldT;
+   double* xt = xm + panel_stride * blockIdx.y + (bd.xw_off + bd.n_head) * MQ;
+   double acc[2][8];
 #pragma unroll
-   for (int e = 0; e < 16; ++e) acc[e] = xt[(long long)(tj * TILE + g * 16 + e) * MQ + q];
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[h][c] = xt[(long long)(tj * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
    if (i + 1 < bd.ntc) {
       for (int idx = tid; idx < TILE * MQ; idx += 256) V[idx >> 5][idx & 31] = xt[(long long)((i + 1) * TILE + (idx >> 5)) * MQ + (idx & 31)];
       mtile_apply<1>(acc, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, V, Lt, tid, -1.0);
@@ -3111,14 +3136,25 @@ __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ 
    if (tj == i) {
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-         V[g * 16 + e][q] = acc[e] * dtail[bd.dt_off + i * TILE + g * 16 + e];
-         acc[e] = 0.0;
-      }
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+         for (int c = 0; c < 8; ++c) {
+            V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c] * dtail[bd.dt_off + i * TILE + 32 * w + 16 * h + er];
+            acc[h][c] = 0.0;
+         }
       mtile_apply<1>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0);
    }
 #pragma unroll
-   for (int e = 0; e < 16; ++e) xt[(long long)(tj * TILE + g * 16 + e) * MQ + q] = acc[e];
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xt[(long long)(tj * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek] = acc[h][c];
+}
+
+// X(:, r) += a * Y(:, r) for nr vectors (grid.y): the refinement update of all right-hand sides in one launch
+__global__ void k_maxpy(double* __restrict__ X, long long x_stride, const double* __restrict__ Y, long long y_stride, double a, long long n) {
+   X += x_stride * blockIdx.y;
+   Y += y_stride * blockIdx.y;
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) X[i] += a * Y[i];
 }
 
 // refinement residual r = b - K x (r holds b on entry): the full (both triangles) row structure is built at analyze time -

@@ -135,22 +135,31 @@ energy_like_blocks = families.time_coupled_blocks
 
 
 @pytest.mark.parametrize("sparse_root", [False, True], ids=["dense_root", "sparse_root"])
-def test_config4_share_energy_like(sparse_root):
-    """256 blocks x 50 000 vars per GPU (BASELINE.json configs[3]: 2048 blocks on 8 GPUs), S = 8000: 95 first-stage
-    variables + 31 linking rows between each of the 255 neighbouring pairs."""
+@pytest.mark.parametrize("chain", ["chain256", "config3_prefix"])
+def test_config4_share_energy_like(sparse_root, chain):
+    """256 blocks x 50 000 vars per GPU (BASELINE.json configs[3]: 2048 blocks on 8 GPUs).
+    chain256: the 256-block chain rounds 3-4 measured - S = 8000: 95 first-stage variables + 31 linking rows between each of the 255
+    neighbouring pairs.  config3_prefix: blocks 0..255 of THE configs[3] chain (2048 blocks, S = 8000, 3 or 4 linking rows per pair) with
+    the linking rows they touch - S = 1083, the instance `bench.py --family time-coupled` runs on one GPU and labels
+    "[BASELINE configs[3] shape on 1 of its 8 GPUs]" (families.config3_chain(n_i).prefix(256))."""
     import torch
     N = int(os.environ.get("PIPS_TEST_CFG3_BLOCKS", 256))
     n_i = int(os.environ.get("PIPS_TEST_CFG3_N", 50000))
     L, n0, bw, nnz_row, seed = 31, 95, 12, 10, 20261004
     t0 = time.time()
-    key = (N, n_i, L, n0, bw, nnz_row, seed)
+    key = (chain, N, n_i, L, n0, bw, nnz_row, seed)
     if key not in _CACHE:          # both root variants see the same instance
         _CACHE.clear()
-        _CACHE[key] = energy_like_blocks(*key)
+        if chain == "chain256":
+            _CACHE[key] = energy_like_blocks(*key[1:])
+        else:
+            ch = families.config3_chain(n_i).prefix(N)
+            assert (ch.n0, ch.bw, ch.nnz_row, ch.seed) == (n0, bw, nnz_row, seed)
+            _CACHE[key] = (ch.blocks(0, N), ch.F0(), ch.my_i, ch.myl)
     blocks, F0, my_i, myl = _CACHE[key]
     S, nleaf = n0 + myl, n_i + my_i
     if N == 256:
-        assert S == 8000
+        assert S == (8000 if chain == "chain256" else 1083)
     bt = pa.LeafBatch(N, S)
     Ks, Bts, diags, vals = [], [], [], []
     for b, (W, T, F) in enumerate(blocks):
@@ -173,7 +182,7 @@ def test_config4_share_energy_like(sparse_root):
     info = bt.info()
     xd0 = pa.gen_diagonal(seed, 0, n0)
     kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0, sparse_root=sparse_root)
-    if sparse_root and (N - 1) * L >= 96:
+    if sparse_root and chain == "chain256" and (N - 1) * L >= 96:
         # a chain of 31-row cliques around 95 hubs: dissected (fronts of <= 188 rows), every linking row in the multifrontal head
         ri = kkt.sparse_root_info()
         assert ri["order"] == "dissected" and ri["n_head"] == myl and ri["m"] == n0 and ri["multifrontal_head"] == 1
@@ -200,8 +209,70 @@ def test_config4_share_energy_like(sparse_root):
     t0 = time.time()
     x0, xl = solve(b0, bl)
     t_sol = time.time() - t0
-    print(f"config-4 share {N} x {n_i} (S = {S}, {'sparse' if sparse_root else 'dense'} root): generate {t_gen:.0f} s, analyze {t_an:.0f} s, "
+    print(f"config-4 share [{chain}] {N} x {n_i} (S = {S}, {'sparse' if sparse_root else 'dense'} root): generate {t_gen:.0f} s, analyze {t_an:.0f} s, "
           f"factorize {t_fac * 1e3:.0f} ms, solveCompressed {t_sol * 1e3:.0f} ms (with transfers), nnzL {info['nnzL']:,}, schur mode {bt.schur_mode()}")
+    F0s = F0.to_scipy()
+    K0 = sp.bmat([[sp.diags(xd0), F0s.T], [F0s, None]], format="csr")
+    assert _arrowhead_residual(Ks, Bts, K0, x0, xl, b0, bl, nleaf) < 1e-9
+    c0v, cl = rng.standard_normal(S), rng.standard_normal(N * nleaf)
+    y0, yl = solve(c0v, cl)
+    z0, zl = solve(2.5 * b0 + c0v, 2.5 * bl + cl)
+    assert np.linalg.norm(z0 - (2.5 * x0 + y0)) / np.linalg.norm(z0) < 1e-8
+    assert np.linalg.norm(zl - (2.5 * xl + yl)) / np.linalg.norm(zl) < 1e-8
+
+
+def test_config5_whole_dense_linking_on_one_gpu():
+    """BASELINE.json configs[4] as a WHOLE on one GPU (it names no GPU count and fits: SC = 2 GB): 256 blocks x 2000 vars, Schur dim
+    16 000.  Full arrowhead residual, exact inertia of every level, linearity."""
+    import torch
+    N, n_i, my_i, seed = 256, 2000, 1000, 20261003
+    rho = 10.0 / n_i
+    n0 = myl = 8000
+    S, nleaf = n0 + myl, n_i + my_i
+    bt = pa.LeafBatch(N, S)
+    Ks, Bts, diags, vals = [], [], [], []
+    for b in range(N):
+        W, T, F, c, xs = pa.gen_block(seed, b + 1, n_i, my_i, n0, myl, rho)
+        K, dpos = pa.kkt_leaf_assemble(n_i, W)
+        Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F)
+        d = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
+        K.val[dpos] = d
+        bt.set_block(b, K, n_i, Bt)
+        low = sp.csr_matrix((K.val.copy(), K.colidx, K.rowptr), shape=(nleaf, nleaf))
+        Ks.append((low + sp.tril(low, -1).T).tocsr())
+        Bts.append(Bt.to_scipy())
+        diags.append(d)
+        vals.append(K.val)
+    bt.analyze(16)
+    for b in range(N):
+        bt.set_values(b, vals[b])
+    F0, c0, x0s = pa.gen_root(seed, n0, myl)
+    xd0 = pa.gen_diagonal(seed, 0, n0)
+    kkt = pa.KktSystem(bt, n0, 0, myl, 0, F0=F0)
+    leaf_diag = torch.tensor(np.concatenate(diags), device="cuda")
+    xd0_d = torch.tensor(xd0, device="cuda")
+    kkt.factorize(leaf_diag, xd0_d)
+    bt.sync()
+    t0 = time.time()
+    kkt.factorize(leaf_diag, xd0_d)
+    bt.sync()
+    t_fac = time.time() - t0
+    for b in (0, N // 2, N - 1):
+        assert bt.inertia(b) == (n_i, my_i, 0)
+    assert kkt.root_inertia() == (n0, myl, 0)
+    rng = np.random.default_rng(4)
+
+    def solve(b0, bl):
+        b0_d, bl_d = torch.tensor(b0, device="cuda"), torch.tensor(bl, device="cuda")
+        kkt.solve_compressed(b0_d, bl_d)
+        bt.sync()
+        return b0_d.cpu().numpy(), bl_d.cpu().numpy()
+
+    b0, bl = rng.standard_normal(S), rng.standard_normal(N * nleaf)
+    t0 = time.time()
+    x0, xl = solve(b0, bl)
+    t_sol = time.time() - t0
+    print(f"configs[4] whole {N} x {n_i} (S = {S}): factorize {t_fac * 1e3:.0f} ms, solveCompressed {t_sol * 1e3:.0f} ms (with transfers), schur mode {bt.schur_mode()}")
     F0s = F0.to_scipy()
     K0 = sp.bmat([[sp.diags(xd0), F0s.T], [F0s, None]], format="csr")
     assert _arrowhead_residual(Ks, Bts, K0, x0, xl, b0, bl, nleaf) < 1e-9

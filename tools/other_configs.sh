@@ -7,6 +7,8 @@ run() { python3 $R/bench.py --no-cpu-baseline "$@" 2>/dev/null | grep '^{' >> $O
 run --blocks-per-gpu 4 --n 1000 --schur-dim 200 --rho 0.01 --steps 20 --warmup 3
 run --blocks-per-gpu 64 --n 10000 --schur-dim 4000 --rho 0.001 --steps 3 --warmup 1
 run --blocks-per-gpu 32 --n 2000 --schur-dim 16000 --rho 0.005 --steps 3 --warmup 1
+# BASELINE configs[4] as a whole on one GPU (256 x 2000, S = 16 000: it names no GPU count and fits)
+run --blocks-per-gpu 256 --n 2000 --schur-dim 16000 --rho 0.005 --steps 3 --warmup 1 --no-ipm
 run --blocks-per-gpu 256 --n 2000 --schur-dim 4000 --rho 0.005 --steps 3 --warmup 1
 PIPS_HIP_DETERMINISTIC=1 python3 $R/bench.py --no-cpu-baseline --no-ipm --steps 3 --warmup 1 2>/dev/null | grep '^{' >> $O
 PIPS_HIP_DETERMINISTIC=1 python3 $R/bench.py --family time-coupled --blocks-per-gpu 256 --n 50000 --no-cpu-baseline --no-ipm --steps 3 --warmup 1 2>/dev/null | grep '^{' >> $O
