@@ -2268,6 +2268,15 @@ struct Engine {
       for (const LevelRange& L : levels) head(L, 0);
       for (const LevelRange& L : levels_top) head(L, 0);
       const TailPlan& p = plan;
+      const bool rows = sweep.enabled && np * 4 <= SWEEP_NRHS_MAX && p.ntc_max > 0;   // the tail sweeps as one launch per direction (tickets, flags)
+      // few tile rows per step (a single leaf): a workgroup takes a quarter of a panel's right-hand sides, so that the chain of a pass - one
+      // workgroup's tile products per step - is four times shorter; many blocks: whole panels, L read once per 32 right-hand sides
+      const bool slices = (long long)sweep.n_tasks * np < 2048;
+      if (rows && slices)
+         hipLaunchKernelGGL(k_mtail_rows_fwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      else if (rows)
+         hipLaunchKernelGGL(k_mtail_rows_fwd<8>, dim3(sweep.n_tasks, np), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      else
       for (int j = 0; j < p.ntc_max; ++j)
          if (p.fwd[j].cnt > 0)
             hipLaunchKernelGGL(k_mtail_fwd, dim3(p.fwd[j].cnt, np), dim3(256), 0, stream, p.d_tasks + p.fwd[j].off, d_blks, d_arena, d_dtail,
@@ -2275,6 +2284,11 @@ struct Engine {
       if (nsn_total > 0)
          hipLaunchKernelGGL(k_mhead_dscale, dim3(grid_for((long long)nsn_total * MQ, 256), np), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
                             d_arena, xm, ps);
+      if (rows && slices)
+         hipLaunchKernelGGL(k_mtail_rows_bwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      else if (rows)
+         hipLaunchKernelGGL(k_mtail_rows_bwd<8>, dim3(sweep.n_tasks, np), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      else
       for (int i = p.ntc_max - 1; i >= 0; --i)
          if (p.bwd[i].cnt > 0)
             hipLaunchKernelGGL(k_mtail_bwd, dim3(p.bwd[i].cnt, np), dim3(256), 0, stream, p.d_tasks + p.bwd[i].off, d_blks, d_arena, d_dtail,

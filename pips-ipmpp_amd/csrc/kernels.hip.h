@@ -3041,34 +3041,42 @@ __global__ void k_mhead_dscale(const SnDesc* __restrict__ sns, int nsn, const Bl
 // case transposes while staging).  (The round-2 version was a scalar multiply-add loop over the LDS tile: DoubleLinearSolver::solve(nrhs)
 // behind the adapters spent 11 of its 13 ms per 160 right-hand sides there and in re-reading L per right-hand side.)
 constexpr int MVQ = MQ + 8;   // LDS row length of V: the four k of a fragment read land in different banks
-template <int TRANSPOSED>
-__device__ __forceinline__ void mtile_apply(double (&acc)[2][8], const double* __restrict__ M, long long ldm,
-                                            const double (*V)[MVQ], double (*Lt)[TILE + 1], int tid, double sign) {
+// KC k of a tile into registers (KC / 2 doubles per thread), as mtile_apply stages them
+template <int TRANSPOSED, int KC>
+__device__ __forceinline__ void mtile_fetch(double (&pre)[KC / 2], const double* __restrict__ M, long long ldm, int c0, int tid) {
+#pragma unroll
+   for (int e = 0; e < KC / 2; ++e) {
+      const int idx = e * 256 + tid;
+      pre[e] = TRANSPOSED ? M[c0 + (idx % KC) + (long long)(idx / KC) * ldm]       // KC rows x 128 columns, the KC rows of a column contiguous
+                          : M[(idx & 127) + (long long)(c0 + (idx >> 7)) * ldm];   // KC columns x 128 rows, rows contiguous
+   }
+}
+// NC column groups of four right-hand sides per workgroup, KC k per LDS stage; prefetched: pre already holds the first KC k of M (the
+// caller asked for them before it waited for the flag of V)
+template <int TRANSPOSED, int NC = 8, int KC = 16>
+__device__ __forceinline__ void mtile_apply(double (&acc)[2][NC], const double* __restrict__ M, long long ldm,
+                                            const double (*V)[MVQ], double (*Lt)[TILE + 1], int tid, double sign, double (&pre)[KC / 2], bool prefetched = false) {
    const int lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, ej = lane & 3;
-   for (int c0 = 0; c0 < TILE; c0 += 16) {
+   // (the next KC k are on their way from memory while these are multiplied: a chunk was a round trip of its own before)
+   if (!prefetched) mtile_fetch<TRANSPOSED, KC>(pre, M, ldm, 0, tid);
+   for (int c0 = 0; c0 < TILE; c0 += KC) {
       __syncthreads();
-      if (!TRANSPOSED) {
 #pragma unroll
-         for (int e = 0; e < 8; ++e) {          // 16 columns x 128 rows, rows contiguous
-            const int idx = e * 256 + tid, cc = idx >> 7, rr = idx & 127;
-            Lt[cc][rr] = M[rr + (long long)(c0 + cc) * ldm];
-         }
-      } else {
-#pragma unroll
-         for (int e = 0; e < 8; ++e) {          // 16 rows x 128 columns, the 16 rows of a column contiguous
-            const int idx = e * 256 + tid, col = idx >> 4, rl = idx & 15;
-            Lt[rl][col] = M[c0 + rl + (long long)col * ldm];
-         }
+      for (int e = 0; e < KC / 2; ++e) {
+         const int idx = e * 256 + tid;
+         if (TRANSPOSED) Lt[idx % KC][idx / KC] = pre[e];
+         else Lt[idx >> 7][idx & 127] = pre[e];
       }
+      if (c0 + KC < TILE) mtile_fetch<TRANSPOSED, KC>(pre, M, ldm, c0 + KC, tid);
       __syncthreads();
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
+      for (int st = 0; st < KC / 4; ++st) {
          const double f0 = Lt[4 * st + ek][32 * w + er], f1 = Lt[4 * st + ek][32 * w + 16 + er];
-         double fc[8];
+         double fc[NC];
 #pragma unroll
-         for (int c = 0; c < 8; ++c) fc[c] = sign * V[c0 + 4 * st + ek][4 * c + ej];
+         for (int c = 0; c < NC; ++c) fc[c] = sign * V[c0 + 4 * st + ek][4 * c + ej];
 #pragma unroll
-         for (int c = 0; c < 8; ++c) {
+         for (int c = 0; c < NC; ++c) {
             acc[0][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], f0, acc[0][c], 0, 0, 0);
             acc[1][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], f1, acc[1][c], 0, 0, 0);
          }
@@ -3087,7 +3095,7 @@ __global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ 
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, ti = task.ti, ld = bd.ldT;
    double* xt = xm + panel_stride * blockIdx.y + (bd.xw_off + bd.n_head) * MQ;
-   double acc[2][8];
+   double acc[2][8], pre[8];
 #pragma unroll
    for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -3097,7 +3105,7 @@ __global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ 
          const int c = idx >> 5, qq = idx & 31;
          V[c][qq] = xt[(long long)((j - 1) * TILE + c) * MQ + qq] * dtail[bd.dt_off + (j - 1) * TILE + c];
       }
-      mtile_apply<0>(acc, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, V, Lt, tid, -1.0);
+      mtile_apply<0>(acc, arena + bd.T + (long long)ti * TILE + (long long)(j - 1) * TILE * ld, ld, V, Lt, tid, -1.0, pre);
    }
    if (ti == j) {
       __syncthreads();
@@ -3105,7 +3113,7 @@ __global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ 
       for (int h = 0; h < 2; ++h)
 #pragma unroll
          for (int c = 0; c < 8; ++c) { V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c]; acc[h][c] = 0.0; }
-      mtile_apply<0>(acc, winv + bd.winv_off + (long long)j * TILE * TILE, TILE, V, Lt, tid, 1.0);
+      mtile_apply<0>(acc, winv + bd.winv_off + (long long)j * TILE * TILE, TILE, V, Lt, tid, 1.0, pre);
    }
 #pragma unroll
    for (int h = 0; h < 2; ++h)
@@ -3124,14 +3132,14 @@ __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ 
    const BlkDesc bd = blks[task.blk];
    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, tj = task.ti, ld = bd.ldT;
    double* xt = xm + panel_stride * blockIdx.y + (bd.xw_off + bd.n_head) * MQ;
-   double acc[2][8];
+   double acc[2][8], pre[8];
 #pragma unroll
    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[h][c] = xt[(long long)(tj * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
    if (i + 1 < bd.ntc) {
       for (int idx = tid; idx < TILE * MQ; idx += 256) V[idx >> 5][idx & 31] = xt[(long long)((i + 1) * TILE + (idx >> 5)) * MQ + (idx & 31)];
-      mtile_apply<1>(acc, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, V, Lt, tid, -1.0);
+      mtile_apply<1>(acc, arena + bd.T + (long long)(i + 1) * TILE + (long long)tj * TILE * ld, ld, V, Lt, tid, -1.0, pre);
    }
    if (tj == i) {
       __syncthreads();
@@ -3142,12 +3150,129 @@ __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ 
             V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c] * dtail[bd.dt_off + i * TILE + 32 * w + 16 * h + er];
             acc[h][c] = 0.0;
          }
-      mtile_apply<1>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0);
+      mtile_apply<1>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0, pre);
    }
 #pragma unroll
    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int c = 0; c < 8; ++c) xt[(long long)(tj * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek] = acc[h][c];
+}
+
+// The tail sweeps of 32 right-hand sides as ONE launch per direction (grid: (block, tile row) tasks x panels), like k_tail_rows_fwd / _bwd
+// for one: a workgroup owns tile row i (forward) / tile column i (backward), takes the pieces of the solution it needs as their flags go up
+// and multiplies on the matrix pipe (mtile_apply).  35 + 35 launches of 25 us each per pass were 3.4 of the 4.4 ms of a solve(160) on one
+// configs[1] block; the chain of a pass is 35 x (tile product + flag).  Same arithmetic as k_mtail_fwd / _bwd, same order per tile row.
+template <int NC>
+__global__ __launch_bounds__(256) void k_mtail_rows_fwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+                                                       const double* __restrict__ dtail, const double* __restrict__ winv, double* __restrict__ xm,
+                                                       long long panel_stride) {
+   __shared__ double V[TILE][MVQ];
+   constexpr int KC = NC == 2 ? 32 : 16;   // (a quarter panel leaves LDS for stages of 32 k: half the barriers)
+   __shared__ double Lt[KC][TILE + 1];
+   __shared__ int sh_t, sh_ok;
+   const int epoch = *a.epoch_ptr;
+   const int t = sweep_ticket(a, &sh_t);
+   const TileTask task = a.tasks[t];
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, i = task.ti, ld = bd.ldT;
+   constexpr int SL = 8 / NC, QS = 4 * NC;   // slices of a panel, right-hand sides per slice
+   double* xt = xm + panel_stride * (blockIdx.y / SL) + (bd.xw_off + bd.n_head) * MQ + QS * (blockIdx.y % SL);
+   int* fl = a.flags + a.flag_stride * blockIdx.y + a.flag_off[task.blk];
+   const int j0 = a.tfirst ? min(i, a.tfirst[a.tfirst_off[task.blk] + i]) : 0;
+   double acc[2][NC], pre[KC / 2];
+#pragma unroll
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[h][c] = xt[(long long)(i * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
+   bool ok = true;
+   for (int j = j0; j < i; ++j) {
+      mtile_fetch<0, KC>(pre, arena + bd.T + (long long)i * TILE + (long long)j * TILE * ld, ld, 0, tid);   // (the tile does not wait for the flag)
+      if (tid == 0) sh_ok = sweep_wait(fl + j, epoch, a.poll_limit) ? 1 : 0;
+      __syncthreads();
+      if (!sh_ok) { ok = false; break; }
+      for (int idx = tid; idx < TILE * QS; idx += 256) {
+         const int c = idx / QS, qq = idx % QS;
+         V[c][qq] = sweep_load(xt + (long long)(j * TILE + c) * MQ + qq) * dtail[bd.dt_off + j * TILE + c];
+      }
+      mtile_apply<0, NC, KC>(acc, arena + bd.T + (long long)i * TILE + (long long)j * TILE * ld, ld, V, Lt, tid, -1.0, pre, true);
+   }
+   if (ok) {
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+         for (int c = 0; c < NC; ++c) { V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c]; acc[h][c] = 0.0; }
+      mtile_apply<0, NC, KC>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0, pre);
+   } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+         for (int c = 0; c < NC; ++c) acc[h][c] = sweep_nan();
+      if (tid == 0) *a.err = 1;
+   }
+#pragma unroll
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sweep_store(xt + (long long)(i * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek, acc[h][c]);
+   sweep_publish(fl + i, epoch);
+   sweep_done(a);
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_mtail_rows_bwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+                                                       const double* __restrict__ dtail, const double* __restrict__ winv, double* __restrict__ xm,
+                                                       long long panel_stride) {
+   __shared__ double V[TILE][MVQ];
+   constexpr int KC = NC == 2 ? 32 : 16;   // (a quarter panel leaves LDS for stages of 32 k: half the barriers)
+   __shared__ double Lt[KC][TILE + 1];
+   __shared__ int sh_t, sh_ok;
+   const int epoch = *a.epoch_ptr;
+   const int t = sweep_ticket(a, &sh_t);
+   const TileTask task = a.tasks[a.n_tasks - 1 - t];   // last tile column first
+   const BlkDesc bd = blks[task.blk];
+   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, i = task.ti, ld = bd.ldT;
+   constexpr int SL = 8 / NC, QS = 4 * NC;   // slices of a panel, right-hand sides per slice
+   double* xt = xm + panel_stride * (blockIdx.y / SL) + (bd.xw_off + bd.n_head) * MQ + QS * (blockIdx.y % SL);
+   int* fl = a.flags + a.flag_stride * blockIdx.y + a.flag_off[task.blk];
+   const int* tf = a.tfirst ? a.tfirst + a.tfirst_off[task.blk] : nullptr;
+   double acc[2][NC], pre[KC / 2];
+#pragma unroll
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[h][c] = xt[(long long)(i * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
+   bool ok = true;
+   for (int k = bd.ntc - 1; k > i; --k) {
+      if (tf && tf[k] > i) continue;   // L(k, i) lies outside the envelope
+      mtile_fetch<1, KC>(pre, arena + bd.T + (long long)k * TILE + (long long)i * TILE * ld, ld, 0, tid);
+      if (tid == 0) sh_ok = sweep_wait(fl + k, epoch, a.poll_limit) ? 1 : 0;
+      __syncthreads();
+      if (!sh_ok) { ok = false; break; }
+      for (int idx = tid; idx < TILE * QS; idx += 256) V[idx / QS][idx % QS] = sweep_load(xt + (long long)(k * TILE + idx / QS) * MQ + idx % QS);
+      mtile_apply<1, NC, KC>(acc, arena + bd.T + (long long)k * TILE + (long long)i * TILE * ld, ld, V, Lt, tid, -1.0, pre, true);
+   }
+   if (ok) {
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+         for (int c = 0; c < NC; ++c) {
+            V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c] * dtail[bd.dt_off + i * TILE + 32 * w + 16 * h + er];
+            acc[h][c] = 0.0;
+         }
+      mtile_apply<1, NC, KC>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0, pre);
+   } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+         for (int c = 0; c < NC; ++c) acc[h][c] = sweep_nan();
+      if (tid == 0) *a.err = 1;
+   }
+#pragma unroll
+   for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sweep_store(xt + (long long)(i * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek, acc[h][c]);
+   sweep_publish(fl + i, epoch);
+   sweep_done(a);
 }
 
 // X(:, r) += a * Y(:, r) for nr vectors (grid.y): the refinement update of all right-hand sides in one launch
