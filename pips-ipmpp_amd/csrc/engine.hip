@@ -754,8 +754,9 @@ struct Engine {
       if (ev_inertia) (void)hipEventDestroy(ev_inertia);
       ev_inertia = nullptr;
       inertia_in_flight = false;
-      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res, &d_hostx}) { if (*q) (void)hipFree(*q); *q = nullptr; }
       mx_cap = 0;
+      hostx_cap = 0;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
@@ -2305,6 +2306,8 @@ struct Engine {
    // length n_total at distance x_stride.
    double *d_mx_xw = nullptr, *d_mx_rhs = nullptr, *d_mx_res = nullptr;
    int mx_cap = 0;
+   double* d_hostx = nullptr;   // device copy of host right-hand sides (pips_hip_ldl_solve), kept between calls
+   size_t hostx_cap = 0;
    static constexpr int MULTI_CHUNK_MAX = 256;   // right-hand sides per pass (eight panels)
    int ensure_multi_buffers(int want = 32) {
       want = std::min(MULTI_CHUNK_MAX, (std::max(want, 32) + MQ - 1) / MQ * MQ);
@@ -3926,8 +3929,14 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    }
    const int nnz_rhs = (int)nz.size();
    if (nnz_rhs == 0) return PIPS_OK;
-   double* d_X = nullptr;
-   HIP_TRY(hipMalloc((void**)&d_X, (size_t)nnz_rhs * row));
+   // (the device copy of the right-hand sides stays with the handle: the reference's loop calls this hundreds of times per factorisation
+   // with the same chunk size, an allocation and a release per call were a fifth of a millisecond each)
+   if (e.hostx_cap < (size_t)nnz_rhs * row) {
+      if (e.d_hostx) { HIP_TRY(hipStreamSynchronize(e.stream)); (void)hipFree(e.d_hostx); e.d_hostx = nullptr; e.hostx_cap = 0; }
+      HIP_TRY(hipMalloc((void**)&e.d_hostx, (size_t)nnz_rhs * row));
+      e.hostx_cap = (size_t)nnz_rhs * row;
+   }
+   double* d_X = e.d_hostx;
    hipError_t err = hipSuccess;
    if (nnz_rhs == nrhs)
       err = hipMemcpy2DAsync(d_X, row, rhs, (size_t)ld * sizeof(double), row, nrhs, hipMemcpyHostToDevice, e.stream);
@@ -3943,7 +3952,6 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
             err = hipMemcpyAsync(rhs + (size_t)nz[q] * ld, d_X + (size_t)q * e.n_total, row, hipMemcpyDeviceToHost, e.stream);
    }
    if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
-   (void)hipFree(d_X);
    if (rc) return rc;
    if (err != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_ldl_solve: %s", hipGetErrorString(err));
    return PIPS_OK;
