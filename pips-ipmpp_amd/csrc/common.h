@@ -192,6 +192,8 @@ int analyze_block(const CsrPattern& K, const CsrPattern& border, int n_primal, c
 struct RootPlanParams {
    int workers = 510;       // workgroup slots for the bulk: 256 compute units x 2, less the chain's unit
    int chain_slots = 2;     // > 0: the chain of the diagonal tiles has a compute unit of its own (a task list of its own); 0: one list
+   int boost = 10, boost_width = 3;   // update priority: tiles within boost_width of the diagonal as if their column were boost columns nearer
+   int max_depth = 24;              // tile columns per update task at most
    int chain_width = 1;     // tiles this close to the diagonal have their trsm and completing update on the chain's list
    int qmin = 4;            // an update that does not finish its tile waits until it is this many tile columns deep
    int urgent = 1;          // tiles within this distance of the chain's diagonal tile are updated whatever the depth

@@ -2736,6 +2736,7 @@ struct DenseLdl {
       if (const char* q = getenv("PIPS_HIP_ROOT_QMIN")) pp.qmin = std::max(1, atoi(q));
       if (const char* q = getenv("PIPS_HIP_ROOT_CHAIN_CU")) pp.chain_slots = atoi(q) != 0 ? 2 : 0;   // 0: one list, the chain wherever its workgroups land (A/B)
       if (pp.chain_slots == 0) pp.workers = 512;
+      if (const char* q = getenv("PIPS_HIP_ROOT_BOOST")) sscanf(q, "%d,%d,%d", &pp.boost, &pp.boost_width, &pp.max_depth);
       std::vector<int> t, tc;
       int rc = build_root_plan(ntc, pp, t, tc, &plan_makespan_us);
       if (rc) return rc;

@@ -29,8 +29,8 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
    std::vector<int> prog((size_t)ntc * ntc, 0), rowdone(ntc, 0);
    std::vector<char> busy((size_t)ntc * ntc, 0), queued((size_t)ntc * ntc, 0), trsm_done((size_t)ntc * ntc, 0), dready(ntc, 0);
    int chain = 0;
-   struct Cand { int prio, j, i; };
-   auto worse = [](const Cand& a, const Cand& b) { return a.prio != b.prio ? a.prio > b.prio : (a.j != b.j ? a.j > b.j : a.i > b.i); };
+   struct Cand { int prio, key, j, i; };   // key: the column the task is ordered by
+   auto worse = [](const Cand& a, const Cand& b) { return a.prio != b.prio ? a.prio > b.prio : (a.key != b.key ? a.key > b.key : (a.j != b.j ? a.j > b.j : a.i > b.i)); };
    typedef std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> Heap;
    Heap heaps[3] = {Heap(worse), Heap(worse), Heap(worse)};   // 0 the chain's, 2 everything else (1 unused)
    struct Event { double t; long long seq; int kind, i, j, k1, cls; };
@@ -47,7 +47,7 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
       const int a = std::min({rowdone[i], rowdone[j], j}), q = a - prog[at(i, j)];
       if (q <= 0) return -1;
       const bool urgent = j <= chain + p.urgent && i <= j + p.urgent;
-      if (a == j || q >= p.qmin || urgent) { k1 = a; return 0; }
+      if (a == j || q >= p.qmin || urgent) { k1 = std::min(a, prog[at(i, j)] + p.max_depth); return 0; }
       return -1;
    };
    // Two classes, two lists (each in the order its tasks start here):
@@ -59,8 +59,13 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
    //  arriving workgroup takes the moment its head is ready, 31.8 ms - in order, so a head that is not ready blocks the ones behind it; and
    //  a second unit of its own for the next diagonals, 29.5 - 30.1 ms - the waiting only moves one diagonal further out; and a head start
    //  of 128 - 400 places in the bulk list for the trsm / completing updates next to the chain: no change, the chain then waits for the
-   //  tile's update before that one.  What the chain waits for where the chip is saturated is bulk work next to it that is in line
-   //  behind a few hundred deep updates; only a scheduler with priorities, not a list, takes that away.  Removed.)
+   //  tile's update before that one.  Both lists taken out of order, only what is ready (64 lanes look at 64 tasks each from a low-water
+   //  mark on, compare-and-swap on a flag per task): 116 ms - the ready deep updates lie thousands of places behind the mark, out of any
+   //  window's reach, while in-order draws let them start early and wait.  What the chain waits for where the chip is saturated is the
+   //  trsm -> update pipeline of the tile rows it needs next: two bulk tasks per column and row, each some 90 us in line behind deep
+   //  updates before it is drawn, so no row advances faster than a column per 250 us and the chain follows.  (A trsm that goes on, in
+   //  the same workgroup, to apply its column to the row's next tile - one turn instead of two - applies to one tile row per column
+   //  only: no change.)  Removed.)
    auto task_class = [&](int kind, int i, int j, int k1) {
       if (p.chain_slots > 0 && (kind == 2 || (kind == 1 && i - j <= p.chain_width) || (kind == 0 && k1 == j && i - j < p.chain_width))) return 0;
       return 2;
@@ -71,7 +76,13 @@ int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, s
       const int kind = startable(i, j, k1);
       if (kind < 0) return;
       queued[at(i, j)] = 1;
-      heaps[task_class(kind, i, j, kind == 0 ? k1 : j)].push(Cand{kind == 2 ? 0 : (kind == 1 ? 1 : 2), j, i});
+      // Updates are taken nearest column first - but the tiles next to the diagonal as if their column were `boost` columns nearer.  Nearest
+      // first makes a column's tiles take their one deep update (everything that is final by then: 50 columns, 1.5 ms at S = 16 000) some
+      // seven columns before the chain arrives - traced: the deep update of tile (60, 59) ended 50 us before DIAG 59 began, the seven
+      // columns that had become final meanwhile followed as ONE task that could only start when the last of them was, and the chain waited
+      // 200 us for it.  The few tiles the chain needs first in a column take their deep update earlier and then keep up column by column.
+      const int jeff = kind == 0 && i - j <= p.boost_width ? std::max(j - p.boost, 0) : j;
+      heaps[task_class(kind, i, j, kind == 0 ? k1 : j)].push(Cand{kind == 2 ? 0 : (kind == 1 ? 1 : 2), jeff, j, i});
    };
 
    double t = 0.0;
