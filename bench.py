@@ -674,7 +674,12 @@ def main():
     if comm is not None:
         comm.close()
     if rank == 0:
+        # the watchdog counts per phase: the timed loop, the CPU baseline and the end-to-end IPM each get the full time (one clock over all of
+        # them would drop the bench line of a large run whose optional sections are long)
+        import faulthandler
+        wd = float(os.environ.get("PIPS_BENCH_WATCHDOG", "3000"))
         if not a.no_cpu_baseline and world == 1:
+            faulthandler.dump_traceback_later(wd, exit=True)
             try:
                 out["cpu_baseline"] = cpu_baseline(pa, a.seed, n_i, my_i, n0, myl, a.rho, n_blocks_total, bpg,
                                                    fam_blocks[0] if fam_blocks is not None else None, whole_block=a.steps >= 20)
@@ -682,6 +687,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": f"{bpg}-block work units/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
         if not a.no_ipm and world == 1:
+            faulthandler.dump_traceback_later(wd, exit=True)
             # "report units/s, and separately end-to-end IPM iterations/s of a full solve with the host driver" - the
             # device-resident harness on the LP of the same generator and shape, outside the timed region of the metric
             try:
@@ -720,7 +726,7 @@ def _leave():
 
 
 if __name__ == "__main__":
-    # a run that stops making progress says where: every thread's Python stack on stderr, then exit code 3 (the driver's bench finishes
+    # a run that stops making progress says where: every thread's Python stack on stderr, then the process exits with status 1 (the driver's bench finishes
     # within minutes; PIPS_BENCH_WATCHDOG=<seconds> for the stress runs of tools/stress_exit.sh)
     import faulthandler
     faulthandler.dump_traceback_later(float(os.environ.get("PIPS_BENCH_WATCHDOG", "3000")), exit=True)

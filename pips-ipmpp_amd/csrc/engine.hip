@@ -42,6 +42,12 @@ static int dev_upload(T** dptr, const std::vector<T>& h, hipStream_t) {
    return PIPS_OK;
 }
 
+// environment switches: value of an integer switch, dflt when it is not set
+static int env_int(const char* name, int dflt) {
+   const char* v = getenv(name);
+   return v ? atoi(v) : dflt;
+}
+
 static inline int grid_for(long long n, int block, int cap = 4096) {
    long long g = (n + block - 1) / block;
    if (g < 1) g = 1;
@@ -788,9 +794,9 @@ struct Engine {
    };
    struct SlotEntry { long long target, slot; };
    bool deterministic = false;
-   // The slot / gather scheme of the head can be had without the rest of deterministic mode (PIPS_HIP_HEAD_SLOTS=1): on config 2
-   // the head phase then takes 5.0 ms against 5.5 ms with FP64 atomics (145 M per factorisation) - not worth 16 bytes of device
-   // memory per contribution and the longer analysis as a default.  Beyond HEAD_SLOTS_MAX contributions deterministic mode refuses.
+   // The slot / gather scheme of the head belongs to deterministic mode (without it, round 2 measured the head phase of config 2 at 5.0 ms
+   // against 5.5 ms with FP64 atomics - not worth 16 bytes of device memory per contribution and the longer analysis; the switch that
+   // selected it alone is gone).  Beyond HEAD_SLOTS_MAX contributions deterministic mode refuses.
    bool head_slots = false;
    bool slot_solves = false;    // single-RHS forward substitution through slots outside deterministic mode too (measured: no gain)
    static constexpr long long HEAD_SLOTS_MAX = 400LL * 1000 * 1000;
@@ -1093,18 +1099,15 @@ struct Engine {
          if (in[b].n <= 0) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_batch_analyze: block %d was never set", b);
       apply_tuning(opt);
       if (sn_width > 0 && !getenv("PIPS_HIP_SN_WIDTH")) opt.max_sn_width = std::min(HEAD_WMAX, sn_width);
-      if (const char* sm = getenv("PIPS_HIP_SCHUR_MODE")) schur_mode = atoi(sm);
       bool any_border = false;
       for (int b = 0; b < nblk; ++b) any_border = any_border || !in[b].btrow.empty();
       {  // the border split (compact front panels) only exists with the multifrontal head
-         const char* env = getenv("PIPS_HIP_MF");
-         const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
-         if ((env && atoi(env) == 0) || (hs && atoi(hs) != 0 && !deterministic)) opt.mf_split_nb_max = 0;
+         if (env_int("PIPS_HIP_MF", 1) == 0) opt.mf_split_nb_max = 0;
       }
       // fronts on the rows of K only where the border split applies (PIPS_HIP_MF_KONLY=1; off by default: on the configs[3] share the fronts fall
       // from 9.7 to 4.0 ms, forming the border rows afterwards costs 8.0 - DESIGN.md 4.1c): not in deterministic mode (the border rows of the dense
       // tail take their head contributions with atomics, k_border_tail) and with supernodes of at most 16 columns (k_border_rows<., 16>)
-      opt.mf_konly = opt.mf_split_nb_max > 0 && !deterministic && opt.max_sn_width <= 16 && getenv("PIPS_HIP_MF_KONLY") && atoi(getenv("PIPS_HIP_MF_KONLY")) != 0;
+      opt.mf_konly = opt.mf_split_nb_max > 0 && !deterministic && opt.max_sn_width <= 16 && env_int("PIPS_HIP_MF_KONLY", 0) != 0;
       int rc = analyze_host(n_threads, schur_mode != 2);
       if (rc) return rc;
       schur_mode_eff = (schur_mode == 2 && any_border) ? 2 : 1;
@@ -1115,9 +1118,7 @@ struct Engine {
       HIP_TRY(hipSetDevice(device));
       release();
       {  // multifrontal head: every block's fronts must fit the LDS; the slot machinery of deterministic mode records scatters
-         const char* env = getenv("PIPS_HIP_MF");
-         const char* hs = getenv("PIPS_HIP_HEAD_SLOTS");
-         mf = !(env && atoi(env) == 0) && !(hs && atoi(hs) != 0 && !deterministic);
+         mf = env_int("PIPS_HIP_MF", 1) != 0;
          const bool mf_wanted = mf;
          auto fronts_fit = [&]() {
             bool ok = mf_wanted;
@@ -1675,7 +1676,7 @@ struct Engine {
       for (int b = 0; b < nblk; ++b) firsts[b] = &sym[b].tile_first;
       // tile columns per launch of the left-looking tail update (TailPlan::build, pair2).  configs[1], ms per unit / ms of update, two boxes:
       // 1 column 125.0 - 126.8 / 73.8 - 74.7; 2: 123.6 - 124.0 / 72.4; 3: 122.0 / 70.8; 4: 120.0 - 121.7 / 70.3 - 71.0; 6: 120.5 / 70.3; 8: 120.8 / 70.9
-      const int pair2 = getenv("PIPS_HIP_TWO_COLUMNS") ? std::max(1, std::min(8, atoi(getenv("PIPS_HIP_TWO_COLUMNS")))) : 4;   // (1: a column per launch)
+      const int pair2 = 4;   // (1: a column per launch; the switch that chose it went with round 6)
       if ((rc = plan.build(h_blks, 0, false, true, &firsts, true, pair2))) return rc;
       if ((rc = sweep.build(h_blks, &firsts))) return rc;
       {
@@ -1720,8 +1721,7 @@ struct Engine {
       ++analysis_gen;
       factored = false;
       head_slots = false;
-      const char* hs_env = getenv("PIPS_HIP_HEAD_SLOTS");
-      const bool want_slots = deterministic || (hs_env && atoi(hs_env) != 0 && schur_mode_eff == 1 && spine_total == 0);
+      const bool want_slots = deterministic;
       if (want_slots && slots_total + vslots_total <= HEAD_SLOTS_MAX) {
          if ((rc = build_deterministic(n_threads))) return rc;
          head_slots = true;
@@ -2733,10 +2733,8 @@ struct DenseLdl {
       if (d_rtasks) return PIPS_OK;
       const int ntc = npad / TILE;
       RootPlanParams pp;
-      if (const char* q = getenv("PIPS_HIP_ROOT_QMIN")) pp.qmin = std::max(1, atoi(q));
       if (const char* q = getenv("PIPS_HIP_ROOT_CHAIN_CU")) pp.chain_slots = atoi(q) != 0 ? 2 : 0;   // 0: one list, the chain wherever its workgroups land (A/B)
       if (pp.chain_slots == 0) pp.workers = 512;
-      if (const char* q = getenv("PIPS_HIP_ROOT_BOOST")) sscanf(q, "%d,%d,%d", &pp.boost, &pp.boost_width, &pp.max_depth);
       std::vector<int> t, tc;
       int rc = build_root_plan(ntc, pp, t, tc, &plan_makespan_us);
       if (rc) return rc;
@@ -3238,7 +3236,7 @@ struct KktSystem {
    // off for these factors (aug_failed_gen).  Several ranks keep the refined witness: the decision to repeat a solveCompressed would
    // have to be taken by all ranks together.  PIPS_HIP_AUG_WITNESS=0: the refined witness everywhere.
    long long aug_failed_gen = -1;
-   bool checked_witness = !(getenv("PIPS_HIP_AUG_WITNESS") && atoi(getenv("PIPS_HIP_AUG_WITNESS")) == 0);
+   bool checked_witness = env_int("PIPS_HIP_AUG_WITNESS", 1) != 0;
    // Every solveCompressed that goes by sweeps is measured like that (pips_hip_kkt_set_solve_check: every k-th one; 0 = the witness
    // only, rounds 4's behaviour): the reference's PARDISO measures and refines EVERY leaf solve (iparm[7] = 2,
    // PardisoProjectSolver.C:72), and one clean right-hand side does not bound the backward error of the next.  Several ranks decide
@@ -3252,7 +3250,7 @@ struct KktSystem {
    bool joint_aug_any = false;        // several ranks: some rank's analysis chose the sweeps (all-reduced once per analysis)
    long long joint_aug_gen = -1;
    double *d_bsave = nullptr, *d_b0save = nullptr;
-   bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting / PIPS_HIP_ROOT_PIVOTING decided; else: Bunch-Kaufman iff root inequality rows are eliminated
+   bool root_pivoting_set = false;   // pips_hip_kkt_set_root_pivoting decided; else: Bunch-Kaufman iff root inequality rows are eliminated
    // phase times of one factorize and the solveCompressed calls after it (pips_hip_kkt_get_timing; on with the batch's timing switch):
    // 0 diagonals + zero SC, 1 leaf factorisation, 2 Schur reduction, 3 finalize, 4 root factorisation (its own stream),
    // 5 Lsolve leaf solves, 6 Lsolve border product + b0 reduction, 7 Dsolve, 8 Ltsolve, 9 x_i = z_i - u_i,
@@ -4194,7 +4192,6 @@ int pips_hip_dense_ldl_create(void** handle, int n, int n_primal, int device) {
    d->device = dev;
    // no inertia hint = a plain DeSymIndefSolver replacement: pivot like dsytrf; with a hint the caller vouches for the quasi-definite order
    d->pivoting = n_primal < 0 ? 1 : 0;
-   if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) d->pivoting = atoi(pv) != 0;
    rc = d->init();
    if (rc) return rc;
    *handle = d.release();
@@ -4324,12 +4321,11 @@ int pips_hip_kkt_create(void** handle, void* batch, int n0, int my0, int myl, in
    k->root->stream = e->stream;
    k->root->thr_rel = e->thr_rel;
    k->root->repl_rel = e->repl_rel;
-   if (const char* pv = getenv("PIPS_HIP_ROOT_PIVOTING")) { k->root->pivoting = atoi(pv) != 0; k->root_pivoting_set = true; }
    int rc = k->root->init();
    if (rc) return rc;
    // several ranks: the dense root factorised column-cyclically over the ranks instead of redundantly on every one of them
    // (PIPS_HIP_ROOT_DISTRIBUTED=1; untimed - see DenseLdl::set_distributed)
-   if (comm && n_ranks > 1 && getenv("PIPS_HIP_ROOT_DISTRIBUTED") && atoi(getenv("PIPS_HIP_ROOT_DISTRIBUTED")) != 0 && (rc = k->root->set_distributed(comm, rank, n_ranks))) return rc;
+   if (comm && n_ranks > 1 && env_int("PIPS_HIP_ROOT_DISTRIBUTED", 0) != 0 && (rc = k->root->set_distributed(comm, rank, n_ranks))) return rc;
    HIP_TRY(hipMalloc((void**)&k->d_SC, (size_t)S * S * sizeof(double)));
    HIP_TRY(hipMalloc((void**)&k->d_t, std::max<size_t>((size_t)e->n_total, 1) * sizeof(double)));
    // constant root blocks added by finalizeKKTdense: A0 at row n0, F0 at row n0+my0, G0 at row n0+my0+myl
@@ -4597,7 +4593,7 @@ static int kkt_factorize_sparse(KktSystem* k, const double* leaf_diag_dev, const
    // main stream): round 4 had one bench run of about two dozen with it not finish inside its time limit and made it opt-in; 148 full-size
    // runs and 60 small ones in round 5 (tools/stress_exit.sh, tools/stress_async.sh, every run under a watchdog) all ended, and the
    // mechanism is the dense root's, which has been the default since round 2.
-   static const bool root_async_env = !(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC") && atoi(getenv("PIPS_HIP_SPARSE_ROOT_ASYNC")) == 0) && !getenv("PIPS_HIP_ROOT_SYNC");
+   static const bool root_async_env = env_int("PIPS_HIP_SPARSE_ROOT_ASYNC", 1) != 0 && !getenv("PIPS_HIP_ROOT_SYNC");
    const bool root_async = root_async_env && k->root_own_stream;
    if (!root_async) {
       const int rec_main = tm.begin_i(e->stream, 13);     // (phase 13 = the root factorisation where it sits on the main stream: critical path)
@@ -5204,7 +5200,7 @@ int pips_symbolic_probe(int n, int n_primal, const int* krow, const int* jcol, i
    AnalyzeOptions opt;
    apply_tuning(opt);
    opt.force_n_head = force_n_head;
-   opt.mf_konly = opt.mf_split_nb_max > 0 && opt.max_sn_width <= 16 && getenv("PIPS_HIP_MF_KONLY") && atoi(getenv("PIPS_HIP_MF_KONLY")) != 0;   // (as Engine::analyze outside deterministic mode)
+   opt.mf_konly = opt.mf_split_nb_max > 0 && opt.max_sn_width <= 16 && env_int("PIPS_HIP_MF_KONLY", 0) != 0;   // (as Engine::analyze outside deterministic mode)
    CsrPattern K{n, n, krow, jcol};
    CsrPattern B{0, n, nullptr, nullptr};
    if (Bt_rowptr && S > 0) B = CsrPattern{S, n, Bt_rowptr, Bt_colidx};
