@@ -2272,7 +2272,7 @@ struct Engine {
       const bool rows = sweep.enabled && np * 4 <= SWEEP_NRHS_MAX && p.ntc_max > 0;   // the tail sweeps as one launch per direction (tickets, flags)
       // few tile rows per step (a single leaf): a workgroup takes a quarter of a panel's right-hand sides, so that the chain of a pass - one
       // workgroup's tile products per step - is four times shorter; many blocks: whole panels, L read once per 32 right-hand sides
-      const bool slices = (long long)sweep.n_tasks * np < 2048;
+      const bool slices = (long long)sweep.n_tasks * np < 2048 && env_int("PIPS_HIP_MULTI", 1) != 2;   // (PIPS_HIP_MULTI=2: whole panels whatever the size - tests)
       if (rows && slices)
          hipLaunchKernelGGL(k_mtail_rows_fwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
       else if (rows)

@@ -90,6 +90,32 @@ def test_leaf_multi_rhs_rows(scheme, n_i, monkeypatch):
                 assert not Xz[k].any()
 
 
+@pytest.mark.parametrize("nrhs", [8, 33, 100, 257, 300])
+@pytest.mark.parametrize("scheme", ["quarter_panels", "whole_panels"])
+def test_leaf_many_rhs_on_the_matrix_pipe(scheme, nrhs, monkeypatch):
+    """solve(nrhs, ...) beyond one panel of 32 interleaved right-hand sides and beyond one pass of 256: every launch takes all panels, the
+    dense tail's sweeps are one launch per direction with a workgroup per (tile row, quarter panel) - a single leaf - or per (tile row,
+    panel) - what large batches take (PIPS_HIP_MULTI=2 forces it here); against SuperLU, and against the same handle one column at a time."""
+    monkeypatch.setenv("PIPS_HIP_MULTI", "1" if scheme == "quarter_panels" else "2")
+    n_i = 1500                                  # a dense tail of several tiles
+    prob = Problem(5, 1, n_i, n_i // 2, 4, 4, 6.0 / n_i)
+    s = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
+    s.matrixChanged()
+    rng = np.random.default_rng(nrhs)
+    R = rng.standard_normal((nrhs, prob.n_leaf))
+    R[nrhs // 2] *= 1e6                         # (the columns of a pass do not see each other)
+    X = R.copy()
+    s.solve(X)
+    lu = spl.splu(prob.K_full(0))
+    for k in range(nrhs):
+        xr = lu.solve(R[k])
+        assert np.linalg.norm(X[k] - xr) / np.linalg.norm(xr) < 1e-9
+    for k in (0, nrhs // 2, nrhs - 1):
+        one = R[k].copy()
+        s.solve(one)
+        assert np.linalg.norm(one - X[k]) / np.linalg.norm(one) < 1e-11
+
+
 def test_refactor_after_diagonal_change():
     """matrixChanged() after mutating the diagonal in place (a2/a3), pattern fixed."""
     prob = Problem(3, 1, 400, 200, 4, 4, 0.02)

@@ -121,3 +121,19 @@ def test_a_wait_that_gives_up_is_reported(monkeypatch):
     x, inertia = factor_solve(M, 1000, np.ones((n, 1)))
     assert inertia == (1000, 500, 0)
     assert np.abs(M @ x[:, 0] - 1.0).max() < 1e-9
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sizes_and_splits(seed):
+    """Dimensions that are no multiple of the tile or the sub-block, inertia hints anywhere from all-negative to all-positive, diagonals over
+    six decades: solution against numpy, inertia exact."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 1400))
+    n_primal = int(rng.integers(0, n + 1))
+    M = quasi_definite(n, n_primal, seed=seed, spread=3.0)
+    B = rng.standard_normal((n, 2))
+    x, inertia = factor_solve(M, n_primal, B)
+    want = np.linalg.solve(M, B)
+    assert inertia == (n_primal, n - n_primal, 0)
+    assert np.abs(x - want).max() <= 1e-9 * np.abs(want).max()
+
