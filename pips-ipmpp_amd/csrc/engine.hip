@@ -654,6 +654,7 @@ struct Engine {
    double* d_bb_out = nullptr;                      // deterministic mode: the blocks' border x border triangles before they join their groups
    std::vector<int> h_bb_off_keep;
    int n_bb = 0, bb_stage = 3072, bb_nbmax = 0, bb_poscap = 0;
+   bool bb_two_per_cu = false;   // k_border_schur: staging area sized for two workgroups per compute unit (bb_plan_size)
    int* d_bb_round_blk = nullptr;                   // deterministic mode: the blocks of round k of k_border_schur
    std::vector<int> bb_round_off;
    std::vector<int> h_root_off_keep;
@@ -1350,7 +1351,7 @@ struct Engine {
          // staging area: as much of the LDS as the packed triangle of the widest border leaves (a batch is one barrier pair and one request
          // latency whatever it holds; the supernodes of the upper levels take 2000+ doubles each), at most 6144 doubles, at least the largest
          // single supernode (bb_plan_size)
-         bb_stage = bb_plan_size().stage;
+         { const BbPlanSize z = bb_plan_size(); bb_stage = z.stage; bb_two_per_cu = z.two_per_cu; }
          long long bb_total = arena_total;   // the border-row arena lives behind the panels in the same allocation (offsets like SnDesc::panel)
          for (int b = 0; b < nblk; ++b) {
             const BlockSym& bs = sym[b];
@@ -1759,19 +1760,28 @@ struct Engine {
    // ---- k_border_schur's LDS need, from the symbolic analysis alone (the same rules as the batching loop of analyze()): staging area,
    //      most row positions of a batch, widest border.  Evaluated at analyze time: a block set whose border rows do not fit (nb near 176
    //      under wide fronts that are nearly all border rows) goes back to whole update matrices there instead of failing in every factor()
-   struct BbPlanSize { int stage = 3072, poscap = 0, nbmax = 0; };
+   struct BbPlanSize { int stage = 3072, poscap = 0, nbmax = 0; bool two_per_cu = false; };
    BbPlanSize bb_plan_size() const {
       BbPlanSize z;
       for (int b = 0; b < nblk; ++b) if (sym[b].mf_split) z.nbmax = std::max(z.nbmax, sym[b].nb);
       const long long tri = ((long long)z.nbmax * (z.nbmax + 1) / 2 + 1) & ~1LL;
       const long long room = 19200 - tri - 4 * 512 / 2 - 64;   // (positions: up to 4 * 512 ints; supernode records)
       z.stage = (int)std::max<long long>(3072, std::min<long long>(6144, room)) & ~1;
+      // two workgroups on a compute unit where half the LDS leaves a staging area of 3072 doubles or more: the walk is a chain of
+      // barriers and request latencies per batch, a second workgroup fills them (configs[3] shape, nb = 103: k_border_schur 3.3 -> 2.1 ms
+      // with 3072 - 4096 doubles and two workgroups per block; 2048 doubles and two or three: 2.7 - 3.2 ms)
+      const long long room2 = 9600 - tri - 4 * 512 / 2 - 64;
+      if (room2 >= 3072) { z.stage = (int)std::min<long long>(4096, room2) & ~1; z.two_per_cu = true; }
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& bs = sym[b];
          if (!bs.mf_split) continue;
          for (const HeadSupernode& hs : bs.sn)
-            if (hs.rb < hs.r) z.stage = std::max<int>(z.stage, hs.w * ((hs.r - hs.rb + 3) / 4 * 4) + ((hs.w + 1) & ~1));
+            if (hs.rb < hs.r) {
+               const int need = hs.w * ((hs.r - hs.rb + 3) / 4 * 4) + ((hs.w + 1) & ~1);
+               if (need > z.stage) { z.stage = need; z.two_per_cu = false; }   // (a supernode beyond the half-LDS area: back to one workgroup's rule)
+            }
       }
+      if (!z.two_per_cu) z.stage = std::max<int>(z.stage, (int)std::max<long long>(3072, std::min<long long>(6144, room)) & ~1);
       for (int b = 0; b < nblk; ++b) {
          const BlockSym& bs = sym[b];
          if (!bs.mf_split) continue;
@@ -1806,7 +1816,7 @@ struct Engine {
       if (!bb_fits(z))   // (analyze() has checked the same formula and taken the split off where it does not hold: an assertion)
          PIPS_FAIL(PIPS_ERR_STATE, "k_border_schur: %zu bytes of LDS for nb = %d (batch of %d doubles, %d rows)", lds, bb_nbmax, bb_stage, bb_poscap);
       // a block's batches are walked by `split` workgroups (each with its own accumulator): enough of them to fill the chip
-      const int split = std::max(1, std::min(16, 256 / std::max(nblk, 1)));
+      const int split = std::max(1, std::min(32, (bb_two_per_cu ? 512 : 256) / std::max(nblk, 1)));
       auto go = [&](auto kern, int cnt, const int* list, double* gb, long long gs, const int* grp, int sp, int ordered, double* out = nullptr,
                     long long out_stride = 0) -> int {
          if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
