@@ -187,14 +187,20 @@ def ipm_end_to_end(pa, seed, N, n_i, my_i, n0, myl, rho, family_blocks=None, fam
         bs.append(T.to_scipy() @ x0s + W.to_scipy() @ xs)
         blink = blink + F.to_scipy() @ xs
     ipm = pa.IpmSolver(n0, myl, blocks, F0, np.concatenate(cs), np.concatenate([blink] + bs))
+    w0, sites0 = pa.host_wait_count(), pa.host_wait_sites()
     t0 = time.perf_counter()
     res = ipm.solve(max_iter=150, mutol=1e-8, artol=1e-8)
     dt = time.perf_counter() - t0
+    waits = pa.host_wait_count() - w0
+    sites = {k: v - sites0.get(k, 0) for k, v in pa.host_wait_sites().items() if v - sites0.get(k, 0) > 0}
     st = ipm.stats()
     ipm.close()
     out = {"status": res["status"], "iterations": res["iterations"], "seconds": round(dt, 3), "iterations_per_s": round(res["iterations"] / dt, 3),
            "objective": res["objective"], "mu": res["mu"], "rel_residual": res["rnorm"] / res["dnorm"], "factorizations": st["factorizations"],
-           "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i)}
+           "solve_compressed": st["solve_compressed"], "variables": int(n0 + N * n_i), "constraints": int(myl + N * my_i),
+           # how often the host stopped for the device inside the library (csrc/common.h counts every synchronisation and blocking copy)
+           "host_waits": int(waits), "host_waits_per_iteration": round(waits / max(res["iterations"], 1), 1),
+           "host_wait_sites": dict(sorted(sites.items(), key=lambda kv: -kv[1])[:8])}
     # the same LP through the CPU PARDISO path (tests/golden/ipm_configs1.json, made by tests/golden/make_ipm_configs1.py in the build
     # container): north_star asks for agreement to 1e-8 relative; tests/test_ipm_gpu.py::test_configs1_matches_the_cpu_pardiso_path asserts it
     try:
@@ -525,9 +531,11 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
+    waits0 = pa.host_wait_count()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    host_waits_per_step = (pa.host_wait_count() - waits0) / max(a.steps, 1)   # (inside the library: csrc/common.h)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -615,6 +623,7 @@ def main():
     accounted = sum(tk[k][0] for k in ("diag_zero", "leaf_factor", "reduce", "finalize", "root_factor_main_stream", "lsolve_leaf", "lsolve_border_reduce",
                                        "root_wait", "dsolve", "ltsolve", "solve_check", "combine"))
     phase_ms = {"step": top, "root_factor_exposed": round(root_exposed, 3), "accounted": round(accounted, 3),
+                "host_waits_per_step": round(host_waits_per_step, 2),   # how often a timed step made the host wait for the device inside the library
                 "instrumented_step_wall": round(t_instr, 3),   # the one step the phases were taken from, host clock around it (events and two extra waits inside)
                 "leaf_factor": {k: round(tm[k][0], 3) for k in ("scatter", "head", "tail_update", "tail_diag", "tail_trsm", "schur")},
                 "leaf_solves": {k: round(tm[k][0], 3) for k in ("solve_permute", "solve_head_fwd", "solve_tail", "solve_head_bwd", "solve_refine")},

@@ -17,6 +17,11 @@ extern "C" {
 #endif
 
 const char* pips_hip_last_error(void);
+/* how often this process has made the host wait for the device inside the library so far (stream / event / device synchronisations and
+ * blocking copies, all counted at one place: csrc/common.h) - a diagnostic: the difference around a call sequence is its number of host stops */
+long long pips_hip_host_wait_count(void);
+/* the same per call site, as lines "file:line count" written into buf (at most cap bytes, NUL-terminated); returns the bytes written */
+int pips_hip_host_wait_sites(char* buf, int cap);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int pips_hip_device_count(void);
 

@@ -203,3 +203,23 @@ struct RootPlanParams {
 int build_root_plan(int ntc, const RootPlanParams& p, std::vector<int>& tasks, std::vector<int>& chain_tasks, double* makespan_us);
 
 }  // namespace pips
+
+// ---- host waits, counted ------------------------------------------------------------------------
+// Every place where the host waits for the device inside this library - stream / event / device synchronisation and the blocking copies -
+// goes through these wrappers, so that "how often does an IPM iteration stop the host" is a number (pips_hip_host_wait_count; bench.py
+// reports it per iteration and per work unit) instead of an estimate.  Only in translation units that include the HIP runtime.
+#ifdef HIP_INCLUDE_HIP_HIP_RUNTIME_H
+#include <atomic>
+namespace pips {
+extern std::atomic<long long> g_host_waits;
+void note_host_wait(const char* file, int line);   // engine.hip: the total, and a table per call site (pips_hip_host_wait_sites)
+inline hipError_t counted_stream_sync(hipStream_t s, const char* f, int l) { note_host_wait(f, l); return (hipStreamSynchronize)(s); }
+inline hipError_t counted_device_sync(const char* f, int l) { note_host_wait(f, l); return (hipDeviceSynchronize)(); }
+inline hipError_t counted_event_sync(hipEvent_t e, const char* f, int l) { note_host_wait(f, l); return (hipEventSynchronize)(e); }
+inline hipError_t counted_memcpy(void* d, const void* s, size_t n, hipMemcpyKind k, const char* f, int l) { note_host_wait(f, l); return (hipMemcpy)(d, s, n, k); }
+}
+#define hipStreamSynchronize(s) ::pips::counted_stream_sync(s, __FILE__, __LINE__)
+#define hipDeviceSynchronize() ::pips::counted_device_sync(__FILE__, __LINE__)
+#define hipEventSynchronize(e) ::pips::counted_event_sync(e, __FILE__, __LINE__)
+#define hipMemcpy(d, s, n, k) ::pips::counted_memcpy(d, s, n, k, __FILE__, __LINE__)
+#endif

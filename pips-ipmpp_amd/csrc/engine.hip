@@ -25,6 +25,27 @@ namespace pips {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
+std::atomic<long long> g_host_waits{0};
+// per call site: a small open-addressed table keyed by (file, line) - the literals' addresses are stable, a site is entered once
+struct WaitSite { std::atomic<const char*> file{nullptr}; std::atomic<int> line{0}; std::atomic<long long> n{0}; };
+static WaitSite g_wait_sites[128];
+void note_host_wait(const char* file, int line) {
+   g_host_waits.fetch_add(1, std::memory_order_relaxed);
+   size_t h = ((size_t)(uintptr_t)file / 8 + (size_t)line * 31) % 128;
+   for (int probe = 0; probe < 128; ++probe, h = (h + 1) % 128) {
+      WaitSite& w = g_wait_sites[h];
+      const char* f = w.file.load(std::memory_order_acquire);
+      if (!f) {
+         const char* expect = nullptr;
+         if (w.file.compare_exchange_strong(expect, file)) { w.line.store(line); f = file; }
+         else f = expect;
+      }
+      if (f == file) {
+         while (w.line.load() == 0) {}   // (the entering thread stores the line right after the file)
+         if (w.line.load() == line) { w.n.fetch_add(1, std::memory_order_relaxed); return; }
+      }
+   }
+}
 const char* last_error() { return g_last_error.c_str(); }
 
 #define HIP_TRY(expr)                                                                              \
@@ -760,7 +781,7 @@ struct Engine {
       h_inertia_pin = nullptr;
       if (ev_inertia) (void)hipEventDestroy(ev_inertia);
       ev_inertia = nullptr;
-      inertia_in_flight = false;
+      inertia_in_flight = inertia_on_host = false;
       for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res, &d_hostx}) { if (*q) (void)hipFree(*q); *q = nullptr; }
       mx_cap = 0;
       hostx_cap = 0;
@@ -2142,6 +2163,7 @@ struct Engine {
       HIP_TRY(hipMemcpyAsync(h_inertia_pin, d_inertia, (size_t)3 * nblk * sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipEventRecord(ev_inertia, stream));
       inertia_in_flight = true;
+      inertia_on_host = false;
       return PIPS_OK;
    }
 
@@ -2480,14 +2502,17 @@ struct Engine {
                          d_norms, nblk);
       HIP_TRY(hipMemcpyAsync(h_norms, d_norms, (size_t)3 * nblk * sizeof(double), hipMemcpyDeviceToHost, stream));
       timer.end(stream);
-      if (refine_mode == 1 && h_amax.empty()) {
-         h_amax.resize(nblk);
-         std::vector<BlkDesc> tmp(nblk);
+      std::vector<BlkDesc> tmp;
+      const bool need_amax = refine_mode == 1 && h_amax.empty();   // (the blocks' largest entries: once per factorisation, with the same wait)
+      if (need_amax) {
+         tmp.resize(nblk);
          HIP_TRY(hipMemcpyAsync(tmp.data(), d_blks, (size_t)nblk * sizeof(BlkDesc), hipMemcpyDeviceToHost, stream));
-         HIP_TRY(hipStreamSynchronize(stream));
-         for (int b = 0; b < nblk; ++b) h_amax[b] = tmp[b].repl_abs / (repl_rel > 0 ? repl_rel : 1.0);
       }
       HIP_TRY(hipStreamSynchronize(stream));
+      if (need_amax) {
+         h_amax.resize(nblk);
+         for (int b = 0; b < nblk; ++b) h_amax[b] = tmp[b].repl_abs / (repl_rel > 0 ? repl_rel : 1.0);
+      }
       double worst = 0.0;
       for (int b = 0; b < nblk; ++b) {
          const double den = refine_mode == 1 ? h_amax[b] * h_norms[2 * nblk + b] + h_norms[nblk + b] : h_norms[nblk + b];
@@ -2502,13 +2527,16 @@ struct Engine {
    // copy - not for whatever was queued behind the factorisation (the leaf solves of an Lsolve, say).
    int* h_inertia_pin = nullptr;
    hipEvent_t ev_inertia = nullptr;
-   bool inertia_in_flight = false;
+   bool inertia_in_flight = false, inertia_on_host = false;
    int fetch_inertia() {
-      if (inertia_in_flight && h_inertia_pin) {
+      if (inertia_in_flight && h_inertia_pin) {   // one wait per factorisation: a query per block (256 of them per IPM iteration) reads the host copy
          HIP_TRY(hipEventSynchronize(ev_inertia));
          std::copy(h_inertia_pin, h_inertia_pin + h_inertia.size(), h_inertia.begin());
+         inertia_in_flight = false;
+         inertia_on_host = true;
          return PIPS_OK;
       }
+      if (inertia_on_host) return PIPS_OK;
       HIP_TRY(hipMemcpyAsync(h_inertia.data(), d_inertia, h_inertia.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       return PIPS_OK;
@@ -3387,6 +3415,20 @@ using namespace pips;
 extern "C" {
 
 const char* pips_hip_last_error(void) { return pips::last_error(); }
+long long pips_hip_host_wait_count(void) { return pips::g_host_waits.load(std::memory_order_relaxed); }
+int pips_hip_host_wait_sites(char* buf, int cap) {
+   int used = 0;
+   if (buf && cap > 0) buf[0] = 0;
+   for (const pips::WaitSite& w : pips::g_wait_sites) {
+      const char* f = w.file.load();
+      if (!f || w.n.load() == 0) continue;
+      const char* base = strrchr(f, '/');
+      const int k = snprintf(buf ? buf + used : nullptr, buf && cap > used ? cap - used : 0, "%s:%d %lld\n", base ? base + 1 : f, w.line.load(), w.n.load());
+      if (k < 0 || !buf || used + k >= cap) break;
+      used += k;
+   }
+   return used;
+}
 
 int pips_hip_device_count(void) {
    int n = 0;

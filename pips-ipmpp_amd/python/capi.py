@@ -41,6 +41,7 @@ _vp = C.c_void_p
 
 lib.pips_hip_last_error.restype = C.c_char_p
 lib.pips_hip_device_count.restype = C.c_int
+lib.pips_hip_host_wait_count.restype = C.c_longlong
 
 # every symbol include/pips_hip.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [
@@ -51,7 +52,7 @@ SYMBOLS = [
     "pips_hip_ldl_solve_dev", "pips_hip_ldl_solve_sparse", "pips_hip_ldl_factor_schur_batch", "pips_hip_ldl_solve_batch", "pips_hip_ldl_solve_batch_dev",
     "pips_hip_ldl_inertia_batch",
     "pips_hip_dense_ldl_create", "pips_hip_dense_ldl_factor", "pips_hip_dense_ldl_factor_dev", "pips_hip_dense_ldl_solve",
-    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_set_distributed", "pips_hip_dense_ldl_destroy", "pips_root_plan_build",
+    "pips_hip_dense_ldl_solve_dev", "pips_hip_dense_ldl_inertia", "pips_hip_dense_ldl_set_pivoting", "pips_hip_dense_ldl_set_distributed", "pips_hip_dense_ldl_destroy", "pips_root_plan_build", "pips_hip_host_wait_count", "pips_hip_host_wait_sites",
     "pips_hip_batch_create", "pips_hip_batch_set_block", "pips_hip_batch_set_options", "pips_hip_batch_set_schur_mode", "pips_hip_batch_set_deterministic", "pips_hip_batch_get_schur_mode", "pips_hip_batch_add_regularization", "pips_hip_batch_set_refinement",
     "pips_hip_batch_last_refinement_steps", "pips_hip_batch_set_refinement_backward_error",
     "pips_hip_batch_last_refinement_measure", "pips_hip_batch_analyze",
@@ -83,6 +84,22 @@ def _check(rc, what):
 
 def device_count():
     return int(lib.pips_hip_device_count())
+
+
+def host_wait_count():
+    """host waits for the device inside the library so far (a diagnostic: take the difference around a call sequence)"""
+    return int(lib.pips_hip_host_wait_count())
+
+
+def host_wait_sites():
+    """{"file:line": count} of the host waits inside the library so far"""
+    buf = C.create_string_buffer(16384)
+    lib.pips_hip_host_wait_sites(buf, 16384)
+    out = {}
+    for ln in buf.value.decode().splitlines():
+        k, v = ln.rsplit(" ", 1)
+        out[k] = int(v)
+    return out
 
 
 def _ptr(a):
