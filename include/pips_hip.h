@@ -40,6 +40,10 @@ int pips_hip_ldl_set_pivot_rule(void* handle, double thr_rel, double repl_rel);
 /* iterative refinement of every solve: at most max_steps steps; tol > 0 stops as soon as ||r||inf <= tol*||rhs||inf
  * (PARDISO: iparm[7]=2, PardisoProjectSolver.C:72), tol = 0 always does max_steps steps.  Default (1, 0). */
 int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol);
+/* same, the stopping test being the normwise backward error ||r||inf / (max|K| ||x||inf + ||rhs||inf) <= tol - what PARDISO's adaptive
+ * refinement looks at; solve(nrhs) decides per chunk of right-hand sides by the worst of them (one number read back, the correction solve only
+ * where the first solve was not accurate enough).  The adapters use (2, 1e-15): iparm[7] = 2, PardisoProjectSolver.C:72 */
+int pips_hip_ldl_set_refinement_backward_error(void* handle, int max_steps, double tol);
 /* symbolic phase (ordering, supernodes, device allocation); pattern-only, done once */
 int pips_hip_ldl_analyze(void* handle);
 /* = DoubleLinearSolver::matrixChanged(): numeric LDL^T of the current values (host array of length nnz, CSR order) */
@@ -82,7 +86,7 @@ int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_ino
 int pips_hip_ldl_solve_batch_dev(void* const* handles, int n, double* x_dev);
 int pips_hip_ldl_inertia_batch(void* const* handles, int n, int* pos, int* neg, int* zero);
 /* diagnostics of the symbolic phase: what[0]=nnz(L) what[1]=n_head what[2]=tail m what[3]=#head supernodes
- * what[4]=#levels what[5]=factor flops (rounded) */
+ * what[4]=#levels what[5]=factor flops (rounded); and what[6]=refinement steps the last solve took */
 int pips_hip_ldl_info(void* handle, int64_t* what, int n_what);
 /* copies the fill-reducing permutation (perm[k] = original index eliminated k-th) */
 int pips_hip_ldl_get_perm(void* handle, int* perm);

@@ -782,9 +782,9 @@ struct Engine {
       if (ev_inertia) (void)hipEventDestroy(ev_inertia);
       ev_inertia = nullptr;
       inertia_in_flight = inertia_on_host = false;
-      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res, &d_hostx}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res, &d_hostx, &d_hostpack}) { if (*q) (void)hipFree(*q); *q = nullptr; }
       mx_cap = 0;
-      hostx_cap = 0;
+      hostx_cap = hostpack_cap = 0;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
       d_sns = nullptr; d_blks = nullptr;
       d_nprimal = nullptr;
@@ -2340,6 +2340,8 @@ struct Engine {
    int mx_cap = 0;
    double* d_hostx = nullptr;   // device copy of host right-hand sides (pips_hip_ldl_solve), kept between calls
    size_t hostx_cap = 0;
+   double* d_hostpack = nullptr;   // packed rows + their indices of pips_hip_ldl_solve_sparse, kept between calls likewise
+   size_t hostpack_cap = 0;
    static constexpr int MULTI_CHUNK_MAX = 256;   // right-hand sides per pass (eight panels)
    int ensure_multi_buffers(int want = 32) {
       want = std::min(MULTI_CHUNK_MAX, (std::max(want, 32) + MQ - 1) / MQ * MQ);
@@ -2362,6 +2364,7 @@ struct Engine {
             if (int rc = solve(X_dev + (long long)r * x_stride)) return rc;
          return PIPS_OK;
       }
+      last_refine_steps = 0;   // (over the chunks: the steps of the last one that took any)
       const bool multi = use_multi(nrhs);
       const int chunk_max = multi ? MULTI_CHUNK_MAX : 32;   // (the per-right-hand-side sweeps keep their 32 work vectors)
       int rc0 = ensure_multi_buffers(std::min(nrhs, chunk_max));
@@ -2376,18 +2379,34 @@ struct Engine {
          if (rc) return rc;
          for (int it = 0; it < refine_steps; ++it) {
             HIP_TRY(hipMemcpyAsync(d_mx_res, d_mx_rhs, (size_t)nr * n_total * sizeof(double), hipMemcpyDeviceToDevice, stream));
-            // r = rhs - K x for every right-hand side: x at stride x_stride, r contiguous -> copy x into a contiguous view first
-            HIP_TRY(hipMemcpy2DAsync(d_mx_xw, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
-                                     (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
+            // r = rhs - K x for every right-hand side: x at stride x_stride, r contiguous -> a contiguous view of x where the caller's is not
             // (d_mx_xw is free between solves; it is at least nr * n_total long because xw_total >= n_total)
+            const double* Xc = X;
+            if (x_stride != n_total) {
+               HIP_TRY(hipMemcpy2DAsync(d_mx_xw, (size_t)n_total * sizeof(double), X, (size_t)x_stride * sizeof(double),
+                                        (size_t)n_total * sizeof(double), nr, hipMemcpyDeviceToDevice, stream));
+               Xc = d_mx_xw;
+            }
             hipLaunchKernelGGL(k_full_spmv_sub, dim3(grid_for(n_total * 8, 256, 65536), nr), dim3(256), 0, stream, d_frowptr, d_fcol, d_fsrc, d_kval,
-                               d_mx_xw, d_mx_res, n_total, d_rowbase, n_total);
+                               Xc, d_mx_res, n_total, d_rowbase, n_total);
             if (n_flong > 0)
                hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong, nr), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval,
-                                  d_mx_xw, d_mx_res, d_rowbase, n_total);
+                                  Xc, d_mx_res, d_rowbase, n_total);
+            if (refine_tol > 0.0 && d_norms) {
+               // adaptive like the single right-hand side (solve()): the worst (block, right-hand side) of the chunk decides for all of it -
+               // one number back to the host, the correction solve only where the first one was not accurate enough
+               HIP_TRY(hipMemsetAsync(d_norms, 0, sizeof(double), stream));
+               hipLaunchKernelGGL(k_mrefine_measure, dim3(nblk, nr), dim3(256), 0, stream, d_blks, d_mx_res, n_total, d_mx_rhs, n_total, Xc, n_total,
+                                  refine_mode == 1 ? 1.0 / (repl_rel > 0 ? repl_rel : 1.0) : 0.0, d_norms);
+               HIP_TRY(hipMemcpyAsync(h_norms, d_norms, sizeof(double), hipMemcpyDeviceToHost, stream));
+               HIP_TRY(hipStreamSynchronize(stream));
+               last_refine_measure = h_norms[0];
+               if (h_norms[0] <= refine_tol) break;
+            }
             rc = multi ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
             if (rc) return rc;
             hipLaunchKernelGGL(k_maxpy, dim3(grid_for(n_total, 256, 1024), nr), dim3(256), 0, stream, X, x_stride, d_mx_res, n_total, 1.0, n_total);
+            ++last_refine_steps;
          }
       }
       HIP_TRY(hipGetLastError());
@@ -3856,6 +3875,16 @@ int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol) {
    if (!h) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
    h->eng.refine_steps = max_steps;
    h->eng.refine_tol = tol;
+   h->eng.refine_mode = 0;
+   return PIPS_OK;
+}
+
+int pips_hip_ldl_set_refinement_backward_error(void* handle, int max_steps, double tol) {
+   LdlHandle* h = (LdlHandle*)handle;
+   if (!h || max_steps < 0 || tol < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_set_refinement_backward_error: bad arguments");
+   h->eng.refine_steps = max_steps;
+   h->eng.refine_tol = tol;
+   h->eng.refine_mode = 1;
    return PIPS_OK;
 }
 
@@ -3950,6 +3979,15 @@ int pips_hip_ldl_factor_schur(void* handle, const double* K_vals_host, const dou
 }
 
 extern "C" int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_inout_host);
+// flags[q] = 1 where column q of X (ld apart, n entries) has an entry that is not zero (a NaN counts)
+__global__ __launch_bounds__(256) void k_columns_nonzero(const double* __restrict__ X, long long ld, int n, int* __restrict__ flags) {
+   const double* v = X + ld * blockIdx.x;
+   int any = 0;
+   for (int i = threadIdx.x; i < n; i += 256) any |= (v[i] != 0.0) ? 1 : 0;
+   any = __syncthreads_or(any);
+   if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1 : 0;
+}
+
 int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || nrhs < 0 || !rhs || ld < h->eng.in[0].n) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_solve: bad arguments");
@@ -3957,6 +3995,7 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
       return group_solve_rows(*h->group, h->group_index, nrhs, rhs, ld, false, "pips_hip_ldl_solve");
    Engine& e = h->eng;
    if (!e.factored) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_solve: factor first");
+   if (nrhs == 0) return PIPS_OK;
    HIP_TRY(hipSetDevice(e.device));
    const size_t row = (size_t)e.n_total * sizeof(double);
    if (nrhs == 1) {
@@ -3967,33 +4006,33 @@ int pips_hip_ldl_solve(void* handle, int nrhs, double* rhs, int ld) {
       HIP_TRY(hipStreamSynchronize(e.stream));
       return PIPS_OK;
    }
-   // all right-hand sides in one pass (one RHS per row of length ld).  Like PardisoSolver::solve (PardisoSolver.C:276-352)
-   // only the non-zero right-hand sides travel and are solved: the blocked Schur loop hands over chunks in which many
-   // border columns are empty (DistributedLinearSystem.C:870-874)
-   std::vector<int> nz;
-   nz.reserve(nrhs);
-   for (int r = 0; r < nrhs; ++r) {
-      const double* v = rhs + (size_t)r * ld;
-      bool any = false;
-      for (int i = 0; i < e.n_total && !any; ++i) any = v[i] != 0.0;
-      if (any) nz.push_back(r);
-   }
-   const int nnz_rhs = (int)nz.size();
-   if (nnz_rhs == 0) return PIPS_OK;
+   // all right-hand sides in one pass (one RHS per row of length ld).  Like PardisoSolver::solve (PardisoSolver.C:276-352) only the non-zero
+   // right-hand sides are solved.  Which ones those are is found on the device AFTER the upload: a scan on the host walks every column up
+   // to its first entry - the border columns of a chunk have theirs in the dual rows, behind 10 000 zeros each, 1.3 ms per call of 160 -
+   // while the whole chunk crosses the link in 0.35 ms and the flags come back with one small copy.
    // (the device copy of the right-hand sides stays with the handle: the reference's loop calls this hundreds of times per factorisation
    // with the same chunk size, an allocation and a release per call were a fifth of a millisecond each)
-   if (e.hostx_cap < (size_t)nnz_rhs * row) {
+   const size_t flag_bytes = ((size_t)nrhs * sizeof(int) + 15) & ~(size_t)15;
+   if (e.hostx_cap < (size_t)nrhs * row + flag_bytes) {
       if (e.d_hostx) { HIP_TRY(hipStreamSynchronize(e.stream)); (void)hipFree(e.d_hostx); e.d_hostx = nullptr; e.hostx_cap = 0; }
-      HIP_TRY(hipMalloc((void**)&e.d_hostx, (size_t)nnz_rhs * row));
-      e.hostx_cap = (size_t)nnz_rhs * row;
+      HIP_TRY(hipMalloc((void**)&e.d_hostx, (size_t)nrhs * row + flag_bytes));
+      e.hostx_cap = (size_t)nrhs * row + flag_bytes;
    }
    double* d_X = e.d_hostx;
+   int* d_flags = (int*)((char*)e.d_hostx + (size_t)nrhs * row);
+   std::vector<int> flags((size_t)nrhs), nz;
+   HIP_TRY(hipMemcpy2DAsync(d_X, row, rhs, (size_t)ld * sizeof(double), row, nrhs, hipMemcpyHostToDevice, e.stream));
+   hipLaunchKernelGGL(k_columns_nonzero, dim3(nrhs), dim3(256), 0, e.stream, d_X, (long long)e.n_total, (int)e.n_total, d_flags);
+   HIP_TRY(hipMemcpyAsync(flags.data(), d_flags, (size_t)nrhs * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+   HIP_TRY(hipStreamSynchronize(e.stream));
+   nz.reserve(nrhs);
+   for (int r = 0; r < nrhs; ++r) if (flags[r]) nz.push_back(r);
+   const int nnz_rhs = (int)nz.size();
+   if (nnz_rhs == 0) return PIPS_OK;
    hipError_t err = hipSuccess;
-   if (nnz_rhs == nrhs)
-      err = hipMemcpy2DAsync(d_X, row, rhs, (size_t)ld * sizeof(double), row, nrhs, hipMemcpyHostToDevice, e.stream);
-   else
+   if (nnz_rhs < nrhs)   // the non-zero columns move to the front (ascending: a column never lands on one that is still to move)
       for (int q = 0; q < nnz_rhs && err == hipSuccess; ++q)
-         err = hipMemcpyAsync(d_X + (size_t)q * e.n_total, rhs + (size_t)nz[q] * ld, row, hipMemcpyHostToDevice, e.stream);
+         if (nz[q] != q) err = hipMemcpyAsync(d_X + (size_t)q * e.n_total, d_X + (size_t)nz[q] * e.n_total, row, hipMemcpyDeviceToDevice, e.stream);
    int rc = err == hipSuccess ? (nnz_rhs == 1 ? e.solve(d_X) : e.solve_multi(d_X, nnz_rhs, e.n_total)) : PIPS_ERR_HIP;
    if (!rc) {
       if (nnz_rhs == nrhs)
@@ -4042,6 +4081,9 @@ int pips_hip_ldl_solve_sparse(void* handle, int nrhs, double* rhs, int ld, const
    const int n = (int)e.n_total;
    std::vector<int> rows, nz;
    for (int i = 0; i < n; ++i) if (col_sparsity[i]) rows.push_back(i);
+   // where most rows are marked the whole columns travel faster than a pack on the host (the union over a chunk of 160 border columns of
+   // configs[1] marks a fifth of the rows; 19 MB cross the link in 0.35 ms): the pack pays below an eighth
+   if ((long long)rows.size() * 8 >= n) return pips_hip_ldl_solve(handle, nrhs, rhs, ld);
    for (int r = 0; r < nrhs; ++r) {
       const double* v = rhs + (size_t)r * ld;
       bool any = false;
@@ -4055,24 +4097,34 @@ int pips_hip_ldl_solve_sparse(void* handle, int nrhs, double* rhs, int ld, const
       const double* v = rhs + (size_t)nz[q] * ld;
       for (int i = 0; i < nr; ++i) packed[(size_t)q * nr + i] = v[rows[i]];
    }
-   double *d_X = nullptr, *d_packed = nullptr;
-   int* d_rows = nullptr;
-   const size_t row = (size_t)n * sizeof(double);
-   hipError_t err = hipMalloc((void**)&d_X, (size_t)nq * row);
-   if (err == hipSuccess) err = hipMalloc((void**)&d_packed, packed.size() * sizeof(double));
-   if (err == hipSuccess) err = hipMalloc((void**)&d_rows, (size_t)nr * sizeof(int));
-   if (err == hipSuccess) err = hipMemcpyAsync(d_packed, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, e.stream);
+   // (device copies kept with the handle, like pips_hip_ldl_solve's: no allocation and release per call)
+   const size_t row = (size_t)n * sizeof(double), pack_bytes = packed.size() * sizeof(double) + (size_t)nr * sizeof(int);
+   if (e.hostx_cap < (size_t)nq * row) {
+      if (e.d_hostx) { HIP_TRY(hipStreamSynchronize(e.stream)); (void)hipFree(e.d_hostx); e.d_hostx = nullptr; e.hostx_cap = 0; }
+      HIP_TRY(hipMalloc((void**)&e.d_hostx, (size_t)nq * row));
+      e.hostx_cap = (size_t)nq * row;
+   }
+   if (e.hostpack_cap < pack_bytes) {
+      if (e.d_hostpack) { HIP_TRY(hipStreamSynchronize(e.stream)); (void)hipFree(e.d_hostpack); e.d_hostpack = nullptr; e.hostpack_cap = 0; }
+      HIP_TRY(hipMalloc((void**)&e.d_hostpack, pack_bytes));
+      e.hostpack_cap = pack_bytes;
+   }
+   double *d_X = e.d_hostx, *d_packed = e.d_hostpack;
+   int* d_rows = (int*)(e.d_hostpack + packed.size());
+   hipError_t err = hipMemcpyAsync(d_packed, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, e.stream);
    if (err == hipSuccess) err = hipMemcpyAsync(d_rows, rows.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice, e.stream);
    if (err == hipSuccess) err = hipMemsetAsync(d_X, 0, (size_t)nq * row, e.stream);
    int rc = PIPS_OK;
    if (err == hipSuccess) {
       hipLaunchKernelGGL(k_expand_rows, dim3(grid_for((long long)nq * nr, 256)), dim3(256), 0, e.stream, d_rows, nr, d_packed, d_X, (long long)n, nq);
       rc = nq == 1 ? e.solve(d_X) : e.solve_multi(d_X, nq, n);
-      for (int q = 0; q < nq && !rc && err == hipSuccess; ++q)
-         err = hipMemcpyAsync(rhs + (size_t)nz[q] * ld, d_X + (size_t)q * n, row, hipMemcpyDeviceToHost, e.stream);
-      if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+      if (!rc && nq == nrhs)
+         err = hipMemcpy2DAsync(rhs, (size_t)ld * sizeof(double), d_X, row, row, nrhs, hipMemcpyDeviceToHost, e.stream);
+      else
+         for (int q = 0; q < nq && !rc && err == hipSuccess; ++q)
+            err = hipMemcpyAsync(rhs + (size_t)nz[q] * ld, d_X + (size_t)q * n, row, hipMemcpyDeviceToHost, e.stream);
+      if (err == hipSuccess) err = hipStreamSynchronize(e.stream);   // (the host vectors packed / rows live until here)
    }
-   for (void* q : {(void*)d_X, (void*)d_packed, (void*)d_rows}) if (q) (void)hipFree(q);
    if (rc) return rc;
    if (err != hipSuccess) PIPS_FAIL(PIPS_ERR_HIP, "pips_hip_ldl_solve_sparse: %s", hipGetErrorString(err));
    return PIPS_OK;
@@ -4218,8 +4270,8 @@ int pips_hip_ldl_info(void* handle, int64_t* what, int n_what) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || h->eng.sym.empty()) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_info: analyze first");
    const BlockSym& s = h->eng.sym[0];
-   int64_t v[6] = {s.nnzL, s.n_head, s.m, (int64_t)s.sn.size(), s.n_levels, (int64_t)s.flops_factor};
-   for (int i = 0; i < n_what && i < 6; ++i) what[i] = v[i];
+   int64_t v[7] = {s.nnzL, s.n_head, s.m, (int64_t)s.sn.size(), s.n_levels, (int64_t)s.flops_factor, (int64_t)h->eng.last_refine_steps};
+   for (int i = 0; i < n_what && i < 7; ++i) what[i] = v[i];
    return PIPS_OK;
 }
 

@@ -3282,6 +3282,43 @@ __global__ void k_maxpy(double* __restrict__ X, long long x_stride, const double
    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) X[i] += a * Y[i];
 }
 
+// The measure of the adaptive refinement for several right-hand sides at once: grid (block, right-hand side); for its pair the workgroup forms
+// ||r||inf, ||rhs||inf and ||x||inf over the block's rows and folds  ||r|| / (amax_scale * max|K_b| ||x|| + ||rhs||)  into ONE number,
+// worst[0], with an integer atomic max (non-negative doubles order like their bit patterns; a NaN or Inf counts as +Inf); amax_scale = 0:
+// the denominator is ||rhs||inf alone (refine_mode 0).  blks[b].repl_abs = repl_rel * max|K_b| (k_block_absmax_finish).
+__global__ __launch_bounds__(256) void k_mrefine_measure(const BlkDesc* __restrict__ blks, const double* __restrict__ R, long long r_stride,
+                                                        const double* __restrict__ B, long long b_stride, const double* __restrict__ X,
+                                                        long long x_stride, double amax_scale, double* __restrict__ worst) {
+   const BlkDesc bd = blks[blockIdx.x];
+   const double inf = __longlong_as_double(0x7ff0000000000000LL);
+   const double* r = R + r_stride * blockIdx.y + bd.x_off;
+   const double* b = B + b_stride * blockIdx.y + bd.x_off;
+   const double* x = X + x_stride * blockIdx.y + bd.x_off;
+   double m[3] = {0.0, 0.0, 0.0};
+   for (int i = threadIdx.x; i < bd.n; i += 256) {
+      const double v[3] = {fabs(r[i]), fabs(b[i]), fabs(x[i])};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) m[q] = fmax(m[q], v[q] <= 1.7976931348623157e308 ? v[q] : inf);
+   }
+   __shared__ double red[3][256];
+#pragma unroll
+   for (int q = 0; q < 3; ++q) red[q][threadIdx.x] = m[q];
+   __syncthreads();
+   for (int h = 128; h > 0; h >>= 1) {
+      if ((int)threadIdx.x < h)
+         for (int q = 0; q < 3; ++q) red[q][threadIdx.x] = fmax(red[q][threadIdx.x], red[q][threadIdx.x + h]);
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) {
+      const double den = amax_scale * bd.repl_abs * red[2][0] + red[1][0];
+      if (den > 0.0) {
+         double q = red[0][0] / den;
+         if (!(q <= 1.7976931348623157e308)) q = inf;   // (Inf / Inf = NaN: never "converged" on a poisoned iterate)
+         if (q > 0.0) atomicMax((unsigned long long*)worst, (unsigned long long)__double_as_longlong(q));
+      }
+   }
+}
+
 // refinement residual r = b - K x (r holds b on entry): the full (both triangles) row structure is built at analyze time -
 // frowptr / fcol (block-local column) / fsrc (index of the value inside kval) - so the product is gather-only, no atomics:
 //   y_i -= sum_j K_ij x_j

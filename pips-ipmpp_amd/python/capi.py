@@ -46,7 +46,7 @@ lib.pips_hip_host_wait_count.restype = C.c_longlong
 # every symbol include/pips_hip.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [
     "pips_hip_last_error", "pips_hip_device_count",
-    "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement",
+    "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement", "pips_hip_ldl_set_refinement_backward_error",
     "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
     "pips_hip_ldl_get_perm", "pips_hip_ldl_set_border", "pips_hip_ldl_factor_schur", "pips_hip_ldl_destroy",
     "pips_hip_ldl_solve_dev", "pips_hip_ldl_solve_sparse", "pips_hip_ldl_factor_schur_batch", "pips_hip_ldl_solve_batch", "pips_hip_ldl_solve_batch_dev",
@@ -267,7 +267,7 @@ class HipLdlSolver:
     SparseSymmetricMatrix (PardisoSolver.h:49-50): mutate `K.val` in place, then call matrixChanged().
     """
 
-    def __init__(self, K, n_primal=-1, device=-1, refine_steps=1, refine_tol=0.0):
+    def __init__(self, K, n_primal=-1, device=-1, refine_steps=1, refine_tol=0.0, backward_error=False):
         self.K = K
         self.n = K.nrows
         self._h = C.c_void_p()
@@ -275,8 +275,9 @@ class HipLdlSolver:
                                        C.c_int(0)), "pips_hip_ldl_create")
         if n_primal >= 0:
             _check(lib.pips_hip_ldl_set_inertia_hint(self._h, C.c_int(n_primal)), "pips_hip_ldl_set_inertia_hint")
-        _check(lib.pips_hip_ldl_set_refinement(self._h, C.c_int(refine_steps), C.c_double(refine_tol)),
-               "pips_hip_ldl_set_refinement")
+        # backward_error: stop on the normwise backward error (what the adapters set: at most 2 steps, 1e-15)
+        _check((lib.pips_hip_ldl_set_refinement_backward_error if backward_error else lib.pips_hip_ldl_set_refinement)(
+            self._h, C.c_int(refine_steps), C.c_double(refine_tol)), "pips_hip_ldl_set_refinement")
 
     def set_pivot_rule(self, thr_rel, repl_rel):
         _check(lib.pips_hip_ldl_set_pivot_rule(self._h, C.c_double(thr_rel), C.c_double(repl_rel)), "set_pivot_rule")
@@ -365,10 +366,10 @@ class HipLdlSolver:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(6, np.int64)
-        _check(lib.pips_hip_ldl_info(self._h, _ptr(what), C.c_int(6)), "pips_hip_ldl_info")
+        what = np.zeros(7, np.int64)
+        _check(lib.pips_hip_ldl_info(self._h, _ptr(what), C.c_int(7)), "pips_hip_ldl_info")
         return dict(nnzL=int(what[0]), n_head=int(what[1]), m=int(what[2]), n_sn=int(what[3]), n_levels=int(what[4]),
-                    flops=int(what[5]))
+                    flops=int(what[5]), last_refinement_steps=int(what[6]))
 
     def close(self):
         if self._h:

@@ -116,6 +116,39 @@ def test_leaf_many_rhs_on_the_matrix_pipe(scheme, nrhs, monkeypatch):
         assert np.linalg.norm(one - X[k]) / np.linalg.norm(one) < 1e-11
 
 
+def test_leaf_many_rhs_refine_only_where_needed():
+    """solve(nrhs) with the adapters' refinement (at most two steps, backward error 1e-15: iparm[7] = 2, PardisoProjectSolver.C:72): a chunk whose
+    first solve is accurate takes no correction solve; a pivot rule that perturbs (threshold far above the small dual pivots) leaves factors
+    the measure rejects - the steps are taken and bring the chunk to the accuracy of the refined single solve."""
+    n_i = 1200
+    prob = Problem(7, 1, n_i, n_i // 2, 4, 4, 6.0 / n_i)
+    K = prob.blocks[0]["K"]
+    rng = np.random.default_rng(3)
+    R = rng.standard_normal((40, prob.n_leaf))
+    lu = spl.splu(prob.K_full(0))
+    s = pa.HipLdlSolver(K, n_primal=prob.n_i, refine_steps=2, refine_tol=1e-15, backward_error=True)
+    s.matrixChanged()
+    X = R.copy()
+    s.solve(X)
+    assert s.info()["last_refinement_steps"] == 0
+    for k in range(40):
+        xr = lu.solve(R[k])
+        assert np.linalg.norm(X[k] - xr) / np.linalg.norm(xr) < 1e-9
+    s.close()
+    s = pa.HipLdlSolver(K, n_primal=prob.n_i, refine_steps=2, refine_tol=1e-15, backward_error=True)
+    s.set_pivot_rule(1e-3, 1e-3)                 # pivots below 1e-3 max|K| are replaced: the factors are those of a perturbed matrix
+    s.matrixChanged()
+    if s.get_inertia()[2] == 0:
+        pytest.skip("no pivot of this block falls under the threshold")
+    X = R.copy()
+    s.solve(X)
+    assert s.info()["last_refinement_steps"] >= 1
+    one = R[5].copy()
+    s.solve(one)
+    assert np.linalg.norm(one - X[5]) / np.linalg.norm(one) < 1e-6
+    s.close()
+
+
 def test_refactor_after_diagonal_change():
     """matrixChanged() after mutating the diagonal in place (a2/a3), pattern fixed."""
     prob = Problem(3, 1, 400, 200, 4, 4, 0.02)

@@ -28,7 +28,7 @@ for b in range(a.blocks):
     K, dpos = pa.kkt_leaf_assemble(n_i, W)
     K.val[dpos] = np.concatenate([pa.gen_diagonal(seed, b + 1, n_i), -1e-8 * np.ones(my_i)])
     Bt = pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F).to_scipy()
-    s = pa.HipLdlSolver(K, n_primal=n_i, refine_steps=1)
+    s = pa.HipLdlSolver(K, n_primal=n_i, refine_steps=2, refine_tol=1e-15, backward_error=True)   # (the adapters' setting: examples/adapter/HipLdlSolver.h)
     if a.level in ("1.5", "1.5b"):
         s.set_border(pa.border_assemble(n_i, my_i, 0, n0, 0, A=T, F=F))
     if a.level == "1.5b":
@@ -43,17 +43,26 @@ for b in range(a.blocks):
         t0 = time.perf_counter(); s.matrixChanged(); t_fac += time.perf_counter() - t0
         t0 = time.perf_counter()
         cols = np.nonzero(np.diff(Bt.indptr) > 0)[0]
+        # the reference keeps ONE dense buffer and one sparsity pattern per leaf system and refills them chunk by chunk (colsBlockDense / colSparsity:
+        # DistributedLinearSystem.C:840-853, std::fill + fromGetColsBlock :895-900, solve in place :903) - the same pages go up and down every time
+        colsBlockDense = np.zeros((a.chunk, Bt.shape[1])); colSparsity = np.zeros(Bt.shape[1], np.int32)
+        # (warm-up of the solve path like the factorisation's above: the solver objects live as long as the linear system, the device buffers of
+        # solve(nrhs) are allocated at its first call of a run, not per factorisation)
+        colsBlockDense[:, :] = np.random.default_rng(b).standard_normal(colsBlockDense.shape); s.solve(colsBlockDense)
+        t0 = time.perf_counter()
         for k in range(0, len(cols), a.chunk):               # K4: dense-ify, K5: multi-RHS solve, K6: sparse product
             ids = cols[k:k + a.chunk]
             t1 = time.perf_counter()
             sub = Bt[ids]
-            dense = np.ascontiguousarray(sub.toarray())
+            dense = colsBlockDense[:len(ids)]
+            dense[:] = 0.0
+            dense[np.repeat(np.arange(len(ids)), np.diff(sub.indptr)), sub.indices] = sub.data
+            colSparsity[:] = 0; colSparsity[sub.indices] = 1
             t2 = time.perf_counter()
             if a.dense_rhs:
                 s.solve(dense)
-            else:       # what the adapter's solve(nrhss, rhss, colSparsity) does with the pattern the reference builds (DistributedLinearSystem.C:903)
-                cs = np.zeros(sub.shape[1], np.int32); cs[np.unique(sub.indices)] = 1
-                s.solve_sparse(dense, cs)
+            else:       # the adapter's solve(nrhss, rhss, colSparsity) with the pattern the reference builds (DistributedLinearSystem.C:903)
+                s.solve_sparse(dense, colSparsity)
             t3 = time.perf_counter()
             SC[ids, :] -= (Bt @ dense.T).T
             t_parts[0] += t2 - t1; t_parts[1] += t3 - t2; t_parts[2] += time.perf_counter() - t3
