@@ -2302,13 +2302,23 @@ struct Engine {
       for (const LevelRange& L : levels_top) head(L, 0);
       const TailPlan& p = plan;
       const bool rows = sweep.enabled && np * 4 <= SWEEP_NRHS_MAX && p.ntc_max > 0;   // the tail sweeps as one launch per direction (tickets, flags)
-      // few tile rows per step (a single leaf): a workgroup takes a quarter of a panel's right-hand sides, so that the chain of a pass - one
-      // workgroup's tile products per step - is four times shorter; many blocks: whole panels, L read once per 32 right-hand sides
-      const bool slices = (long long)sweep.n_tasks * np < 2048 && env_int("PIPS_HIP_MULTI", 1) != 2;   // (PIPS_HIP_MULTI=2: whole panels whatever the size - tests)
-      if (rows && slices)
-         hipLaunchKernelGGL(k_mtail_rows_fwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
-      else if (rows)
-         hipLaunchKernelGGL(k_mtail_rows_fwd<8>, dim3(sweep.n_tasks, np), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      // few tile rows per step (a single leaf): a workgroup takes a quarter or a half of a panel's right-hand sides, so that the chain of a pass -
+      // one workgroup's tile products per step - is shorter; many blocks: whole panels, L read once per 32 right-hand sides.  Every workgroup
+      // of the launch must be resident for the slices to advance side by side (two per compute unit: the whole tile sits in registers), so the
+      // finest slicing that keeps the launch within 512 workgroups is taken
+      const long long wg = (long long)sweep.n_tasks * np;
+      const int forced = env_int("PIPS_HIP_MULTI", 1);   // (2: whole panels whatever the size, 4: half panels - tests)
+      const int sl = forced == 2 ? 1 : forced == 4 ? 2 : wg * 4 <= 512 ? 4 : wg * 2 <= 512 ? 2 : 1;
+      auto tail_rows = [&](int backward) {
+         const SweepArgs sa = sweep.args(0, stream);
+         if (sl == 4 && !backward) hipLaunchKernelGGL(k_mtail_rows_fwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sa, d_blks, d_arena, d_dtail, d_winv, xm, ps);
+         else if (sl == 4) hipLaunchKernelGGL(k_mtail_rows_bwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sa, d_blks, d_arena, d_dtail, d_winv, xm, ps);
+         else if (sl == 2 && !backward) hipLaunchKernelGGL(k_mtail_rows_fwd<4>, dim3(sweep.n_tasks, np * 2), dim3(256), 0, stream, sa, d_blks, d_arena, d_dtail, d_winv, xm, ps);
+         else if (sl == 2) hipLaunchKernelGGL(k_mtail_rows_bwd<4>, dim3(sweep.n_tasks, np * 2), dim3(256), 0, stream, sa, d_blks, d_arena, d_dtail, d_winv, xm, ps);
+         else if (!backward) hipLaunchKernelGGL(k_mtail_rows_fwd<8>, dim3(sweep.n_tasks, np), dim3(256), 0, stream, sa, d_blks, d_arena, d_dtail, d_winv, xm, ps);
+         else hipLaunchKernelGGL(k_mtail_rows_bwd<8>, dim3(sweep.n_tasks, np), dim3(256), 0, stream, sa, d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      };
+      if (rows) tail_rows(0);
       else
       for (int j = 0; j < p.ntc_max; ++j)
          if (p.fwd[j].cnt > 0)
@@ -2317,10 +2327,7 @@ struct Engine {
       if (nsn_total > 0)
          hipLaunchKernelGGL(k_mhead_dscale, dim3(grid_for((long long)nsn_total * MQ, 256), np), dim3(256), 0, stream, d_sns, nsn_total, d_blks,
                             d_arena, xm, ps);
-      if (rows && slices)
-         hipLaunchKernelGGL(k_mtail_rows_bwd<2>, dim3(sweep.n_tasks, np * 4), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
-      else if (rows)
-         hipLaunchKernelGGL(k_mtail_rows_bwd<8>, dim3(sweep.n_tasks, np), dim3(256), 0, stream, sweep.args(0, stream), d_blks, d_arena, d_dtail, d_winv, xm, ps);
+      if (rows) tail_rows(1);
       else
       for (int i = p.ntc_max - 1; i >= 0; --i)
          if (p.bwd[i].cnt > 0)

@@ -3084,6 +3084,45 @@ __device__ __forceinline__ void mtile_apply(double (&acc)[2][NC], const double* 
    }
 }
 
+// The whole tile in registers (64 doubles per thread), for the single-launch sweeps: a tile row's chain is flag -> V -> product -> next
+// flag, and with a stage of the tile requested one stage ahead every stage of every product waited for its round trip (four per product,
+// 16 us per step of the chain).  Here a product's tile is complete in registers before its flag is waited for, and while its stages move to
+// LDS the stages of the NEXT tile of the row (the next column's, at last the diagonal block's inverse) are requested into their places.
+template <int TRANSPOSED, int KC>
+__device__ __forceinline__ void mtile_fetch_all(double (&T)[TILE / 2], const double* __restrict__ M, long long ldm, int tid) {
+#pragma unroll
+   for (int s = 0; s < TILE / KC; ++s) mtile_fetch<TRANSPOSED, KC>(*(double (*)[KC / 2]) & T[s * (KC / 2)], M, ldm, s * KC, tid);
+}
+template <int TRANSPOSED, int NC, int KC>
+__device__ __forceinline__ void mtile_apply_whole(double (&acc)[2][NC], double (&T)[TILE / 2], const double (*V)[MVQ], double (*Lt)[TILE + 1], int tid,
+                                                  double sign, const double* __restrict__ Mnext, long long ldnext) {
+   const int lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, ej = lane & 3;
+#pragma unroll
+   for (int s = 0; s < TILE / KC; ++s) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < KC / 2; ++e) {
+         const int idx = e * 256 + tid;
+         if (TRANSPOSED) Lt[idx % KC][idx / KC] = T[s * (KC / 2) + e];
+         else Lt[idx >> 7][idx & 127] = T[s * (KC / 2) + e];
+      }
+      if (Mnext) mtile_fetch<TRANSPOSED, KC>(*(double (*)[KC / 2]) & T[s * (KC / 2)], Mnext, ldnext, s * KC, tid);
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < KC / 4; ++st) {
+         const double f0 = Lt[4 * st + ek][32 * w + er], f1 = Lt[4 * st + ek][32 * w + 16 + er];
+         double fc[NC];
+#pragma unroll
+         for (int c = 0; c < NC; ++c) fc[c] = sign * V[s * KC + 4 * st + ek][4 * c + ej];
+#pragma unroll
+         for (int c = 0; c < NC; ++c) {
+            acc[0][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], f0, acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fc[c], f1, acc[1][c], 0, 0, 0);
+         }
+      }
+   }
+}
+
 // tail forward step j for 32 right-hand sides: tiles i >= j:  b_i -= L(i,j-1) (d z)_{j-1} ; tile i == j: z_j = Winv_j b_j.  grid (tasks, panels)
 __global__ __launch_bounds__(256) void k_mtail_fwd(const TileTask* __restrict__ tasks, const BlkDesc* __restrict__ blks,
                                                   const double* __restrict__ arena, const double* __restrict__ dtail,
@@ -3163,11 +3202,11 @@ __global__ __launch_bounds__(256) void k_mtail_bwd(const TileTask* __restrict__ 
 // and multiplies on the matrix pipe (mtile_apply).  35 + 35 launches of 25 us each per pass were 3.4 of the 4.4 ms of a solve(160) on one
 // configs[1] block; the chain of a pass is 35 x (tile product + flag).  Same arithmetic as k_mtail_fwd / _bwd, same order per tile row.
 template <int NC>
-__global__ __launch_bounds__(256) void k_mtail_rows_fwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+__global__ __launch_bounds__(256, 2) void k_mtail_rows_fwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
                                                        const double* __restrict__ dtail, const double* __restrict__ winv, double* __restrict__ xm,
                                                        long long panel_stride) {
    __shared__ double V[TILE][MVQ];
-   constexpr int KC = NC == 2 ? 32 : 16;   // (a quarter panel leaves LDS for stages of 32 k: half the barriers)
+   constexpr int KC = NC <= 4 ? 32 : 16;   // (a slice of a panel leaves LDS for stages of 32 k: half the barriers)
    __shared__ double Lt[KC][TILE + 1];
    __shared__ int sh_t, sh_ok;
    const int epoch = *a.epoch_ptr;
@@ -3179,14 +3218,17 @@ __global__ __launch_bounds__(256) void k_mtail_rows_fwd(SweepArgs a, const BlkDe
    double* xt = xm + panel_stride * (blockIdx.y / SL) + (bd.xw_off + bd.n_head) * MQ + QS * (blockIdx.y % SL);
    int* fl = a.flags + a.flag_stride * blockIdx.y + a.flag_off[task.blk];
    const int j0 = a.tfirst ? min(i, a.tfirst[a.tfirst_off[task.blk] + i]) : 0;
-   double acc[2][NC], pre[KC / 2];
+   double acc[2][NC], T[TILE / 2];
 #pragma unroll
    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[h][c] = xt[(long long)(i * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
    bool ok = true;
+   const double* Wi = winv + bd.winv_off + (long long)i * TILE * TILE;
+   const double* Li = arena + bd.T + (long long)i * TILE;
+   if (j0 < i) mtile_fetch_all<0, KC>(T, Li + (long long)j0 * TILE * ld, ld, tid);   // (no tile waits for a flag)
+   else mtile_fetch_all<0, KC>(T, Wi, TILE, tid);
    for (int j = j0; j < i; ++j) {
-      mtile_fetch<0, KC>(pre, arena + bd.T + (long long)i * TILE + (long long)j * TILE * ld, ld, 0, tid);   // (the tile does not wait for the flag)
       if (tid == 0) sh_ok = sweep_wait(fl + j, epoch, a.poll_limit) ? 1 : 0;
       __syncthreads();
       if (!sh_ok) { ok = false; break; }
@@ -3194,7 +3236,8 @@ __global__ __launch_bounds__(256) void k_mtail_rows_fwd(SweepArgs a, const BlkDe
          const int c = idx / QS, qq = idx % QS;
          V[c][qq] = sweep_load(xt + (long long)(j * TILE + c) * MQ + qq) * dtail[bd.dt_off + j * TILE + c];
       }
-      mtile_apply<0, NC, KC>(acc, arena + bd.T + (long long)i * TILE + (long long)j * TILE * ld, ld, V, Lt, tid, -1.0, pre, true);
+      const bool last = j + 1 == i;
+      mtile_apply_whole<0, NC, KC>(acc, T, V, Lt, tid, -1.0, last ? Wi : Li + (long long)(j + 1) * TILE * ld, last ? (long long)TILE : (long long)ld);
    }
    if (ok) {
       __syncthreads();
@@ -3202,7 +3245,7 @@ __global__ __launch_bounds__(256) void k_mtail_rows_fwd(SweepArgs a, const BlkDe
       for (int h = 0; h < 2; ++h)
 #pragma unroll
          for (int c = 0; c < NC; ++c) { V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c]; acc[h][c] = 0.0; }
-      mtile_apply<0, NC, KC>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0, pre);
+      mtile_apply_whole<0, NC, KC>(acc, T, V, Lt, tid, 1.0, nullptr, 0);
    } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -3219,11 +3262,11 @@ __global__ __launch_bounds__(256) void k_mtail_rows_fwd(SweepArgs a, const BlkDe
 }
 
 template <int NC>
-__global__ __launch_bounds__(256) void k_mtail_rows_bwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
+__global__ __launch_bounds__(256, 2) void k_mtail_rows_bwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
                                                        const double* __restrict__ dtail, const double* __restrict__ winv, double* __restrict__ xm,
                                                        long long panel_stride) {
    __shared__ double V[TILE][MVQ];
-   constexpr int KC = NC == 2 ? 32 : 16;   // (a quarter panel leaves LDS for stages of 32 k: half the barriers)
+   constexpr int KC = NC <= 4 ? 32 : 16;   // (a slice of a panel leaves LDS for stages of 32 k: half the barriers)
    __shared__ double Lt[KC][TILE + 1];
    __shared__ int sh_t, sh_ok;
    const int epoch = *a.epoch_ptr;
@@ -3235,20 +3278,27 @@ __global__ __launch_bounds__(256) void k_mtail_rows_bwd(SweepArgs a, const BlkDe
    double* xt = xm + panel_stride * (blockIdx.y / SL) + (bd.xw_off + bd.n_head) * MQ + QS * (blockIdx.y % SL);
    int* fl = a.flags + a.flag_stride * blockIdx.y + a.flag_off[task.blk];
    const int* tf = a.tfirst ? a.tfirst + a.tfirst_off[task.blk] : nullptr;
-   double acc[2][NC], pre[KC / 2];
+   double acc[2][NC], T[TILE / 2];
 #pragma unroll
    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[h][c] = xt[(long long)(i * TILE + 32 * w + 16 * h + er) * MQ + 4 * c + ek];
    bool ok = true;
-   for (int k = bd.ntc - 1; k > i; --k) {
-      if (tf && tf[k] > i) continue;   // L(k, i) lies outside the envelope
-      mtile_fetch<1, KC>(pre, arena + bd.T + (long long)k * TILE + (long long)i * TILE * ld, ld, 0, tid);
+   const double* Wi = winv + bd.winv_off + (long long)i * TILE * TILE;
+   const double* Ci = arena + bd.T + (long long)i * TILE * ld;   // tile column i
+   // the tiles of column i inside the envelope, last tile row first; below(k) = the next one under k, i if none is left
+   auto below = [&](int k) { for (--k; k > i; --k) if (!(tf && tf[k] > i)) return k; return i; };
+   int k = below(bd.ntc);
+   if (k > i) mtile_fetch_all<1, KC>(T, Ci + (long long)k * TILE, ld, tid);   // (no tile waits for a flag)
+   else mtile_fetch_all<1, KC>(T, Wi, TILE, tid);
+   while (k > i) {
       if (tid == 0) sh_ok = sweep_wait(fl + k, epoch, a.poll_limit) ? 1 : 0;
       __syncthreads();
       if (!sh_ok) { ok = false; break; }
       for (int idx = tid; idx < TILE * QS; idx += 256) V[idx / QS][idx % QS] = sweep_load(xt + (long long)(k * TILE + idx / QS) * MQ + idx % QS);
-      mtile_apply<1, NC, KC>(acc, arena + bd.T + (long long)k * TILE + (long long)i * TILE * ld, ld, V, Lt, tid, -1.0, pre, true);
+      const int kn = below(k);
+      mtile_apply_whole<1, NC, KC>(acc, T, V, Lt, tid, -1.0, kn > i ? Ci + (long long)kn * TILE : Wi, kn > i ? (long long)ld : (long long)TILE);
+      k = kn;
    }
    if (ok) {
       __syncthreads();
@@ -3259,7 +3309,7 @@ __global__ __launch_bounds__(256) void k_mtail_rows_bwd(SweepArgs a, const BlkDe
             V[32 * w + 16 * h + er][4 * c + ek] = acc[h][c] * dtail[bd.dt_off + i * TILE + 32 * w + 16 * h + er];
             acc[h][c] = 0.0;
          }
-      mtile_apply<1, NC, KC>(acc, winv + bd.winv_off + (long long)i * TILE * TILE, TILE, V, Lt, tid, 1.0, pre);
+      mtile_apply_whole<1, NC, KC>(acc, T, V, Lt, tid, 1.0, nullptr, 0);
    } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h)

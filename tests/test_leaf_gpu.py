@@ -91,12 +91,12 @@ def test_leaf_multi_rhs_rows(scheme, n_i, monkeypatch):
 
 
 @pytest.mark.parametrize("nrhs", [8, 33, 100, 257, 300])
-@pytest.mark.parametrize("scheme", ["quarter_panels", "whole_panels"])
+@pytest.mark.parametrize("scheme", ["by_size", "half_panels", "whole_panels"])
 def test_leaf_many_rhs_on_the_matrix_pipe(scheme, nrhs, monkeypatch):
     """solve(nrhs, ...) beyond one panel of 32 interleaved right-hand sides and beyond one pass of 256: every launch takes all panels, the
-    dense tail's sweeps are one launch per direction with a workgroup per (tile row, quarter panel) - a single leaf - or per (tile row,
-    panel) - what large batches take (PIPS_HIP_MULTI=2 forces it here); against SuperLU, and against the same handle one column at a time."""
-    monkeypatch.setenv("PIPS_HIP_MULTI", "1" if scheme == "quarter_panels" else "2")
+    dense tail's sweeps are one launch per direction with a workgroup per (tile row, quarter or half panel) - a single leaf, by the size of
+    the launch - or per (tile row, panel) - what large batches take (PIPS_HIP_MULTI=4 / 2 force the two here); against SuperLU, and against the same handle one column at a time."""
+    monkeypatch.setenv("PIPS_HIP_MULTI", {"by_size": "1", "half_panels": "4", "whole_panels": "2"}[scheme])
     n_i = 1500                                  # a dense tail of several tiles
     prob = Problem(5, 1, n_i, n_i // 2, 4, 4, 6.0 / n_i)
     s = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
