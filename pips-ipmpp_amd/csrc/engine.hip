@@ -19,6 +19,7 @@
 #include "common.h"
 #include "kernels.hip.h"
 #include "rootkernel.hip.h"
+#include "tailkernel.hip.h"
 #include "pips_hip.h"
 
 namespace pips {
@@ -86,6 +87,7 @@ struct TailPlan {
    std::vector<TaskList> upd, upd_diag, diag, trsm, fwd, bwd, trail, trail_next;
    TaskList schur;
    TileTask* d_tasks = nullptr;
+   std::vector<TileTask> h_tasks;   // host copy (the single-launch factorisation re-lists them: TailSingle::build)
 
    // panel == 0: pure left-looking (tile column j is updated once, with everything to its left: minimal traffic on C,
    //   one task per tile of the column - right when many blocks share every launch).
@@ -209,6 +211,7 @@ struct TailPlan {
                for (int tj = 0; tj <= ti; ++tj) all.push_back({b, ti, tj, 0});
          }
       end(schur);
+      h_tasks = all;
       return dev_upload(&d_tasks, all, nullptr);
    }
    void release() {
@@ -340,6 +343,88 @@ struct PhaseTimer {
    ~PhaseTimer() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
 
+// Host side of k_tail_ldl (tailkernel.hip.h): the tasks of the column launches of a TailPlan as ONE list in the driver's order, dealt to
+// eight lists by tile row; the flags and the template they start from.
+struct TailSingle {
+   TailLdlArgs args{};
+   TileTask* d_tasks = nullptr;
+   int* d_flags = nullptr;
+   int* d_flags_init = nullptr;
+   long long* d_flag_off = nullptr;
+   int* d_ctl = nullptr;
+   long long n_flags = 0;
+   int n_tasks = 0;
+   void release() {
+      for (void* q : {(void*)d_tasks, (void*)d_flags, (void*)d_flags_init, (void*)d_flag_off, (void*)d_ctl}) if (q) (void)hipFree(q);
+      d_tasks = nullptr; d_flags = d_flags_init = d_ctl = nullptr; d_flag_off = nullptr;
+   }
+   int build(const TailPlan& p, const std::vector<BlkDesc>& blks, hipStream_t stream) {
+      release();
+      const int nblk = (int)blks.size();
+      std::vector<long long> foff(nblk + 1, 0);
+      for (int b = 0; b < nblk; ++b) foff[b + 1] = foff[b] + (long long)blks[b].ntr * blks[b].ntc + blks[b].ntr + blks[b].ntc;
+      n_flags = foff[nblk];
+      // the template: prog of a tile = the first K its first update starts from (an update waits for prog >= its k0: the one before it has
+      // stored the tile), = its tile column where it takes no update at all (trsm / the diagonal role wait for prog >= tile column)
+      std::vector<int> init((size_t)std::max<long long>(n_flags, 1), 0);
+      for (int b = 0; b < nblk; ++b)
+         for (int ti = 0; ti < blks[b].ntr; ++ti)
+            for (int tj = 0; tj < blks[b].ntc; ++tj) init[foff[b] + (long long)ti * blks[b].ntc + tj] = -1;
+      std::vector<TileTask> order;
+      auto take = [&](const TaskList& l, int kind) {
+         for (long long q = l.off; q < l.off + l.cnt; ++q) {
+            TileTask t = p.h_tasks[q];
+            if (t.blk < 0) continue;
+            if (kind == ROOT_UPD) {
+               int& pr = init[foff[t.blk] + (long long)t.ti * blks[t.blk].ntc + t.tj];
+               if (pr < 0) pr = t.pad & 0xffff;
+            } else
+               t.pad = 0;
+            t.blk |= kind << 24;
+            order.push_back(t);
+         }
+      };
+      // first tile column of every tile row (its envelope): the trsm of a row commit in column order from there (root_do)
+      std::vector<int> row_first((size_t)std::max<long long>(n_flags, 1), 1 << 20);
+      for (int j = 0; j < p.ntc_max; ++j)
+         for (long long q = p.trsm[j].off; q < p.trsm[j].off + p.trsm[j].cnt; ++q) {
+            const TileTask& t = p.h_tasks[q];
+            if (t.blk >= 0) { int& f = row_first[foff[t.blk] + t.ti]; f = std::min(f, t.tj); }
+         }
+      for (int j = 0; j < p.ntc_max; ++j) {
+         take(p.upd_diag[j], ROOT_UPD);
+         take(p.diag[j], ROOT_DIAG);
+         take(p.upd[j], ROOT_UPD);
+         const size_t before = order.size();
+         take(p.trsm[j], ROOT_TRSM);
+         for (size_t q = before; q < order.size(); ++q) order[q].pad = row_first[foff[order[q].blk & 0xffffff] + order[q].ti];
+      }
+      for (int b = 0; b < nblk; ++b)
+         for (int ti = 0; ti < blks[b].ntr; ++ti)
+            for (int tj = 0; tj < blks[b].ntc; ++tj) { int& pr = init[foff[b] + (long long)ti * blks[b].ntc + tj]; if (pr < 0) pr = tj; }
+      // eight lists: runs of tasks of one (block, tile row) go to the lists round-robin, every list keeps the order
+      std::vector<std::vector<TileTask>> lists(8);
+      int run = -1, last_b = -2, last_i = -2;
+      for (const TileTask& t : order) {
+         const int b = t.blk & 0xffffff;
+         if (b != last_b || t.ti != last_i) { ++run; last_b = b; last_i = t.ti; }
+         lists[run & 7].push_back(t);
+      }
+      std::vector<TileTask> all;
+      for (int x = 0; x < 8; ++x) { args.xoff[x] = (int)all.size(); all.insert(all.end(), lists[x].begin(), lists[x].end()); }
+      args.xoff[8] = (int)all.size();
+      n_tasks = (int)all.size();
+      if (all.empty()) all.push_back({0, 0, 0, 0});
+      int rc;
+      if ((rc = dev_upload(&d_tasks, all, stream)) || (rc = dev_upload(&d_flags_init, init, stream)) || (rc = dev_upload(&d_flag_off, foff, stream))) return rc;
+      HIP_TRY(hipMalloc((void**)&d_flags, init.size() * sizeof(int)));
+      HIP_TRY(hipMalloc((void**)&d_ctl, 16 * sizeof(int)));
+      HIP_TRY(hipMemsetAsync(d_ctl, 0, 16 * sizeof(int), stream));
+      args.tasks = d_tasks; args.flags = d_flags; args.flag_off = d_flag_off; args.ctl = d_ctl;
+      return PIPS_OK;
+   }
+};
+
 struct TailCtx {
    const BlkDesc* d_blks;
    const TailPlan* plan;
@@ -386,6 +471,7 @@ struct TailCtx {
    int bk_orig_ld = 0, bk_orig_rowmajor = 0;
    const int* d_bk_perm = nullptr;
    int bk_isolate = 0;
+   const TailSingle* single = nullptr;   // the leaf tails as one dependency-driven launch (tailkernel.hip.h) instead of the column loop
 };
 constexpr int GEMM_CTR_SLOTS = 4096;
 constexpr int GEMM_BAL_MIN_TASKS = 1024;   // below two full rounds of the chip a static one-task-per-workgroup launch does as well
@@ -430,7 +516,42 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
       return PIPS_OK;
    };
    int rc;
-   for (int j = 0; j < p.ntc_max; ++j) {
+   if (c.single && c.single->n_tasks > 0) {
+      const TailSingle& ts = *c.single;
+      if (c.timer) c.timer->begin(c.stream, 2);
+      HIP_TRY(hipMemcpyAsync(ts.d_flags, ts.d_flags_init, (size_t)ts.n_flags * sizeof(int), hipMemcpyDeviceToDevice, c.stream));
+      HIP_TRY(hipMemsetAsync(ts.d_ctl, 0, 9 * sizeof(int), c.stream));   // (the tickets; the error word stays until it is read)
+      TailLdlArgs ta = ts.args;
+      ta.n_tasks = ts.n_tasks;
+      const char* trace_file = getenv("PIPS_HIP_TAIL_TRACE");   // diagnostics: per-task clocks of this launch into a file (tools/tail_trace.py)
+      long long* d_trace = nullptr;
+      const size_t n_trace = (size_t)3 * ts.n_tasks + 32 * (size_t)(p.ntc_max + 1);
+      if (trace_file) {
+         HIP_TRY(hipMalloc((void**)&d_trace, n_trace * sizeof(long long)));
+         HIP_TRY(hipMemsetAsync(d_trace, 0, n_trace * sizeof(long long), c.stream));
+         ta.trace = d_trace;
+      }
+      hipLaunchKernelGGL(k_tail_ldl, dim3(512), dim3(512), 0, c.stream, ta);
+      if (c.timer) c.timer->end(c.stream);
+      if (trace_file) {
+         std::vector<long long> h(n_trace);
+         std::vector<TileTask> ht((size_t)ts.n_tasks);
+         HIP_TRY(hipStreamSynchronize(c.stream));
+         HIP_TRY(hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+         HIP_TRY(hipMemcpy(ht.data(), ts.d_tasks, ht.size() * sizeof(TileTask), hipMemcpyDeviceToHost));
+         (void)hipFree(d_trace);
+         if (FILE* f = fopen(trace_file, "w")) {   // ticket, list, kind, block, ti, tj, K range, the three clocks
+            for (int t = 0; t < ts.n_tasks; ++t) {
+               int x = 0;
+               while (x < 7 && t >= ts.args.xoff[x + 1]) ++x;
+               fprintf(f, "%d %d %d %d %d %d %d %lld %lld %lld\n", t, x, ht[t].blk >> 24, ht[t].blk & 0xffffff, ht[t].ti, ht[t].tj, ht[t].pad, h[3 * (size_t)t], h[3 * (size_t)t + 1],
+                       h[3 * (size_t)t + 2]);
+            }
+            fclose(f);
+         }
+      }
+   }
+   for (int j = 0; !c.single && j < p.ntc_max; ++j) {
       if ((rc = main_writes(j))) return rc;
       const bool ahead = c.side && p.upd_diag[j].cnt > 0;   // left-looking batch: diagonal tiles first, factorised on the side stream
       if (ahead) {
@@ -796,9 +917,13 @@ struct Engine {
       d_psign = nullptr;
       plan.release();
       sweep.release();
+      tsingle.release();
    }
 
    SweepRt sweep;
+   TailSingle tsingle;                               // the tails as one dependency-driven launch (tailkernel.hip.h)
+   bool tail_single = false;                         // ... decided at analyze time: the tails are then assembled in a scratch region (BlkDesc::T_in)
+   long long tail_scratch = 0;                       // doubles of that region, behind the panels and the border-row arena
    hipStream_t side = nullptr;                       // diagonal tiles of the tail are factorised here, beside the column update
    hipEvent_t ev_diag_in = nullptr, ev_diag_out = nullptr;
    // ---- deterministic mode (pips_hip_batch_set_deterministic): no FP64 atomics on the path.  Every scattered contribution of
@@ -1060,6 +1185,11 @@ struct Engine {
          c.det_defer_reduce = det_global && defer_group_reduce;   // (only the kkt paths finish the reduction themselves)
       }
       c.sweep = &sweep;
+      if (tail_single) {
+         tsingle.args.blks = d_blks; tsingle.args.arena = d_arena; tsingle.args.uarena = d_uarena; tsingle.args.winv = d_winv; tsingle.args.dtail = d_dtail;
+         tsingle.args.pref = d_pref; tsingle.args.psign = d_psign; tsingle.args.psign_off = d_psign_off; tsingle.args.inertia = d_inertia;
+         c.single = &tsingle;
+      }
       return c;
    }
 
@@ -1448,6 +1578,23 @@ struct Engine {
          h_spine_off[b + 1] = (int)h_spine.size();
       }
       spine_total = (int)h_spine.size();
+      // ---- the tails as one launch (tailkernel.hip.h; opt-in, PIPS_HIP_TAIL_SINGLE=1: measured slower than the column launches, DESIGN.md
+      // 4.2a): multifrontal head (every producer of the tail panel goes by BlkDesc::T_in), no deterministic mode (its slot records hold
+      // panel addresses), room for a second copy of the tail panels
+      {
+         long long scratch = 0;
+         for (int b = 0; b < nblk; ++b) scratch += sym[b].arena - sym[b].T_off;
+         size_t free_b = 0, total_b = 0;
+         (void)hipMemGetInfo(&free_b, &total_b);
+         const double need = 8.0 * (double)(arena_total + bb_doubles + scratch + uarena_total) + 4e9;
+         tail_single = mf && !deterministic && scratch > 0 && env_int("PIPS_HIP_TAIL_SINGLE", 0) != 0 && need < (double)free_b;
+         tail_scratch = tail_single ? scratch : 0;
+         long long at = arena_total + bb_doubles;
+         for (int b = 0; b < nblk; ++b) {
+            h_blks[b].T_in = tail_single ? at : h_blks[b].T;
+            at += sym[b].arena - sym[b].T_off;
+         }
+      }
       // ---- concatenated index arrays
       std::vector<int> h_rowidx, h_sncol, h_bmap, h_perm, h_upd;
       h_upd.reserve(upd_base[nblk]);
@@ -1468,8 +1615,10 @@ struct Engine {
          h_perm_off[b] = (long long)h_perm.size();
          h_perm.insert(h_perm.end(), s.perm.begin(), s.perm.end());
          // multifrontal head: the fronts read their panel entries from the value arrays (k_front), nobody reads them from the arena
-         for (size_t p = 0; p < s.a_dst.size(); ++p) h_kdst[kptr[b] + p] = (mf && s.a_front[p]) ? -1 : h_blks[b].arena_off + s.a_dst[p];
-         for (size_t p = 0; p < s.b_dst.size(); ++p) h_bdst[bptr[b] + p] = (mf && s.b_front[p]) ? -1 : h_blks[b].arena_off + s.b_dst[p];
+         // (entries of the tail panel land where the tail is assembled: BlkDesc::T_in)
+         auto dst = [&](long long rel) { return rel >= s.T_off ? h_blks[b].T_in + (rel - s.T_off) : h_blks[b].arena_off + rel; };
+         for (size_t p = 0; p < s.a_dst.size(); ++p) h_kdst[kptr[b] + p] = (mf && s.a_front[p]) ? -1 : dst(s.a_dst[p]);
+         for (size_t p = 0; p < s.b_dst.size(); ++p) h_bdst[bptr[b] + p] = (mf && s.b_front[p]) ? -1 : dst(s.b_dst[p]);
          for (int i = 0; i < s.n; ++i) {
             long long dp = -1;
             for (int p = in[b].krow[i]; p < in[b].krow[i + 1]; ++p)
@@ -1569,7 +1718,8 @@ struct Engine {
       }
 
       // ---- device allocation / upload
-      HIP_TRY(hipMalloc((void**)&d_arena, std::max<long long>(arena_total + bb_doubles, 1) * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&d_arena, std::max<long long>(arena_total + bb_doubles + tail_scratch, 1) * sizeof(double)));
+      if (tail_single) HIP_TRY(hipMemsetAsync(d_arena, 0, (size_t)arena_total * sizeof(double), stream));   // (tiles of the panels outside the envelopes are never written: they read as zero)
       if (bb_doubles > 0) HIP_TRY(hipMemsetAsync(d_arena + arena_total, 0, (size_t)bb_doubles * sizeof(double), stream));   // (the padding rows of the border-row arena stay zero)
       HIP_TRY(hipMalloc((void**)&d_uarena, std::max<long long>(uarena_total, 1) * sizeof(double)));
       HIP_TRY(hipMalloc((void**)&d_kval, std::max<long long>(nnzK_total, 1) * sizeof(double)));
@@ -1701,6 +1851,11 @@ struct Engine {
       const int pair2 = 4;   // (1: a column per launch; the switch that chose it went with round 6)
       if ((rc = plan.build(h_blks, 0, false, true, &firsts, true, pair2))) return rc;
       if ((rc = sweep.build(h_blks, &firsts))) return rc;
+      if (tail_single) {
+         if ((rc = tsingle.build(plan, h_blks, stream))) return rc;
+         tsingle.args.poll_limit = env_int("PIPS_HIP_ROOT_POLL_LIMIT", 400000) > 0 ? (long long)env_int("PIPS_HIP_ROOT_POLL_LIMIT", 400000) * 50 : 0;   // (a deep update runs a millisecond)
+         tsingle.args.diag_blocked = env_int("PIPS_HIP_ROOT_DIAG_BARRIERS", 0) ? 0 : 1;
+      }
       {
          // border-backward sweep: worth it where the border rows of the factor (what it reads on top of a backward sweep) are no
          // more than what the forward sweep it saves would read, with a margin for the chain and the launches it also saves
@@ -2157,10 +2312,13 @@ struct Engine {
       if (timer.on) (void)hipEventRecord(timer.recs[total_rec].b, stream);
       h_amax.clear();
       if (!h_inertia_pin) {
-         HIP_TRY(hipHostMalloc((void**)&h_inertia_pin, (size_t)std::max(3 * nblk, 1) * sizeof(int), hipHostMallocDefault));
+         HIP_TRY(hipHostMalloc((void**)&h_inertia_pin, (size_t)(3 * nblk + 1) * sizeof(int), hipHostMallocDefault));
+         h_inertia_pin[3 * nblk] = 0;
          HIP_TRY(hipEventCreateWithFlags(&ev_inertia, hipEventDisableTiming));
       }
       HIP_TRY(hipMemcpyAsync(h_inertia_pin, d_inertia, (size_t)3 * nblk * sizeof(int), hipMemcpyDeviceToHost, stream));
+      if (tail_single)   // (the error word of the single-launch tail factorisation travels with the counters)
+         HIP_TRY(hipMemcpyAsync(h_inertia_pin + 3 * nblk, tsingle.d_ctl + 9, sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipEventRecord(ev_inertia, stream));
       inertia_in_flight = true;
       inertia_on_host = false;
@@ -2560,6 +2718,15 @@ struct Engine {
          std::copy(h_inertia_pin, h_inertia_pin + h_inertia.size(), h_inertia.begin());
          inertia_in_flight = false;
          inertia_on_host = true;
+         if (tail_single && h_inertia_pin[3 * nblk]) {
+            h_inertia_pin[3 * nblk] = 0;
+            int fi[6] = {0, 0, 0, 0, 0, 0};   // the first wait that gave up: kind, tile, K range, block + 1
+            (void)hipMemcpy(fi, tsingle.d_ctl + 10, sizeof(fi), hipMemcpyDeviceToHost);
+            HIP_TRY(hipMemsetAsync(tsingle.d_ctl + 9, 0, 7 * sizeof(int), stream));
+            PIPS_FAIL(PIPS_ERR_HIP, "the single-launch factorisation of the dense tails (PIPS_HIP_TAIL_SINGLE) gave up waiting for a tile after %lld polls - first: task "
+                                    "kind %d on tile (%d, %d) of block %d; its factors are unusable.  Another process holding the device for seconds can cause that",
+                      tsingle.args.poll_limit, fi[1], fi[2], fi[3], fi[5] - 1);
+         }
          return PIPS_OK;
       }
       if (inertia_on_host) return PIPS_OK;
@@ -2816,7 +2983,7 @@ struct DenseLdl {
       const int ntc = npad / TILE;
       HIP_TRY(hipMemsetAsync(d_rflags, 0, ((size_t)8 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int), stream));
       RootArgs a{};
-      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad;
+      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad; a.ldu = npad;
       a.C = d_C; a.R = d_R; a.U = d_U; a.winv = d_winv; a.dtail = d_dtail; a.pref = d_pref; a.psign = d_psign; a.inertia = d_inertia;
       a.ctl = d_rflags; a.prog = d_rflags + 8; a.rowdone = a.prog + (size_t)ntc * ntc; a.dready = a.rowdone + ntc;
       a.blk = d_blks; a.poll_limit = root_poll_limit;

@@ -53,6 +53,8 @@ struct BlkDesc {
    double repl_abs;           // replacement when no reference magnitude exists (structurally zero diagonal)
    long long lv_off;          // multifrontal head: offset of the block's leaf values inside the leaf-value arena
    long long k_off, b_off;    // offsets of the block's K values / border values (Engine::d_kval, d_bval): k_front reads its panel entries there
+   long long T_in;            // where the tail panel is ASSEMBLED (scatter, root fronts, border rows of the head) and accumulated: = T when the tail is
+                              // factorised in place (launch per step), a scratch region behind the panels when it is one launch (tailkernel.hip.h)
 };
 
 struct TileTask { int blk, ti, tj, pad; };
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_arena_clear(const BlkDesc* __restrict__
    // tail: a workgroup takes whole columns, its threads run down the rows
    for (int c = blockIdx.x; c < bd.m_pad; c += gridDim.x) {
       const int r0 = c / TILE * TILE;
-      double2_t* col = (double2_t*)(arena + bd.T + (long long)c * bd.ldT + r0);
+      double2_t* col = (double2_t*)(arena + bd.T_in + (long long)c * bd.ldT + r0);
       const int n2 = (bd.ldT - r0) / 2;
       for (int i = threadIdx.x; i < n2; i += blockDim.x) col[i] = z;
    }
@@ -170,7 +172,7 @@ __global__ void k_tail_pad_diag(const BlkDesc* __restrict__ blks, double* __rest
    const int b = blockIdx.x;
    if (b >= nblk) return;
    const BlkDesc bd = blks[b];
-   for (int t = bd.m + threadIdx.x; t < bd.m_pad; t += blockDim.x) arena[bd.T + t + (long long)t * bd.ldT] = 1.0;
+   for (int t = bd.m + threadIdx.x; t < bd.m_pad; t += blockDim.x) arena[bd.T_in + t + (long long)t * bd.ldT] = 1.0;
 }
 
 // pivot reference magnitudes:
@@ -231,7 +233,7 @@ __global__ void k_pref_tail(const BlkDesc* __restrict__ blks, const double* __re
                             int overwrite) {
    const BlkDesc bd = blks[blockIdx.y];
    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < bd.m_pad; t += gridDim.x * blockDim.x) {
-      const double v = fabs(arena[bd.T + t + (long long)t * bd.ldT]);
+      const double v = fabs(arena[bd.T_in + t + (long long)t * bd.ldT]);
       double* q = pref + bd.xw_off + bd.n_head + t;
       *q = overwrite ? v : fmax(*q, v);
    }
@@ -442,7 +444,7 @@ __device__ __forceinline__ void head_factor_body(const SnDesc& sn, const BlkDesc
    }
    const int n = bd.n, n_head = bd.n_head;
    if (b0 < sn.rb) {   // target columns in the dense tail
-      double* T = arena + bd.T;
+      double* T = arena + bd.T_in;
       for_pairs(b0, sn.rb, [&](int a, int b) {
          const int ra = rows[a], cb = rows[b];
          const int tr = ra < n ? ra - n_head : bd.m_pad + (ra - n);
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void k_head_factor_simple(const SnDesc* __rest
          for (int a = 0; a < SIMPLE_RMAX; ++a)
             if (a < r && ro[a] < bd.n) lfval[lp[a]] = l[a];
       }
-      double* T = arena + bd.T;
+      double* T = arena + bd.T_in;
       const int* bm = bmap + bd.bmap_off;
       const int n = bd.n, n_head = bd.n_head;
       // multifrontal head: a leaf below a front leaves its rank-one update to that front (k_front reads d and l from the panel)
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(256) void k_root_assemble(const int* __restrict__ b
    __shared__ long long s_rows[256], s_U[256];
    const int blk = blk_list ? blk_list[blockIdx.x] : blockIdx.x;
    const BlkDesc bd = blks[blk];
-   double* T = arena + bd.T;
+   double* T = arena + bd.T_in;
    const int* bm = bmap + bd.bmap_off;
    const int n = bd.n, n_head = bd.n_head, c = blockIdx.y;
    double* S_ = gbuf ? gbuf + gstride * blk_group[blk] : SC;
@@ -1183,7 +1185,7 @@ __global__ __launch_bounds__(64) void k_border_tail(const int* __restrict__ list
    if (lane < ns) tcol[lane] = rowidx[C.rows + q0 + lane] - bd.n_head;
    __syncthreads();
    const double* LbC = arena + C.bb;
-   double* T = arena + bd.T;
+   double* T = arena + bd.T_in;
    for (int a = lane; a < nbc; a += 64) {
       double lb[WMAX];
 #pragma unroll
@@ -1548,6 +1550,12 @@ __global__ __launch_bounds__(256) void k_head_solve_simple(const SnDesc* __restr
 // to that bookkeeping; the wait is placed by hand (dma_wait) right before the barrier that hands the buffer over.
 __device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base) {
    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base;
+   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
+}
+// the same where the shared object arrives as a function argument (rootkernel.hip.h: root_do is called from two kernels): the LDS address is
+// wave-uniform by construction, which the compiler cannot see there
+__device__ __forceinline__ void glds16_arg(const double* gptr_lane, double* lds_base) {
+   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base);
    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
