@@ -2983,7 +2983,7 @@ struct DenseLdl {
       const int ntc = npad / TILE;
       HIP_TRY(hipMemsetAsync(d_rflags, 0, ((size_t)8 + (size_t)ntc * ntc + 2 * (size_t)ntc) * sizeof(int), stream));
       RootArgs a{};
-      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad; a.ldu = npad;
+      a.tasks = d_rtasks; a.n_tasks = n_rtasks; a.n_bulk = n_rbulk; a.ntc = ntc; a.ld = npad;
       a.C = d_C; a.R = d_R; a.U = d_U; a.winv = d_winv; a.dtail = d_dtail; a.pref = d_pref; a.psign = d_psign; a.inertia = d_inertia;
       a.ctl = d_rflags; a.prog = d_rflags + 8; a.rowdone = a.prog + (size_t)ntc * ntc; a.dready = a.rowdone + ntc;
       a.blk = d_blks; a.poll_limit = root_poll_limit;

@@ -1552,12 +1552,6 @@ __device__ __forceinline__ void glds16(const double* gptr_lane, double* lds_base
    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base;
    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
 }
-// the same where the shared object arrives as a function argument (rootkernel.hip.h: root_do is called from two kernels): the LDS address is
-// wave-uniform by construction, which the compiler cannot see there
-__device__ __forceinline__ void glds16_arg(const double* gptr_lane, double* lds_base) {
-   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base);
-   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
-}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Staging: both panels are column-major with the tile's 128 rows contiguous, so one LDS-DMA wave-instruction moves one
@@ -3101,8 +3095,10 @@ __device__ __forceinline__ void mtile_fetch_all(double (&T)[TILE / 2], const dou
 #pragma unroll
    for (int s = 0; s < TILE / KC; ++s) mtile_fetch<TRANSPOSED, KC>(*(double (*)[KC / 2]) & T[s * (KC / 2)], M, ldm, s * KC, tid);
 }
+// (MV: row length of V - the right-hand sides of the slice, padded so that the four k of a fragment read land in different banks)
+template <int NC> constexpr int mtile_mv() { return NC == 2 ? 8 : 4 * NC + 8; }
 template <int TRANSPOSED, int NC, int KC>
-__device__ __forceinline__ void mtile_apply_whole(double (&acc)[2][NC], double (&T)[TILE / 2], const double (*V)[MVQ], double (*Lt)[TILE + 1], int tid,
+__device__ __forceinline__ void mtile_apply_whole(double (&acc)[2][NC], double (&T)[TILE / 2], const double (*V)[mtile_mv<NC>()], double (*Lt)[TILE + 1], int tid,
                                                   double sign, const double* __restrict__ Mnext, long long ldnext) {
    const int lane = tid & 63, w = tid >> 6, er = lane & 15, ek = lane >> 4, ej = lane & 3;
 #pragma unroll
@@ -3213,7 +3209,7 @@ template <int NC>
 __global__ __launch_bounds__(256, 2) void k_mtail_rows_fwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
                                                        const double* __restrict__ dtail, const double* __restrict__ winv, double* __restrict__ xm,
                                                        long long panel_stride) {
-   __shared__ double V[TILE][MVQ];
+   __shared__ double V[TILE][mtile_mv<NC>()];
    constexpr int KC = NC <= 4 ? 32 : 16;   // (a slice of a panel leaves LDS for stages of 32 k: half the barriers)
    __shared__ double Lt[KC][TILE + 1];
    __shared__ int sh_t, sh_ok;
@@ -3273,7 +3269,7 @@ template <int NC>
 __global__ __launch_bounds__(256, 2) void k_mtail_rows_bwd(SweepArgs a, const BlkDesc* __restrict__ blks, const double* __restrict__ arena,
                                                        const double* __restrict__ dtail, const double* __restrict__ winv, double* __restrict__ xm,
                                                        long long panel_stride) {
-   __shared__ double V[TILE][MVQ];
+   __shared__ double V[TILE][mtile_mv<NC>()];
    constexpr int KC = NC <= 4 ? 32 : 16;   // (a slice of a panel leaves LDS for stages of 32 k: half the barriers)
    __shared__ double Lt[KC][TILE + 1];
    __shared__ int sh_t, sh_ok;

@@ -25,7 +25,6 @@ namespace pips {
 struct RootArgs {
    const TileTask* tasks;   // blk = kind (0 UPD, 1 TRSM, 2 DIAG), ti, tj, pad = k0 | k1 << 16: the bulk list, then the chain's list
    int n_tasks, n_bulk, ntc, ld;   // n_tasks = all of them: [0, n_bulk) bulk, the rest the chain's
-   int ldu;                 // leading dimension of U (the root: = ld; a leaf's tail: its U has the tail's rows only)
    double *C, *R, *U, *winv, *dtail;
    const double* pref;
    const signed char* psign;
@@ -35,14 +34,12 @@ struct RootArgs {
    const BlkDesc* blk;      // thr_rel / repl_rel / repl_abs / m of the one block
    long long poll_limit;
    int diag_blocked;        // 1: root_diag_blocked, 0: the 128-barrier algorithm (A/B)
-   int* fail;               // where the first wait that gave up leaves (kind, ti, tj, K range, block) - nullptr: not recorded
    long long* trace;        // diagnostics (PIPS_HIP_ROOT_TRACE): per ticket the 100 MHz clock at the draw, after the waits, at the end
 };
 constexpr int ROOT_UPD = 0, ROOT_TRSM = 1, ROOT_DIAG = 2;
 
 __device__ __forceinline__ void glds16_sc1(const double* gptr_lane, double* lds_base) {   // LDS-DMA past the L2 (agent scope)
-   // (wave-uniform by construction; where the shared object arrives as a function argument the compiler cannot see that)
-   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base);
+   const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base;
    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(gptr_lane), "s"(lds) : "memory", "m0");
 }
 
@@ -87,8 +84,8 @@ __device__ __forceinline__ void root_mainloop(GemmShared& sh, const double* Ap, 
       for (int q = 0; q < KB / 8; ++q) {
          const int k = wave + 8 * q;
          if (A_SC1) glds16_sc1(Al + (long long)(st * KB + k) * lda, &As[buf][k * LDSW]);
-         else glds16_arg(Al + (long long)(st * KB + k) * lda, &As[buf][k * LDSW]);
-         glds16_arg(Bl + (long long)(st * KB + k) * ldb, &Bs[buf][k * LDSW]);
+         else glds16(Al + (long long)(st * KB + k) * lda, &As[buf][k * LDSW]);
+         glds16(Bl + (long long)(st * KB + k) * ldb, &Bs[buf][k * LDSW]);
       }
    };
    if (nst > 0) issue(0, 0);
@@ -352,6 +349,9 @@ __device__ __forceinline__ void root_diag_wave_steps(double (&v)[DB], double* __
       }
    }
 }
+// (WHO: one out-of-line instance per calling kernel - k_root_ldl 0, k_tail_ldl 1: with a single caller the compiler knows which shared
+// object shp is; shared between the two kernels this function, on the root's chain, made S = 8000 17 % slower)
+template <int WHO>
 __device__ __noinline__ void root_diag_wave(RootDiagShared2* shp, int b, int rows_left, double thr_rel, double repl_rel, double repl_abs,
                                             double* __restrict__ Lout, int ld) {
    RootDiagShared2& sh = *shp;
@@ -404,6 +404,7 @@ __device__ __noinline__ void root_diag_wave(RootDiagShared2* shp, int b, int row
    for (int c = lane >> 5; c < DB; c += 2) S1[c * DLD + r] = S2[r * DLD + c] * dir;
 }
 
+template <int WHO = 0>
 __device__ __forceinline__ bool root_diag_blocked(const RootArgs& a, RootDiagShared2& sh, int j) {
    __builtin_amdgcn_s_setprio(3);
    const BlkDesc bd = a.blk[0];
@@ -456,7 +457,7 @@ __device__ __forceinline__ bool root_diag_blocked(const RootArgs& a, RootDiagSha
 #pragma unroll
             for (int i = b; i < 4; ++i) { sh.park[np][lane] = ys[OB(i, jj)][0]; sh.park[np + 1][lane] = ys[OB(i, jj)][1]; np += 2; }
          if (stamp && tid == 0) stamp[1 + 6 * b] = wall_clock64();
-         root_diag_wave(&sh, b, bd.m - j * TILE - 32 * b, bd.thr_rel, bd.repl_rel, bd.repl_abs, Lout + 32 * b + (long long)(32 * b) * ld, ld);
+         root_diag_wave<WHO>(&sh, b, bd.m - j * TILE - 32 * b, bd.thr_rel, bd.repl_rel, bd.repl_abs, Lout + 32 * b + (long long)(32 * b) * ld, ld);
          if (stamp && tid == 0) stamp[2 + 6 * b] = wall_clock64();
          np = 0;
 #pragma unroll
@@ -550,10 +551,10 @@ union RootShared {
 };
 
 // one task of the launch (index t into the joint list); every thread of the workgroup calls it with the same t
-// one task: kind, tile (ti, tj), pad = the K range of an update; t = its ticket (for the trace only)
-__device__ __noinline__ void root_do(const RootArgs& a, RootShared& sh, int& s_ok, int kind, int ti, int tj, int pad, int t) {
+__device__ __noinline__ void root_task(const RootArgs& a, RootShared& sh, int& s_ok, int t) {
    if (a.trace && threadIdx.x == 0) a.trace[3 * (long long)t] = wall_clock64();
-   const int ntc = a.ntc, ld = a.ld, ldu = a.ldu;
+   const TileTask task = a.tasks[t];
+   const int kind = task.blk, ti = task.ti, tj = task.tj, ntc = a.ntc, ld = a.ld;
    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int wr = wave & 1, wc = wave >> 1;
    bool ok = true;
@@ -568,7 +569,7 @@ __device__ __noinline__ void root_do(const RootArgs& a, RootShared& sh, int& s_o
             root_diag_role(a, sh.d, tj);
          }
       }
-      else if (tid == 0) { a.ctl[1] = 1; if (a.fail && atomicCAS(a.fail, 0, 1) == 0) { a.fail[1] = kind; a.fail[2] = ti; a.fail[3] = tj; a.fail[4] = pad; } }
+      else if (tid == 0) a.ctl[1] = 1;
       root_publish(a.dready + tj, 1);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
       return;
@@ -579,12 +580,12 @@ __device__ __noinline__ void root_do(const RootArgs& a, RootShared& sh, int& s_o
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[i][c] = 0.0;
    if (kind == ROOT_UPD) {
-      const int k0 = pad & 0xffff, k1 = pad >> 16;
+      const int k0 = task.pad & 0xffff, k1 = task.pad >> 16;
       ok = root_wait_ge(a.rowdone + ti, k1, a.poll_limit, &s_ok);
       if (ok && ti != tj) ok = root_wait_ge(a.rowdone + tj, k1, a.poll_limit, &s_ok);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 1] = wall_clock64();
       if (ok) {
-         root_mainloop<false>(sh.g, a.R + (long long)ti * TILE + (long long)k0 * TILE * ld, ld, a.U + (long long)tj * TILE + (long long)k0 * TILE * ldu, ldu,
+         root_mainloop<false>(sh.g, a.R + (long long)ti * TILE + (long long)k0 * TILE * ld, ld, a.U + (long long)tj * TILE + (long long)k0 * TILE * ld, ld,
                               (k1 - k0) * TILE, acc, lane, wave, wr, wc);
          ok = root_wait_ge(a.prog + (long long)ti * ntc + tj, k0, a.poll_limit, &s_ok);   // the update before this one has stored the tile
       }
@@ -605,7 +606,7 @@ __device__ __noinline__ void root_do(const RootArgs& a, RootShared& sh, int& s_o
                   __hip_atomic_store(c0 + i * 16 + (long long)((2 * h + c) * 4) * ld, cv[i][c] - acc[i][2 * h + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);
          }
-      } else if (tid == 0) { a.ctl[1] = 1; if (a.fail && atomicCAS(a.fail, 0, 1) == 0) { a.fail[1] = kind; a.fail[2] = ti; a.fail[3] = tj; a.fail[4] = pad; } }
+      } else if (tid == 0) a.ctl[1] = 1;
       root_publish(a.prog + (long long)ti * ntc + tj, k1);
       if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
       return;
@@ -623,30 +624,18 @@ __device__ __noinline__ void root_do(const RootArgs& a, RootShared& sh, int& s_o
 #pragma unroll
       for (int c = 0; c < 8; ++c) dsc[c] = a.dtail[col0 + 4 * c];
       double* l0 = a.R + row0 + (long long)col0 * ld;
-      double* u0 = a.U + row0 + (long long)col0 * ldu;
+      double* u0 = a.U + row0 + (long long)col0 * ld;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
          for (int c = 0; c < 8; ++c) root_store(l0 + i * 16 + (long long)(c * 4) * ld, acc[i][c]);
-      if (ti < ntc) {   // (a leaf's tail: the tile rows of the border below the square have no rows in U)
 #pragma unroll
-         for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) root_store(u0 + i * 16 + (long long)(c * 4) * ldu, acc[i][c] * dsc[c]);
-      }
-   } else if (tid == 0) { a.ctl[1] = 1; if (a.fail && atomicCAS(a.fail, 0, 1) == 0) { a.fail[1] = kind; a.fail[2] = ti; a.fail[3] = tj; a.fail[4] = pad; } }
-   // rowdone[ti] = tj + 1 says "every L(ti, k), k <= tj, is final": the trsm of a row commit in column order.  In the root each one
-   // depends on its predecessor anyway (its tile took an update with that column); in a leaf's tail with a tile envelope neighbouring
-   // columns of a row may have nothing to do with each other, finish in any order - and the later store would take the flag back.
-   // pad = the first tile column of the row (its envelope); a trsm waits for what it waits before and for nothing later in the list.
-   if (tj > pad) (void)root_wait_ge(a.rowdone + ti, tj, a.poll_limit, &s_ok);
+         for (int c = 0; c < 8; ++c) root_store(u0 + i * 16 + (long long)(c * 4) * ld, acc[i][c] * dsc[c]);
+   } else if (tid == 0) a.ctl[1] = 1;
    root_publish(a.rowdone + ti, tj + 1);
    if (a.trace && tid == 0) a.trace[3 * (long long)t + 2] = wall_clock64();
-}
-
-__device__ __forceinline__ void root_task(const RootArgs& a, RootShared& sh, int& s_ok, int t) {
-   const TileTask task = a.tasks[t];
-   root_do(a, sh, s_ok, task.blk, task.ti, task.tj, task.pad, t);
 }
 
 // the next task of a list (the workgroup waits inside root_task for what the task needs), -1 when the list is empty
