@@ -623,3 +623,38 @@ def test_border_split_that_would_not_fit_the_lds_is_taken_off_at_analyze_time(mo
     bt.analyze(2)
     assert bt.info()["blocks_with_border_split"] == N
     bt.close()
+
+
+def test_host_pointer_solves_leading_dimension_and_row_pack():
+    """pips_hip_ldl_solve with rows longer than the system (ld > n: what lies behind a row's first n entries is not touched), zero columns found
+    on the device and moved out of the pass; pips_hip_ldl_solve_sparse with a colSparsity that marks few rows (the pack on the host, taken
+    below an eighth of the rows) and with one that marks most (whole columns travel) - all against the plain dense call."""
+    n_i = 900
+    prob = Problem(11, 1, n_i, n_i // 2, 4, 4, 6.0 / n_i)
+    n = prob.n_leaf
+    s = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
+    s.matrixChanged()
+    rng = np.random.default_rng(2)
+    R = rng.standard_normal((24, n))
+    R[[2, 9, 23]] = 0.0
+    want = R.copy()
+    s.solve(want)
+    assert not want[[2, 9, 23]].any()
+    wide = np.full((24, n + 7), 7.5)
+    wide[:, :n] = R
+    s.solve(wide)
+    assert np.abs(wide[:, :n] - want).max() <= 1e-12 * np.abs(want).max() and np.all(wide[:, n:] == 7.5)
+    for frac in (1.0 / 16.0, 0.6):
+        rows = np.sort(rng.choice(n, size=int(frac * n), replace=False))
+        cs = np.zeros(n, np.int32)
+        cs[rows] = 1
+        Rs = np.zeros((24, n))
+        Rs[:, rows] = rng.standard_normal((24, len(rows)))
+        Rs[[0, 11]] = 0.0
+        ref = Rs.copy()
+        s.solve(ref)
+        got = Rs.copy()
+        s.solve_sparse(got, cs)
+        assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+        assert not got[[0, 11]].any()
+    s.close()
