@@ -44,6 +44,10 @@ int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol);
  * refinement looks at; solve(nrhs) decides per chunk of right-hand sides by the worst of them (one number read back, the correction solve only
  * where the first solve was not accurate enough).  The adapters use (2, 1e-15): iparm[7] = 2, PardisoProjectSolver.C:72 */
 int pips_hip_ldl_set_refinement_backward_error(void* handle, int max_steps, double tol);
+/* deterministic mode of this leaf (see pips_hip_batch_set_deterministic): factor(), solve() and solve(nrhs) repeat to the bit - no FP64
+ * atomics on their path; several right-hand sides go panel by panel through the slot / gather forward substitution.  Before the first
+ * factorisation.  (The reference's breakdown tests compare bitwise between runs: pipsdef.h:35,108.) */
+int pips_hip_ldl_set_deterministic(void* handle, int on);
 /* symbolic phase (ordering, supernodes, device allocation); pattern-only, done once */
 int pips_hip_ldl_analyze(void* handle);
 /* = DoubleLinearSolver::matrixChanged(): numeric LDL^T of the current values (host array of length nnz, CSR order) */
@@ -86,7 +90,8 @@ int pips_hip_ldl_solve_batch(void* const* handles, int n, double* const* rhs_ino
 int pips_hip_ldl_solve_batch_dev(void* const* handles, int n, double* x_dev);
 int pips_hip_ldl_inertia_batch(void* const* handles, int n, int* pos, int* neg, int* zero);
 /* diagnostics of the symbolic phase: what[0]=nnz(L) what[1]=n_head what[2]=tail m what[3]=#head supernodes
- * what[4]=#levels what[5]=factor flops (rounded); and what[6]=refinement steps the last solve took */
+ * what[4]=#levels what[5]=factor flops (rounded); and what[6]=refinement steps the last solve took, what[7]=how the last solve(nrhs) went
+ * (0 one sweep per right-hand side, 1 interleaved panels on the matrix pipe, 2 the same with the deterministic forward substitution) */
 int pips_hip_ldl_info(void* handle, int64_t* what, int n_what);
 /* copies the fill-reducing permutation (perm[k] = original index eliminated k-th) */
 int pips_hip_ldl_get_perm(void* handle, int* perm);

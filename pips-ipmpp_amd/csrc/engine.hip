@@ -889,7 +889,8 @@ struct Engine {
       d_bg_ent = nullptr; d_bg_ptr = d_bg_slot = nullptr; d_bg_idx = nullptr; d_bg_val = nullptr; n_bg_targets = n_bg_ent = 0; det_aug_ready = false;
       if (d_slot_val) (void)hipFree(d_slot_val);
       if (d_vslot_val) (void)hipFree(d_vslot_val);
-      d_slot_val = d_vslot_val = nullptr;
+      if (d_mvslot) (void)hipFree(d_mvslot);
+      d_slot_val = d_vslot_val = d_mvslot = nullptr;
       void* ptrs[] = {d_arena, d_kval, d_bval, d_winv, d_dtail, d_xw, d_rhs, d_res, d_stage, d_pref, d_norms, d_kdst, d_bdst, d_kdiag, d_kptr,
                       d_psign_off, d_perm_off, d_rowbase, d_bt_xoff, d_sns, d_blks, d_rowidx, d_upd, d_sncol, d_bmap, d_perm, d_spine, d_spine_off, d_schur_cols, d_schur_slot, d_sctab, d_frowptr, d_fcol, d_fsrc, d_flong,
                       d_inertia, d_nprimal, d_krowptr, d_kcolidx, d_bt_rowptr, d_bt_colidx, d_bt_rowsc, d_psign};
@@ -949,6 +950,8 @@ struct Engine {
    static constexpr long long HEAD_SLOTS_MAX = 400LL * 1000 * 1000;
    long long slots_total = 0, vslots_total = 0;
    double *d_slot_val = nullptr, *d_vslot_val = nullptr;
+   int last_multi_path = 0;      // how the last solve(nrhs) went: 0 one sweep per right-hand side, 1 interleaved panels, 2 interleaved panels with the slot / gather forward substitution
+   double* d_mvslot = nullptr;   // deterministic mode, several right-hand sides: the forward substitution's slots for one panel of MQ (solve_multi)
    std::vector<GatherList> g_levels, gv_levels;   // targets inside the head, per level (factorisation / forward substitution)
    GatherList g_tail, g_sc, gv_tail;
    std::vector<SlotEntry> sc_e_keep;
@@ -2202,7 +2205,8 @@ struct Engine {
          g_tail.release(); g_sc.release(); gv_tail.release();
          if (d_slot_val) (void)hipFree(d_slot_val);
          if (d_vslot_val) (void)hipFree(d_vslot_val);
-         d_slot_val = d_vslot_val = nullptr;
+         if (d_mvslot) (void)hipFree(d_mvslot);
+         d_slot_val = d_vslot_val = d_mvslot = nullptr;
          if ((rc = build_deterministic(1))) return rc;
       }
       return PIPS_OK;
@@ -2456,8 +2460,33 @@ struct Engine {
          const int begin = L.simple_cnt > 0 ? L.simple_begin : (L.small_cnt > 0 ? L.small_begin : L.large_begin);
          hipLaunchKernelGGL(k_mhead, dim3((cnt + 3) / 4, np), dim3(256), 0, stream, d_sns, begin, cnt, d_blks, d_rowidx, d_arena, xm, backward, ps);
       };
+      if (deterministic) {
+         // forward substitution without atomics, like solve_once's: every contribution of a supernode goes to its slot (MQ right-hand sides
+         // wide: d_mvslot, one panel at a time), every level first takes what the lower levels left for its columns, in the recorded order;
+         // the simple leaves by target row where that list exists.  One panel per call (the caller cuts the right-hand sides into panels).
+         if (np != 1 || !d_mvslot) PIPS_FAIL(PIPS_ERR_STATE, "deterministic mode: several right-hand sides go panel by panel");
+         auto mgather = [&](const GatherList& g) {
+            if (g.n_targets > 0)
+               hipLaunchKernelGGL(k_mgather_slots, dim3(grid_for(g.n_targets * 32, 256)), dim3(256), 0, stream, g.n_targets, g.d_tgt, g.d_off, g.d_slots, d_mvslot, xm);
+         };
+         for (size_t li = 0; li < levels.size(); ++li) {
+            const LevelRange& L = levels[li];
+            mgather(gv_levels[li]);
+            if (L.simple_cnt > 0 && lf_rows > 0)
+               hipLaunchKernelGGL(k_mleaf_fwd_gather, dim3(grid_for(lf_rows * 32, 256)), dim3(256), 0, stream, d_lf_rows, d_lf_ptr, d_lf_src, d_lf_val, xm, (int)lf_rows);
+            else if (L.simple_cnt > 0)
+               hipLaunchKernelGGL(k_mhead, dim3((L.simple_cnt + 3) / 4, 1), dim3(256), 0, stream, d_sns, L.simple_begin, L.simple_cnt, d_blks, d_rowidx, d_arena, xm, 0, ps,
+                                  d_mvslot);
+            const int begin = L.small_cnt > 0 ? L.small_begin : L.large_begin;
+            const int cnt = L.small_cnt + L.large_cnt;
+            if (cnt > 0)
+               hipLaunchKernelGGL(k_mhead, dim3((cnt + 3) / 4, 1), dim3(256), 0, stream, d_sns, begin, cnt, d_blks, d_rowidx, d_arena, xm, 0, ps, d_mvslot);
+         }
+         mgather(gv_tail);
+      } else {
       for (const LevelRange& L : levels) head(L, 0);
       for (const LevelRange& L : levels_top) head(L, 0);
+      }
       const TailPlan& p = plan;
       const bool rows = sweep.enabled && np * 4 <= SWEEP_NRHS_MAX && p.ntc_max > 0;   // the tail sweeps as one launch per direction (tickets, flags)
       // few tile rows per step (a single leaf): a workgroup takes a quarter or a half of a panel's right-hand sides, so that the chain of a pass -
@@ -2524,14 +2553,19 @@ struct Engine {
    int solve_multi(double* X_dev, int nrhs, long long x_stride) {
       if (!factored) PIPS_FAIL(PIPS_ERR_STATE, "solve called before factor");
       HIP_TRY(hipSetDevice(device));
-      if (deterministic) {   // one right-hand side at a time through the atomics-free sweeps
+      // deterministic mode: the interleaved sweeps panel by panel with the slot / gather forward substitution (solve_once_multi) where the
+      // slots of a panel fit 4 GB (MQ doubles per contribution of the head: a leaf handle, a small batch), else one right-hand side at a time
+      const bool det_multi = deterministic && head_slots && use_multi(nrhs) && vslots_total > 0 && (double)vslots_total * MQ * sizeof(double) <= 4e9;
+      last_multi_path = det_multi ? 2 : (deterministic || !use_multi(nrhs)) ? 0 : 1;
+      if (deterministic && !det_multi) {   // one right-hand side at a time through the atomics-free sweeps
          for (int r = 0; r < nrhs; ++r)
             if (int rc = solve(X_dev + (long long)r * x_stride)) return rc;
          return PIPS_OK;
       }
+      if (det_multi && !d_mvslot) HIP_TRY(hipMalloc((void**)&d_mvslot, (size_t)vslots_total * MQ * sizeof(double)));
       last_refine_steps = 0;   // (over the chunks: the steps of the last one that took any)
       const bool multi = use_multi(nrhs);
-      const int chunk_max = multi ? MULTI_CHUNK_MAX : 32;   // (the per-right-hand-side sweeps keep their 32 work vectors)
+      const int chunk_max = det_multi ? MQ : multi ? MULTI_CHUNK_MAX : 32;   // (the per-right-hand-side sweeps keep their 32 work vectors)
       int rc0 = ensure_multi_buffers(std::min(nrhs, chunk_max));
       if (rc0) return rc0;
       for (int r0 = 0; r0 < nrhs; r0 += chunk_max) {
@@ -4053,6 +4087,14 @@ int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol) {
    return PIPS_OK;
 }
 
+int pips_hip_ldl_set_deterministic(void* handle, int on) {
+   LdlHandle* h = (LdlHandle*)handle;
+   if (!h) PIPS_FAIL(PIPS_ERR_ARG, "null handle");
+   if (h->eng.analyzed) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_set_deterministic: before the first factorisation (the symbolic phase builds the slot lists)");
+   h->eng.deterministic = on != 0;
+   return PIPS_OK;
+}
+
 int pips_hip_ldl_set_refinement_backward_error(void* handle, int max_steps, double tol) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || max_steps < 0 || tol < 0) PIPS_FAIL(PIPS_ERR_ARG, "pips_hip_ldl_set_refinement_backward_error: bad arguments");
@@ -4444,8 +4486,8 @@ int pips_hip_ldl_info(void* handle, int64_t* what, int n_what) {
    LdlHandle* h = (LdlHandle*)handle;
    if (!h || h->eng.sym.empty()) PIPS_FAIL(PIPS_ERR_STATE, "pips_hip_ldl_info: analyze first");
    const BlockSym& s = h->eng.sym[0];
-   int64_t v[7] = {s.nnzL, s.n_head, s.m, (int64_t)s.sn.size(), s.n_levels, (int64_t)s.flops_factor, (int64_t)h->eng.last_refine_steps};
-   for (int i = 0; i < n_what && i < 7; ++i) what[i] = v[i];
+   int64_t v[8] = {s.nnzL, s.n_head, s.m, (int64_t)s.sn.size(), s.n_levels, (int64_t)s.flops_factor, (int64_t)h->eng.last_refine_steps, (int64_t)h->eng.last_multi_path};
+   for (int i = 0; i < n_what && i < 8; ++i) what[i] = v[i];
    return PIPS_OK;
 }
 

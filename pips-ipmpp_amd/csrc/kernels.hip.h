@@ -2949,7 +2949,7 @@ __global__ void k_mpermute(const BlkDesc* __restrict__ blks, const int* __restri
 // split the below-rows.  sns are taken four per workgroup.
 template <int WB>
 __device__ __forceinline__ void mhead_body(const SnDesc& sn, const BlkDesc& bd, const int* __restrict__ rowidx,
-                                           const double* __restrict__ arena, double* __restrict__ xm, int backward) {
+                                           const double* __restrict__ arena, double* __restrict__ xm, int backward, double* __restrict__ slots) {
    const int w = sn.w, r = sn.r, ld = sn.ld, lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
    const double* P = arena + sn.panel;
    double* xb = xm + bd.xw_off * MQ;
@@ -2978,7 +2978,9 @@ __device__ __forceinline__ void mhead_body(const SnDesc& sn, const BlkDesc& bd, 
 #pragma unroll
          for (int k = 0; k < WB; ++k)
             if (k < w) s += P[w + a + (long long)k * ld] * y[k];
-         atomic_add_f64(xb + (long long)ra * MQ + q, -s);
+         // deterministic mode: every contribution into its own slot (SnDesc::vslot + a, MQ right-hand sides wide); k_mgather_slots adds them per target
+         if (slots) slots[(sn.vslot + a) * MQ + q] = -s;
+         else atomic_add_f64(xb + (long long)ra * MQ + q, -s);
       }
    } else {
       double part[WB];
@@ -3014,15 +3016,39 @@ __device__ __forceinline__ void mhead_body(const SnDesc& sn, const BlkDesc& bd, 
 
 __global__ __launch_bounds__(256) void k_mhead(const SnDesc* __restrict__ sns, int sn_begin, int cnt,
                                               const BlkDesc* __restrict__ blks, const int* __restrict__ rowidx,
-                                              const double* __restrict__ arena, double* __restrict__ xm, int backward, long long panel_stride = 0) {
+                                              const double* __restrict__ arena, double* __restrict__ xm, int backward, long long panel_stride = 0,
+                                              double* __restrict__ slots = nullptr) {
    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
    if (i >= cnt) return;
    xm += panel_stride * blockIdx.y;
    const SnDesc sn = sns[sn_begin + i];
    const BlkDesc bd = blks[sn.blk];
-   if (sn.w == 1) mhead_body<1>(sn, bd, rowidx, arena, xm, backward);
-   else if (sn.w <= 8) mhead_body<8>(sn, bd, rowidx, arena, xm, backward);
-   else mhead_body<HEAD_WMAX>(sn, bd, rowidx, arena, xm, backward);
+   if (sn.w == 1) mhead_body<1>(sn, bd, rowidx, arena, xm, backward, slots);
+   else if (sn.w <= 8) mhead_body<8>(sn, bd, rowidx, arena, xm, backward, slots);
+   else mhead_body<HEAD_WMAX>(sn, bd, rowidx, arena, xm, backward, slots);
+}
+
+// deterministic mode, one panel of MQ right-hand sides: target row t of the list takes the sum of its slots in the list's order
+// (k_gather_slots for MQ interleaved vectors); a wave takes two targets, its halves the right-hand sides of one each
+__global__ __launch_bounds__(256) void k_mgather_slots(long long n_targets, const long long* __restrict__ tgt, const long long* __restrict__ off,
+                                                      const long long* __restrict__ slots, const double* __restrict__ val, double* __restrict__ xm) {
+   const long long t = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 5;
+   const int q = threadIdx.x & 31;
+   if (t >= n_targets) return;
+   double s = 0.0;
+   for (long long p = off[t]; p < off[t + 1]; ++p) s += val[slots[p] * MQ + q];
+   xm[tgt[t] * MQ + q] += s;
+}
+
+// the simple leaves' forward substitution as a gather by target row (k_leaf_fwd_gather) for a panel of MQ interleaved right-hand sides:
+// no atomics, the order of a row's sum is the order of its list
+__global__ __launch_bounds__(256) void k_mleaf_fwd_gather(const int* __restrict__ rows, const int* __restrict__ ptr, const int* __restrict__ src,
+                                                         const double* __restrict__ val, double* __restrict__ xm, int n) {
+   const int t = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 5), q = threadIdx.x & 31;
+   if (t >= n) return;
+   double s = 0.0;
+   for (int p = ptr[t]; p < ptr[t + 1]; ++p) s += val[p] * xm[(long long)src[p] * MQ + q];
+   xm[(long long)rows[t] * MQ + q] -= s;
 }
 
 __global__ void k_mhead_dscale(const SnDesc* __restrict__ sns, int nsn, const BlkDesc* __restrict__ blks,

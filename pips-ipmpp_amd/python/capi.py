@@ -46,7 +46,7 @@ lib.pips_hip_host_wait_count.restype = C.c_longlong
 # every symbol include/pips_hip.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [
     "pips_hip_last_error", "pips_hip_device_count",
-    "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement", "pips_hip_ldl_set_refinement_backward_error",
+    "pips_hip_ldl_create", "pips_hip_ldl_set_inertia_hint", "pips_hip_ldl_set_pivot_rule", "pips_hip_ldl_set_refinement", "pips_hip_ldl_set_refinement_backward_error", "pips_hip_ldl_set_deterministic",
     "pips_hip_ldl_analyze", "pips_hip_ldl_factor", "pips_hip_ldl_solve", "pips_hip_ldl_inertia", "pips_hip_ldl_info",
     "pips_hip_ldl_get_perm", "pips_hip_ldl_set_border", "pips_hip_ldl_factor_schur", "pips_hip_ldl_destroy",
     "pips_hip_ldl_solve_dev", "pips_hip_ldl_solve_sparse", "pips_hip_ldl_factor_schur_batch", "pips_hip_ldl_solve_batch", "pips_hip_ldl_solve_batch_dev",
@@ -282,6 +282,10 @@ class HipLdlSolver:
     def set_pivot_rule(self, thr_rel, repl_rel):
         _check(lib.pips_hip_ldl_set_pivot_rule(self._h, C.c_double(thr_rel), C.c_double(repl_rel)), "set_pivot_rule")
 
+    def set_deterministic(self, on=True):
+        """before the first factorisation: factor / solve / solve(nrhs) of this leaf repeat to the bit"""
+        _check(lib.pips_hip_ldl_set_deterministic(self._h, C.c_int(1 if on else 0)), "pips_hip_ldl_set_deterministic")
+
     def analyze(self):
         _check(lib.pips_hip_ldl_analyze(self._h), "pips_hip_ldl_analyze")
 
@@ -366,10 +370,10 @@ class HipLdlSolver:
         return p.value, n.value, z.value
 
     def info(self):
-        what = np.zeros(7, np.int64)
-        _check(lib.pips_hip_ldl_info(self._h, _ptr(what), C.c_int(7)), "pips_hip_ldl_info")
+        what = np.zeros(8, np.int64)
+        _check(lib.pips_hip_ldl_info(self._h, _ptr(what), C.c_int(8)), "pips_hip_ldl_info")
         return dict(nnzL=int(what[0]), n_head=int(what[1]), m=int(what[2]), n_sn=int(what[3]), n_levels=int(what[4]),
-                    flops=int(what[5]), last_refinement_steps=int(what[6]))
+                    flops=int(what[5]), last_refinement_steps=int(what[6]), last_multi_path=int(what[7]))
 
     def close(self):
         if self._h:

@@ -263,3 +263,39 @@ def test_ipm_is_bit_reproducible(monkeypatch):
         runs.append((res["iterations"], ipm.trace().tobytes(), ipm.iterate()["x"].tobytes(), ipm.iterate()["z"].tobytes()))
         ipm.close()
     assert all(r == runs[0] for r in runs)
+
+
+@pytest.mark.parametrize("n_i", [300, 1500, 2400])
+def test_several_right_hand_sides_in_deterministic_mode(n_i, monkeypatch):
+    """DoubleLinearSolver::solve(nrhs) of a leaf handle in deterministic mode (pips_hip_ldl_set_deterministic): the interleaved panels with the slot / gather forward substitution instead of
+    one right-hand side at a time - bit-identical over runs and handles, equal to the single solves of the same handle to rounding, and to
+    SuperLU."""
+    import scipy.sparse.linalg as spl
+    prob = Problem(5, 1, n_i, n_i // 2, 4, 4, 6.0 / n_i)
+    rng = np.random.default_rng(1)
+    R = rng.standard_normal((70, prob.n_leaf))       # three panels, the last one partly filled
+    R[13] = 0.0
+    runs, levels_seen = [], set()
+    for rep in range(2):
+        s = pa.HipLdlSolver(prob.blocks[0]["K"], n_primal=prob.n_i)
+        s.set_deterministic()
+        s.matrixChanged()
+        for again in range(2):
+            X = R.copy()
+            s.solve(X)
+            assert s.info()["last_multi_path"] == 2
+            levels_seen.add(s.info()["n_levels"])
+            runs.append(X)
+        ones = np.stack([s.solve(R[k].copy()) for k in (0, 31, 32, 69)])
+        s.close()
+    for X in runs[1:]:
+        assert np.array_equal(X, runs[0])
+    assert not runs[0][13].any()
+    print("head levels", levels_seen)
+    lu = spl.splu(prob.K_full(0))
+    for k in range(70):
+        if k != 13:
+            xr = lu.solve(R[k])
+            assert np.linalg.norm(runs[0][k] - xr) / np.linalg.norm(xr) < 1e-9
+    for i, k in enumerate((0, 31, 32, 69)):
+        assert np.linalg.norm(ones[i] - runs[0][k]) / np.linalg.norm(ones[i]) < 1e-11
