@@ -27,7 +27,7 @@ public:
       check(pips_hip_ldl_create(&h, st.n, st.krowM, st.jcolM, device, 0), "create");
       check(pips_hip_ldl_set_inertia_hint(h, n_primal), "hint");   // expected inertia (locnx, locmy+locmz)
       // refinement like PARDISO's: at most two steps, taken only where the first solve misses the backward error (iparm[7] = 2,
-      // PardisoProjectSolver.C:72); solve(nrhs) decides per chunk by its worst right-hand side
+      // PardisoProjectSolver.C:72); solve(nrhs) decides per right-hand side
       check(pips_hip_ldl_set_refinement_backward_error(h, 2, 1e-15), "refinement");
       // the symbolic phase runs once, with the first factorisation (the pattern never changes, DistributedLeafLinearSystem.C:10-42): a
       // border declared before that (declare_border) becomes part of it

@@ -41,8 +41,8 @@ int pips_hip_ldl_set_pivot_rule(void* handle, double thr_rel, double repl_rel);
  * (PARDISO: iparm[7]=2, PardisoProjectSolver.C:72), tol = 0 always does max_steps steps.  Default (1, 0). */
 int pips_hip_ldl_set_refinement(void* handle, int max_steps, double tol);
 /* same, the stopping test being the normwise backward error ||r||inf / (max|K| ||x||inf + ||rhs||inf) <= tol - what PARDISO's adaptive
- * refinement looks at; solve(nrhs) decides per chunk of right-hand sides by the worst of them (one number read back, the correction solve only
- * where the first solve was not accurate enough).  The adapters use (2, 1e-15): iparm[7] = 2, PardisoProjectSolver.C:72 */
+ * refinement looks at; solve(nrhs) decides per right-hand side (the measures of a chunk read back with one copy, the correction solve only for
+ * the columns whose first solve was not accurate enough).  The adapters use (2, 1e-15): iparm[7] = 2, PardisoProjectSolver.C:72 */
 int pips_hip_ldl_set_refinement_backward_error(void* handle, int max_steps, double tol);
 /* deterministic mode of this leaf (see pips_hip_batch_set_deterministic): factor(), solve() and solve(nrhs) repeat to the bit - no FP64
  * atomics on their path; several right-hand sides go panel by panel through the slot / gather forward substitution.  Before the first

@@ -904,7 +904,11 @@ struct Engine {
       if (ev_inertia) (void)hipEventDestroy(ev_inertia);
       ev_inertia = nullptr;
       inertia_in_flight = inertia_on_host = false;
-      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res, &d_hostx, &d_hostpack}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      for (double** q : {&d_mx_xw, &d_mx_rhs, &d_mx_res, &d_hostx, &d_hostpack, &d_mmeasure}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+      if (d_midx) (void)hipFree(d_midx);
+      d_midx = nullptr;
+      if (h_mmeasure) (void)hipHostFree(h_mmeasure);
+      h_mmeasure = nullptr;
       mx_cap = 0;
       hostx_cap = hostpack_cap = 0;
       d_kdst = d_bdst = d_kdiag = d_kptr = d_psign_off = d_perm_off = d_rowbase = d_bt_xoff = nullptr;
@@ -2532,6 +2536,8 @@ struct Engine {
    // length n_total at distance x_stride.
    double *d_mx_xw = nullptr, *d_mx_rhs = nullptr, *d_mx_res = nullptr;
    int mx_cap = 0;
+   double *d_mmeasure = nullptr, *h_mmeasure = nullptr;   // solve_multi: the refinement measure per right-hand side (device / pinned)
+   int* d_midx = nullptr;                                // ... and the columns that take the correction solve
    double* d_hostx = nullptr;   // device copy of host right-hand sides (pips_hip_ldl_solve), kept between calls
    size_t hostx_cap = 0;
    double* d_hostpack = nullptr;   // packed rows + their indices of pips_hip_ldl_solve_sparse, kept between calls likewise
@@ -2547,6 +2553,11 @@ struct Engine {
          HIP_TRY(hipMalloc((void**)&d_mx_rhs, (size_t)want * std::max<long long>(n_total, 1) * sizeof(double)));
          HIP_TRY(hipMalloc((void**)&d_mx_res, (size_t)want * std::max<long long>(n_total, 1) * sizeof(double)));
          mx_cap = want;
+      }
+      if (!d_mmeasure) {   // per right-hand side: the measure of the adaptive refinement (device / pinned host, behind it the list of columns to correct)
+         HIP_TRY(hipMalloc((void**)&d_mmeasure, MULTI_CHUNK_MAX * sizeof(double)));
+         HIP_TRY(hipMalloc((void**)&d_midx, MULTI_CHUNK_MAX * sizeof(int)));
+         HIP_TRY(hipHostMalloc((void**)&h_mmeasure, MULTI_CHUNK_MAX * (sizeof(double) + sizeof(int)), hipHostMallocDefault));
       }
       return PIPS_OK;
    }
@@ -2591,20 +2602,36 @@ struct Engine {
             if (n_flong > 0)
                hipLaunchKernelGGL(k_full_spmv_sub_long, dim3(n_flong, nr), dim3(256), 0, stream, d_flong, d_frowptr, d_fcol, d_fsrc, d_kval,
                                   Xc, d_mx_res, d_rowbase, n_total);
-            if (refine_tol > 0.0 && d_norms) {
-               // adaptive like the single right-hand side (solve()): the worst (block, right-hand side) of the chunk decides for all of it -
-               // one number back to the host, the correction solve only where the first one was not accurate enough
-               HIP_TRY(hipMemsetAsync(d_norms, 0, sizeof(double), stream));
+            int n_fix = nr;   // right-hand sides that take the correction solve: all of them, or (adaptive) those whose measure says so
+            if (refine_tol > 0.0 && d_mmeasure) {
+               // adaptive like the single right-hand side (solve()), per right-hand side like PARDISO: every column's worst block is measured,
+               // one small copy back to the host, and the correction solve takes only the columns that were not accurate enough - their
+               // residuals moved side by side to the front (ascending: a column never lands on one that is still to move)
+               HIP_TRY(hipMemsetAsync(d_mmeasure, 0, (size_t)nr * sizeof(double), stream));
                hipLaunchKernelGGL(k_mrefine_measure, dim3(nblk, nr), dim3(256), 0, stream, d_blks, d_mx_res, n_total, d_mx_rhs, n_total, Xc, n_total,
-                                  refine_mode == 1 ? 1.0 / (repl_rel > 0 ? repl_rel : 1.0) : 0.0, d_norms);
-               HIP_TRY(hipMemcpyAsync(h_norms, d_norms, sizeof(double), hipMemcpyDeviceToHost, stream));
+                                  refine_mode == 1 ? 1.0 / (repl_rel > 0 ? repl_rel : 1.0) : 0.0, d_mmeasure);
+               HIP_TRY(hipMemcpyAsync(h_mmeasure, d_mmeasure, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, stream));
                HIP_TRY(hipStreamSynchronize(stream));
-               last_refine_measure = h_norms[0];
-               if (h_norms[0] <= refine_tol) break;
+               int* fix = (int*)(h_mmeasure + MULTI_CHUNK_MAX);
+               n_fix = 0;
+               double worst = 0.0;
+               for (int q = 0; q < nr; ++q) {
+                  if (!(h_mmeasure[q] <= worst)) worst = h_mmeasure[q];
+                  if (!(h_mmeasure[q] <= refine_tol)) fix[n_fix++] = q;
+               }
+               last_refine_measure = worst;
+               if (n_fix == 0) break;
+               if (n_fix < nr) {
+                  for (int i = 0; i < n_fix; ++i)
+                     if (fix[i] != i)
+                        HIP_TRY(hipMemcpyAsync(d_mx_res + (size_t)i * n_total, d_mx_res + (size_t)fix[i] * n_total, (size_t)n_total * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                  HIP_TRY(hipMemcpyAsync(d_midx, fix, (size_t)n_fix * sizeof(int), hipMemcpyHostToDevice, stream));
+               }
             }
-            rc = multi ? solve_once_multi(d_mx_res, nr, n_total, d_mx_xw) : solve_once(d_mx_res, nr, n_total, d_mx_xw);
+            rc = (multi && (n_fix > 1 || det_multi)) ? solve_once_multi(d_mx_res, n_fix, n_total, d_mx_xw) : solve_once(d_mx_res, n_fix, n_total, d_mx_xw);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_maxpy, dim3(grid_for(n_total, 256, 1024), nr), dim3(256), 0, stream, X, x_stride, d_mx_res, n_total, 1.0, n_total);
+            if (n_fix < nr) hipLaunchKernelGGL(k_maxpy_idx, dim3(grid_for(n_total, 256, 1024), n_fix), dim3(256), 0, stream, X, x_stride, d_mx_res, n_total, 1.0, n_total, d_midx);
+            else hipLaunchKernelGGL(k_maxpy, dim3(grid_for(n_total, 256, 1024), nr), dim3(256), 0, stream, X, x_stride, d_mx_res, n_total, 1.0, n_total);
             ++last_refine_steps;
          }
       }

@@ -3355,6 +3355,14 @@ __global__ __launch_bounds__(256, 2) void k_mtail_rows_bwd(SweepArgs a, const Bl
    sweep_done(a);
 }
 
+// X(:, idx[r]) += a * Y(:, r): the refinement update of the right-hand sides that took a correction solve (their corrections side by side in Y)
+__global__ void k_maxpy_idx(double* __restrict__ X, long long x_stride, const double* __restrict__ Y, long long y_stride, double a, long long n,
+                            const int* __restrict__ idx) {
+   X += x_stride * idx[blockIdx.y];
+   Y += y_stride * blockIdx.y;
+   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) X[i] += a * Y[i];
+}
+
 // X(:, r) += a * Y(:, r) for nr vectors (grid.y): the refinement update of all right-hand sides in one launch
 __global__ void k_maxpy(double* __restrict__ X, long long x_stride, const double* __restrict__ Y, long long y_stride, double a, long long n) {
    X += x_stride * blockIdx.y;
@@ -3363,8 +3371,8 @@ __global__ void k_maxpy(double* __restrict__ X, long long x_stride, const double
 }
 
 // The measure of the adaptive refinement for several right-hand sides at once: grid (block, right-hand side); for its pair the workgroup forms
-// ||r||inf, ||rhs||inf and ||x||inf over the block's rows and folds  ||r|| / (amax_scale * max|K_b| ||x|| + ||rhs||)  into ONE number,
-// worst[0], with an integer atomic max (non-negative doubles order like their bit patterns; a NaN or Inf counts as +Inf); amax_scale = 0:
+// ||r||inf, ||rhs||inf and ||x||inf over the block's rows and folds  ||r|| / (amax_scale * max|K_b| ||x|| + ||rhs||)  into the number of its
+// right-hand side, worst[right-hand side], with an integer atomic max (non-negative doubles order like their bit patterns; a NaN or Inf counts as +Inf); amax_scale = 0:
 // the denominator is ||rhs||inf alone (refine_mode 0).  blks[b].repl_abs = repl_rel * max|K_b| (k_block_absmax_finish).
 __global__ __launch_bounds__(256) void k_mrefine_measure(const BlkDesc* __restrict__ blks, const double* __restrict__ R, long long r_stride,
                                                         const double* __restrict__ B, long long b_stride, const double* __restrict__ X,
@@ -3394,7 +3402,7 @@ __global__ __launch_bounds__(256) void k_mrefine_measure(const BlkDesc* __restri
       if (den > 0.0) {
          double q = red[0][0] / den;
          if (!(q <= 1.7976931348623157e308)) q = inf;   // (Inf / Inf = NaN: never "converged" on a poisoned iterate)
-         if (q > 0.0) atomicMax((unsigned long long*)worst, (unsigned long long)__double_as_longlong(q));
+         if (q > 0.0) atomicMax((unsigned long long*)(worst + blockIdx.y), (unsigned long long)__double_as_longlong(q));
       }
    }
 }

@@ -149,6 +149,38 @@ def test_leaf_many_rhs_refine_only_where_needed():
     s.close()
 
 
+def test_leaf_many_rhs_refine_per_column():
+    """The correction solve of solve(nrhs) takes only the columns whose own measure asks for it: with a tolerance between the measures of the
+    columns (border columns of a block: sparse right-hand sides, some of which come out of the first solve above 1e-16-ish) the result
+    of every column equals either its refined or its unrefined solution, and all of them the reference."""
+    n_i = 2000
+    prob = Problem(9, 1, n_i, n_i // 2, 60, 40, 5.0 / n_i)
+    K = prob.blocks[0]["K"]
+    Bt = prob.Bt_scipy(0)
+    cols = np.nonzero(np.diff(Bt.indptr) > 0)[0][:96]
+    R = np.ascontiguousarray(Bt[cols].toarray())
+    lu = spl.splu(prob.K_full(0))
+    sols = {}
+    for name, steps, tol in (("never", 0, 0.0), ("always", 1, 0.0), ("some", 2, 2e-16), ("none_needed", 2, 1e-10)):
+        s = pa.HipLdlSolver(K, n_primal=prob.n_i, refine_steps=steps, refine_tol=tol, backward_error=tol > 0)
+        s.set_deterministic()      # (so that the handles agree to the bit and "left as the first solve gave it" can be checked)
+        s.matrixChanged()
+        X = R.copy()
+        s.solve(X)
+        sols[name] = (X, s.info()["last_refinement_steps"])
+        s.close()
+    assert sols["none_needed"][1] == 0 and np.array_equal(sols["none_needed"][0], sols["never"][0])
+    for k in range(len(cols)):
+        xr = lu.solve(R[k])
+        for name in sols:
+            assert np.linalg.norm(sols[name][0][k] - xr) / np.linalg.norm(xr) < 1e-9
+    X, steps = sols["some"]
+    same_as_never = [np.array_equal(X[k], sols["never"][0][k]) for k in range(len(cols))]
+    if steps > 0:      # (some column asked for it; the others were left as the first solve gave them)
+        assert not all(same_as_never)
+    print("columns left unrefined:", sum(same_as_never), "of", len(cols), "steps", steps)
+
+
 def test_refactor_after_diagonal_change():
     """matrixChanged() after mutating the diagonal in place (a2/a3), pattern fixed."""
     prob = Problem(3, 1, 400, 200, 4, 4, 0.02)
