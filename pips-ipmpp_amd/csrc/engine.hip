@@ -1585,8 +1585,8 @@ struct Engine {
          h_spine_off[b + 1] = (int)h_spine.size();
       }
       spine_total = (int)h_spine.size();
-      // ---- the tails as one launch (tailkernel.hip.h; opt-in, PIPS_HIP_TAIL_SINGLE=1: measured slower than the column launches, DESIGN.md
-      // 4.2a): multifrontal head (every producer of the tail panel goes by BlkDesc::T_in), no deterministic mode (its slot records hold
+      // ---- the tails as one launch (tailkernel.hip.h; the default for batches of up to 16 blocks, slower than the column launches for the
+      // large ones: DESIGN.md 4.2a): multifrontal head (every producer of the tail panel goes by BlkDesc::T_in), no deterministic mode (its slot records hold
       // panel addresses), room for a second copy of the tail panels
       {
          long long scratch = 0;
@@ -1594,7 +1594,11 @@ struct Engine {
          size_t free_b = 0, total_b = 0;
          (void)hipMemGetInfo(&free_b, &total_b);
          const double need = 8.0 * (double)(arena_total + bb_doubles + scratch + uarena_total) + 4e9;
-         tail_single = mf && !deterministic && scratch > 0 && env_int("PIPS_HIP_TAIL_SINGLE", 0) != 0 && need < (double)free_b;
+         // few blocks: the column launches are a chain of ~4 launches per tile column whatever the batch holds, and the one launch wins
+         // (leaf factorisation of configs[1] blocks: 1 block 8.43 -> 8.29 ms, 4: 13.0 -> 12.4, 8: 19.2 -> 17.9, 16: 31.5 -> 30.6; from
+         // 32 blocks on it loses: 54.3 -> 56.8, 64: 77 -> 86).  PIPS_HIP_TAIL_SINGLE=0 / 1 forces one side.
+         const int want_single = env_int("PIPS_HIP_TAIL_SINGLE", nblk <= 16 ? 1 : 0);
+         tail_single = mf && !deterministic && scratch > 0 && want_single != 0 && need < (double)free_b;
          tail_scratch = tail_single ? scratch : 0;
          long long at = arena_total + bb_doubles;
          for (int b = 0; b < nblk; ++b) {

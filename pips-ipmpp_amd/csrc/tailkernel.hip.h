@@ -6,7 +6,9 @@
 // a trsm launch - 34 + 44 launches per configs[1] factorisation, each of which drains before the next starts, the trsm launches
 // memory-bound and alone on the device.  Here the SAME tasks with the same K ranges (TailPlan: groups of four tile columns, the tiles
 // of a tile row side by side) form one list in the driver's order; a workgroup draws the next task of its XCD's share of the list and
-// waits only for the tiles that task reads.
+// waits only for the tiles that task reads.  The default for batches of up to 16 blocks (a leaf handle, the sparse root's one-block engine),
+// where the chain of launches per tile column is the factorisation; large batches keep the column launches, which are within 4 % of
+// their slot-time bound.
 //
 // Where the tiles live.  A tile is accumulated with agent-scope loads and stores - and an agent-scope STORE leaves its line in the
 // writer's L2 (tools/coh_probe: a plain load on that XCD afterwards returns the old value in 91 % of the cases, after agent-scope

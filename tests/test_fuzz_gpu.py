@@ -43,6 +43,9 @@ def test_random_configuration(case, monkeypatch):
     monkeypatch.setenv("PIPS_HIP_MULTI", str(int(rng.integers(0, 2))))
     # (drawn from a generator of its own so that the cases above keep their shapes) fronts on the rows of K only where the border split applies
     monkeypatch.setenv("PIPS_HIP_MF_KONLY", str(int(np.random.default_rng(7000 + case).integers(0, 2))))
+    # (likewise) the tails as the column launches on every third case: batches this small take the single launch by default
+    if np.random.default_rng(9000 + case).integers(0, 3) == 0:
+        monkeypatch.setenv("PIPS_HIP_TAIL_SINGLE", "0")
     prob = Problem(500 + case, N, n_i, my_i, n0, myl, rho, diag_lo=float(rng.choice([-2, -4])), diag_hi=float(rng.choice([2, 4])))
     if structured:
         for blk in prob.blocks:

@@ -1,5 +1,5 @@
-"""The dense tails of the leaf blocks as ONE dependency-driven launch (csrc/tailkernel.hip.h, opt-in PIPS_HIP_TAIL_SINGLE=1; DESIGN.md 4.2a: built,
-parity-green, measured slower than the column launches): the same factors, Schur contribution and inertia as the launch-per-step driver -
+"""The dense tails of the leaf blocks as ONE dependency-driven launch (csrc/tailkernel.hip.h; the default for batches of up to 16 blocks,
+PIPS_HIP_TAIL_SINGLE=0 / 1 forces a side): the same factors, Schur contribution and inertia as the launch-per-step driver -
 with a tile envelope (all of K in the tail: the primal tile rows couple to nothing left of their diagonal, their trsm finish in any order),
 with padded tile rows, over several blocks and over repeated factorisations."""
 import numpy as np
@@ -16,7 +16,7 @@ def _schur(prob, cut, monkeypatch, single):
     if single:
         monkeypatch.setenv("PIPS_HIP_TAIL_SINGLE", "1")
     else:
-        monkeypatch.delenv("PIPS_HIP_TAIL_SINGLE", raising=False)
+        monkeypatch.setenv("PIPS_HIP_TAIL_SINGLE", "0")
     S = prob.S
     bt = pa.LeafBatch(prob.N, S)
     for b in range(prob.N):
