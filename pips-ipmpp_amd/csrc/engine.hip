@@ -353,7 +353,7 @@ struct TailSingle {
    long long* d_flag_off = nullptr;
    int* d_ctl = nullptr;
    long long n_flags = 0;
-   int n_tasks = 0;
+   int n_tasks = 0, n_blocks = 0;
    void release() {
       for (void* q : {(void*)d_tasks, (void*)d_flags, (void*)d_flags_init, (void*)d_flag_off, (void*)d_ctl}) if (q) (void)hipFree(q);
       d_tasks = nullptr; d_flags = d_flags_init = d_ctl = nullptr; d_flag_off = nullptr;
@@ -361,6 +361,7 @@ struct TailSingle {
    int build(const TailPlan& p, const std::vector<BlkDesc>& blks, hipStream_t stream) {
       release();
       const int nblk = (int)blks.size();
+      n_blocks = nblk;
       std::vector<long long> foff(nblk + 1, 0);
       for (int b = 0; b < nblk; ++b) foff[b + 1] = foff[b] + (long long)blks[b].ntr * blks[b].ntc + blks[b].ntr + blks[b].ntc;
       n_flags = foff[nblk];
@@ -531,7 +532,10 @@ static int tail_factor(const TailCtx& c, double* SC, int ldSC) {
          HIP_TRY(hipMemsetAsync(d_trace, 0, n_trace * sizeof(long long), c.stream));
          ta.trace = d_trace;
       }
-      hipLaunchKernelGGL(k_tail_ldl, dim3(512), dim3(512), 0, c.stream, ta);
+      // two workgroups per compute unit; a single block has fewer tasks ready than that and its diagonal tiles - the chain - run 3 x faster on a
+      // compute unit of their own: one workgroup per unit there (a leaf handle's factorisation 6.9 -> 6.6 ms, level 1.5 1.03 -> 0.98 s per unit;
+      // 8 blocks: 17.7 -> 17.9 ms, so only there)
+      hipLaunchKernelGGL(k_tail_ldl, dim3(ts.n_blocks <= 2 ? 256 : 512), dim3(512), 0, c.stream, ta);
       if (c.timer) c.timer->end(c.stream);
       if (trace_file) {
          std::vector<long long> h(n_trace);
