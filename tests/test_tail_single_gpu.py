@@ -56,3 +56,19 @@ def test_one_launch_matches_the_column_launches(shape, cut, monkeypatch):
         sl = slice(b * prob.n_leaf, (b + 1) * prob.n_leaf)
         assert np.linalg.norm(Kf @ xa[sl] - rhs[sl]) / np.linalg.norm(rhs[sl]) < 1e-10
     assert np.linalg.norm(xa - xb) / np.linalg.norm(xb) < 1e-9
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_shapes_both_sides_agree(case, monkeypatch):
+    """random batch sizes, block sizes, fills and cuts: one launch against the column launches"""
+    rng = np.random.default_rng(4000 + case)
+    N = int(rng.integers(1, 6))
+    n_i = int(rng.choice([640, 900, 1300, 1800, 2300]))
+    n0, myl = int(rng.integers(3, 120)), int(rng.integers(0, 90))
+    prob = Problem(600 + case, N, n_i, n_i // 2, n0, myl, float(rng.choice([3.0, 6.0, 10.0])) / n_i)
+    cut = str(rng.choice(["model", "all_tail"]))
+    (sc_a, _), rhs, xa = _schur(prob, cut, monkeypatch, True)
+    (sc_b, _), _, xb = _schur(prob, cut, monkeypatch, False)
+    scale = max(np.abs(sc_b).max(), 1e-300)
+    assert np.abs(sc_a - sc_b).max() / scale < 1e-10
+    assert np.linalg.norm(xa - xb) / np.linalg.norm(xb) < 1e-8
