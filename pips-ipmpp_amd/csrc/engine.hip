@@ -1599,8 +1599,9 @@ struct Engine {
          (void)hipMemGetInfo(&free_b, &total_b);
          const double need = 8.0 * (double)(arena_total + bb_doubles + scratch + uarena_total) + 4e9;
          // few blocks: the column launches are a chain of ~4 launches per tile column whatever the batch holds, and the one launch wins
-         // (leaf factorisation of configs[1] blocks: 1 block 8.43 -> 8.29 ms, 4: 13.0 -> 12.4, 8: 19.2 -> 17.9, 16: 31.5 -> 30.6; from
-         // 32 blocks on it loses: 54.3 -> 56.8, 64: 77 -> 86).  PIPS_HIP_TAIL_SINGLE=0 / 1 forces one side.
+         // (leaf factorisation of configs[1] blocks, profiles/r6_tail_single_by_blocks.txt: 1 block 8.41 -> 7.48 ms, 4: 13.2 -> 12.1,
+         // 8: 19.3 -> 17.8, 16: 31.1 -> 30.4; from 24 blocks on it loses: 43.0 -> 43.7, 32: 54.2 -> 56.4, 64: 101 -> 110).
+         // PIPS_HIP_TAIL_SINGLE=0 / 1 forces one side.
          const int want_single = env_int("PIPS_HIP_TAIL_SINGLE", nblk <= 16 ? 1 : 0);
          tail_single = mf && !deterministic && scratch > 0 && want_single != 0 && need < (double)free_b;
          tail_scratch = tail_single ? scratch : 0;
